@@ -1,0 +1,252 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference with the stubs in oracle/stubs) on seeded synthetic inputs.
+
+Run in the build container only:   python -m oracle.make_goldens
+The reference never travels; only these input/output vectors are committed.
+Weights are not stored: they are regenerated anywhere from
+afm.synth.make_tensor_for(state_dict_key, shape, seed) (name-keyed generator).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.append(os.path.join(ROOT, "afford-motion_amd"))   # appended: reference's `models` wins
+
+from oracle._refimport import import_reference, to_attr  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TEXTS = ["a person walks forward and sits down on the chair", "a man picks up something from the table"]
+
+
+def cmdm_cfg(num_points=1024, time_emb_dim=512, data_repr="h3d", input_feats=263, max_length=20):
+    return dict(name="CMDM", input_feats=input_feats, data_repr=data_repr, time_emb_dim=time_emb_dim,
+                contact_model=dict(contact_type="contact_cont_joints", contact_joints=[0, 10, 11, 12, 20, 21],
+                                   planes=[32, 64, 128, 256], num_points=num_points, blocks=[2, 2, 2, 2]),
+                text_model=dict(version="ViT-B/32", max_length=max_length),
+                arch="trans_enc", latent_dim=512, mask_motion=True, num_layers=[1, 1, 1, 1, 1],
+                num_heads=8, dropout=0.1, dim_feedforward=1024)
+
+
+def cdm_cfg(num_points=256, time_emb_dim=128, max_length=20):
+    return dict(name="CDM", input_feats=6, data_repr="contact_cont_joints", time_emb_dim=time_emb_dim,
+                text_model=dict(version="ViT-B/32", max_length=max_length),
+                scene_model=dict(name="PointTransformerSeg", use_scene_model=False, use_color=False,
+                                 use_openscene=False, num_points=num_points, point_feat_dim=32,
+                                 pretrained_weight="", freeze=True),
+                arch="Perceiver",
+                arch_perceiver=dict(last_dim=256, point_pos_emb=True, encoder_q_input_channels=512,
+                                    encoder_kv_input_channels=256, encoder_num_heads=8, encoder_widening_factor=1,
+                                    encoder_dropout=0.1, encoder_residual_dropout=0.0, encoder_self_attn_num_layers=2,
+                                    decoder_q_input_channels=256, decoder_kv_input_channels=512, decoder_num_heads=8,
+                                    decoder_widening_factor=1, decoder_dropout=0.1, decoder_residual_dropout=0.0))
+
+
+def diffusion_cfg(steps=1000, respacing=""):
+    return dict(predict_xstart=True, steps=steps, noise_schedule="cosine", timestep_respacing=respacing,
+                rescale_timesteps=False, loss_type="MSE", learn_sigma=False, sigma_small=True)
+
+
+@contextlib.contextmanager
+def recorded_randn_like(noises):
+    """Feed `th.randn_like` (gaussian_diffusion.py:431) from a recorded list."""
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: next(it).to(x)
+    try:
+        yield
+    finally:
+        torch.randn_like = orig
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    from afm import synth
+    base, gd = import_reference()
+    import models.modules as rmod
+    import models.scene_models.pointtransformer as rpt
+    from models.functions import encode_text_clip
+    torch.manual_seed(0)
+    os.makedirs(GOLD, exist_ok=True)
+
+    # (i) schedule tables ---------------------------------------------------------------
+    probe = np.array([0, 1, 2, 10, 100, 250, 499])
+    for T, resp in ((1000, ""), (500, ""), (1000, "5"), (1000, "50")):
+        d = base.create_gaussian_diffusion(to_attr(dict(diffusion=diffusion_cfg(T, resp))))
+        idx = probe[probe < d.num_timesteps]
+        idx = np.unique(np.append(idx, d.num_timesteps - 1))
+        tabs = {k: getattr(d, k) for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod",
+                                            "sqrt_one_minus_alphas_cumprod", "posterior_variance",
+                                            "posterior_log_variance_clipped", "posterior_mean_coef1",
+                                            "posterior_mean_coef2")}
+        save(f"schedule_T{T}_r{resp or 'none'}", probe=idx, timestep_map=np.array(d.timestep_map),
+             **{k: v[idx] for k, v in tabs.items()}, **{k + "_sum": v.sum() for k, v in tabs.items()})
+
+    # (v) per-module I/O ----------------------------------------------------------------
+    te = rmod.TimestepEmbedder(512, 512, max_len=1000).eval()
+    synth.fill_module_(te)
+    t = torch.tensor([0, 1, 499, 999])
+    save("timestep_embedder", t=t, out=te(t), pe_rows=te.pe[t, 0])
+
+    layer = torch.nn.TransformerEncoderLayer(d_model=512, nhead=8, dim_feedforward=1024, dropout=0.1,
+                                             activation="gelu", batch_first=True).eval()
+    enc = torch.nn.TransformerEncoder(layer, num_layers=1, enable_nested_tensor=False).eval()
+    synth.fill_module_(enc)
+    x = synth.gaussian("enc_layer_x", (2, 24, 512))
+    mask = torch.zeros(2, 24, dtype=torch.bool)
+    mask[0, 20:] = True
+    mask[1, 13:] = True
+    with torch.no_grad():
+        save("encoder_layer_T24", x=x, mask=mask, out=enc(x, src_key_padding_mask=mask))
+
+    n, B = 256, 2
+    p = synth.scene_cloud(B, n, seed=11).reshape(B * n, 3)
+    o = torch.tensor([n, 2 * n], dtype=torch.int32)
+    for stride in (4, 8):
+        td = rpt.TransitionDown(32, 64, stride=stride, nsample=16).eval()
+        synth.fill_module_(td)
+        feat = synth.gaussian("td_x", (B * n, 32))
+        with torch.no_grad():
+            n_p, y, n_o = td([p, feat, o])
+        save(f"transition_down_s{stride}", p=p, x=feat, o=o, n_p=n_p, y=y, n_o=n_o)
+    td1 = rpt.TransitionDown(9, 32, stride=1, nsample=8).eval()
+    synth.fill_module_(td1)
+    feat9 = synth.gaussian("td1_x", (B * n, 9))
+    with torch.no_grad():
+        save("transition_down_s1", x=feat9, y=td1([p, feat9, o])[1])
+
+    n = 128
+    p = synth.scene_cloud(B, n, seed=12).reshape(B * n, 3)
+    o = torch.tensor([n, 2 * n], dtype=torch.int32)
+    for c, k in ((32, 8), (64, 16)):
+        blk = rpt.PointTransformerBlock(c, c, 8, nsample=k).eval()
+        synth.fill_module_(blk)
+        feat = synth.gaussian("ptb_x", (B * n, c))
+        with torch.no_grad():
+            lay = blk.transformer2([p, feat, o])
+            y = blk([p, feat, o])[1]
+        save(f"pt_block_c{c}_k{k}", p=p, x=feat, o=o, layer_out=lay, y=y)
+
+    N = 1024
+    sme = rmod.SceneMapEncoder(point_feat_dim=6, planes=[32, 64, 128, 256], blocks=[2, 2, 2, 2], num_points=N).eval()
+    synth.fill_module_(sme)
+    xyz = synth.scene_cloud(B, N, seed=13)
+    con = synth.contact_map(B, N, seed=13)
+    with torch.no_grad():
+        save("scene_map_encoder_N1024", xyz=xyz, contact=con, out=sme(xyz, con))
+
+    # reduced CMDM / CDM ---------------------------------------------------------------
+    L = 16
+    cfg = to_attr(dict(model=cmdm_cfg(num_points=N), diffusion=diffusion_cfg(1000, "")))
+    model, diff = base.create_model_and_diffusion(cfg, device="cpu")
+    model.eval()
+    synth.fill_module_(model)
+    text_feat = encode_text_clip(model.text_model, TEXTS, max_length=20, device="cpu").float()
+    x = synth.gaussian("cmdm_x", (B, L, 263))
+    x_mask = torch.zeros(B, L, dtype=torch.bool)
+    x_mask[1, 12:] = True
+    kw = dict(c_text=TEXTS, c_pc_xyz=xyz, c_pc_contact=con, x_mask=x_mask, info_dummy=[0, 1])
+    t = torch.tensor([999, 3])
+    with torch.no_grad():
+        out = model(x, t, **kw)
+        cont_emb = model.contact_encoder(xyz, con)
+    save("cmdm_forward_N1024_L16", x=x, t=t, text_feat=text_feat, xyz=xyz, contact=con, x_mask=x_mask,
+         cont_emb=cont_emb, out=out)
+    keys = sorted(k for k in model.state_dict().keys() if "text_model" not in k)
+    with open(os.path.join(GOLD, "cmdm_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(f"{k} {tuple(model.state_dict()[k].shape)}" for k in keys) + "\n")
+
+    # (ii) single p_sample steps
+    for tt in (999, 500, 1, 0):
+        noise = synth.gaussian(f"p_sample_noise_{tt}", (B, L, 263))
+        tvec = torch.tensor([tt] * B)
+        with recorded_randn_like([noise]), torch.no_grad():
+            o_ = diff.p_sample(model, x, tvec, clip_denoised=False, model_kwargs=kw)
+        save(f"cmdm_p_sample_t{tt}", x=x, noise=noise, sample=o_["sample"], pred_xstart=o_["pred_xstart"])
+
+    # (iii) loops with recorded noise
+    for steps, resp, tag in ((1000, "5", "r5"), (20, "", "T20")):
+        d = base.create_gaussian_diffusion(to_attr(dict(diffusion=diffusion_cfg(steps, resp))))
+        nz = [synth.gaussian(f"loop_{tag}_{j}", (B, L, 263)) for j in range(d.num_timesteps)]
+        xT = synth.gaussian(f"loop_{tag}_xT", (B, L, 263))
+        with recorded_randn_like(nz):
+            s = d.p_sample_loop(model, (B, L, 263), noise=xT, clip_denoised=False, model_kwargs=kw, progress=False)
+        save(f"cmdm_loop_{tag}", sample=s)     # inputs are regenerated by name; only the output is stored
+
+    # (iv) training losses (eval mode: dropout off)
+    x0 = synth.gaussian("train_x0", (B, L, 263))
+    tn = synth.gaussian("train_noise", (B, L, 263))
+    tt = torch.tensor([17, 803])
+    with torch.no_grad():
+        l_m = diff.training_losses(model, x0, tt, model_kwargs=kw, noise=tn)
+        kw2 = {k: v for k, v in kw.items() if k != "x_mask"}
+        model.mask_motion = False
+        l_n = diff.training_losses(model, x0, tt, model_kwargs=kw2, noise=tn)
+        model.mask_motion = True
+    save("cmdm_training_losses", t=tt, loss_masked=l_m["loss"], mse_masked=l_m["mse"], loss_nomask=l_n["loss"])
+
+    # HUMANISE-style CMDM variant: 66-d 'pos' motion, time_emb_dim 128
+    cfg2 = to_attr(dict(model=cmdm_cfg(num_points=N, time_emb_dim=128, data_repr="pos", input_feats=66, max_length=32)))
+    m2 = base.create_model(cfg2, device="cpu").eval()
+    synth.fill_module_(m2)
+    x2 = synth.gaussian("cmdm_pos_x", (B, L, 66))
+    with torch.no_grad():
+        save("cmdm_forward_pos66", out=m2(x2, t, **kw))
+
+    # CDM / Perceiver
+    Nc = 256
+    ccfg = to_attr(dict(model=cdm_cfg(num_points=Nc), diffusion=diffusion_cfg(500, "")))
+    cdm, cdiff = base.create_model_and_diffusion(ccfg, device="cpu")
+    cdm.eval()
+    synth.fill_module_(cdm)
+    cxyz = synth.scene_cloud(B, Nc, seed=14)
+    cx = synth.gaussian("cdm_x", (B, Nc, 6))
+    ckw = dict(c_text=TEXTS, c_pc_xyz=cxyz)
+    tc = torch.tensor([499, 7])
+    with torch.no_grad():
+        save("cdm_forward_N256", x=cx, t=tc, text_feat=text_feat, xyz=cxyz, out=cdm(cx, tc, **ckw))
+    keys = sorted(k for k in cdm.state_dict().keys() if "text_model" not in k)
+    with open(os.path.join(GOLD, "cdm_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(f"{k} {tuple(cdm.state_dict()[k].shape)}" for k in keys) + "\n")
+    d = base.create_gaussian_diffusion(to_attr(dict(diffusion=diffusion_cfg(500, "4"))))
+    nz = [synth.gaussian(f"cdm_loop_{j}", (B, Nc, 6)) for j in range(d.num_timesteps)]
+    xT = synth.gaussian("cdm_loop_xT", (B, Nc, 6))
+    with recorded_randn_like(nz):
+        s = d.p_sample_loop(cdm, (B, Nc, 6), noise=xT, clip_denoised=False, model_kwargs=ckw, progress=False)
+    save("cdm_loop_r4", sample=s)
+
+    # HUMANISE-style CDM: 32-d per-point scene feature supplied (41 input channels)
+    ccfg2 = cdm_cfg(num_points=Nc, max_length=32)
+    ccfg2["scene_model"].update(use_scene_model=True, use_openscene=True, point_feat_dim=32)
+    cdm2 = base.create_model(to_attr(dict(model=ccfg2)), device="cpu").eval()
+    synth.fill_module_(cdm2)
+    pf = synth.gaussian("cdm_pc_feat", (B, Nc, 32))
+    with torch.no_grad():
+        save("cdm_forward_feat32", pc_feat=pf, out=cdm2(cx, tc, c_pc_feat=pf, **ckw))
+
+    # (vi) ADM -> AMDM glue: denormalize+clip (datasets/humanml3d.py:494-511), dist = sqrt(-2 ln c sigma^2)
+    # (utils/evaluate.py:56-66), consumer exp(-d^2 / 2 sigma^2) (datasets/humanml3d.py:773-774); sigma = 0.8
+    sig, mean, std = 0.8, np.float32(0.1), np.float32(0.5)
+    raw = synth.gaussian("glue_sample", (2, 64, 6))
+    contact = (raw.numpy() * std + mean).clip(1e-20, 1.0)
+    dist = np.sqrt(-2 * np.log(contact) * sig ** 2)
+    cond = np.exp(-0.5 * dist ** 2 / sig ** 2)
+    save("adm_to_amdm_glue", sample=raw, mean=mean, std=std, sigma=sig, dist=dist, cond=cond)
+
+
+if __name__ == "__main__":
+    main()
