@@ -1,0 +1,127 @@
+"""ctypes binding of libafm_hip.so (include/afm_hip.h) - the thin FFI layer between the
+Python host code and the hand-written gfx950 kernels.
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+Tensors are passed as raw device pointers (``tensor.data_ptr()``) plus explicit sizes; work is
+enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libafm_hip.so")
+_lib = None
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+MAX_LAYERS = 16
+
+c_f32p = C.c_void_p
+i32, i64, u64 = C.c_int32, C.c_int64, C.c_uint64
+
+
+class AfmError(RuntimeError):
+    pass
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [
+        ("A", c_f32p), ("lda", i64), ("W", c_f32p), ("ldw", i64), ("C", c_f32p), ("ldc", i64),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("bias", c_f32p), ("scale", c_f32p), ("residual", c_f32p), ("ldr", i64),
+        ("rowtab", c_f32p), ("rowtab_period", i32), ("act", i32),
+        ("a_grp", i32), ("a_stride", i32), ("a_off", i32),
+        ("c_grp", i32), ("c_stride", i32), ("c_off", i32),
+        ("ddpm_xt", c_f32p), ("ddpm_noise", c_f32p), ("ddpm_out", c_f32p), ("ldx", i64),
+        ("ddpm_c1", c_f32p), ("ddpm_c2", c_f32p), ("ddpm_sigma", c_f32p), ("rows_per_sample", i32),
+    ]
+
+
+class EncoderLayerWeights(C.Structure):
+    _fields_ = [(n, c_f32p) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+        "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
+
+
+class CmdmWeights(C.Structure):
+    _fields_ = [
+        ("d", i32), ("heads", i32), ("ff", i32), ("n_layers", i32), ("motion_dim", i32), ("n_cond", i32),
+        ("motion_adapter_w", c_f32p), ("motion_adapter_b", c_f32p),
+        ("motion_layer_w", c_f32p), ("motion_layer_b", c_f32p),
+        ("time_table", c_f32p), ("n_timesteps", i32), ("pos_table", c_f32p),
+        ("layer", EncoderLayerWeights * MAX_LAYERS),
+    ]
+
+
+class DdpmArgs(C.Structure):
+    _fields_ = [("noise", c_f32p), ("x_next", c_f32p), ("c1", c_f32p), ("c2", c_f32p), ("sigma", c_f32p),
+                ("seed", u64), ("sample_index0", i64), ("step", i32)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "afm_version": (C.c_int, []),
+    "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
+    "afm_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, C.c_void_p]),
+    "afm_ddpm_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
+    "afm_randn": (C.c_int, [c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
+    "afm_masked_mse": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, C.c_void_p]),
+    "afm_cmdm_workspace_bytes": (i64, [C.POINTER(CmdmWeights), i32, i32]),
+    "afm_cmdm_forward": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
+                                   C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p]),
+    "afm_cmdm_sched_scratch_bytes": (i64, [i32, i32]),
+    "afm_cmdm_sample_loop": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
+                                       c_f32p, c_f32p, i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, C.c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load (once) and type every export.  Raises AfmError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise AfmError(f"{_LIB_PATH} not found: build it with `python afford-motion_amd/build_hip.py` "
+                       "(the HIP path has no CPU or eager fallback)")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "workspace too small", -3: "unsupported shape"}.get(rc, f"hipError {rc}")
+        raise AfmError(f"{what} failed: {kind}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AfmError("afford-motion_amd runs on the MI355X HIP path only; got a CPU tensor "
+                           "(the CPU oracle lives in oracle/ and is test infrastructure)")
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """float32 + contiguous view/copy of ``t``."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

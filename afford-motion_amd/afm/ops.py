@@ -1,0 +1,134 @@
+"""Tensor-level wrappers of the primitive C-ABI entry points (include/afm_hip.h).
+
+Each function mirrors the PyTorch call the reference makes at that point of the path
+(F.linear, F.layer_norm, the attention inside nn.TransformerEncoderLayer, the DDPM update),
+takes/returns torch tensors on the GPU and enqueues the HIP kernel on the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import ffi
+
+RowMap = Tuple[int, int, int]   # (group, stride, offset): row r -> (r // group) * stride + offset + r % group
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ffi.ACT_NONE,
+           scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           rowtab: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           rows: Optional[int] = None, a_map: Optional[RowMap] = None, c_map: Optional[RowMap] = None) -> torch.Tensor:
+    """``act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)]`` on f32 MFMA.
+
+    x [..., K] (or a 2-D row pool when ``a_map`` gathers rows), weight [N, K] as in nn.Linear.
+    With ``out`` given (2-D row pool [R, N]) and ``c_map``, rows are scattered into it."""
+    lib = ffi.load()
+    ffi.require_gpu(x, weight)
+    x = ffi.f32c(x)
+    weight = ffi.f32c(weight)
+    K = x.shape[-1]
+    N = weight.shape[0]
+    assert weight.shape[1] == K, (weight.shape, x.shape)
+    M = rows if rows is not None else x.numel() // K
+    if out is None:
+        out = torch.empty(*(x.shape[:-1] if rows is None else (M,)), N, device=x.device, dtype=torch.float32)
+    a = ffi.LinearArgs()
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc = x.data_ptr(), x.stride(-2) if x.dim() > 1 else K, weight.data_ptr(), K, out.data_ptr(), N
+    a.M, a.N, a.K = M, N, K
+    keep = [x, weight, out]
+    for name, t in (("bias", bias), ("scale", scale)):
+        if t is not None:
+            t = ffi.f32c(t)
+            assert t.numel() == N
+            keep.append(t)
+            setattr(a, name, t.data_ptr())
+    if residual is not None:
+        residual = ffi.f32c(residual)
+        keep.append(residual)
+        a.residual, a.ldr = residual.data_ptr(), N
+    if rowtab is not None:
+        rowtab = ffi.f32c(rowtab)
+        keep.append(rowtab)
+        a.rowtab, a.rowtab_period = rowtab.data_ptr(), rowtab.shape[0]
+    a.act = act
+    if a_map:
+        a.a_grp, a.a_stride, a.a_off = a_map
+    if c_map:
+        a.c_grp, a.c_stride, a.c_off = c_map
+    ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
+    return out
+
+
+def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
+    """qkv [B, T, 3*d] (packed in_proj output) -> softmax(QK^T/sqrt(dh) + mask) V, [B, T, d]."""
+    lib = ffi.load()
+    ffi.require_gpu(qkv)
+    qkv = ffi.f32c(qkv)
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    out = torch.empty(B, T, d, device=qkv.device, dtype=torch.float32)
+    km = None
+    if key_mask is not None:
+        km = key_mask.to(torch.uint8).contiguous()
+        assert km.shape == (B, T)
+    ffi.check(lib.afm_mha_fwd(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, ffi.stream_of(qkv)),
+              "afm_mha_fwd")
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = ffi.load()
+    ffi.require_gpu(x)
+    x = ffi.f32c(x)
+    out = torch.empty_like(x) if out is None else out
+    dim = x.shape[-1]
+    w, b = ffi.f32c(weight), ffi.f32c(bias)
+    ffi.check(lib.afm_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), x.numel() // dim, dim, eps,
+                                ffi.stream_of(x)), "afm_layernorm")
+    return out
+
+
+def ddpm_step(x0: torch.Tensor, x_t: torch.Tensor, noise: Optional[torch.Tensor], c1: torch.Tensor, c2: torch.Tensor,
+              sigma: torch.Tensor, *, seed: int = 0, sample_index0: int = 0, step: int = 0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x_{t-1} = (c1*x0 + c2*x_t) + sigma*noise, per-sample coefficients [B] (no fma contraction)."""
+    lib = ffi.load()
+    ffi.require_gpu(x0, x_t)
+    x0, x_t = ffi.f32c(x0), ffi.f32c(x_t)
+    B = x0.shape[0]
+    per = x0.numel() // max(B, 1)
+    out = torch.empty_like(x0) if out is None else out
+    nz = None if noise is None else ffi.f32c(noise)
+    c1, c2, sigma = ffi.f32c(c1), ffi.f32c(c2), ffi.f32c(sigma)
+    ffi.check(lib.afm_ddpm_step(x0.data_ptr(), x_t.data_ptr(), ffi.ptr(nz), out.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+                                sigma.data_ptr(), B, per, seed & (2**64 - 1), sample_index0, step, ffi.stream_of(x0)),
+              "afm_ddpm_step")
+    return out
+
+
+def randn(shape, device, *, seed: int, sample_index0: int = 0, step: int = 0) -> torch.Tensor:
+    """Counter-based N(0,1) noise keyed by (seed, global sample index, step, element)."""
+    lib = ffi.load()
+    out = torch.empty(*shape, device=device, dtype=torch.float32)
+    ffi.require_gpu(out)
+    B = shape[0]
+    ffi.check(lib.afm_randn(out.data_ptr(), B, out.numel() // max(B, 1), seed & (2**64 - 1), sample_index0, step,
+                            ffi.stream_of(out)), "afm_randn")
+    return out
+
+
+def masked_mse(target: torch.Tensor, pred: torch.Tensor, frame_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """Per-sample MSE over the un-padded frames: [B, L, D] x2 (+ [B, L] bool, True = padded) -> [B]."""
+    lib = ffi.load()
+    ffi.require_gpu(target, pred)
+    target, pred = ffi.f32c(target), ffi.f32c(pred)
+    B, D = target.shape[0], target.shape[-1]
+    L = target.numel() // max(B * D, 1)
+    km = None if frame_mask is None else frame_mask.reshape(B, L).to(torch.uint8).contiguous()
+    out = torch.empty(B, device=target.device, dtype=torch.float32)
+    ffi.check(lib.afm_masked_mse(target.data_ptr(), pred.data_ptr(), ffi.ptr(km), out.data_ptr(), B, L, D,
+                                 ffi.stream_of(target)), "afm_masked_mse")
+    return out

@@ -1,0 +1,148 @@
+"""Point-cloud branch of the hot path: TransitionDown ("set abstraction"), PointTransformerLayer /
+Block and SceneMapEncoder (reference models/scene_models/pointtransformer.py:9-123,
+models/modules.py:124-167), eval mode.
+
+The nn.Modules below are parameter containers with the reference's state-dict keys; the math runs
+in the HIP point kernels (afm/pointops.py -> csrc/pointops.hip, csrc/pointnet.hip):
+  * furthest point sampling and brute-force kNN replace the external `pointops_cuda`;
+  * the gather is never materialised: gather + Linear + BN + ReLU + max-pool is one kernel,
+    and the whole vector-attention layer (gather, position MLP, weight MLP, softmax over the k
+    neighbours, weighted sum) is one kernel;
+  * kNN is computed once per resolution level and shared by every layer of that level (the
+    reference recomputes the identical query twice per layer, pointtransformer.py:29-30);
+  * every sample has the same number of points, so batch offsets are implicit.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ffi, ops, pointops
+
+
+def _bn_fold(bn: nn.BatchNorm1d):
+    """eval-mode BatchNorm as y = x * scale + shift."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return scale, bn.bias - bn.running_mean * scale
+
+
+class PointTransformerLayer(nn.Module):
+    def __init__(self, in_planes, out_planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes, self.share_planes, self.nsample = out_planes, share_planes, nsample
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.ReLU(inplace=True), nn.Linear(3, out_planes))
+        self.linear_w = nn.Sequential(nn.BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(mid_planes, mid_planes // share_planes),
+                                      nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(out_planes // share_planes, out_planes // share_planes))
+
+    def run(self, p: torch.Tensor, x: torch.Tensor, knn_idx: torch.Tensor, out_scale=None, out_shift=None, relu=False):
+        """p [n,3], x [n,c], knn_idx [n,k] (global rows) -> [n,c]; optional fused y*scale+shift (+ReLU)."""
+        c = self.out_planes
+        wqkv = torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], 0)
+        bqkv = torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], 0)
+        qkv = ops.linear(x, wqkv, bqkv)                                            # [n, 3c]
+        ps, pb = _bn_fold(self.linear_p[1])
+        w0s, w0b = _bn_fold(self.linear_w[0])
+        w3s, w3b = _bn_fold(self.linear_w[3])
+        return pointops.pt_attention(
+            p, qkv, knn_idx, c, self.share_planes,
+            self.linear_p[0].weight, self.linear_p[0].bias, ps, pb, self.linear_p[3].weight, self.linear_p[3].bias,
+            w0s, w0b, self.linear_w[2].weight, self.linear_w[2].bias, w3s, w3b,
+            self.linear_w[5].weight, self.linear_w[5].bias, out_scale, out_shift, relu)
+
+
+class TransitionDown(nn.Module):
+    def __init__(self, in_planes, out_planes, stride=1, nsample=16):
+        super().__init__()
+        self.stride, self.nsample = stride, nsample
+        if stride != 1:
+            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.pool = nn.MaxPool1d(nsample)
+        else:
+            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+        self.bn = nn.BatchNorm1d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def run(self, p: torch.Tensor, x: torch.Tensor, batch: int):
+        """p [B*n,3], x [B*n,c] -> (p', x') with n' = n // stride points per sample."""
+        scale, shift = _bn_fold(self.bn)
+        if self.stride == 1:
+            return p, ops.linear(x, self.linear.weight, shift, scale=scale, act=ffi.ACT_RELU)
+        n = p.shape[0] // batch
+        m = n // self.stride
+        idx = pointops.furthest_point_sampling(p, batch, n, m)                      # [B*m] global rows
+        n_p = pointops.gather_rows(p, idx)                                         # [B*m, 3]
+        knn_idx, _ = pointops.knn(self.nsample, p, n_p, batch, n, m)                # [B*m, k]
+        y = pointops.transition_down(p, x, n_p, knn_idx, self.linear.weight, scale, shift)
+        return n_p, y
+
+
+class PointTransformerBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, in_planes, planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.bn1 = nn.BatchNorm1d(planes)
+        self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
+        self.bn2 = nn.BatchNorm1d(planes)
+        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+
+    def run(self, p, x, knn_idx):
+        s1, b1 = _bn_fold(self.bn1)
+        s2, b2 = _bn_fold(self.bn2)
+        s3, b3 = _bn_fold(self.bn3)
+        y = ops.linear(x, self.linear1.weight, b1, scale=s1, act=ffi.ACT_RELU)
+        y = self.transformer2.run(p, y, knn_idx, out_scale=s2, out_shift=b2, relu=True)
+        y = ops.linear(y, self.linear3.weight, b3, scale=s3, residual=x)           # bn3(linear3) + identity
+        return pointops.relu_(y)
+
+
+class SceneMapEncoder(nn.Module):
+    """[xyz | per-point feature] -> N/64 group tokens of width planes[-1] (modules.py:124-167)."""
+
+    def __init__(self, point_feat_dim: int, planes: List, blocks: List, num_points: int = 8192) -> None:
+        super().__init__()
+        self.num_points = num_points
+        self.c = point_feat_dim + 3
+        self.in_planes = self.c
+        share_planes = 8
+        self.strides, self.nsamples = [1, 4, 4, 4], [8, 16, 16, 16]
+        for i in range(4):
+            setattr(self, f"enc{i + 1}", self._make_enc(planes[i], blocks[i], share_planes, self.strides[i], self.nsamples[i]))
+
+    @property
+    def num_groups(self):
+        return self.num_points // 64
+
+    def _make_enc(self, planes, blocks, share_planes, stride, nsample):
+        layers = [TransitionDown(self.in_planes, planes, stride, nsample)]
+        self.in_planes = planes
+        for _ in range(1, blocks):
+            layers.append(PointTransformerBlock(planes, planes, share_planes, nsample=nsample))
+        return nn.Sequential(*layers)
+
+    def forward(self, p: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        ffi.require_gpu(p, x)
+        with torch.no_grad():
+            B, N = p.shape[0], p.shape[1]
+            p0 = ffi.f32c(p).reshape(B * N, 3)
+            x0 = p0 if self.c == 3 else torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+            for lvl in range(4):
+                enc = getattr(self, f"enc{lvl + 1}")
+                p0, x0 = enc[0].run(p0, x0, B)
+                n = p0.shape[0] // B
+                if len(enc) > 1:
+                    knn_idx, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)  # shared by every block of the level
+                    for blk in list(enc)[1:]:
+                        x0 = blk.run(p0, x0, knn_idx)
+            return x0.view(B, -1, x0.shape[-1])

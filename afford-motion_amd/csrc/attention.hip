@@ -1,0 +1,191 @@
+// afm_mha_fwd: softmax(Q K^T / sqrt(dh) + key_mask) V for the CMDM encoder (T <= ~330 tokens, dh = 64).
+//
+// gfx950 design
+//   * one workgroup per (sample, head); one wave per 32-query block (T = 326 -> 11 waves = 704 threads,
+//     B*H = 256 workgroups = one per CU at the headline batch of 32).
+//   * K/V are streamed in 32-key blocks through a double-buffered LDS stage shared by all waves
+//     (coalesced float4 global loads, one barrier per block); Q lives in registers for the whole pass.
+//   * "Swapped" products on v_mfma_f32_32x32x2_f32 so that nothing is ever transposed or shuffled:
+//       S^T = K Q^T   (A = K block, B = Q^T): lane l holds query (l&31), 16 keys  -> softmax is lane-local
+//       O^T = V^T P^T (A = V^T,    B = P^T): the P registers ARE the B operand, V is read row-wise
+//     The MFMA k index of S^T is permuted (lane-half h uses head dims 32h .. 32h+31) so each lane reads
+//     its K row as 8 x ds_read_b128; K rows are padded to 68 floats (conflict-free 16-lane groups).
+//   * online softmax in f32 (running max / sum per query), masked keys get -inf exactly like
+//     masked_fill(-inf) in the reference; fully masked 32-key blocks are skipped (their weight is 0).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int KB = 32;           // keys per block
+constexpr int LDKK = 68;         // padded K row (floats)
+constexpr int MAX_WAVES = 12;      // 3 waves per SIMD -> 168 VGPRs each, no spills
+
+template <int NST>
+__global__ __launch_bounds__(64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
+                                                       float* __restrict__ out, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                               // [2][KB][LDKK]
+    float* Vs = smem + 2 * KB * LDKK;               // [2][KB][DH]
+    float* madd = Vs + 2 * KB * DH;                 // [nkb*KB] additive mask (0 / -inf)
+    int* blk_valid = reinterpret_cast<int*>(madd + ((T + KB - 1) / KB) * KB);   // [nkb]
+
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int D = H * DH, ld = 3 * D;
+    const int nkb = (T + KB - 1) / KB, nqb = nkb;
+    const float* base = qkv + (int64_t)b * T * ld + h * DH;
+    const float NEG_INF = -INFINITY;
+
+    for (int i = tid; i < nkb; i += blockDim.x) blk_valid[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nkb * KB; i += blockDim.x) {
+        const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
+        madd[i] = ok ? 0.0f : NEG_INF;
+        if (ok) blk_valid[i / KB] = 1;              // benign race: every writer stores 1
+    }
+
+    // cooperative K/V block loader: 1024 float4 per block (512 K + 512 V), NST per thread (NST * blockDim >= 1024)
+    float4 stage[NST];
+    auto load_block = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * blockDim.x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 1024) {
+                const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
+                const int key = kb * KB + row;
+                if (key < T) v = *reinterpret_cast<const float4*>(base + (int64_t)key * ld + (1 + isv) * D + c4 * 4);
+            }
+            stage[i] = v;
+        }
+    };
+    auto store_block = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * blockDim.x;
+            if (e < 1024) {
+                const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
+                float* dst = isv ? (Vs + (buf * KB + row) * DH + c4 * 4) : (Ks + (buf * KB + row) * LDKK + c4 * 4);
+                *reinterpret_cast<float4*>(dst) = stage[i];
+            }
+        }
+    };
+
+    for (int q0 = 0; q0 < nqb; q0 += nw) {
+        const int qb = q0 + wave;
+        const bool active = qb < nqb;
+        // Q fragment: query row (clamped), head dims 32*hh .. 32*hh+31, pre-scaled
+        float q[32];
+        {
+            const int qrow = min(qb * 32 + r32, T - 1);
+            const float* qp = base + (int64_t)(active ? qrow : 0) * ld + hh * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(qp + i * 4);
+                q[4 * i + 0] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
+            }
+        }
+        float m_run = NEG_INF, l_run = 0.0f;
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+        __syncthreads();                 // previous pass done with LDS; madd/blk_valid visible
+        load_block(0);
+        store_block(0);
+        __syncthreads();
+
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < nkb) load_block(kb + 1);
+            if (active && blk_valid[kb]) {
+                // ---- S^T = K Q^T  (32 MFMA steps over the 64 head dims)
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                const float* kp = Ks + (buf * KB + r32) * LDKK + hh * 32;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 kv = *reinterpret_cast<const float4*>(kp + i * 4);
+                    s = mfma32(kv.x, q[4 * i + 0], s);
+                    s = mfma32(kv.y, q[4 * i + 1], s);
+                    s = mfma32(kv.z, q[4 * i + 2], s);
+                    s = mfma32(kv.w, q[4 * i + 3], s);
+                }
+                // ---- mask + online softmax; reg r <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
+                float mx = NEG_INF;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ma = *reinterpret_cast<const float4*>(madd + kb * KB + 8 * g + 4 * hh);
+                    s[4 * g + 0] += ma.x; s[4 * g + 1] += ma.y; s[4 * g + 2] += ma.z; s[4 * g + 3] += ma.w;
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);
+                const float m_safe = (m_new == NEG_INF) ? 0.0f : m_new;
+                const float alpha = __expf(m_run - m_safe);
+                float rs = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = __expf(s[r] - m_safe);
+                    rs += s[r];
+                }
+                rs += __shfl_xor(rs, 32);
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                // ---- O^T += V^T P^T : step r multiplies key (r&3) + 8*(r>>2) + 4*hh
+                const float* vp = Vs + buf * KB * DH + r32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float v0 = vp[key * DH], v1 = vp[key * DH + 32];
+                    o0 = mfma32(v0, s[r], o0);
+                    o1 = mfma32(v1, s[r], o1);
+                }
+            }
+            if (kb + 1 < nkb) store_block(buf ^ 1);
+            __syncthreads();
+        }
+
+        if (active) {
+            const int qrow = qb * 32 + r32;
+            if (qrow < T) {
+                const float inv = 1.0f / l_run;
+                float* op = out + ((int64_t)b * T + qrow) * D + h * DH + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<float4*>(op + 8 * g) =
+                        make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                    *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                        make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
+                           int32_t dh, void* stream) {
+    if (!qkv || !out || B < 0 || T <= 0 || H <= 0) return AFM_E_BADARG;
+    if (dh != DH) return AFM_E_UNSUPPORTED;
+    if ((((uintptr_t)qkv) & 15) || (((uintptr_t)out) & 15)) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    const int nqb = (T + 31) / 32;
+    int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
+    const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nqb * KB) * sizeof(float) + (size_t)nqb * sizeof(int);
+    if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;
+    const float scale = 1.0f / sqrtf((float)dh);
+    if (nw >= 8)
+        hipLaunchKernelGGL(mha_fwd_kernel<2>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, qkv, key_mask, out, T, H, scale);
+    else
+        hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, qkv, key_mask, out, T, H, scale);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}

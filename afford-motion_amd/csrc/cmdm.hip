@@ -1,0 +1,226 @@
+// CMDM (`trans_enc`) denoiser step and the native p_sample_loop driver.
+//
+// Token layout per sample (reference cmdm.py:161): [time | n_cond step-invariant tokens | L motion].
+// Per step only the time token and the L motion tokens change, so the host pre-computes the
+// n_cond condition tokens (text + contact groups, adapters and positional encoding applied) once
+// per sampling run; the time token is a table lookup (TimestepEmbedder depends on t only).
+//
+// Launch sequence per step (all on one stream, no host sync):
+//   prologue (time token + cond copy + key mask) -> motion_adapter GEMM (scatter into the token
+//   buffer, +bias +positional rows) -> n_layers x { in_proj GEMM, flash MHA, out_proj GEMM(+bias
+//   +residual), LN, FFN1 GEMM(+bias+GELU), FFN2 GEMM(+bias+residual), LN } -> motion_layer GEMM
+//   (gather motion tokens, +bias, fused DDPM posterior update).
+#include "common.h"
+
+extern "C" int afm_linear(const afm_linear_args*, void*);
+extern "C" int afm_mha_fwd(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, void*);
+extern "C" int afm_layernorm(const float*, const float*, const float*, float*, int64_t, int32_t, float, void*);
+extern "C" int afm_randn(float*, int32_t, int64_t, uint64_t, int64_t, int32_t, void*);
+
+namespace {
+
+inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+struct Workspace {
+    float *seq0, *y, *x1, *tmp, *qkv, *att, *hid, *noise;
+    uint8_t* keymask;
+    int64_t bytes;
+};
+
+Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
+    const int64_t T = 1 + w.n_cond + L, M = (int64_t)B * T, d = w.d;
+    char* p = (char*)base;
+    int64_t off = 0;
+    auto take = [&](int64_t nbytes) { char* r = p ? p + off : nullptr; off += align256(nbytes); return r; };
+    Workspace ws;
+    ws.seq0 = (float*)take(M * d * 4);
+    ws.y = (float*)take(M * d * 4);
+    ws.x1 = (float*)take(M * d * 4);
+    ws.tmp = (float*)take(M * d * 4);
+    ws.qkv = (float*)take(M * 3 * d * 4);
+    ws.att = (float*)take(M * d * 4);
+    ws.hid = (float*)take(M * (int64_t)w.ff * 4);
+    ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
+    ws.keymask = (uint8_t*)take(M);
+    ws.bytes = off;
+    return ws;
+}
+
+// grid (B, 1 + n_cond): token 0 = time_table[t] + pos[0]; tokens 1..n_cond = cond copy; also key mask.
+__global__ __launch_bounds__(128) void prologue_kernel(float* __restrict__ seq0, const float* __restrict__ time_table,
+                                                       const float* __restrict__ pos_table, const int64_t* __restrict__ t,
+                                                       const float* __restrict__ cond, const uint8_t* __restrict__ frame_mask,
+                                                       uint8_t* __restrict__ keymask, int T, int L, int n_cond, int d,
+                                                       int n_timesteps, int copy_cond) {
+    const int b = blockIdx.x, tok = blockIdx.y;
+    float* dst = seq0 + ((int64_t)b * T + tok) * d;
+    if (tok == 0) {
+        int64_t ti = t[b];
+        ti = ti < 0 ? 0 : (ti >= n_timesteps ? n_timesteps - 1 : ti);
+        const float* src = time_table + ti * d;
+        for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+            const float4 a = *reinterpret_cast<const float4*>(src + c);
+            const float4 p = *reinterpret_cast<const float4*>(pos_table + c);
+            *reinterpret_cast<float4*>(dst + c) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        }
+        if (keymask)
+            for (int i = threadIdx.x; i < T; i += blockDim.x)
+                keymask[(int64_t)b * T + i] = (i < 1 + n_cond) ? 0 : frame_mask[(int64_t)b * L + (i - 1 - n_cond)];
+    } else if (copy_cond) {
+        const float* src = cond + ((int64_t)b * n_cond + (tok - 1)) * d;
+        for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
+            *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    }
+}
+
+// per-step per-sample schedule rows for the whole loop: row j <-> spaced timestep i = n_steps-1-j
+__global__ void expand_schedule_kernel(const int64_t* __restrict__ tmap, const float* __restrict__ c1,
+                                       const float* __restrict__ c2, const float* __restrict__ sg, int n_steps, int B,
+                                       int64_t* __restrict__ t_all, float* __restrict__ c1_all, float* __restrict__ c2_all,
+                                       float* __restrict__ sg_all) {
+    const int64_t n = (int64_t)n_steps * B;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = n_steps - 1 - (int)(e / B);
+        t_all[e] = tmap[i]; c1_all[e] = c1[i]; c2_all[e] = c2[i]; sg_all[e] = sg[i];
+    }
+}
+
+#define AFM_TRY(expr) do { int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
+
+int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, const float* cond,
+                 const uint8_t* frame_mask, float* x0_out, const afm_ddpm_args* ddpm, int B, int L, const Workspace& ws,
+                 bool copy_cond, hipStream_t s) {
+    const int d = w.d, T = 1 + w.n_cond + L;
+    const int M = B * T;
+    uint8_t* keymask = frame_mask ? ws.keymask : nullptr;
+
+    hipLaunchKernelGGL(prologue_kernel, dim3(B, 1 + w.n_cond), dim3(128), 0, s, ws.seq0, w.time_table, w.pos_table, t, cond,
+                       frame_mask, keymask, T, L, w.n_cond, d, w.n_timesteps, copy_cond ? 1 : 0);
+    AFM_CHECK_LAUNCH();
+
+    {   // motion_adapter (cmdm.py:159) scattered to token rows 1+n_cond.., + positional encoding (cmdm.py:162)
+        afm_linear_args a = {};
+        a.A = x_t; a.lda = w.motion_dim; a.W = w.motion_adapter_w; a.ldw = w.motion_dim;
+        a.C = ws.seq0; a.ldc = d; a.M = B * L; a.N = d; a.K = w.motion_dim;
+        a.bias = w.motion_adapter_b;
+        a.rowtab = w.pos_table + (int64_t)(1 + w.n_cond) * d; a.rowtab_period = L;
+        a.c_grp = L; a.c_stride = T; a.c_off = 1 + w.n_cond;
+        AFM_TRY(afm_linear(&a, s));
+    }
+
+    const float* X = ws.seq0;
+    for (int li = 0; li < w.n_layers; ++li) {
+        const afm_encoder_layer_weights& lw = w.layer[li];
+        afm_linear_args a = {};
+        a.A = X; a.lda = d; a.W = lw.in_proj_w; a.ldw = d; a.C = ws.qkv; a.ldc = 3 * d;
+        a.M = M; a.N = 3 * d; a.K = d; a.bias = lw.in_proj_b;
+        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(afm_mha_fwd(ws.qkv, keymask, ws.att, B, T, w.heads, d / w.heads, s));
+        a = {};
+        a.A = ws.att; a.lda = d; a.W = lw.out_proj_w; a.ldw = d; a.C = ws.tmp; a.ldc = d;
+        a.M = M; a.N = d; a.K = d; a.bias = lw.out_proj_b; a.residual = X; a.ldr = d;
+        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(afm_layernorm(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, M, d, 1e-5f, s));
+        a = {};
+        a.A = ws.x1; a.lda = d; a.W = lw.lin1_w; a.ldw = d; a.C = ws.hid; a.ldc = w.ff;
+        a.M = M; a.N = w.ff; a.K = d; a.bias = lw.lin1_b; a.act = AFM_ACT_GELU;
+        AFM_TRY(afm_linear(&a, s));
+        a = {};
+        a.A = ws.hid; a.lda = w.ff; a.W = lw.lin2_w; a.ldw = w.ff; a.C = ws.tmp; a.ldc = d;
+        a.M = M; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.x1; a.ldr = d;
+        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(afm_layernorm(ws.tmp, lw.norm2_w, lw.norm2_b, ws.y, M, d, 1e-5f, s));
+        X = ws.y;
+    }
+
+    {   // motion_layer (cmdm.py:195) on the motion tokens only (cmdm.py:169), optional DDPM update
+        afm_linear_args a = {};
+        a.A = X; a.lda = d; a.W = w.motion_layer_w; a.ldw = d;
+        a.C = x0_out; a.ldc = w.motion_dim; a.M = B * L; a.N = w.motion_dim; a.K = d;
+        a.bias = w.motion_layer_b;
+        a.a_grp = L; a.a_stride = T; a.a_off = 1 + w.n_cond;
+        if (ddpm) {
+            const float* nz = ddpm->noise;
+            if (!nz) {
+                AFM_TRY(afm_randn(ws.noise, B, (int64_t)L * w.motion_dim, ddpm->seed, ddpm->sample_index0, ddpm->step, s));
+                nz = ws.noise;
+            }
+            a.ddpm_xt = x_t; a.ddpm_noise = nz; a.ddpm_out = ddpm->x_next; a.ldx = w.motion_dim;
+            a.ddpm_c1 = ddpm->c1; a.ddpm_c2 = ddpm->c2; a.ddpm_sigma = ddpm->sigma; a.rows_per_sample = L;
+        }
+        AFM_TRY(afm_linear(&a, s));
+    }
+    return 0;
+}
+
+int validate(const afm_cmdm_weights* w, int B, int L) {
+    if (!w || B < 0 || L <= 0) return AFM_E_BADARG;
+    if (w->d <= 0 || (w->d & 3) || w->heads <= 0 || w->d % w->heads || w->ff <= 0 || (w->ff & 3)) return AFM_E_BADARG;
+    if (w->n_layers <= 0 || w->n_layers > AFM_MAX_LAYERS || w->n_cond < 0 || w->motion_dim <= 0) return AFM_E_BADARG;
+    if (w->d / w->heads != 64) return AFM_E_UNSUPPORTED;
+    if (!w->motion_adapter_w || !w->motion_layer_w || !w->time_table || !w->pos_table) return AFM_E_BADARG;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int afm_version(void) { return AFM_ABI_VERSION; }
+
+extern "C" int64_t afm_cmdm_workspace_bytes(const afm_cmdm_weights* w, int32_t B, int32_t L) {
+    if (validate(w, B, L) != 0) return AFM_E_BADARG;
+    return carve(*w, B, L, nullptr).bytes;
+}
+
+extern "C" int afm_cmdm_forward(const afm_cmdm_weights* w, const float* x_t, const int64_t* t, const float* cond_tokens,
+                                const uint8_t* frame_mask, float* x0_out, const afm_ddpm_args* ddpm, int32_t B, int32_t L,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    AFM_TRY(validate(w, B, L));
+    if (!x_t || !t || (w->n_cond > 0 && !cond_tokens) || !workspace) return AFM_E_BADARG;
+    if (!x0_out && !ddpm) return AFM_E_BADARG;
+    if (ddpm && (!ddpm->x_next || !ddpm->c1 || !ddpm->c2 || !ddpm->sigma)) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    const Workspace ws = carve(*w, B, L, workspace);
+    if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
+    return forward_impl(*w, x_t, t, cond_tokens, frame_mask, x0_out, ddpm, B, L, ws, true, (hipStream_t)stream);
+}
+
+extern "C" int64_t afm_cmdm_sched_scratch_bytes(int32_t n_steps, int32_t B) {
+    if (n_steps <= 0 || B < 0) return AFM_E_BADARG;
+    return align256((int64_t)n_steps * B * 8) + 3 * align256((int64_t)n_steps * B * 4);
+}
+
+extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_tokens, const uint8_t* frame_mask,
+                                    const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                                    const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed,
+                                    int64_t sample_index0, int32_t B, int32_t L, void* sched_scratch, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    AFM_TRY(validate(w, B, L));
+    if (!x || (w->n_cond > 0 && !cond_tokens) || !d_timestep_map || !d_c1 || !d_c2 || !d_sigma || n_steps <= 0 ||
+        !sched_scratch || !workspace)
+        return AFM_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const Workspace ws = carve(*w, B, L, workspace);
+    if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
+
+    char* sp = (char*)sched_scratch;
+    const int64_t nb = (int64_t)n_steps * B;
+    int64_t* t_all = (int64_t*)sp; sp += align256(nb * 8);
+    float* c1_all = (float*)sp; sp += align256(nb * 4);
+    float* c2_all = (float*)sp; sp += align256(nb * 4);
+    float* sg_all = (float*)sp;
+    hipLaunchKernelGGL(expand_schedule_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, d_timestep_map, d_c1, d_c2,
+                       d_sigma, n_steps, B, t_all, c1_all, c2_all, sg_all);
+    AFM_CHECK_LAUNCH();
+
+    const int64_t per_step = (int64_t)B * L * w->motion_dim;
+    for (int j = 0; j < n_steps; ++j) {
+        afm_ddpm_args dd = {};
+        dd.noise = step_noise ? step_noise + (int64_t)j * per_step : nullptr;
+        dd.x_next = x;                       // in place: each element is read then written by the same lane
+        dd.c1 = c1_all + (int64_t)j * B; dd.c2 = c2_all + (int64_t)j * B; dd.sigma = sg_all + (int64_t)j * B;
+        dd.seed = seed; dd.sample_index0 = sample_index0; dd.step = j;
+        AFM_TRY(forward_impl(*w, x, t_all + (int64_t)j * B, cond_tokens, frame_mask, nullptr, &dd, B, L, ws, j == 0, s));
+    }
+    return 0;
+}

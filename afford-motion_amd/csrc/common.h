@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 kernels (wave64, f32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "afm_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AFM_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)
+
+// D[i][j] += sum_k A[i][k] * B[k][j] on v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles/SIMD).
+// lane l supplies a = A[i = l&31][k = l>>5], b = B[k = l>>5][j = l&31];
+// lane l, reg r of the result holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case AFM_ACT_GELU: return gelu_erf(v);
+        case AFM_ACT_RELU: return fmaxf(v, 0.0f);
+        case AFM_ACT_SILU: return silu(v);
+        default: return v;
+    }
+}
+
+// ---- Philox4x32-10 counter-based generator (Salmon et al. 2011), Box-Muller normals.
+// counter = (element/4 low, element/4 high, step, 0), key = seed ^ hash(global sample index).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// 4 standard normals for (seed, sample, step, quad index q = element / 4)
+__device__ __forceinline__ void philox_normal4(uint64_t seed, int64_t sample, int32_t step, uint64_t q, float (&z)[4]) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)step, (uint32_t)(sample >> 32)};
+    uint32_t k0 = (uint32_t)seed ^ ((uint32_t)sample * 0x9E3779B1u), k1 = (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu;
+    philox4x32_10(c, k0, k1);
+    const float S = 2.3283064365386963e-10f;          // 2^-32
+    float u0 = ((float)c[0] + 0.5f) * S, u1 = (float)c[1] * S;
+    float u2 = ((float)c[2] + 0.5f) * S, u3 = (float)c[3] * S;
+    u0 = fminf(u0, 0.99999994f); u2 = fminf(u2, 0.99999994f);
+    float r0 = sqrtf(-2.0f * __logf(u0)), r1 = sqrtf(-2.0f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u1, &s0, &c0);
+    __sincosf(6.283185307179586f * u3, &s1, &c1);
+    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}

@@ -1,0 +1,170 @@
+// LayerNorm, DDPM posterior update, Philox normal generator.
+// All three are HBM/L2-streaming kernels: float4 accesses, one wave per LayerNorm row.
+#include "common.h"
+
+namespace {
+
+// one wave per row; the row lives in registers (dim <= 64 * 4 * MAXV)
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int64_t rows, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xp = x + row * dim;
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (c < dim) ? *reinterpret_cast<const float4*>(xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < dim) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+    float* yp = y + row * dim;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < dim) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 bb = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+            *reinterpret_cast<float4*>(yp + c) = o;
+        }
+    }
+}
+
+// x_next = (c1*x0 + c2*x_t) + sigma*noise with every product and sum individually rounded
+// (bit-identical to the reference's float32 torch expression).
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x0, const float* __restrict__ xt,
+                                                        const float* __restrict__ noise, float* __restrict__ xn,
+                                                        const float* __restrict__ c1, const float* __restrict__ c2,
+                                                        const float* __restrict__ sigma, int64_t per_sample, uint64_t seed,
+                                                        int64_t sample0, int step) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.y;
+    const float a1 = c1[b], a2 = c2[b], sg = sigma[b];
+    const int64_t base = (int64_t)b * per_sample;
+    const int64_t nquad = (per_sample + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+        float z[4];
+        if (!noise) philox_normal4(seed, sample0 + b, step, (uint64_t)q, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t i = q * 4 + e;
+            if (i < per_sample) {
+                const float nz = noise ? noise[base + i] : z[e];
+                const float m1 = a1 * x0[base + i];
+                const float m2 = a2 * xt[base + i];
+                const float mean = m1 + m2;
+                const float sn = sg * nz;
+                xn[base + i] = mean + sn;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t per_sample, uint64_t seed,
+                                                    int64_t sample0, int step) {
+    const int b = blockIdx.y;
+    const int64_t base = (int64_t)b * per_sample;
+    const int64_t nquad = (per_sample + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+        float z[4];
+        philox_normal4(seed, sample0 + b, step, (uint64_t)q, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < per_sample) out[base + q * 4 + e] = z[e];
+    }
+}
+
+// per-sample masked MSE: sum((a-b)^2 * keep) / (sum(keep) * D), one workgroup per sample
+__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const uint8_t* __restrict__ mask, float* __restrict__ out, int L, int D) {
+    __shared__ float red[2][4];
+    const int s = blockIdx.x;
+    const int64_t base = (int64_t)s * L * D;
+    float acc = 0.f, cnt = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)L * D; i += blockDim.x) {
+        const int l = (int)(i / D);
+        const bool keep = !(mask && mask[(int64_t)s * L + l]);
+        const float d = a[base + i] - b[base + i];
+        if (keep) { acc += d * d; cnt += 1.0f; }
+    }
+    acc = wave_sum(acc); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc; red[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sa = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float sc = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        out[s] = sa / sc;            // sc == sum(keep) * D because every kept frame contributes D elements
+    }
+}
+
+}  // namespace
+
+extern "C" int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_mask, float* out, int32_t B,
+                              int32_t L, int32_t D, void* stream) {
+    if (!target || !pred || !out || B < 0 || L <= 0 || D <= 0) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, target, pred, frame_mask, out, L, D);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
+                             float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || dim <= 0 || (dim & 3)) return AFM_E_BADARG;
+    if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return AFM_E_BADARG;
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(256), grid((unsigned)((rows + 3) / 4));
+    if (dim <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
+    else if (dim <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
+    else if (dim <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
+    else if (dim <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
+    else return AFM_E_UNSUPPORTED;
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_ddpm_step(const float* x0, const float* x_t, const float* noise, float* x_next, const float* c1,
+                             const float* c2, const float* sigma, int32_t B, int64_t per_sample, uint64_t seed,
+                             int64_t sample_index0, int32_t step, void* stream) {
+    if (!x0 || !x_t || !x_next || !c1 || !c2 || !sigma || B < 0 || per_sample <= 0) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    const int64_t nquad = (per_sample + 3) >> 2;
+    unsigned gx = (unsigned)((nquad + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x0, x_t, noise, x_next, c1, c2, sigma,
+                       per_sample, seed, sample_index0, step);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_randn(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0, int32_t step,
+                         void* stream) {
+    if (!out || B < 0 || per_sample <= 0) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    const int64_t nquad = (per_sample + 3) >> 2;
+    unsigned gx = (unsigned)((nquad + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(randn_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, out, per_sample, seed, sample_index0, step);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}

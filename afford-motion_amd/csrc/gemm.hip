@@ -1,0 +1,202 @@
+// afm_linear: C = act(scale * (A @ W^T) + bias) + residual + rowtab, optional fused DDPM update.
+//
+// gfx950 design
+//   * v_mfma_f32_32x32x2_f32 (exact f32 products + f32 accumulate; 157 TF peak = 1/16 of bf16).
+//     The 64-cycle MFMA is so long that LDS / L2 bandwidth is never the limiter; what matters is
+//     keeping every SIMD issuing MFMAs back to back and filling 256 CUs (tile choice below).
+//   * 256 threads = 4 waves in a 2x2 grid; each wave owns a (BM/2)x(BN/2) block of 32x32 MFMA tiles.
+//   * K is consumed in tiles of 32.  Inside a tile the K index is PERMUTED: lane-half h of the wave
+//     multiplies k = 16*h + s in MFMA step s (both operands use the same map, the sum over k is
+//     order-free), so a lane's 16 operands of a row are contiguous -> 4 x ds_read_b128 per row.
+//   * LDS rows are padded to 36 floats (144 B): conflict-free for ds_read_b128's 16-lane groups.
+//   * global -> registers (next tile) is issued before the MFMA block of the current tile and
+//     written to the other LDS buffer afterwards: one barrier per K tile.
+//   * XCD-aware tile order: the 8 XCDs each walk a contiguous range of tiles (A row-panels are
+//     reused out of the XCD's own L2; W (<= 3 MB) stays L2 resident).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;     // padded LDS row (floats)
+
+struct RowMap {
+    int grp, stride, off;
+    __device__ __forceinline__ int64_t operator()(int r) const {
+        return grp ? (int64_t)(r / grp) * stride + off + (r % grp) : (int64_t)r;
+    }
+};
+
+template <int ROWS, bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, RowMap map, int row0, int nrows,
+                                          int k0, int K, int tid, float4 (&reg)[ROWS / 32]) {
+    const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int r = row0 + r0 + 32 * i;
+        const int k = k0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nrows) {
+            const float* p = base + map(r) * ld + k;
+            if (VEC) {
+                if (k < K) v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k + 0 < K) v.x = p[0];
+                if (k + 1 < K) v.y = p[1];
+                if (k + 2 < K) v.z = p[2];
+                if (k + 3 < K) v.w = p[3];
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const float4 (&reg)[ROWS / 32]) {
+    const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i)
+        *reinterpret_cast<float4*>(lds + (r0 + 32 * i) * LDK + c4 * 4) = reg[i];
+}
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p, int nbm, int nbn) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+    constexpr int STAGE = (BM + BN) * LDK;          // floats per LDS stage: A tile then W tile
+
+    // XCD-aware bijective remap: block b runs on XCD b % 8; give each XCD a contiguous tile range.
+    const int nblk = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off}, ident{0, 0, 0};
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 32], rw[BN / 32];
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile<BM, VEC>(p.A, p.lda, amap, bm * BM, p.M, 0, p.K, tid, ra);
+    load_tile<BN, VEC>(p.W, p.ldw, ident, bn * BN, p.N, 0, p.K, tid, rw);
+    store_tile<BM>(lds, tid, ra);
+    store_tile<BN>(lds + BM * LDK, tid, rw);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<BM, VEC>(p.A, p.lda, amap, bm * BM, p.M, (kt + 1) * BK, p.K, tid, ra);
+            load_tile<BN, VEC>(p.W, p.ldw, ident, bn * BN, p.N, (kt + 1) * BK, p.K, tid, rw);
+        }
+        const float* a_base = lds + cur * STAGE + (wm * (BM / 2) + r32) * LDK + hh * 16;
+        const float* w_base = lds + cur * STAGE + BM * LDK + (wn * (BN / 2) + r32) * LDK + hh * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDK + j * 4);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const float4*>(w_base + i * 32 * LDK + j * 4);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = mfma32(af[tm].x, bf[tn].x, acc[tm][tn]);
+                    acc[tm][tn] = mfma32(af[tm].y, bf[tn].y, acc[tm][tn]);
+                    acc[tm][tn] = mfma32(af[tm].z, bf[tn].z, acc[tm][tn]);
+                    acc[tm][tn] = mfma32(af[tm].w, bf[tn].w, acc[tm][tn]);
+                }
+        }
+        if (kt + 1 < nk) {
+            store_tile<BM>(lds + (cur ^ 1) * STAGE, tid, ra);
+            store_tile<BN>(lds + (cur ^ 1) * STAGE + BM * LDK, tid, rw);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column (l & 31), rows (r&3) + 8*(r>>2) + 4*(l>>5) of each 32x32 tile
+    const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int gcol = bn * BN + wn * (BN / 2) + tn * 32 + r32;
+        if (gcol >= p.N) continue;
+        const float sc = p.scale ? p.scale[gcol] : 1.0f;
+        const float bi = p.bias ? p.bias[gcol] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int grow = bm * BM + wm * (BM / 2) + tm * 32 + mfma_row(r, lane);
+                if (grow >= p.M) continue;
+                float v = acc[tm][tn][r];
+                if (p.scale) v *= sc;
+                v += bi;
+                v = apply_act(v, p.act);
+                const int64_t orow = cmap(grow);
+                if (p.residual) v += p.residual[orow * p.ldr + gcol];
+                if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
+                if (p.C) p.C[orow * p.ldc + gcol] = v;
+                if (p.ddpm_out) {
+                    const int b = grow / p.rows_per_sample;
+                    const int64_t ix = orow * p.ldx + gcol;
+                    p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    dim3 grid(nbm * nbn), block(256);
+    if (vec)
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, true>), grid, block, 0, s, a, nbm, nbn);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, false>), grid, block, 0, s, a, nbm, nbn);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+inline double tile_cost(int M, int N, int bm, int bn, double eff) {
+    const long nb = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const long waves = (nb + 255) / 256;          // one resident round per 256 CUs
+    return (double)waves * bm * bn / eff;
+}
+
+}  // namespace
+
+extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
+    if (!args) return AFM_E_BADARG;
+    const afm_linear_args& a = *args;
+    if (!a.A || !a.W || a.M < 0 || a.N <= 0 || a.K <= 0) return AFM_E_BADARG;
+    if (!a.C && !a.ddpm_out) return AFM_E_BADARG;
+    if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
+        return AFM_E_BADARG;
+    if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
+    if (a.M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
+                     (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
+    // pick the tile that minimises (rounds over 256 CUs) x (work per tile); smaller tiles pay a
+    // little efficiency.  M = B*T = 10432 with N = 512 is the case this exists for.
+    const double c128 = tile_cost(a.M, a.N, 128, 128, 1.00);
+    const double c64x128 = tile_cost(a.M, a.N, 64, 128, 0.95);
+    const double c64 = tile_cost(a.M, a.N, 64, 64, 0.85);
+    if (c128 <= c64x128 && c128 <= c64) return launch<128, 128>(a, vec, s);
+    if (c64x128 <= c64) return launch<64, 128>(a, vec, s);
+    return launch<64, 64>(a, vec, s);
+}

@@ -1,0 +1,3 @@
+"""`from diffusion import gaussian_diffusion as gd` (reference models/base.py:29) -> afm.diffusion."""
+from afm.diffusion import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,  # noqa: F401
+                           betas_for_alpha_bar, get_named_beta_schedule)

@@ -1,0 +1,189 @@
+/*
+ * afm_hip.h - C-ABI of libafm_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * afford-motion diffusion denoising hot path.
+ *
+ * The reference (pure Python on PyTorch) has no FFI of its own; its only native dependency on
+ * this path is the external CUDA extension `pointops_cuda` (reference
+ * models/scene_models/pointops.py:7) and ATen's fused transformer kernels.  Every entry point
+ * below names the reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions ("C-ABI face"):
+ *   - extern "C", plain pointers and sizes; all pointers are DEVICE pointers unless named h_*.
+ *   - every function returns 0 on success, a positive hipError_t, or a negative AFM_E_* code.
+ *   - no allocation, no host synchronisation, no global state: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*); the caller owns all memory and keeps it alive until the
+ *     stream is synchronised.  Thread-safe by construction.
+ *   - all matrices are row-major float32; indices int32; masks uint8 (1 = padded/ignored).
+ */
+#ifndef AFM_HIP_H
+#define AFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFM_ABI_VERSION 1
+
+#define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
+#define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
+#define AFM_E_UNSUPPORTED (-3)
+
+/* activation codes for afm_linear */
+#define AFM_ACT_NONE 0
+#define AFM_ACT_GELU 1        /* exact erf GELU (nn.GELU / activation='gelu')   */
+#define AFM_ACT_RELU 2
+#define AFM_ACT_SILU 3
+
+int afm_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * afm_linear: C = act(scale * (A @ W^T) + bias) + residual + rowtab[row % period]
+ * Replaces F.linear / nn.Linear (+ the elementwise op that follows it) wherever the reference
+ * calls one on this path: cmdm.py:146,156,159,195; nn.TransformerEncoderLayer's in_proj /
+ * out_proj / linear1 / linear2 (cmdm.py:66-77); modules.py:52-53,317-319,377,651-661;
+ * pointtransformer.py:28,49,51,115-120 (with eval-mode BatchNorm folded into scale/bias).
+ * f32 MFMA (v_mfma_f32_32x32x2_f32): exact-f32 products, f32 accumulate.
+ *
+ *   A [M,K] (row stride lda), W [N,K] (row stride ldw, the nn.Linear weight layout),
+ *   C [M,N] (row stride ldc).  bias/scale [N] or NULL.  residual [M,N] (stride ldr) or NULL,
+ *   indexed by the OUTPUT row.  rowtab [period,N] or NULL.
+ *   Row remaps (0 = identity): logical row r reads A row (r / a_grp) * a_stride + a_off + r % a_grp
+ *   and writes C row (r / c_grp) * c_stride + c_off + r % c_grp  (token gather / scatter of
+ *   cmdm.py:161,169).
+ */
+typedef struct {
+    const float* A; int64_t lda;
+    const float* W; int64_t ldw;
+    float* C; int64_t ldc;
+    int32_t M, N, K;
+    const float* bias;
+    const float* scale;
+    const float* residual; int64_t ldr;
+    const float* rowtab; int32_t rowtab_period;
+    int32_t act;
+    int32_t a_grp, a_stride, a_off;
+    int32_t c_grp, c_stride, c_off;
+    /* optional fused DDPM update on the output (gaussian_diffusion.py:209-231,431-439):
+     * x_next[r,n] = c1[r / rows_per_sample] * C[r,n] + c2[..] * x_t[r,n] + sigma[..] * noise[r,n]
+     * (all [M,N] with row stride ldx).  C itself (pred_xstart) is still written if C != NULL. */
+    const float* ddpm_xt; const float* ddpm_noise; float* ddpm_out; int64_t ldx;
+    const float* ddpm_c1; const float* ddpm_c2; const float* ddpm_sigma; int32_t rows_per_sample;
+} afm_linear_args;
+
+int afm_linear(const afm_linear_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * afm_mha_fwd: multi-head self-attention core, softmax(QK^T / sqrt(dh) + key mask) V.
+ * Replaces the attention inside nn.TransformerEncoderLayer's fast path
+ * (torch._transformer_encoder_layer_fwd, reached from cmdm.py:167).
+ *   qkv [B*T, 3*H*dh] packed as in_proj output (q | k | v), out [B*T, H*dh];
+ *   key_mask [B,T] uint8, 1 = padded key (-inf), or NULL.  dh must be 64.
+ * Flash-style single pass, S^T = K Q^T and O^T = V^T P^T on f32 MFMA, K/V tiles staged in LDS.
+ */
+int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out,
+                int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
+
+/* afm_layernorm: y = LN(x) * gamma + beta over the last dim (eps 1e-5).  Replaces nn.LayerNorm
+ * (norm1 / norm2 of the encoder layer, modules.py:399-400,459,653).  In-place allowed. */
+int afm_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                  int64_t rows, int32_t dim, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * afm_ddpm_step: x_next = (c1[b] * x0 + c2[b] * x_t) + sigma[b] * noise, evaluated WITHOUT fma
+ * contraction so it is bit-identical to the reference's float32 expression
+ * (gaussian_diffusion.py:222-225 and :439) given the same inputs.  c1/c2/sigma are per-sample
+ * [B] device arrays the host gathers from the float32-cast schedule tables
+ * (sigma = (t != 0) * exp(0.5 * posterior_log_variance_clipped[t])).
+ * If noise == NULL, counter-based Philox4x32-10 + Box-Muller noise keyed by
+ * (seed, sample_index0 + b, step, element) is generated in-kernel (sharding-invariant).
+ */
+int afm_ddpm_step(const float* x0, const float* x_t, const float* noise, float* x_next,
+                  const float* c1, const float* c2, const float* sigma,
+                  int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0,
+                  int32_t step, void* stream);
+
+/* afm_randn: standalone Philox normal generator with the same keying as afm_ddpm_step
+ * (replaces th.randn / th.randn_like, gaussian_diffusion.py:431,514). */
+int afm_randn(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0,
+              int32_t step, void* stream);
+
+/* afm_masked_mse: out[b] = sum((target - pred)^2 * keep) / (sum(keep) * D) over [L, D], keep = !frame_mask.
+ * Replaces the loss reduction of training_losses (gaussian_diffusion.py:815-818, sum_flat nn.py:93-97). */
+int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_mask, float* out,
+                   int32_t B, int32_t L, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CMDM (`trans_enc`) denoiser forward, sampling form.  Replaces CMDM.forward (cmdm.py:118-196)
+ * with the step-invariant condition tokens supplied pre-computed (they depend only on
+ * c_text / c_pc_xyz / c_pc_contact, see afm_cmdm_cond_tokens in the Python host layer).
+ */
+typedef struct {
+    const float* in_proj_w;  const float* in_proj_b;    /* [3d,d], [3d]  self_attn.in_proj_*      */
+    const float* out_proj_w; const float* out_proj_b;   /* [d,d],  [d]   self_attn.out_proj.*     */
+    const float* lin1_w; const float* lin1_b;           /* [ff,d], [ff]  linear1.*                */
+    const float* lin2_w; const float* lin2_b;           /* [d,ff], [d]   linear2.*                */
+    const float* norm1_w; const float* norm1_b;         /* [d]           norm1.*                  */
+    const float* norm2_w; const float* norm2_b;         /* [d]           norm2.*                  */
+} afm_encoder_layer_weights;
+
+#define AFM_MAX_LAYERS 16
+
+typedef struct {
+    int32_t d, heads, ff, n_layers;        /* latent_dim, num_heads, dim_feedforward, sum(num_layers) */
+    int32_t motion_dim;                    /* input_feats (263 'h3d', 66 'pos')                        */
+    int32_t n_cond;                        /* number of step-invariant tokens after the time token      */
+    const float* motion_adapter_w; const float* motion_adapter_b;   /* [d, motion_dim], [d]  */
+    const float* motion_layer_w;   const float* motion_layer_b;     /* [motion_dim, d], [motion_dim] */
+    const float* time_table;               /* [n_timesteps, d] TimestepEmbedder output for every t (modules.py:52-53) */
+    int32_t n_timesteps;
+    const float* pos_table;                /* [>= 1+n_cond+L, d] sinusoid table (modules.py:10-26)    */
+    afm_encoder_layer_weights layer[AFM_MAX_LAYERS];
+} afm_cmdm_weights;
+
+/* bytes of workspace afm_cmdm_forward needs for (B, L). */
+int64_t afm_cmdm_workspace_bytes(const afm_cmdm_weights* w, int32_t B, int32_t L);
+
+/* One denoiser evaluation (+ optional fused DDPM update).
+ *   x_t [B,L,motion_dim]; t [B] int64 ORIGINAL timesteps (after respace.py:124-129 mapping);
+ *   cond_tokens [B, n_cond, d] = adapters(conditions) + positional encoding of positions 1..n_cond;
+ *   frame_mask [B,L] uint8 (1 = padded frame) or NULL (mask_motion False);
+ *   x0_out [B,L,motion_dim] (may be NULL when ddpm != NULL).
+ *   ddpm: if non-NULL, also writes x_next (see afm_ddpm_args).
+ */
+typedef struct {
+    const float* noise;      /* [B,L,motion_dim] or NULL -> Philox */
+    float* x_next;           /* [B,L,motion_dim] */
+    const float* c1; const float* c2; const float* sigma;   /* [B] */
+    uint64_t seed; int64_t sample_index0; int32_t step;
+} afm_ddpm_args;
+
+int afm_cmdm_forward(const afm_cmdm_weights* w, const float* x_t, const int64_t* t,
+                     const float* cond_tokens, const uint8_t* frame_mask, float* x0_out,
+                     const afm_ddpm_args* ddpm, int32_t B, int32_t L,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Whole p_sample_loop (gaussian_diffusion.py:442-536) enqueued from native code with no host
+ * synchronisation and no host<->device traffic: for i = n_steps-1 .. 0: x <- p_sample(x, t = i).
+ *   d_timestep_map [n_steps] int64 (respace.py timestep_map), d_c1/d_c2/d_sigma [n_steps] float32
+ *   schedule rows (posterior_mean_coef1/2 and (i != 0) * exp(0.5 * posterior_log_variance_clipped)),
+ *   all DEVICE arrays indexed by the spaced step i.
+ *   x [B,L,motion_dim] holds x_T on entry and the final sample on exit.
+ *   step_noise: [n_steps, B, L, motion_dim] device (row j = j-th executed step, t = n_steps-1-j)
+ *   or NULL -> Philox keyed by (seed, sample_index0 + b, step = j).
+ *   sched_scratch: device scratch of >= afm_cmdm_sched_scratch_bytes(n_steps, B) bytes.
+ */
+int64_t afm_cmdm_sched_scratch_bytes(int32_t n_steps, int32_t B);
+
+int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_tokens,
+                         const uint8_t* frame_mask, const float* step_noise,
+                         const int64_t* d_timestep_map, const float* d_c1, const float* d_c2,
+                         const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0,
+                         int32_t B, int32_t L, void* sched_scratch, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFM_HIP_H */

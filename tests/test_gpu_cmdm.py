@@ -1,0 +1,118 @@
+"""`-m gpu`: CMDM denoiser + DDPM loop on the HIP path vs reference goldens and the CPU oracle.
+Tolerances (f32 MFMA, exact-f32 products): one forward 2e-4 abs on O(1) outputs; 20-step loop with
+shared noise 1e-3."""
+import pytest
+import torch
+
+from afm import synth
+from afm.config import to_config
+from afm.base import create_model_and_diffusion, create_gaussian_diffusion
+from conftest import golden
+from gpu_util import dev, load_named_weights, report
+
+pytestmark = pytest.mark.gpu
+
+
+def cmdm_cfg(num_points=1024, steps=1000, respacing="", input_feats=263, data_repr="h3d", time_emb_dim=512):
+    return to_config(dict(
+        model=dict(name="CMDM", input_feats=input_feats, data_repr=data_repr, time_emb_dim=time_emb_dim,
+                   contact_model=dict(contact_type="contact_cont_joints", contact_joints=[0, 10, 11, 12, 20, 21],
+                                      planes=[32, 64, 128, 256], num_points=num_points, blocks=[2, 2, 2, 2]),
+                   text_model=dict(version="ViT-B/32", max_length=20), arch="trans_enc", latent_dim=512,
+                   mask_motion=True, num_layers=[1, 1, 1, 1, 1], num_heads=8, dropout=0.1, dim_feedforward=1024),
+        diffusion=dict(predict_xstart=True, steps=steps, noise_schedule="cosine", timestep_respacing=respacing,
+                       rescale_timesteps=False, loss_type="MSE", learn_sigma=False, sigma_small=True)))
+
+
+@pytest.fixture(scope="module")
+def cmdm():
+    cfg = cmdm_cfg()
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    return model.to(dev()).eval(), diff
+
+
+def _kw(g, with_encoder=False):
+    kw = dict(c_text_feat=g["text_feat"].to(dev()), x_mask=g["x_mask"].to(dev()), info_dummy=[0, 1])
+    if with_encoder:
+        kw.update(c_pc_xyz=g["xyz"].to(dev()), c_pc_contact=g["contact"].to(dev()))
+    else:
+        kw.update(c_cont_emb=g["cont_emb"].to(dev()))
+    return kw
+
+
+def test_forward_vs_reference_golden(cmdm):
+    model, _ = cmdm
+    g = golden("cmdm_forward_N1024_L16")
+    out = model(g["x"].to(dev()), g["t"].to(dev()), **_kw(g))
+    report("CMDM forward (cont_emb given) vs reference", out, g["out"], 2e-4)
+
+
+@pytest.mark.parametrize("tt", [999, 500, 1, 0])
+def test_p_sample_vs_reference_golden(cmdm, tt):
+    model, diff = cmdm
+    g, gs = golden("cmdm_forward_N1024_L16"), golden(f"cmdm_p_sample_t{tt}")
+    t = torch.tensor([tt, tt], device=dev())
+    out = diff.p_sample(model, gs["x"].to(dev()), t, clip_denoised=False, model_kwargs=_kw(g), noise=gs["noise"].to(dev()))
+    report(f"p_sample t={tt} pred_xstart", out["pred_xstart"], gs["pred_xstart"], 2e-4)
+    report(f"p_sample t={tt} sample", out["sample"], gs["sample"], 2e-4)
+
+
+@pytest.mark.parametrize("steps,resp,tag", [(1000, "5", "r5"), (20, "", "T20")])
+def test_sample_loop_vs_reference_golden(cmdm, steps, resp, tag):
+    """Native loop (afm_cmdm_sample_loop, fused DDPM epilogue) and the generic python loop both
+    reproduce the reference's p_sample_loop with the recorded per-step noise."""
+    model, _ = cmdm
+    diff = create_gaussian_diffusion(cmdm_cfg(steps=steps, respacing=resp))
+    g = golden("cmdm_forward_N1024_L16")
+    want = golden(f"cmdm_loop_{tag}")["sample"]
+    nz = torch.stack([synth.gaussian(f"loop_{tag}_{j}", (2, 16, 263)) for j in range(diff.num_timesteps)]).to(dev())
+    xT = synth.gaussian(f"loop_{tag}_xT", (2, 16, 263)).to(dev())
+    native = diff.p_sample_loop(model, (2, 16, 263), noise=xT, clip_denoised=False, model_kwargs=_kw(g), step_noise=nz)
+    report(f"native loop {tag}", native, want, 1e-3)
+    assert torch.equal(xT.cpu(), synth.gaussian(f"loop_{tag}_xT", (2, 16, 263)))      # caller's x_T untouched
+    generic = None
+    for out in diff.p_sample_loop_progressive(model, (2, 16, 263), noise=xT, clip_denoised=False, model_kwargs=_kw(g), step_noise=nz):
+        generic = out["sample"]
+    report(f"generic loop {tag}", generic, want, 1e-3)
+    report(f"native vs generic {tag}", native, generic.cpu(), 1e-5)
+
+
+def test_training_losses_vs_reference_golden(cmdm):
+    model, diff = cmdm
+    g, gl = golden("cmdm_forward_N1024_L16"), golden("cmdm_training_losses")
+    x0, tn = synth.gaussian("train_x0", (2, 16, 263)).to(dev()), synth.gaussian("train_noise", (2, 16, 263)).to(dev())
+    with torch.no_grad():
+        l = diff.training_losses(model, x0, gl["t"].to(dev()), model_kwargs=_kw(g), noise=tn)
+    report("training loss (masked)", l["loss"], gl["loss_masked"], 1e-4)
+
+
+def test_full_size_vs_oracle():
+    """BASELINE config [1] shape (B=2 here for oracle time): L=196, 128 contact tokens, T=326."""
+    from oracle import denoiser_ref as dr, shapes as sh
+    cfg = cmdm_cfg(num_points=8192)
+    model, _ = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    B, L = 2, 196
+    x = synth.gaussian("full_x", (B, L, 263)); t = torch.tensor([999, 17])
+    cont = synth.gaussian("full_cont", (B, 128, 256)); text = synth.text_feature(B)
+    mask = synth.frame_mask(B, L, seed=3)
+    want = dr.cmdm_forward(sh.weights(sh.cmdm()), x, t, text, x_mask=mask, cont_emb=cont)
+    got = model(x.to(dev()), t.to(dev()), c_text_feat=text.to(dev()), c_cont_emb=cont.to(dev()), x_mask=mask.to(dev()))
+    report("CMDM forward L=196 T=326 vs oracle", got, want, 3e-4)
+
+
+def test_sharding_invariance_of_native_loop(cmdm):
+    """Philox noise is keyed by the global sample index: sampling 2 samples at once equals sampling
+    them one by one with sample_index0 = 0 / 1 (what rank r does for its shard)."""
+    model, _ = cmdm
+    diff = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="4"))
+    g = golden("cmdm_forward_N1024_L16")
+    kw = _kw(g)
+    both = diff.p_sample_loop(model, (2, 16, 263), clip_denoised=False, model_kwargs=kw, seed=11)
+    parts = []
+    for b in range(2):
+        kwb = {k: (v[b:b + 1] if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        parts.append(diff.p_sample_loop(model, (1, 16, 263), clip_denoised=False, model_kwargs=kwb, seed=11, sample_index0=b))
+    report("sharded vs whole", torch.cat(parts), both.cpu(), 1e-5)

@@ -1,0 +1,155 @@
+"""`-m gpu`: primitive HIP kernels (through the C-ABI) vs the CPU oracle / plain torch-CPU math.
+Tolerances: f32 MFMA GEMM 2e-4 abs on O(1..30) outputs (K <= 1024, exact-f32 products, different
+summation order); attention / LayerNorm 2e-5; DDPM update and Philox are bit-exact / statistical."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from afm import ffi, ops, synth
+from conftest import golden
+from gpu_util import dev, report
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_loaded_and_versioned():
+    lib = ffi.load()
+    assert lib.afm_version() == 1
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (326, 512, 512), (1000, 1536, 512), (777, 263, 512),
+                                   (392, 512, 263), (64, 64, 9), (10432, 512, 1024), (33, 96, 35), (5, 7, 3)])
+def test_linear_shapes(M, N, K):
+    x = synth.gaussian("lin_x", (M, K)); w = synth.gaussian("lin_w", (N, K)) / math.sqrt(K); b = synth.gaussian("lin_b", (N,))
+    want = F.linear(x.double(), w.double(), b.double()).float()
+    got = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()))
+    report(f"linear {M}x{N}x{K}", got, want, 2e-4)
+
+
+def test_linear_detects_transposed_layouts():
+    # asymmetric operands + identity A (guide: always A=I-check with asymmetric B)
+    K = N = 64
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 100.0
+    got = ops.linear(torch.eye(K, device=dev()), w.to(dev()))
+    report("linear identity", got, w.t().contiguous(), 1e-6)
+
+
+@pytest.mark.parametrize("act,fn", [(ffi.ACT_GELU, F.gelu), (ffi.ACT_RELU, F.relu), (ffi.ACT_SILU, F.silu)])
+def test_linear_epilogues(act, fn):
+    M, N, K = 300, 192, 128
+    x, w = synth.gaussian("e_x", (M, K)), synth.gaussian("e_w", (N, K)) / math.sqrt(K)
+    b, sc, res = synth.gaussian("e_b", (N,)), 1 + 0.1 * synth.gaussian("e_s", (N,)), synth.gaussian("e_r", (M, N))
+    tab = synth.gaussian("e_t", (7, N))
+    want = fn((x.double() @ w.double().t()) * sc.double() + b.double()) + res.double() + tab.double()[torch.arange(M) % 7]
+    got = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()), act=act, scale=sc.to(dev()), residual=res.to(dev()), rowtab=tab.to(dev()))
+    report(f"linear epilogue act={act}", got, want.float(), 2e-4)
+
+
+def test_linear_row_remaps():
+    # gather motion tokens out of / scatter into a [B, T, d] token pool (cmdm.py:161,169)
+    B, L, T, off, K, N = 3, 5, 9, 4, 64, 32
+    pool = synth.gaussian("rm_pool", (B * T, K)); w = synth.gaussian("rm_w", (N, K)) / 8
+    want = F.linear(pool.view(B, T, K)[:, off:off + L].reshape(B * L, K), w)
+    got = ops.linear(pool.to(dev()), w.to(dev()), rows=B * L, a_map=(L, T, off))
+    report("linear a_map gather", got, want, 1e-4)
+    x = synth.gaussian("rm_x", (B * L, K))
+    out = torch.zeros(B * T, N, device=dev())
+    ops.linear(x.to(dev()), w.to(dev()), out=out, c_map=(L, T, off))
+    want2 = torch.zeros(B, T, N); want2[:, off:off + L] = F.linear(x, w).view(B, L, N)
+    report("linear c_map scatter", out, want2.view(B * T, N), 1e-4)
+
+
+def test_encoder_layer_golden():
+    """One TransformerEncoderLayer (post-LN, key padding mask) against the REFERENCE's output."""
+    from oracle import shapes as sh
+    g = golden("encoder_layer_T24")
+    sd = {k: v.to(dev()) for k, v in sh.weights(sh.encoder_layer("layers.0")).items()}
+    p = "layers.0."
+    x = g["x"].to(dev()); B, T, D = x.shape
+    qkv = ops.linear(x, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"])
+    a = ops.mha(qkv, g["mask"].to(dev()), 8)
+    y = ops.linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], residual=x)
+    x1 = ops.layernorm(y, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    h = ops.linear(x1, sd[p + "linear1.weight"], sd[p + "linear1.bias"], act=ffi.ACT_GELU)
+    y2 = ops.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"], residual=x1)
+    out = ops.layernorm(y2, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    report("encoder layer vs reference golden", out, g["out"], 1e-4)
+
+
+@pytest.mark.parametrize("B,T,masked", [(2, 326, True), (1, 190, False), (3, 37, True), (2, 32, False), (1, 420, True)])
+def test_mha(B, T, masked):
+    H, dh = 8, 64
+    qkv = synth.gaussian("mha_qkv", (B, T, 3 * H * dh))
+    mask = None
+    if masked:
+        mask = torch.zeros(B, T, dtype=torch.bool)
+        for b in range(B):
+            mask[b, T - 1 - 7 * b - T // 3:] = True
+        mask[0, 5] = True                                    # a hole in the middle, not only suffix padding
+    q, k, v = (z.view(B, T, H, dh).transpose(1, 2).double() for z in qkv.chunk(3, -1))
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, H * dh).float()
+    got = ops.mha(qkv.to(dev()), None if mask is None else mask.to(dev()), H)
+    report(f"mha B{B} T{T} masked={masked}", got, want, 2e-5)
+
+
+def test_mha_softmax_rescale_branch():
+    """Force the running max to jump in a late key block (spiked key) - exercises the online-softmax rescale."""
+    B, T, H, dh = 1, 160, 8, 64
+    qkv = synth.gaussian("mha_spike", (B, T, 3 * H * dh)) * 0.3
+    qkv[0, 150, H * dh:2 * H * dh] = qkv[0, 3, :H * dh] * 40.0      # key 150 aligned with query 3, huge score
+    q, k, v = (z.view(B, T, H, dh).transpose(1, 2).double() for z in qkv.chunk(3, -1))
+    want = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B, T, H * dh).float()
+    report("mha rescale", ops.mha(qkv.to(dev()), None, H), want, 2e-5)
+
+
+@pytest.mark.parametrize("rows,dim", [(10, 512), (1001, 512), (64, 256), (7, 1024), (33, 128)])
+def test_layernorm(rows, dim):
+    x = synth.gaussian("ln_x", (rows, dim)) * 3 + 1
+    w, b = 1 + 0.1 * synth.gaussian("ln_w", (dim,)), synth.gaussian("ln_b", (dim,))
+    report(f"layernorm {rows}x{dim}", ops.layernorm(x.to(dev()), w.to(dev()), b.to(dev())), F.layer_norm(x, (dim,), w, b, 1e-5), 2e-5)
+
+
+def test_ddpm_step_bit_exact():
+    """Same float32 expression as gaussian_diffusion.py:222-225,439 -> bit-identical to torch-CPU."""
+    from oracle import diffusion_ref as df
+    s = df.Schedule(1000)
+    B, L, D = 4, 196, 263
+    x0, xt, nz = (synth.gaussian(n, (B, L, D)) for n in ("dd_x0", "dd_xt", "dd_nz"))
+    t = torch.tensor([999, 500, 1, 0])
+    c1 = df._extract(s.posterior_mean_coef1, t, x0.shape); c2 = df._extract(s.posterior_mean_coef2, t, x0.shape)
+    lv = df._extract(s.posterior_log_variance_clipped, t, x0.shape)
+    nzm = (t != 0).float().view(-1, 1, 1)
+    want = (c1 * x0 + c2 * xt) + nzm * torch.exp(0.5 * lv) * nz
+    f = lambda a: torch.from_numpy(a).float()[t]
+    sig = (t != 0).float() * torch.exp(0.5 * f(s.posterior_log_variance_clipped))
+    got = ops.ddpm_step(x0.to(dev()), xt.to(dev()), nz.to(dev()), f(s.posterior_mean_coef1).to(dev()),
+                        f(s.posterior_mean_coef2).to(dev()), sig.to(dev()))
+    assert torch.equal(got.cpu(), want), (got.cpu() - want).abs().max()
+
+
+def test_philox_randn_statistics_and_sharding_invariance():
+    B, per = 8, 196 * 263
+    a = ops.randn((B, per), dev(), seed=7, sample_index0=0, step=3).cpu()
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs(((a ** 4).mean() / a.var() ** 2).item() - 3.0) < 0.05              # kurtosis of a normal
+    lo = ops.randn((4, per), dev(), seed=7, sample_index0=0, step=3).cpu()
+    hi = ops.randn((4, per), dev(), seed=7, sample_index0=4, step=3).cpu()
+    assert torch.equal(torch.cat([lo, hi]), a)                                     # invariant to how B is sharded
+    assert not torch.equal(ops.randn((B, per), dev(), seed=7, step=4).cpu(), a)
+    assert abs(np.corrcoef(a[0].numpy(), a[1].numpy())[0, 1]) < 0.02
+
+
+def test_masked_mse():
+    B, L, D = 3, 20, 263
+    a, b = synth.gaussian("mse_a", (B, L, D)), synth.gaussian("mse_b", (B, L, D))
+    m = torch.zeros(B, L, dtype=torch.bool); m[0, 12:] = True; m[2, 3:] = True
+    keep = (~m).float().unsqueeze(-1)
+    want = (((a - b) ** 2) * keep).sum((1, 2)) / (keep.sum((1, 2)) * D)
+    report("masked mse", ops.masked_mse(a.to(dev()), b.to(dev()), m.to(dev())), want, 1e-5)
+    report("unmasked mse", ops.masked_mse(a.to(dev()), b.to(dev()), None), ((a - b) ** 2).mean((1, 2)), 1e-5)

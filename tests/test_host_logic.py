@@ -1,0 +1,128 @@
+"""CPU tests of the host layer: registry / config / diffusion tables / state-dict surface / C-ABI exports.
+No kernel is launched here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from afm import base, ffi
+from afm import diffusion as gd
+from afm.config import load_config, to_config
+from afm.registry import Registry
+from conftest import GOLDEN, ROOT, golden
+
+
+def test_registry_behaviour():
+    reg = Registry("thing")
+
+    @reg.register()
+    class A:
+        pass
+
+    class B:
+        pass
+    reg.register(B)
+    assert reg.get("A") is A and reg.get("B") is B and "A" in reg
+    with pytest.raises(AssertionError):
+        reg.register(A)
+    with pytest.raises(KeyError):
+        reg.get("missing")
+    assert dict(iter(reg)) == {"A": A, "B": B}
+
+
+def test_drop_in_import_paths_register_models():
+    import models                                   # noqa: F401  side-effect registration like the reference
+    from models.base import Model, create_model_and_diffusion  # noqa: F401
+    from diffusion import gaussian_diffusion as g2
+    from diffusion.respace import SpacedDiffusion, space_timesteps  # noqa: F401
+    from utils.misc import compute_repr_dimesion
+    assert "CMDM" in Model and "CDM" in Model
+    assert compute_repr_dimesion("h3d") == 263 and compute_repr_dimesion("pos") == 66
+    assert compute_repr_dimesion("contact_cont_joints") == 6
+    assert g2.get_named_beta_schedule is gd.get_named_beta_schedule
+
+
+def test_config_composition_and_overrides():
+    cfg = load_config("text_to_motion_contact_motion_gen", "cmdm",
+                      ["model.data_repr=h3d", "model.text_model.max_length=20", "diffusion.steps=500"])
+    assert cfg.model.contact_model.num_points == 8192           # ${task.dataset.num_points}
+    assert cfg.diffusion.steps == 500 and cfg.model.text_model.max_length == 20
+    assert cfg.model.num_layers == [1, 1, 1, 1, 1]
+    cdm = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.scene_model.use_scene_model=False"])
+    assert cdm.model.scene_model.use_color is False and cdm.model.arch_perceiver.encoder_q_input_channels == 512
+
+
+@pytest.mark.parametrize("T,resp", [(1000, ""), (500, ""), (1000, "5"), (1000, "50")])
+def test_diffusion_tables_match_reference(T, resp):
+    g = golden(f"schedule_T{T}_r{resp or 'none'}")
+    cfg = to_config(dict(diffusion=dict(predict_xstart=True, steps=T, noise_schedule="cosine", timestep_respacing=resp,
+                                        rescale_timesteps=False, loss_type="MSE", learn_sigma=False, sigma_small=True)))
+    d = base.create_gaussian_diffusion(cfg)
+    assert isinstance(d, gd.SpacedDiffusion) and d.timestep_map == g["timestep_map"].tolist()
+    idx = g["probe"].numpy()
+    for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_variance",
+              "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_allclose(getattr(d, k)[idx], g[k].numpy(), rtol=1e-12, atol=0)
+        np.testing.assert_allclose(getattr(d, k).sum(), g[k + "_sum"].numpy(), rtol=1e-12)
+
+
+def test_space_timesteps_and_errors():
+    assert gd.space_timesteps(300, [10, 15, 20]) == gd.space_timesteps(300, "10,15,20")
+    assert len(gd.space_timesteps(1000, "ddim50")) == 50
+    with pytest.raises(ValueError):
+        gd.space_timesteps(10, [20])
+    with pytest.raises(NotImplementedError):
+        gd.get_named_beta_schedule("sigmoid", 10)
+    with pytest.raises(NotImplementedError):      # dead configurations are rejected loudly, not silently mis-sampled
+        gd.GaussianDiffusion(betas=[0.1], model_mean_type=gd.ModelMeanType.EPSILON,
+                             model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+
+
+def _cmdm_cfg():
+    return load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263"])
+
+
+def test_cmdm_state_dict_keys_match_reference():
+    model = base.create_model(_cmdm_cfg(), device="cpu")
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    want = {}
+    for line in open(os.path.join(GOLDEN, "cmdm_state_dict_keys.txt")):
+        k, shp = line.strip().split(" ", 1)
+        want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
+    # the golden listing was dumped at num_points=1024: same keys / shapes (weights do not depend on N)
+    assert have == want
+    assert sum(p.numel() for p in model.parameters()) == 12204111
+
+
+def test_product_path_refuses_cpu_tensors():
+    model = base.create_model(_cmdm_cfg(), device="cpu").eval()
+    with pytest.raises(ffi.AfmError):
+        with torch.no_grad():
+            model(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long), c_text_feat=torch.zeros(1, 512),
+                  c_cont_emb=torch.zeros(1, 128, 256), x_mask=torch.zeros(1, 8, dtype=torch.bool))
+    with pytest.raises(NotImplementedError):       # training path is not built yet: loud, no eager fallback
+        model.train()(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "afford-motion_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "afm_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(afm_\w+)\s*\(", hdr, re.M))
+    assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
+    if not os.path.exists(ffi.lib_path()):
+        pytest.skip("libafm_hip.so not built (run python afford-motion_amd/build_hip.py)")
+    lib = ctypes.CDLL(ffi.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), f"missing export {name}"
+    assert ffi.load().afm_version() == 1            # pure host call, no GPU needed
