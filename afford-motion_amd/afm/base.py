@@ -11,6 +11,7 @@ Model = Registry("model")
 
 def create_model(cfg, *args, **kwargs) -> nn.Module:
     """`Model.get(cfg.model.name)(cfg.model, *args, **kwargs)` (reference models/base.py:9-18)."""
+    from . import cdm, cmdm  # noqa: F401  (registration by import side effect, like the reference's models/__init__.py)
     return Model.get(cfg.model.name)(cfg.model, *args, **kwargs)
 
 

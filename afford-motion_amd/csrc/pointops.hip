@@ -1,0 +1,173 @@
+// Furthest point sampling, brute-force kNN and row gather: replacements for the external CUDA
+// extension `pointops_cuda` the reference calls (models/scene_models/pointops.py:23,42,91-94).
+//
+// Index semantics (bit-exact against oracle/pointops_ref.py):
+//   d2 = (dx*dx + dy*dy) + dz*dz in float32 with fma contraction OFF;
+//   FPS: start at the first point of the sample, tmp initialised to 1e10, ties -> lowest index;
+//   kNN: neighbours ascending in (d2, index) lexicographic order.
+// Every sample has the same point count, so batch offsets are implicit (sample b owns rows
+// [b*n, (b+1)*n)); returned indices are GLOBAL row numbers like the reference's.
+//
+// gfx950 design
+//   * FPS is latency-bound (m-1 dependent rounds): one workgroup per sample, every point and its
+//     running min-distance live in registers, arg-max = 64-bit (dist bits | ~index) keys reduced with
+//     6 cross-lane steps per wave + one LDS hop across <= 16 waves, ONE barrier per round.
+//   * kNN: one lane per query, candidates streamed through an LDS tile (broadcast reads), the k best
+//     kept as a sorted register array with a branch-free insertion.
+#include "common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
+    __shared__ unsigned long long keys[2][16];
+    const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    const float* P = xyz + (int64_t)b * n * 3;
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int i = s * T + tid;
+        const bool ok = i < n;
+        px[s] = ok ? P[i * 3 + 0] : 0.f; py[s] = ok ? P[i * 3 + 1] : 0.f; pz[s] = ok ? P[i * 3 + 2] : 0.f;
+        tmp[s] = 1e10f;
+    }
+    int cur = 0;
+    if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
+    for (int j = 1; j < m; ++j) {
+        const float cx = P[cur * 3 + 0], cy = P[cur * 3 + 1], cz = P[cur * 3 + 2];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int i = s * T + tid;
+            if (i < n) {
+                const float dx = px[s] - cx, dy = py[s] - cy, dz = pz[s] - cz;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                tmp[s] = fminf(tmp[s], d);
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(tmp[s]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+                best = key > best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) keys[j & 1][wave] = best;
+        __syncthreads();
+        unsigned long long k = keys[j & 1][(lane < nw) ? lane : 0];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(k, o);
+            k = other > k ? other : k;
+        }
+        cur = __builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)));
+        if (tid == 0) idx_out[(int64_t)b * m + j] = b * n + cur;
+    }
+}
+
+constexpr int KNN_TILE = 1024;
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, const float* __restrict__ qxyz, int n, int m,
+                                                  int* __restrict__ idx_out, float* __restrict__ d2_out) {
+    __shared__ float tile[3 * KNN_TILE];             // interleaved x,y,z exactly as in memory (coalesced fill)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int q = blockIdx.x * blockDim.x + tid;
+    const bool valid = q < m;
+    const float* Q = qxyz + ((int64_t)b * m + (valid ? q : 0)) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    const float* P = xyz + (int64_t)b * n * 3;
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = -1; }
+    for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+        const int cnt = min(KNN_TILE, n - t0);
+        for (int f = tid; f < cnt * 3; f += blockDim.x) tile[f] = P[(int64_t)t0 * 3 + f];
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) {
+            const float dx = qx - tile[3 * i], dy = qy - tile[3 * i + 1], dz = qz - tile[3 * i + 2];
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d < bd[K - 1]) {
+                // sorted insert; strict '<' keeps the earlier (lower) index in front on equal distances
+#pragma unroll
+                for (int j = K - 1; j > 0; --j) {
+                    const bool up = d < bd[j - 1];
+                    const bool here = d < bd[j];
+                    bd[j] = up ? bd[j - 1] : (here ? d : bd[j]);
+                    bi[j] = up ? bi[j - 1] : (here ? (t0 + i) : bi[j]);
+                }
+                if (d < bd[0]) { bd[0] = d; bi[0] = t0 + i; }
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j > 0 && bi[j] < 0) { bi[j] = bi[j - 1]; bd[j] = bd[j - 1]; }     // fewer than K points: repeat the last
+            idx_out[((int64_t)b * m + q) * K + j] = b * n + bi[j];
+            d2_out[((int64_t)b * m + q) * K + j] = bd[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t rows, int c) {
+    const int64_t total = rows * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c;
+        out[e] = src[(int64_t)idx[r] * c + (e - r * c)];
+    }
+}
+
+}  // namespace
+
+extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream) {
+    if (!xyz || !idx_out || B < 0 || n <= 0 || m < 0 || m > n) return AFM_E_BADARG;
+    if (B == 0 || m == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int T = ((n + 63) / 64) * 64;
+    if (T > 1024) T = 1024;
+    const int ppt = (n + T - 1) / T;
+#define AFM_FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(T), 0, s, xyz, n, m, idx_out)
+    if (ppt <= 1) AFM_FPS(1);
+    else if (ppt <= 2) AFM_FPS(2);
+    else if (ppt <= 4) AFM_FPS(4);
+    else if (ppt <= 8) AFM_FPS(8);
+    else if (ppt <= 16) AFM_FPS(16);
+    else if (ppt <= 32) AFM_FPS(32);
+    else return AFM_E_UNSUPPORTED;
+#undef AFM_FPS
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_knn(int32_t k, const float* xyz, const float* new_xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out,
+                       float* dist2_out, void* stream) {
+    if (!xyz || !new_xyz || !idx_out || !dist2_out || B < 0 || n <= 0 || m < 0) return AFM_E_BADARG;
+    if (B == 0 || m == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((m + 255) / 256, B), block(256);
+    switch (k) {
+        case 3: hipLaunchKernelGGL(knn_kernel<3>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;
+        case 8: hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;
+        case 16: hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;
+        default: return AFM_E_UNSUPPORTED;
+    }
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_gather_rows(const float* src, const int32_t* idx, float* out, int64_t rows, int32_t c, void* stream) {
+    if (!src || !idx || !out || rows < 0 || c <= 0) return AFM_E_BADARG;
+    if (rows == 0) return 0;
+    const int64_t total = rows * c;
+    unsigned g = (unsigned)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, idx, out, rows, c);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
