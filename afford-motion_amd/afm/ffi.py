@@ -32,12 +32,20 @@ class LinearArgs(C.Structure):
         ("A", c_f32p), ("lda", i64), ("W", c_f32p), ("ldw", i64), ("C", c_f32p), ("ldc", i64),
         ("M", i32), ("N", i32), ("K", i32),
         ("bias", c_f32p), ("scale", c_f32p), ("residual", c_f32p), ("ldr", i64),
-        ("rowtab", c_f32p), ("rowtab_period", i32), ("act", i32),
+        ("rowtab", c_f32p), ("rowtab_period", i32), ("act", i32), ("act_post", i32),
         ("a_grp", i32), ("a_stride", i32), ("a_off", i32),
         ("c_grp", i32), ("c_stride", i32), ("c_off", i32),
         ("ddpm_xt", c_f32p), ("ddpm_noise", c_f32p), ("ddpm_out", c_f32p), ("ldx", i64),
         ("ddpm_c1", c_f32p), ("ddpm_c2", c_f32p), ("ddpm_sigma", c_f32p), ("rows_per_sample", i32),
     ]
+
+
+class PtAttentionArgs(C.Structure):
+    _fields_ = [("p", c_f32p), ("qkv", c_f32p), ("knn_idx", C.c_void_p), ("out", c_f32p),
+                ("n", i32), ("channels", i32), ("nsample", i32), ("share_planes", i32)] + \
+               [(n, c_f32p) for n in ("lp0_w", "lp0_b", "lp_bn_scale", "lp_bn_shift", "lp3_w", "lp3_b", "w0_bn_scale",
+                                      "w0_bn_shift", "w2_w", "w2_b", "w3_bn_scale", "w3_bn_shift", "w5_w", "w5_b",
+                                      "out_scale", "out_shift")] + [("relu", i32)]
 
 
 class EncoderLayerWeights(C.Structure):
@@ -70,6 +78,12 @@ EXPORTS = {
     "afm_ddpm_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
     "afm_randn": (C.c_int, [c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
     "afm_masked_mse": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, C.c_void_p]),
+    "afm_fps": (C.c_int, [c_f32p, i32, i32, i32, C.c_void_p, C.c_void_p]),
+    "afm_knn": (C.c_int, [i32, c_f32p, c_f32p, i32, i32, i32, C.c_void_p, c_f32p, C.c_void_p]),
+    "afm_gather_rows": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),
+    "afm_transition_down": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, C.c_void_p, i32, c_f32p, i32, c_f32p, c_f32p, c_f32p,
+                                      i32, C.c_void_p]),
+    "afm_pt_attention": (C.c_int, [C.POINTER(PtAttentionArgs), C.c_void_p]),
     "afm_cmdm_workspace_bytes": (i64, [C.POINTER(CmdmWeights), i32, i32]),
     "afm_cmdm_forward": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
                                    C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p]),

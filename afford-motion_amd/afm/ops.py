@@ -17,10 +17,11 @@ RowMap = Tuple[int, int, int]   # (group, stride, offset): row r -> (r // group)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ffi.ACT_NONE,
+           act_post: int = ffi.ACT_NONE,
            scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            rowtab: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            rows: Optional[int] = None, a_map: Optional[RowMap] = None, c_map: Optional[RowMap] = None) -> torch.Tensor:
-    """``act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)]`` on f32 MFMA.
+    """``act_post(act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)])`` on f32 MFMA.
 
     x [..., K] (or a 2-D row pool when ``a_map`` gathers rows), weight [N, K] as in nn.Linear.
     With ``out`` given (2-D row pool [R, N]) and ``c_map``, rows are scattered into it."""
@@ -52,7 +53,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         rowtab = ffi.f32c(rowtab)
         keep.append(rowtab)
         a.rowtab, a.rowtab_period = rowtab.data_ptr(), rowtab.shape[0]
-    a.act = act
+    a.act, a.act_post = act, act_post
     if a_map:
         a.a_grp, a.a_stride, a.a_off = a_map
     if c_map:

@@ -103,8 +103,7 @@ class PointTransformerBlock(nn.Module):
         s3, b3 = _bn_fold(self.bn3)
         y = ops.linear(x, self.linear1.weight, b1, scale=s1, act=ffi.ACT_RELU)
         y = self.transformer2.run(p, y, knn_idx, out_scale=s2, out_shift=b2, relu=True)
-        y = ops.linear(y, self.linear3.weight, b3, scale=s3, residual=x)           # bn3(linear3) + identity
-        return pointops.relu_(y)
+        return ops.linear(y, self.linear3.weight, b3, scale=s3, residual=x, act_post=ffi.ACT_RELU)   # relu(bn3(linear3) + identity)
 
 
 class SceneMapEncoder(nn.Module):

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
                 const int64_t orow = cmap(grow);
                 if (p.residual) v += p.residual[orow * p.ldr + gcol];
                 if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
+                v = apply_act(v, p.act_post);
                 if (p.C) p.C[orow * p.ldc + gcol] = v;
                 if (p.ddpm_out) {
                     const int b = grow / p.rows_per_sample;

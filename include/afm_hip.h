@@ -39,7 +39,7 @@ extern "C" {
 int afm_version(void);
 
 /* ------------------------------------------------------------------------------------------
- * afm_linear: C = act(scale * (A @ W^T) + bias) + residual + rowtab[row % period]
+ * afm_linear: C = act_post(act(scale * (A @ W^T) + bias) + residual + rowtab[row % period])
  * Replaces F.linear / nn.Linear (+ the elementwise op that follows it) wherever the reference
  * calls one on this path: cmdm.py:146,156,159,195; nn.TransformerEncoderLayer's in_proj /
  * out_proj / linear1 / linear2 (cmdm.py:66-77); modules.py:52-53,317-319,377,651-661;
@@ -62,7 +62,8 @@ typedef struct {
     const float* scale;
     const float* residual; int64_t ldr;
     const float* rowtab; int32_t rowtab_period;
-    int32_t act;
+    int32_t act;                    /* AFM_ACT_* applied before the residual               */
+    int32_t act_post;               /* AFM_ACT_* applied after residual / rowtab (ReLU(bn3(.) + identity), pointtransformer.py:120-122) */
     int32_t a_grp, a_stride, a_off;
     int32_t c_grp, c_stride, c_off;
     /* optional fused DDPM update on the output (gaussian_diffusion.py:209-231,431-439):
@@ -113,6 +114,53 @@ int afm_randn(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t 
  * Replaces the loss reduction of training_losses (gaussian_diffusion.py:815-818, sum_flat nn.py:93-97). */
 int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_mask, float* out,
                    int32_t B, int32_t L, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Point-cloud operators.  Every sample holds the same number of points, so the reference's
+ * offset arrays are implicit: sample b owns rows [b*n, (b+1)*n).  Returned indices are GLOBAL rows.
+ *
+ * afm_fps replaces pointops_cuda.furthestsampling_cuda (pointops.py:10-27; called from
+ * TransitionDown.forward, pointtransformer.py:61): start at the sample's first point, running
+ * min squared distance initialised to 1e10, arg-max each round (ties -> lowest index).
+ * afm_knn replaces pointops_cuda.knnquery_cuda (pointops.py:30-45): brute force, neighbours in
+ * ascending (dist2, index) order; dist2 is the SQUARED distance (the wrapper's sqrt is the caller's).
+ * Both evaluate d2 = (dx*dx + dy*dy) + dz*dz in float32 without fma contraction (bit-exact indices
+ * against oracle/pointops_ref.py).  k in {3, 8, 16}.
+ */
+int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream);
+int afm_knn(int32_t k, const float* xyz, const float* new_xyz, int32_t B, int32_t n, int32_t m,
+            int32_t* idx_out, float* dist2_out, void* stream);
+/* out[r, :] = src[idx[r], :]  (the `p[idx.long(), :]` of pointtransformer.py:62) */
+int afm_gather_rows(const float* src, const int32_t* idx, float* out, int64_t rows, int32_t c, void* stream);
+
+/* afm_transition_down: fused "set abstraction" of TransitionDown.forward (pointtransformer.py:53-69,
+ * stride != 1, eval-mode BN folded to scale/shift):
+ *   out[i, o] = max_j ReLU(scale[o] * (W[o,:] . [p[knn[i,j]] - new_p[i] ; x[knn[i,j]]]) + shift[o])
+ * p [R,3], x [R,c], new_p [M,3], knn_idx [M,nsample] (nsample must be 16), weight [cout, 3+c].
+ * The grouped (M, nsample, 3+c) tensor of pointops.queryandgroup (pointops.py:79-100) is never built. */
+int afm_transition_down(const float* p, const float* x, int32_t c, const float* new_p, const int32_t* knn_idx,
+                        int32_t nsample, const float* weight, int32_t cout, const float* scale, const float* shift,
+                        float* out, int32_t M, void* stream);
+
+/* afm_pt_attention: PointTransformerLayer.forward after the q/k/v projections (pointtransformer.py:26-38):
+ *   p_r = lp3(ReLU(BN(lp0(p_j - p_i)))),  w = softmax_j(w5(ReLU(BN(w2(ReLU(BN(k_j - q_i + p_r))))))),
+ *   out[i, c] = sum_j (v_j + p_r)[c] * w[j, c mod (C/share_planes)],  then optional out*out_scale+out_shift, ReLU.
+ * qkv [n, 3C] = [linear_q(x) | linear_k(x) | linear_v(x)], knn_idx [n, nsample] (self-kNN, nsample 8 or 16).
+ * BatchNorms are passed folded (scale, shift). */
+typedef struct {
+    const float* p; const float* qkv; const int32_t* knn_idx; float* out;
+    int32_t n, channels, nsample, share_planes;
+    const float* lp0_w; const float* lp0_b;              /* linear_p.0  [3,3],[3]      */
+    const float* lp_bn_scale; const float* lp_bn_shift;  /* linear_p.1  BN(3)          */
+    const float* lp3_w; const float* lp3_b;              /* linear_p.3  [C,3],[C]      */
+    const float* w0_bn_scale; const float* w0_bn_shift;  /* linear_w.0  BN(C)          */
+    const float* w2_w; const float* w2_b;                /* linear_w.2  [C/s, C],[C/s] */
+    const float* w3_bn_scale; const float* w3_bn_shift;  /* linear_w.3  BN(C/s)        */
+    const float* w5_w; const float* w5_b;                /* linear_w.5  [C/s,C/s],[C/s]*/
+    const float* out_scale; const float* out_shift;      /* optional fused bn2 of the block, or NULL */
+    int32_t relu;
+} afm_pt_attention_args;
+int afm_pt_attention(const afm_pt_attention_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CMDM (`trans_enc`) denoiser forward, sampling form.  Replaces CMDM.forward (cmdm.py:118-196)

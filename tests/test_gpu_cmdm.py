@@ -116,3 +116,15 @@ def test_sharding_invariance_of_native_loop(cmdm):
         kwb = {k: (v[b:b + 1] if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
         parts.append(diff.p_sample_loop(model, (1, 16, 263), clip_denoised=False, model_kwargs=kwb, seed=11, sample_index0=b))
     report("sharded vs whole", torch.cat(parts), both.cpu(), 1e-5)
+
+
+def test_forward_with_scene_encoder_vs_reference_golden(cmdm):
+    """Whole CMDM.forward including the SceneMapEncoder (FPS, kNN, set abstraction, vector attention)."""
+    model, _ = cmdm
+    g = golden("cmdm_forward_N1024_L16")
+    out = model(g["x"].to(dev()), g["t"].to(dev()), **_kw(g, with_encoder=True))
+    report("CMDM forward (full, with contact encoder) vs reference", out, g["out"], 3e-4)
+    model.hoist_conditions = False                 # "faithful" mode recomputes the conditions per call
+    out2 = model(g["x"].to(dev()), g["t"].to(dev()), **_kw(g, with_encoder=True))
+    model.hoist_conditions = True
+    assert torch.equal(out.cpu(), out2.cpu())      # hoisting is exactly output-neutral

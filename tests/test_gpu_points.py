@@ -1,0 +1,105 @@
+"""`-m gpu`: point-cloud kernels (FPS, kNN, fused set abstraction, vector attention, SceneMapEncoder)
+vs the reference goldens and the CPU oracle.  Indices are bit-exact; float outputs within 2e-4."""
+import pytest
+import torch
+
+from afm import pointops, synth
+from afm import scene as S
+from conftest import golden
+from gpu_util import dev, load_named_weights, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 200, 50), (3, 512, 128), (2, 2048, 512), (2, 8192, 2048), (1, 8192, 1024), (2, 100, 100), (1, 64, 1)])
+def test_fps_bit_exact(B, n, m):
+    from oracle import pointops_ref as po
+    p = synth.scene_cloud(B, n, seed=21).reshape(B * n, 3)
+    o = torch.arange(1, B + 1, dtype=torch.int32) * n
+    no = torch.arange(1, B + 1, dtype=torch.int32) * m
+    want = po.furthest_sampling(p, o, no)
+    got = pointops.furthest_point_sampling(p.to(dev()), B, n, m).cpu()
+    assert torch.equal(got, want), f"{(got != want).sum().item()} of {got.numel()} indices differ"
+
+
+def test_fps_ties_pick_lowest_index():
+    # duplicated points (real chunks contain them, prepare/generate_contact_data.py:418-423): ties -> lowest index
+    from oracle import pointops_ref as po
+    base = synth.scene_cloud(1, 64, seed=22).reshape(64, 3)
+    p = torch.cat([base, base], 0).contiguous()                      # every point twice, one sample of 128
+    o, no = torch.tensor([128], dtype=torch.int32), torch.tensor([32], dtype=torch.int32)
+    want = po.furthest_sampling(p, o, no)
+    got = pointops.furthest_point_sampling(p.to(dev()), 1, 128, 32).cpu()
+    assert torch.equal(got, want) and got.max() < 64
+
+
+@pytest.mark.parametrize("k,B,n,m", [(8, 2, 300, 300), (16, 2, 2048, 512), (16, 2, 8192, 2048), (8, 1, 8192, 8192), (3, 2, 128, 512), (16, 1, 16, 16)])
+def test_knn_bit_exact(k, B, n, m):
+    from oracle import pointops_ref as po
+    p = synth.scene_cloud(B, n, seed=23).reshape(B * n, 3)
+    q = p if m == n else synth.scene_cloud(B, m, seed=24).reshape(B * m, 3)
+    o = torch.arange(1, B + 1, dtype=torch.int32) * n
+    no = torch.arange(1, B + 1, dtype=torch.int32) * m
+    wi, wd = po.knn_query(k, p, q, o, no)
+    gi, gd = pointops.knn(k, p.to(dev()), q.to(dev()), B, n, m)
+    assert torch.equal(gi.cpu(), wi), f"{(gi.cpu() != wi).sum().item()} of {wi.numel()} indices differ"
+    assert torch.equal(gd.cpu(), wd)
+
+
+@pytest.mark.parametrize("stride", [4, 8])
+def test_transition_down_vs_reference_golden(stride):
+    g = golden(f"transition_down_s{stride}")
+    td = load_named_weights(S.TransitionDown(32, 64, stride=stride, nsample=16)).to(dev()).eval()
+    n_p, y = td.run(g["p"].to(dev()), g["x"].to(dev()), 2)
+    assert torch.equal(n_p.cpu(), g["n_p"])
+    report(f"TransitionDown stride {stride}", y, g["y"], 2e-4)
+
+
+def test_transition_down_stride1_vs_reference_golden():
+    g = golden("transition_down_s1")
+    td = load_named_weights(S.TransitionDown(9, 32, stride=1, nsample=8)).to(dev()).eval()
+    _, y = td.run(torch.zeros(512, 3, device=dev()), g["x"].to(dev()), 2)
+    report("TransitionDown stride 1", y, g["y"], 2e-4)
+
+
+@pytest.mark.parametrize("c,k", [(32, 8), (64, 16)])
+def test_point_transformer_block_vs_reference_golden(c, k):
+    g = golden(f"pt_block_c{c}_k{k}")
+    blk = load_named_weights(S.PointTransformerBlock(c, c, 8, nsample=k)).to(dev()).eval()
+    p, x = g["p"].to(dev()), g["x"].to(dev())
+    knn_idx, _ = pointops.knn(k, p, p, 2, 128, 128)
+    report(f"PointTransformerLayer c{c} k{k}", blk.transformer2.run(p, x, knn_idx), g["layer_out"], 2e-4)
+    report(f"PointTransformerBlock c{c} k{k}", blk.run(p, x, knn_idx), g["y"], 2e-4)
+
+
+@pytest.mark.parametrize("c,k,n", [(128, 16, 256), (256, 16, 64)])
+def test_point_transformer_block_wide_vs_oracle(c, k, n):
+    from oracle import scene_ref as sr, shapes as sh
+    sd = {"b." + kk: v for kk, v in sh.weights(sh.pt_block("", c)).items()}
+    blk = load_named_weights(S.PointTransformerBlock(c, c, 8, nsample=k)).to(dev()).eval()
+    p = synth.scene_cloud(2, n, seed=31).reshape(2 * n, 3); x = synth.gaussian("ptw_x", (2 * n, c))
+    o = torch.tensor([n, 2 * n], dtype=torch.int32)
+    want = sr.point_transformer_block(sd, "b", p, x, o, k)
+    knn_idx, _ = pointops.knn(k, p.to(dev()), p.to(dev()), 2, n, n)
+    report(f"PointTransformerBlock c{c}", blk.run(p.to(dev()), x.to(dev()), knn_idx), want, 3e-4)
+
+
+def test_scene_map_encoder_vs_reference_golden():
+    g = golden("scene_map_encoder_N1024")
+    enc = load_named_weights(S.SceneMapEncoder(6, [32, 64, 128, 256], [2, 2, 2, 2], num_points=1024)).to(dev()).eval()
+    report("SceneMapEncoder N=1024", enc(g["xyz"].to(dev()), g["contact"].to(dev())), g["out"], 3e-4)
+
+
+def test_set_abstraction_full_size_vs_oracle():
+    """BASELINE config [3]: N = 8192 -> 2048 (faithful stride 4) and -> 1024 (stride 8), vs the CPU oracle."""
+    from oracle import scene_ref as sr, shapes as sh
+    B, n = 2, 8192
+    p = synth.scene_cloud(B, n, seed=41).reshape(B * n, 3); x = synth.gaussian("sa_x", (B * n, 32))
+    o = torch.arange(1, B + 1, dtype=torch.int32) * n
+    for stride in (4, 8):
+        sd = {"td." + k: v for k, v in sh.weights(sh.transition_down("", 32, 64, stride)).items()}
+        wp, wy, _, aux = sr.transition_down(sd, "td", p, x, o, stride, 16)
+        td = load_named_weights(S.TransitionDown(32, 64, stride=stride, nsample=16)).to(dev()).eval()
+        n_p, y = td.run(p.to(dev()), x.to(dev()), B)
+        assert torch.equal(n_p.cpu(), wp)
+        report(f"set abstraction 8192->{n // stride}", y, wy, 2e-4)
