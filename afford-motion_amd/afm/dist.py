@@ -1,0 +1,82 @@
+"""Multi-GPU sampling: shard the flattened (batch x k_sample) dimension over the ranks of one node,
+replicate the (<= 50 MB) weights, run each rank's loop independently and gather once at the end.
+
+The reference samples its k repeats sequentially on one GPU (test.py:88-101) and has no
+inference-time parallelism; samples are independent for the whole loop in eval mode (SURVEY.md
+section 8e), so the only collective is one all_gather of [B/G, L, D] float32 (RCCL over xGMI on the
+GPU box - torch's "nccl" backend; gloo in the CPU tests).  Noise is keyed by the GLOBAL sample index,
+so the gathered result does not depend on the number of ranks.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Callable, Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_process_group(backend: str = None) -> Tuple[int, int, int]:
+    """One process per GPU (launched by torch.distributed.run); no-op for a single process."""
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [start, start+count) of `total` samples; the first total % world ranks get one extra."""
+    base, extra = divmod(total, world)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def shard_kwargs(kwargs: Dict[str, Any], start: int, count: int, total: int) -> Dict[str, Any]:
+    """Slice every per-sample entry (tensor or list whose leading size is `total`) of a batch dict."""
+    out = {}
+    for k, v in kwargs.items():
+        if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == total:
+            out[k] = v[start:start + count]
+        elif isinstance(v, (list, tuple)) and len(v) == total:
+            out[k] = v[start:start + count]
+        else:
+            out[k] = v
+    return out
+
+
+def sharded_sample(sample_fn: Callable[[Dict[str, Any], int, int], torch.Tensor], total: int, model_kwargs: Dict[str, Any],
+                   rank: int = None, world: int = None, gather: bool = True) -> torch.Tensor:
+    """Run ``sample_fn(shard_kwargs, count, sample_index0) -> [count, ...]`` on this rank's shard and
+    all_gather the shards in rank order -> [total, ...] on every rank (one collective, at the end)."""
+    if rank is None or world is None:
+        rank, world, _ = env_rank_world()
+    start, count = shard_range(total, rank, world)
+    local = sample_fn(shard_kwargs(model_kwargs, start, count, total), count, start)
+    if world == 1 or not gather:
+        return local
+    counts = [shard_range(total, r, world)[1] for r in range(world)]
+    mx = max(counts)
+    pad = local if count == mx else torch.cat([local, local.new_zeros((mx - count,) + tuple(local.shape[1:]))], 0)
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous())
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+
+def adm_to_amdm_condition(sample: torch.Tensor, sigma: float = 0.8, mean: float = 0.0, std: float = 1.0) -> torch.Tensor:
+    """In-process ADM -> AMDM hand-off (the reference goes through .npy files): denormalise + clip to
+    [1e-20, 1] (datasets/humanml3d.py:494-511), dist = sqrt(-2 ln(c) sigma^2) (utils/evaluate.py:56-66),
+    consumer c = exp(-dist^2 / (2 sigma^2)) (datasets/humanml3d.py:773-774)."""
+    contact = (sample * std + mean).clamp(1e-20, 1.0)
+    d = torch.sqrt(-2 * torch.log(contact) * sigma ** 2)
+    return torch.exp(-0.5 * d ** 2 / sigma ** 2)

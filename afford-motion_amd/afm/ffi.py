@@ -48,6 +48,10 @@ class PtAttentionArgs(C.Structure):
                                       "out_scale", "out_shift")] + [("relu", i32)]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", i64), ("total_ms", C.c_double), ("total_work", C.c_double)]
+
+
 class EncoderLayerWeights(C.Structure):
     _fields_ = [(n, c_f32p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
@@ -84,6 +88,8 @@ EXPORTS = {
     "afm_transition_down": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, C.c_void_p, i32, c_f32p, i32, c_f32p, c_f32p, c_f32p,
                                       i32, C.c_void_p]),
     "afm_pt_attention": (C.c_int, [C.POINTER(PtAttentionArgs), C.c_void_p]),
+    "afm_profile_enable": (C.c_int, [i32]),
+    "afm_profile_read": (C.c_int, [C.POINTER(ProfileEntry), i32]),
     "afm_cmdm_workspace_bytes": (i64, [C.POINTER(CmdmWeights), i32, i32]),
     "afm_cmdm_forward": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
                                    C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p]),
@@ -139,3 +145,17 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+def profile_enable(on: bool) -> None:
+    check(load().afm_profile_enable(1 if on else 0), "afm_profile_enable")
+
+
+def profile_read():
+    """-> {kernel name: dict(launches, total_ms, total_work)} since the last read (synchronises)."""
+    buf = (ProfileEntry * 32)()
+    n = load().afm_profile_read(buf, 32)
+    if n < 0:
+        check(n, "afm_profile_read")
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, total_ms=buf[i].total_ms, total_work=buf[i].total_work)
+            for i in range(n)}

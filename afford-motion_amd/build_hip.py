@@ -19,7 +19,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "afm", "libafm_hip.so")
 OBJ = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Werror=pass-failed",          # a failed `#pragma unroll` demotes register arrays to scratch
+         "-Rpass-analysis=kernel-resource-usage"]
+MAX_SCRATCH_BYTES = 32       # per lane; anything larger means an accumulator array left the register file
 
 
 def _stale(target, deps):
@@ -43,7 +45,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def cc(job):
         s, o = job
         r = subprocess.run([hipcc] + FLAGS + ["-c", s, "-o", o], capture_output=True, text=True)
-        return s, r.returncode, r.stdout + r.stderr
+        log = r.stdout + r.stderr
+        rc = r.returncode
+        keep = []
+        name = "?"
+        skip = 0
+        for line in log.splitlines():
+            if skip and ("|" in line[:8] or not line.strip()):      # source excerpt printed under a remark
+                continue
+            skip = 0
+            if "remark:" in line:
+                skip = 1
+                if "Function Name:" in line:
+                    name = line.split("Function Name:")[1].split("[")[0].strip()
+                if "ScratchSize [bytes/lane]:" in line:
+                    sz = int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0])
+                    if sz > MAX_SCRATCH_BYTES:
+                        keep.append(f"error: kernel {name} uses {sz} B/lane of scratch (register array spilled)")
+                        rc = rc or 1
+                continue
+            keep.append(line)
+        return s, rc, "\n".join(keep)
 
     with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         for s, rc, log in ex.map(cc, jobs):

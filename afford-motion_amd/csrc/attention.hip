@@ -13,6 +13,7 @@
 //   * online softmax in f32 (running max / sum per query), masked keys get -inf exactly like
 //     masked_fill(-inf) in the reference; fully masked 32-key blocks are skipped (their weight is 0).
 #include "common.h"
+#include "profile.h"
 #include <math.h>
 
 namespace {
@@ -182,6 +183,7 @@ extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out
     const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nqb * KB) * sizeof(float) + (size_t)nqb * sizeof(int);
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;
     const float scale = 1.0f / sqrtf((float)dh);
+    AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)T * T * dh, (hipStream_t)stream);
     if (nw >= 8)
         hipLaunchKernelGGL(mha_fwd_kernel<2>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, qkv, key_mask, out, T, H, scale);
     else

@@ -1,6 +1,7 @@
 // LayerNorm, DDPM posterior update, Philox normal generator.
 // All three are HBM/L2-streaming kernels: float4 accesses, one wave per LayerNorm row.
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -134,6 +135,7 @@ extern "C" int afm_layernorm(const float* x, const float* gamma, const float* be
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256), grid((unsigned)((rows + 3) / 4));
+    AfmProf prof(AFM_PROF_LN, 8.0 * rows * dim, s);
     if (dim <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
     else if (dim <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
     else if (dim <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);

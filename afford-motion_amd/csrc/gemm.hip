@@ -14,6 +14,7 @@
 //   * XCD-aware tile order: the 8 XCDs each walk a contiguous range of tiles (A row-panels are
 //     reused out of the XCD's own L2; W (<= 3 MB) stays L2 resident).
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -27,25 +28,22 @@ struct RowMap {
     }
 };
 
+// One thread stages ROWS/32 rows x 4 consecutive k of a [ROWS x 32] tile.  Row base pointers are
+// computed ONCE (row remap / clamping out of the K loop); rows past the matrix edge are clamped to the
+// last valid row (their products are never stored), only the K tail is zero-filled.
 template <int ROWS, bool VEC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, RowMap map, int row0, int nrows,
-                                          int k0, int K, int tid, float4 (&reg)[ROWS / 32]) {
-    const int c4 = tid & 7, r0 = tid >> 3;
+__device__ __forceinline__ void load_tile(const float* const (&rowp)[ROWS / 32], int k, int K, float4 (&reg)[ROWS / 32]) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
-        const int r = row0 + r0 + 32 * i;
-        const int k = k0 + c4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nrows) {
-            const float* p = base + map(r) * ld + k;
-            if (VEC) {
-                if (k < K) v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (k + 0 < K) v.x = p[0];
-                if (k + 1 < K) v.y = p[1];
-                if (k + 2 < K) v.z = p[2];
-                if (k + 3 < K) v.w = p[3];
-            }
+        const float* p = rowp[i] + k;
+        if (VEC) {
+            if (k < K) v = *reinterpret_cast<const float4*>(p);
+        } else {
+            if (k + 0 < K) v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+            if (k + 3 < K) v.w = p[3];
         }
         reg[i] = v;
     }
@@ -59,11 +57,24 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, con
         *reinterpret_cast<float4*>(lds + (r0 + 32 * i) * LDK + c4 * 4) = reg[i];
 }
 
+// epilogue math for one output element (compact: instantiated once, looped over, never unrolled 64x)
+__device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int grow, int64_t orow, int gcol) {
+    if (p.scale) v *= p.scale[gcol];
+    if (p.bias) v += p.bias[gcol];
+    if (p.act) v = apply_act(v, p.act);
+    if (p.residual) v += p.residual[orow * p.ldr + gcol];
+    if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
+    if (p.act_post) v = apply_act(v, p.act_post);
+    return v;
+}
+
 template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p, int nbm, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
     constexpr int STAGE = (BM + BN) * LDK;          // floats per LDS stage: A tile then W tile
+    constexpr int LDC = BN + 4;                     // padded row of the epilogue staging tile
+    constexpr int LDS_FLOATS = (2 * STAGE > BM * LDC) ? 2 * STAGE : BM * LDC;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     // XCD-aware bijective remap: block b runs on XCD b % 8; give each XCD a contiguous tile range.
     const int nblk = nbm * nbn;
@@ -77,8 +88,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
+    const int c4 = tid & 7, r0 = tid >> 3;
 
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off}, ident{0, 0, 0};
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off};
+    const float* arow[BM / 32];
+    const float* wrow[BN / 32];
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) arow[i] = p.A + amap(min(bm * BM + r0 + 32 * i, p.M - 1)) * p.lda;
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) wrow[i] = p.W + (int64_t)min(bn * BN + r0 + 32 * i, p.N - 1) * p.ldw;
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -89,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
 
     float4 ra[BM / 32], rw[BN / 32];
     const int nk = (p.K + BK - 1) / BK;
-    load_tile<BM, VEC>(p.A, p.lda, amap, bm * BM, p.M, 0, p.K, tid, ra);
-    load_tile<BN, VEC>(p.W, p.ldw, ident, bn * BN, p.N, 0, p.K, tid, rw);
+    load_tile<BM, VEC>(arow, c4 * 4, p.K, ra);
+    load_tile<BN, VEC>(wrow, c4 * 4, p.K, rw);
     store_tile<BM>(lds, tid, ra);
     store_tile<BN>(lds + BM * LDK, tid, rw);
     __syncthreads();
@@ -98,27 +117,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<BM, VEC>(p.A, p.lda, amap, bm * BM, p.M, (kt + 1) * BK, p.K, tid, ra);
-            load_tile<BN, VEC>(p.W, p.ldw, ident, bn * BN, p.N, (kt + 1) * BK, p.K, tid, rw);
+            load_tile<BM, VEC>(arow, (kt + 1) * BK + c4 * 4, p.K, ra);
+            load_tile<BN, VEC>(wrow, (kt + 1) * BK + c4 * 4, p.K, rw);
         }
         const float* a_base = lds + cur * STAGE + (wm * (BM / 2) + r32) * LDK + hh * 16;
         const float* w_base = lds + cur * STAGE + BM * LDK + (wn * (BN / 2) + r32) * LDK + hh * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float4 af[TM], bf[TN];
+            float af[TM][4], bf[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDK + j * 4);
+            for (int i = 0; i < TM; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(a_base + i * 32 * LDK + j * 4);
+                af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
+            }
 #pragma unroll
-            for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const float4*>(w_base + i * 32 * LDK + j * 4);
+            for (int i = 0; i < TN; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(w_base + i * 32 * LDK + j * 4);
+                bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
+            }
+            // independent accumulators back to back (never two dependent MFMAs in a row when TM*TN > 1)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = mfma32(af[tm].x, bf[tn].x, acc[tm][tn]);
-                    acc[tm][tn] = mfma32(af[tm].y, bf[tn].y, acc[tm][tn]);
-                    acc[tm][tn] = mfma32(af[tm].z, bf[tn].z, acc[tm][tn]);
-                    acc[tm][tn] = mfma32(af[tm].w, bf[tn].w, acc[tm][tn]);
-                }
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(af[tm][e], bf[tn][e], acc[tm][tn]);
         }
         if (kt + 1 < nk) {
             store_tile<BM>(lds + (cur ^ 1) * STAGE, tid, ra);
@@ -127,34 +150,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column (l & 31), rows (r&3) + 8*(r>>2) + 4*(l>>5) of each 32x32 tile
+    // ---- epilogue.  Stage the accumulators through LDS (lane holds column l&31, rows
+    // (r&3) + 8*(r>>2) + 4*(l>>5) of each 32x32 tile -> conflict-free column-contiguous writes), then
+    // stream rows out with 16-byte accesses: bias / residual / row-table reads and the C store are
+    // fully coalesced and the epilogue math exists once instead of 16*TM*TN times.
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
+    __syncthreads();
+
     const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int gcol = bn * BN + wn * (BN / 2) + tn * 32 + r32;
-        if (gcol >= p.N) continue;
-        const float sc = p.scale ? p.scale[gcol] : 1.0f;
-        const float bi = p.bias ? p.bias[gcol] : 0.0f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int grow = bm * BM + wm * (BM / 2) + tm * 32 + mfma_row(r, lane);
-                if (grow >= p.M) continue;
-                float v = acc[tm][tn][r];
-                if (p.scale) v *= sc;
-                v += bi;
-                v = apply_act(v, p.act);
-                const int64_t orow = cmap(grow);
-                if (p.residual) v += p.residual[orow * p.ldr + gcol];
-                if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
-                v = apply_act(v, p.act_post);
-                if (p.C) p.C[orow * p.ldc + gcol] = v;
-                if (p.ddpm_out) {
-                    const int b = grow / p.rows_per_sample;
-                    const int64_t ix = orow * p.ldx + gcol;
-                    p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
-                }
+    const int col0 = bn * BN;
+    const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && !p.ddpm_out &&
+                         ((((uintptr_t)p.C) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) | ((uintptr_t)p.scale) | ((uintptr_t)p.rowtab)) & 15) == 0;
+    if (vec_out) {
+        for (int e = tid; e < BM * (BN / 4); e += 256) {
+            const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
+            const int grow = bm * BM + row, gcol = col0 + cq;
+            if (grow >= p.M || gcol >= p.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(lds + row * LDC + cq);
+            const int64_t orow = cmap(grow);
+            if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + gcol); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+            if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+            if (p.residual) { const float4 t = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.rowtab) { const float4 t = *reinterpret_cast<const float4*>(p.rowtab + (int64_t)(grow % p.rowtab_period) * p.N + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.act_post) { v.x = apply_act(v.x, p.act_post); v.y = apply_act(v.y, p.act_post); v.z = apply_act(v.z, p.act_post); v.w = apply_act(v.w, p.act_post); }
+            *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
+        }
+    } else {
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int row = e / BN, c = e % BN;
+            const int grow = bm * BM + row, gcol = col0 + c;
+            if (grow >= p.M || gcol >= p.N) continue;
+            const int64_t orow = cmap(grow);
+            const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol);
+            if (p.C) p.C[orow * p.ldc + gcol] = v;
+            if (p.ddpm_out) {
+                const int b = grow / p.rows_per_sample;
+                const int64_t ix = orow * p.ldx + gcol;
+                p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
             }
         }
     }
@@ -164,6 +203,7 @@ template <int BM, int BN>
 int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     dim3 grid(nbm * nbn), block(256);
+    AfmProf prof(BM == 128 ? AFM_PROF_GEMM128 : (BN == 128 ? AFM_PROF_GEMM64x128 : AFM_PROF_GEMM64), 2.0 * a.M * a.N * a.K, s);
     if (vec)
         hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, true>), grid, block, 0, s, a, nbm, nbn);
     else

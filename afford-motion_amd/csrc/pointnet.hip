@@ -13,6 +13,7 @@
 //      fused BatchNorm+ReLU of the enclosing block.  One wave per point; the channel-parallel phases
 //      keep (v + p_r) in registers, the (neighbour, weight-channel)-parallel phases go through LDS.
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -286,6 +287,7 @@ extern "C" int afm_transition_down(const float* p, const float* x, int32_t c, co
     if (nsample != TD_K) return AFM_E_UNSUPPORTED;          // every strided TransitionDown of the reference uses k = 16
     if (M == 0) return 0;
     const dim3 grid((unsigned)(((int64_t)M * TD_K + 127) / 128), (cout + 63) / 64), block(256);
+    AfmProf prof(AFM_PROF_TD, 2.0 * M * TD_K * (3 + c) * cout, (hipStream_t)stream);
     hipLaunchKernelGGL(transition_down_kernel, grid, block, 0, (hipStream_t)stream, p, x, c, new_p, knn_idx, weight, cout, scale,
                        shift, out, M);
     AFM_CHECK_LAUNCH();
@@ -311,6 +313,7 @@ extern "C" int afm_pt_attention(const afm_pt_attention_args* g, void* stream) {
     int quads = (g->n + 3) / 4;
     const dim3 grid(quads < 2048 ? quads : 2048), block(256);
     hipStream_t s = (hipStream_t)stream;
+    AfmProf prof(AFM_PROF_PTATTN, 2.0 * g->n * KN * ((double)C * CS + CS * CS + 5.0 * C), s);
 #define AFM_PT(CPL_, KN_, NE_)                                                                                             \
     do {                                                                                                                   \
         if (lds > 64 * 1024)                                                                                               \

@@ -15,6 +15,7 @@
 //   * kNN: one lane per query, candidates streamed through an LDS tile (broadcast reads), the k best
 //     kept as a sorted register array with a branch-free insertion.
 #include "common.h"
+#include "profile.h"
 #pragma clang fp contract(off)
 
 namespace {
@@ -132,13 +133,13 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
     int T = ((n + 63) / 64) * 64;
     if (T > 1024) T = 1024;
     const int ppt = (n + T - 1) / T;
+    AfmProf prof(AFM_PROF_FPS, (double)B * (m - 1) * n, s);
 #define AFM_FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(T), 0, s, xyz, n, m, idx_out)
     if (ppt <= 1) AFM_FPS(1);
     else if (ppt <= 2) AFM_FPS(2);
     else if (ppt <= 4) AFM_FPS(4);
     else if (ppt <= 8) AFM_FPS(8);
     else if (ppt <= 16) AFM_FPS(16);
-    else if (ppt <= 32) AFM_FPS(32);
     else return AFM_E_UNSUPPORTED;
 #undef AFM_FPS
     AFM_CHECK_LAUNCH();
@@ -151,6 +152,7 @@ extern "C" int afm_knn(int32_t k, const float* xyz, const float* new_xyz, int32_
     if (B == 0 || m == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((m + 255) / 256, B), block(256);
+    AfmProf prof(AFM_PROF_KNN, (double)B * m * n, s);
     switch (k) {
         case 3: hipLaunchKernelGGL(knn_kernel<3>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;
         case 8: hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;

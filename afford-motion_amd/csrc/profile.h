@@ -1,0 +1,15 @@
+#pragma once
+#include <hip/hip_runtime.h>
+enum {
+    AFM_PROF_GEMM128 = 0, AFM_PROF_GEMM64x128, AFM_PROF_GEMM64, AFM_PROF_MHA, AFM_PROF_LN, AFM_PROF_MISC, AFM_PROF_FPS,
+    AFM_PROF_KNN, AFM_PROF_TD, AFM_PROF_PTATTN, AFM_PROF_CDM, AFM_PROF_NTAGS
+};
+bool afm_prof_on();
+void afm_prof_begin(int tag, double work, hipStream_t s, void** handle);
+void afm_prof_end(void* handle, hipStream_t s);
+// RAII bracket around one launch
+struct AfmProf {
+    void* h; hipStream_t s;
+    AfmProf(int tag, double work, hipStream_t st) : h(nullptr), s(st) { if (afm_prof_on()) afm_prof_begin(tag, work, st, &h); }
+    ~AfmProf() { if (h) afm_prof_end(h, s); }
+};

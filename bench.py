@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Benchmark of the north-star hot path: denoising steps/sec of the CMDM (AMDM) `p_sample_loop`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one `p_sample` (CMDM denoiser forward over the rank's batch + DDPM posterior update) of
+BASELINE.json configs[1]: B = 32 samples per GPU, L = 196 frames, D = 263, N = 8192 scene points
+(128 contact-group tokens), hoisted step-invariant conditions, synthetic inputs, name-keyed random weights.
+Weak scaling: every rank runs its own 32 samples (global sample indices rank*32 ...), one all_gather at
+the end; value = (ranks x K steps) / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "afford-motion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU, L, D, NPTS = 32, 196, 263, 8192
+F32_MFMA_PEAK_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+DOMINANT = "gemm_f32_mfma<128,128>"
+
+
+def step_flops(batch: int, frames: int = L, groups: int = NPTS // 64) -> float:
+    """Algorithmic FLOPs of one CMDM step: 5 encoder layers + motion adapters + time MLP."""
+    T = 2 + groups + frames
+    return batch * (5 * T * (4194304 + 2048 * T) + 2 * (2 * 263 * 512 * frames) + 2 * 2 * 512 * 512)
+
+
+def build(dev, steps_cfg: str):
+    from afm import synth
+    from afm.base import create_model_and_diffusion
+    from afm.config import load_config
+    cfg = load_config("text_to_motion_contact_motion_gen", "cmdm",
+                      ["model.data_repr=h3d", "model.input_feats=263", "model.text_model.max_length=20", "diffusion.steps=1000",
+                       f"diffusion.timestep_respacing='{steps_cfg}'"])
+    model, diff = create_model_and_diffusion(cfg, device=dev)
+    synth.fill_module_(model)
+    return model.to(dev).eval(), diff, cfg
+
+
+def cpu_baseline(n_steps: int = 3):
+    """The reference's CPU path = its PyTorch-CPU math (oracle restatement, checked against the reference
+    by tests/test_oracle_golden.py) on this host's cores, same B/L/T, conditions hoisted."""
+    from afm import synth
+    from oracle import denoiser_ref as dr, diffusion_ref as df, shapes as sh
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = sh.weights(sh.cmdm())
+    x = synth.gaussian("bench_x", (B_PER_GPU, L, D))
+    text, cont = synth.text_feature(B_PER_GPU), synth.gaussian("bench_cont", (B_PER_GPU, NPTS // 64, 256))
+    mask = synth.frame_mask(B_PER_GPU, L, all_valid=True)
+    s = df.Schedule(1000)
+    model = lambda xx, t, **k: dr.cmdm_forward(sd, xx, t, text, x_mask=mask, cont_emb=cont)
+    nz = synth.gaussian("bench_nz", (B_PER_GPU, L, D))
+    t = torch.full((B_PER_GPU,), 500)
+    with torch.no_grad():
+        df.p_sample(s, model, x, t, nz)                                   # warm-up
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            x = df.p_sample(s, model, x, t, nz)["sample"]
+        dt = (time.perf_counter() - t0) / n_steps
+    return {"value": round(1.0 / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_steps} p_sample steps at B={B_PER_GPU}, L={L}, T=326 tokens, f32, conditions hoisted "
+                      f"(torch-CPU restatement of the reference, {1e3 * dt:.0f} ms/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--latency-runs", type=int, default=3, help="full 1000-step loops for the p50 sample latency (N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from afm import dist as adist, ffi, synth
+    rank, world, local = adist.init_process_group()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    ffi.load()
+
+    K, W = args.steps, args.warmup
+    model, diff_k, cfg = build(dev, str(K))
+    from afm.base import create_gaussian_diffusion
+    cfg.diffusion.timestep_respacing = str(max(W, 1))
+    diff_w = create_gaussian_diffusion(cfg)
+
+    # synthetic batch of this rank (global sample indices rank*B ...), resident in HBM before any timing
+    B = B_PER_GPU
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, NPTS).to(dev),
+              c_pc_contact=synth.contact_map(B, NPTS).to(dev), x_mask=synth.frame_mask(B, L, all_valid=True).to(dev))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.condition_tokens(**kw)                      # one-off: SceneMapEncoder (FPS, kNN, set abstraction, attention)
+    torch.cuda.synchronize()
+    setup_ms = 1e3 * (time.perf_counter() - t0)
+
+    def run(diffusion, seed):
+        x = diffusion.p_sample_loop(model, (B, L, D), clip_denoised=False, model_kwargs=kw, seed=seed, sample_index0=rank * B)
+        if world > 1:                                  # the path's only collective: gather the shards at the end
+            out = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(out, x)
+        return x
+
+    if W > 0:
+        run(diff_w, 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(diff_k, 2)                                     # exactly K steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    # roofline of the dominant kernel: same K steps again with every launch bracketed by HIP events
+    roof = None
+    if rank == 0:
+        ffi.profile_enable(True)
+        ffi.profile_read()
+        run(diff_k, 2)
+        prof = ffi.profile_read()
+        ffi.profile_enable(False)
+        g = prof.get(DOMINANT)
+        if g:
+            ach = g["total_work"] / (g["total_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * g["total_ms"] / g["launches"], 2), "launches": g["launches"],
+                    "flops_per_launch": g["total_work"] / g["launches"],
+                    "all_kernels_ms_per_step": {k: round(v["total_ms"] / K, 4) for k, v in prof.items()}}
+
+    lat = None
+    if rank == 0 and world == 1 and args.latency_runs > 0:
+        cfg.diffusion.timestep_respacing = ""
+        diff_full = create_gaussian_diffusion(cfg)
+        ts = []
+        for i in range(args.latency_runs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(diff_full, 10 + i)
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        lat = {"p50_ms": round(statistics.median(ts), 1), "runs": args.latency_runs, "steps": 1000, "batch": B}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        ms = 1e3 * dt / K
+        line = {
+            "metric": "denoising steps/sec (B=32, L=196, N=8192)", "value": round(world * K / dt, 2), "unit": "steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CMDM trans_enc p_sample_loop, HumanML3D t2m_contact_motion config (BASELINE configs[1])",
+                       "batch_per_gpu": B, "frames": L, "motion_dim": D, "scene_points": NPTS, "tokens": 2 + NPTS // 64 + L,
+                       "conditions": "hoisted (step-invariant, computed once: setup_ms)", "parallelism": f"batch-shard x{world}"},
+            "algorithmic_tflops": round(step_flops(B) * world * K / dt / 1e12, 2),
+            "setup_ms": round(setup_ms, 2),
+            "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

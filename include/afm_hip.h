@@ -231,6 +231,20 @@ int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_
                          int32_t B, int32_t L, void* sched_scratch, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Opt-in profiler (measurement only, no reference counterpart): when enabled, every kernel launch of
+ * this library is bracketed by HIP events on its own stream.  afm_profile_read synchronises, returns
+ * per-kernel totals since the last read (work = algorithmic FLOPs, or bytes for streaming kernels) and
+ * clears them.  Returns the number of entries written, or a negative AFM_E_* code. */
+typedef struct {
+    const char* name;       /* kernel name as it appears in rocprofv3 kernel traces (template args abbreviated) */
+    int64_t launches;
+    double total_ms;
+    double total_work;
+} afm_profile_entry;
+int afm_profile_enable(int32_t on);
+int afm_profile_read(afm_profile_entry* out, int32_t max_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+"""World-size-2 `gloo` tests (CPU) of the N>1 path: contiguous sharding of the (batch x k_sample)
+dimension, sample-index keyed work, one all_gather at the end, result independent of the rank count."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from afm import dist as adist
+
+
+def test_shard_range_covers_everything():
+    for total in (1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [adist.shard_range(total, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == total
+            assert [s for s, _ in spans] == [sum(c for _, c in spans[:r]) for r in range(world)]
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_shard_kwargs_slices_only_per_sample_entries():
+    kw = dict(x_mask=torch.zeros(6, 4), c_text=["a"] * 6, sigma=0.8, table=torch.zeros(3, 2))
+    out = adist.shard_kwargs(kw, 2, 3, 6)
+    assert out["x_mask"].shape == (3, 4) and len(out["c_text"]) == 3 and out["sigma"] == 0.8 and out["table"].shape == (3, 2)
+
+
+def _fake_sampler(kw, count, index0):
+    """Deterministic per GLOBAL sample index (what Philox keying gives the real sampler)."""
+    idx = torch.arange(index0, index0 + count, dtype=torch.float32)
+    return idx[:, None, None] * 10 + kw["cond"][:, None, None] + torch.arange(6, dtype=torch.float32).view(1, 2, 3)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_process_group("gloo")
+    kw = dict(cond=torch.arange(total, dtype=torch.float32) * 0.5, flag=True)
+    out = adist.sharded_sample(_fake_sampler, total, kw, rank, world)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_two_rank_gather_matches_single_process(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29611 + total
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = adist.sharded_sample(_fake_sampler, total, dict(cond=torch.arange(total, dtype=torch.float32) * 0.5, flag=True), 0, 1)
+    assert torch.equal(got[0], want) and torch.equal(got[1], want)
+
+
+def test_adm_to_amdm_glue_matches_reference_golden():
+    from conftest import golden
+    g = golden("adm_to_amdm_glue")
+    cond = adist.adm_to_amdm_condition(g["sample"], sigma=float(g["sigma"]), mean=float(g["mean"]), std=float(g["std"]))
+    assert torch.allclose(cond, g["cond"].float(), atol=1e-6)
