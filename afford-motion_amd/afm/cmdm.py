@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -121,6 +122,9 @@ class CMDM(TextEncoderMixin, nn.Module):
         self.motion_layer = nn.Linear(self.latent_dim, self.motion_dim, bias=True)
 
         self.hoist_conditions = True
+        # sub-batches of the native sampling loop, each on its own HIP stream (AFM_LOOP_STREAMS overrides)
+        self.loop_streams = int(os.environ.get("AFM_LOOP_STREAMS", "2"))
+        self._side_streams: List[torch.cuda.Stream] = []
         self._pack = None          # (version, CmdmWeights, keep-alive tensors)
         self._cond_cache = None    # (key, cond_tokens)
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -232,14 +236,25 @@ class CMDM(TextEncoderMixin, nn.Module):
             tab = diffusion.tables(x.device)
             n = diffusion.num_timesteps
             sched = torch.empty(lib.afm_cmdm_sched_scratch_bytes(n, B), dtype=torch.uint8, device=x.device)
-            ws = self._workspace(w, B, L, x.device)
+            nsub = max(1, min(int(self.loop_streams), B))
+            while len(self._side_streams) < nsub:
+                self._side_streams.append(torch.cuda.Stream(device=x.device))
+            handles = (C.c_void_p * nsub)(*[s.cuda_stream for s in self._side_streams[:nsub]])
+            nbytes = lib.afm_cmdm_loop_workspace_bytes(C.byref(w), B, L, nsub)
+            if nbytes < 0:
+                ffi.check(int(nbytes), "afm_cmdm_loop_workspace_bytes")
+            key = ("loop", B, L, nsub, str(x.device))
+            if key not in self._ws:
+                self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=x.device)}
+            ws = self._ws[key]
             if step_noise is not None:
                 step_noise = ffi.f32c(step_noise.to(x.device))
                 assert step_noise.shape == (n,) + tuple(x.shape), step_noise.shape
             ffi.check(lib.afm_cmdm_sample_loop(C.byref(w), x.data_ptr(), cond.data_ptr(), ffi.ptr(fm), ffi.ptr(step_noise),
                                                tab.timestep_map.data_ptr(), tab.coef1.data_ptr(), tab.coef2.data_ptr(),
                                                tab.sigma.data_ptr(), n, seed & (2**64 - 1), sample_index0, B, L,
-                                               sched.data_ptr(), ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
+                                               sched.data_ptr(), ws.data_ptr(), ws.numel(), nsub if nsub > 1 else 0,
+                                               handles if nsub > 1 else None, ffi.stream_of(x)),
                       "afm_cmdm_sample_loop")
             # keep scratch alive until the stream has consumed it
             self._last_loop_scratch = (sched, step_noise, cond, fm)

@@ -94,8 +94,10 @@ EXPORTS = {
     "afm_cmdm_forward": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
                                    C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p]),
     "afm_cmdm_sched_scratch_bytes": (i64, [i32, i32]),
+    "afm_cmdm_loop_workspace_bytes": (i64, [C.POINTER(CmdmWeights), i32, i32, i32]),
     "afm_cmdm_sample_loop": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
-                                       c_f32p, c_f32p, i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, C.c_void_p]),
+                                       c_f32p, c_f32p, i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, i32,
+                                       C.POINTER(C.c_void_p), C.c_void_p]),
 }
 
 

@@ -189,19 +189,39 @@ extern "C" int64_t afm_cmdm_sched_scratch_bytes(int32_t n_steps, int32_t B) {
     return align256((int64_t)n_steps * B * 8) + 3 * align256((int64_t)n_steps * B * 4);
 }
 
+namespace {
+inline void sub_range(int B, int n, int s, int* start, int* count) {
+    const int base = B / n, extra = B % n;
+    *count = base + (s < extra ? 1 : 0);
+    *start = s * base + (s < extra ? s : extra);
+}
+}  // namespace
+
+extern "C" int64_t afm_cmdm_loop_workspace_bytes(const afm_cmdm_weights* w, int32_t B, int32_t L, int32_t n_streams) {
+    if (validate(w, B, L) != 0 || n_streams < 0) return AFM_E_BADARG;
+    const int n = n_streams > 1 ? (n_streams < B ? n_streams : (B > 0 ? B : 1)) : 1;
+    int64_t total = 0;
+    for (int s = 0; s < n; ++s) {
+        int st, cnt;
+        sub_range(B, n, s, &st, &cnt);
+        total += carve(*w, cnt, L, nullptr).bytes;
+    }
+    return total;
+}
+
 extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_tokens, const uint8_t* frame_mask,
                                     const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
                                     const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed,
                                     int64_t sample_index0, int32_t B, int32_t L, void* sched_scratch, void* workspace,
-                                    int64_t workspace_bytes, void* stream) {
+                                    int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream) {
     AFM_TRY(validate(w, B, L));
     if (!x || (w->n_cond > 0 && !cond_tokens) || !d_timestep_map || !d_c1 || !d_c2 || !d_sigma || n_steps <= 0 ||
-        !sched_scratch || !workspace)
+        !sched_scratch || !workspace || n_streams < 0 || (n_streams > 1 && !side_streams))
         return AFM_E_BADARG;
     if (B == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const Workspace ws = carve(*w, B, L, workspace);
-    if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
+    hipStream_t s0 = (hipStream_t)stream;
+    int nsub = n_streams > 1 ? (n_streams < B ? n_streams : B) : 1;
+    if (nsub > 16) nsub = 16;
 
     char* sp = (char*)sched_scratch;
     const int64_t nb = (int64_t)n_steps * B;
@@ -209,18 +229,61 @@ extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const f
     float* c1_all = (float*)sp; sp += align256(nb * 4);
     float* c2_all = (float*)sp; sp += align256(nb * 4);
     float* sg_all = (float*)sp;
-    hipLaunchKernelGGL(expand_schedule_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, d_timestep_map, d_c1, d_c2,
+    hipLaunchKernelGGL(expand_schedule_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s0, d_timestep_map, d_c1, d_c2,
                        d_sigma, n_steps, B, t_all, c1_all, c2_all, sg_all);
     AFM_CHECK_LAUNCH();
 
-    const int64_t per_step = (int64_t)B * L * w->motion_dim;
-    for (int j = 0; j < n_steps; ++j) {
-        afm_ddpm_args dd = {};
-        dd.noise = step_noise ? step_noise + (int64_t)j * per_step : nullptr;
-        dd.x_next = x;                       // in place: each element is read then written by the same lane
-        dd.c1 = c1_all + (int64_t)j * B; dd.c2 = c2_all + (int64_t)j * B; dd.sigma = sg_all + (int64_t)j * B;
-        dd.seed = seed; dd.sample_index0 = sample_index0; dd.step = j;
-        AFM_TRY(forward_impl(*w, x, t_all + (int64_t)j * B, cond_tokens, frame_mask, nullptr, &dd, B, L, ws, j == 0, s));
+    // carve one workspace per sub-batch
+    Workspace ws[16];
+    int start[16], count[16];
+    hipStream_t st[16];
+    {
+        char* base = (char*)workspace;
+        int64_t off = 0;
+        for (int s = 0; s < nsub; ++s) {
+            sub_range(B, nsub, s, &start[s], &count[s]);
+            ws[s] = carve(*w, count[s], L, base + off);
+            off += ws[s].bytes;
+            st[s] = nsub > 1 ? (hipStream_t)side_streams[s] : s0;
+        }
+        if (off > workspace_bytes) return AFM_E_WORKSPACE;
     }
-    return 0;
+    hipEvent_t fork = nullptr;
+    if (nsub > 1) {      // side streams start after everything already queued on `stream` (inputs, schedule rows)
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        (void)hipEventRecord(fork, s0);
+        for (int s = 0; s < nsub; ++s) (void)hipStreamWaitEvent(st[s], fork, 0);
+    }
+
+    const int T = 1 + w->n_cond + L;
+    (void)T;
+    const int64_t row = (int64_t)L * w->motion_dim;
+    int rc = 0;
+    for (int j = 0; j < n_steps && rc == 0; ++j) {
+        for (int s = 0; s < nsub && rc == 0; ++s) {
+            if (count[s] == 0) continue;
+            afm_ddpm_args dd = {};
+            dd.noise = step_noise ? step_noise + ((int64_t)j * B + start[s]) * row : nullptr;
+            dd.x_next = x + (int64_t)start[s] * row;      // in place: each element is read then written by the same lane
+            dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s];
+            dd.sigma = sg_all + (int64_t)j * B + start[s];
+            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = j;
+            rc = forward_impl(*w, x + (int64_t)start[s] * row, t_all + (int64_t)j * B + start[s],
+                              cond_tokens ? cond_tokens + (int64_t)start[s] * w->n_cond * w->d : nullptr,
+                              frame_mask ? frame_mask + (int64_t)start[s] * L : nullptr, nullptr, &dd, count[s], L, ws[s], j == 0,
+                              st[s]);
+        }
+    }
+    if (nsub > 1) {      // join: `stream` continues only after every sub-batch loop has finished
+        for (int s = 0; s < nsub; ++s) {
+            hipEvent_t done;
+            if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) {
+                (void)hipEventRecord(done, st[s]);
+                (void)hipStreamWaitEvent(s0, done, 0);
+                (void)hipEventDestroy(done);
+            }
+        }
+        (void)hipEventDestroy(fork);
+    }
+    return rc;
 }

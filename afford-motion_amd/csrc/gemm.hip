@@ -13,6 +13,7 @@
 //     written to the other LDS buffer afterwards: one barrier per K tile.
 //   * XCD-aware tile order: the 8 XCDs each walk a contiguous range of tiles (A row-panels are
 //     reused out of the XCD's own L2; W (<= 3 MB) stays L2 resident).
+#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 
@@ -212,12 +213,6 @@ int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
     return 0;
 }
 
-inline double tile_cost(int M, int N, int bm, int bn, double eff) {
-    const long nb = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    const long waves = (nb + 255) / 256;          // one resident round per 256 CUs
-    return (double)waves * bm * bn / eff;
-}
-
 }  // namespace
 
 extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
@@ -232,12 +227,13 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                      (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
-    // pick the tile that minimises (rounds over 256 CUs) x (work per tile); smaller tiles pay a
-    // little efficiency.  M = B*T = 10432 with N = 512 is the case this exists for.
-    const double c128 = tile_cost(a.M, a.N, 128, 128, 1.00);
-    const double c64x128 = tile_cost(a.M, a.N, 64, 128, 0.95);
-    const double c64 = tile_cost(a.M, a.N, 64, 64, 0.85);
-    if (c128 <= c64x128 && c128 <= c64) return launch<128, 128>(a, vec, s);
-    if (c64x128 <= c64) return launch<64, 128>(a, vec, s);
+    // Tile choice (measured on MI355X, tools/probe_*.py, profiles/round1_notes.md): with the 64-cycle f32 MFMA
+    // neither LDS nor L2 bandwidth limits; what limits is keeping every SIMD's matrix pipe busy across the
+    // barrier / load phases of its waves.  64x64 tiles (72 VGPRs, 36 KB LDS -> 4 workgroups = 4 waves per SIMD,
+    // fine-grained tails) beat 64x128 and 128x128 on every GEMM shape of the encoder (2.79 vs 2.95 vs 3.30
+    // ms/step), so they are the default; the larger instantiations stay selectable for experiments.
+    static const int forced = []() { const char* e = getenv("AFM_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 1) return launch<128, 128>(a, vec, s);
+    if (forced == 2) return launch<64, 128>(a, vec, s);
     return launch<64, 64>(a, vec, s);
 }

@@ -221,15 +221,22 @@ int afm_cmdm_forward(const afm_cmdm_weights* w, const float* x_t, const int64_t*
  *   step_noise: [n_steps, B, L, motion_dim] device (row j = j-th executed step, t = n_steps-1-j)
  *   or NULL -> Philox keyed by (seed, sample_index0 + b, step = j).
  *   sched_scratch: device scratch of >= afm_cmdm_sched_scratch_bytes(n_steps, B) bytes.
+ *   Sub-batching: samples are independent for the whole loop, so the batch may be split into
+ *   n_streams contiguous sub-batches, sub-batch s running its own loop on side_streams[s] (caller-owned
+ *   hipStream_t handles; NULL / 0 = everything on `stream`).  One sub-batch's kernels fill the
+ *   wave-quantisation tails of the other's; results are bit-identical to the single-stream run.
+ *   `stream` is joined with every side stream before the call returns its work to the caller
+ *   (event wait, no host sync).  workspace must hold afm_cmdm_loop_workspace_bytes(w, B, L, n_streams).
  */
 int64_t afm_cmdm_sched_scratch_bytes(int32_t n_steps, int32_t B);
+int64_t afm_cmdm_loop_workspace_bytes(const afm_cmdm_weights* w, int32_t B, int32_t L, int32_t n_streams);
 
 int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_tokens,
                          const uint8_t* frame_mask, const float* step_noise,
                          const int64_t* d_timestep_map, const float* d_c1, const float* d_c2,
                          const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0,
                          int32_t B, int32_t L, void* sched_scratch, void* workspace,
-                         int64_t workspace_bytes, void* stream);
+                         int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Opt-in profiler (measurement only, no reference counterpart): when enabled, every kernel launch of

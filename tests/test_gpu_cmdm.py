@@ -128,3 +128,17 @@ def test_forward_with_scene_encoder_vs_reference_golden(cmdm):
     out2 = model(g["x"].to(dev()), g["t"].to(dev()), **_kw(g, with_encoder=True))
     model.hoist_conditions = True
     assert torch.equal(out.cpu(), out2.cpu())      # hoisting is exactly output-neutral
+
+
+def test_sub_batch_streams_are_bit_identical(cmdm):
+    """Splitting the batch over HIP side streams (tail filling) must not change a single bit."""
+    model, _ = cmdm
+    diff = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="6"))
+    g = golden("cmdm_forward_N1024_L16")
+    kw = _kw(g)
+    outs = []
+    for n in (1, 2):
+        model.loop_streams = n
+        outs.append(diff.p_sample_loop(model, (2, 16, 263), clip_denoised=False, model_kwargs=kw, seed=5).cpu())
+    model.loop_streams = 2
+    assert torch.equal(outs[0], outs[1])

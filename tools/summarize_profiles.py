@@ -1,0 +1,44 @@
+"""Condense rocprofv3 outputs (kernel stats + PMC passes) into a markdown summary (profiles/<round>_summary.md)."""
+import collections, csv, glob, json, os, sys
+out = sys.argv[1]
+
+
+def short(n):
+    n = n.replace("void (anonymous namespace)::", "").split("(")[0]
+    return n
+
+
+print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
+try:
+    print("bench line under rocprof: `" + open(os.path.join(out, "bench_under_rocprof.json")).read().strip()[:400] + " ...`\n")
+except OSError:
+    pass
+st = glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv"))
+if st:
+    print("## kernel-trace --stats (top kernels)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+    for r in list(csv.DictReader(open(st[0])))[:14]:
+        print(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |")
+for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(out, tag, "*", "*counter_collection.csv"))
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == ctr:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    print(f"\n## {ctr} per launch (rocprofv3 units: KiB; FETCH_SIZE on gfx950 counts 64 B per 128 B request -> x2 for wide streaming reads)\n")
+    print("| kernel | launches | mean KiB | mean MB (raw) |\n|---|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:10]:
+        print(f"| `{k}` | {len(v)} | {sum(v)/len(v):.0f} | {sum(v)/len(v)*1024/1e6:.2f} |")
+f = glob.glob(os.path.join(out, "pmc_sq", "*", "*counter_collection.csv"))
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print("\n## SQ counters per launch (means)\n\n| kernel | MFMA busy / (cycles x 1024 SIMDs) | waves/SIMD | WAIT_ANY % | WAIT_INST % | ACTIVE % | LDS conflict |\n|---|---|---|---|---|---|---|")
+    for k, c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0])))[:8]:
+        m = {a: sum(b) / len(b) for a, b in c.items()}
+        cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8 or 1
+        wc = m.get("SQ_WAVE_CYCLES", 0) or 1
+        print(f"| `{k}` | {m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0)/(cyc*1024):.3f} | {wc*4/cyc/1024:.2f} | {100*m.get('SQ_WAIT_ANY',0)/wc:.1f} | "
+              f"{100*m.get('SQ_WAIT_INST_ANY',0)/wc:.1f} | {100*m.get('SQ_ACTIVE_INST_ANY',0)/wc:.1f} | {m.get('SQ_LDS_BANK_CONFLICT',0):.0f} |")
