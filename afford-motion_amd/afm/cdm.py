@@ -1,13 +1,197 @@
-"""CDM / ADM denoiser (Perceiver) - filled in after the CMDM path."""
+"""CDM / ADM denoiser (`Perceiver`): drop-in for the reference's `models.cdm.CDM`
+(reference models/cdm.py:411-513 with `ContactPerceiver` :88-188) - same registry name, constructor,
+config keys, call signature and state-dict keys; forward on the HIP path (csrc/perceiver.hip).
+
+Only `arch='Perceiver'` is built (every shipped script selects it); the scene
+backbone of the HUMANISE variant (`use_scene_model=True` without openscene features) is a "next" row, so
+per-point scene features must be supplied as `c_pc_feat` (the `use_openscene` path of cdm.py:495-505) or be absent.
+"""
 from __future__ import annotations
 
+import ctypes as C
+from typing import List
+
+import torch
 import torch.nn as nn
 
+from . import ffi
 from .base import Model
+from .cmdm import TimestepEmbedder, _param_version
+from .text import TextEncoderMixin, lang_feat_dim_type
+
+
+class _Wrap(nn.Module):
+    """Key-compatible stand-in for the reference's `Residual(module)` wrapper (modules.py:222-231)."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.module = module
+
+
+class _MHA(nn.Module):
+    """Parameter container of MultiHeadAttention (modules.py:234-299)."""
+
+    def __init__(self, q_in: int, kv_in: int):
+        super().__init__()
+        self.q_proj = nn.Linear(q_in, q_in)
+        self.k_proj = nn.Linear(kv_in, q_in)
+        self.v_proj = nn.Linear(kv_in, q_in)
+        self.o_proj = nn.Linear(q_in, q_in)
+
+
+class _CrossAttention(nn.Module):
+    def __init__(self, q_in: int, kv_in: int):
+        super().__init__()
+        self.q_norm = nn.LayerNorm(q_in)
+        self.kv_norm = nn.LayerNorm(kv_in)
+        self.attention = _MHA(q_in, kv_in)
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, ch: int):
+        super().__init__()
+        self.norm = nn.LayerNorm(ch)
+        self.attention = _MHA(ch, ch)
+
+
+def _mlp(ch: int, widening: int) -> nn.Sequential:
+    return nn.Sequential(nn.LayerNorm(ch), nn.Linear(ch, widening * ch), nn.GELU(), nn.Linear(widening * ch, ch))
+
+
+class ContactPerceiver(nn.Module):
+    """Parameter container with the reference's names (cdm.py:88-153)."""
+
+    def __init__(self, arch_cfg, contact_dim: int, point_feat_dim: int, text_feat_dim: int, time_emb_dim: int) -> None:
+        super().__init__()
+        a = arch_cfg
+        if a.encoder_widening_factor != 1 or a.decoder_widening_factor != 1:
+            raise NotImplementedError("widening_factor != 1 is not used by any reference config")
+        self.point_pos_emb = a.point_pos_emb
+        self.dq, self.dkv = a.encoder_q_input_channels, a.encoder_kv_input_channels
+        assert a.decoder_q_input_channels == self.dkv and a.decoder_kv_input_channels == self.dq
+        self.enc_heads, self.dec_heads, self.n_self = a.encoder_num_heads, a.decoder_num_heads, a.encoder_self_attn_num_layers
+        self.feat_dim = contact_dim + point_feat_dim + (3 if self.point_pos_emb else 0)
+        self.language_adapter = nn.Linear(text_feat_dim, self.dq, bias=True)
+        self.time_embedding_adapter = nn.Linear(time_emb_dim, self.dq, bias=True)
+        self.encoder_adapter = nn.Linear(self.feat_dim, self.dkv, bias=True)
+        self.decoder_adapter = nn.Linear(self.dkv, self.dkv, bias=True)
+        self.encoder_cross_attn = nn.Sequential(_Wrap(_CrossAttention(self.dq, self.dkv)), _Wrap(_mlp(self.dq, 1)))
+        self.encoder_self_attn = nn.Sequential(*[nn.Sequential(_Wrap(_SelfAttention(self.dq)), _Wrap(_mlp(self.dq, 1)))
+                                                 for _ in range(self.n_self)])
+        self.decoder_cross_attn = nn.Sequential(_Wrap(_CrossAttention(self.dkv, self.dq)), _Wrap(_mlp(self.dkv, 1)))
 
 
 @Model.register()
-class CDM(nn.Module):
+class CDM(TextEncoderMixin, nn.Module):
     def __init__(self, cfg, *args, **kwargs):
         super().__init__()
-        raise NotImplementedError("CDM Perceiver HIP path not built yet")
+        self.device = kwargs["device"] if "device" in kwargs else "cpu"
+        self.contact_type = cfg.data_repr
+        self.contact_dim = cfg.input_feats
+        self.time_emb_dim = cfg.time_emb_dim
+        self.timestep_embedder = TimestepEmbedder(self.time_emb_dim, self.time_emb_dim, max_len=1000)
+        self.text_model_name = cfg.text_model.version
+        self.text_max_length = cfg.text_model.max_length
+        self.text_feat_dim, self.text_feat_type = lang_feat_dim_type(self.text_model_name)
+        self._init_text_encoder()
+        sm = cfg.scene_model
+        if not sm.use_scene_model:
+            self.point_feat_dim = 0
+        elif sm.use_openscene:
+            self.point_feat_dim = sm.point_feat_dim
+        else:
+            raise NotImplementedError("frozen PointTransformerSeg scene backbone (cdm.py:444-446,508) is a later row "
+                                      "(SURVEY.md section 8f-2); supply per-point features via use_openscene / c_pc_feat")
+        self.arch = cfg.arch
+        if self.arch != "Perceiver":
+            raise NotImplementedError(f"arch={self.arch!r}: only 'Perceiver' is selected by the reference's scripts")
+        self.arch_cfg = cfg.arch_perceiver
+        self.contact_model = ContactPerceiver(self.arch_cfg, contact_dim=self.contact_dim, point_feat_dim=self.point_feat_dim,
+                                              text_feat_dim=self.text_feat_dim, time_emb_dim=self.time_emb_dim)
+        self.contact_layer = nn.Linear(self.arch_cfg.last_dim, self.contact_dim, bias=True)
+        self._pack = None
+        self._ws = {}
+
+    # ------------------------------------------------------------------ weight pack
+    def _weights(self) -> ffi.CdmWeights:
+        ver = _param_version(self)
+        if self._pack is not None and self._pack[0] == ver:
+            return self._pack[1]
+        if self.contact_layer.weight.device.type != "cuda":
+            raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
+        keep: List[torch.Tensor] = []
+
+        def P(t):
+            t = ffi.f32c(t.detach())
+            keep.append(t)
+            return t.data_ptr()
+
+        def lin(dst, m: nn.Linear):
+            dst.w, dst.b = P(m.weight), P(m.bias)
+
+        def ln(dst, m: nn.LayerNorm):
+            dst.g, dst.b = P(m.weight), P(m.bias)
+
+        def mha(dst, m: _MHA):
+            lin(dst.q, m.q_proj); lin(dst.k, m.k_proj); lin(dst.v, m.v_proj); lin(dst.o, m.o_proj)
+
+        def mlp(dst, m: nn.Sequential):
+            ln(dst.norm, m[0]); lin(dst.fc1, m[1]); lin(dst.fc2, m[3])
+
+        cm = self.contact_model
+        w = ffi.CdmWeights()
+        w.contact_dim, w.feat_dim, w.dq, w.dkv = self.contact_dim, cm.feat_dim, cm.dq, cm.dkv
+        w.enc_heads, w.dec_heads, w.n_self = cm.enc_heads, cm.dec_heads, cm.n_self
+        w.text_dim, w.time_dim, w.n_timesteps = self.text_feat_dim, self.time_emb_dim, self.timestep_embedder.pe.shape[0]
+        w.time_table = P(self.timestep_embedder.table())
+        lin(w.language_adapter, cm.language_adapter); lin(w.time_embedding_adapter, cm.time_embedding_adapter)
+        lin(w.encoder_adapter, cm.encoder_adapter); lin(w.decoder_adapter, cm.decoder_adapter)
+        ca = cm.encoder_cross_attn[0].module
+        ln(w.enc_q_norm, ca.q_norm); ln(w.enc_kv_norm, ca.kv_norm); mha(w.enc_attn, ca.attention)
+        mlp(w.enc_mlp, cm.encoder_cross_attn[1].module)
+        for i, layer in enumerate(cm.encoder_self_attn):
+            sa = layer[0].module
+            ln(w.self_norm[i], sa.norm); mha(w.self_attn[i], sa.attention); mlp(w.self_mlp[i], layer[1].module)
+        da = cm.decoder_cross_attn[0].module
+        ln(w.dec_q_norm, da.q_norm); ln(w.dec_kv_norm, da.kv_norm); mha(w.dec_attn, da.attention)
+        mlp(w.dec_mlp, cm.decoder_cross_attn[1].module)
+        lin(w.contact_layer, self.contact_layer)
+        self._pack = (ver, w, keep)
+        return w
+
+    def _features(self, x, kwargs) -> torch.Tensor:
+        """cat(x_t, per-point features, xyz) exactly as cdm.py:495-505 + ContactPerceiver.forward :167-171."""
+        parts = [x]
+        if self.point_feat_dim > 0:
+            pf = kwargs["c_pc_feat"]
+            if self.point_feat_dim == 1 and pf.shape[-1] != 1:
+                raise NotImplementedError("openscene text-similarity feature (cdm.py:500-503)")
+            parts.append(pf.to(x))
+        if self.contact_model.point_pos_emb:
+            parts.append(kwargs["c_pc_xyz"].to(x))
+        return torch.cat(parts, dim=-1).contiguous()
+
+    def forward(self, x, timesteps, **kwargs):
+        """x [B, N, contact_dim], timesteps [B] -> predicted x_0 (same shape)."""
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("CDM backward is a later row (SURVEY.md section 8f-3); call under torch.no_grad() / eval()")
+        ffi.require_gpu(x)
+        with torch.no_grad():
+            lib = ffi.load()
+            x = ffi.f32c(x)
+            B, N, _ = x.shape
+            w = self._weights()
+            feat = self._features(x, kwargs)
+            text = ffi.f32c(self.encode_text(kwargs).to(x.device))
+            t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+            key = (B, N, str(x.device))
+            if key not in self._ws:
+                nbytes = lib.afm_cdm_workspace_bytes(C.byref(w), B, N)
+                if nbytes < 0:
+                    ffi.check(int(nbytes), "afm_cdm_workspace_bytes")
+                self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=x.device)}
+            ws = self._ws[key]
+            out = torch.empty_like(x)
+            ffi.check(lib.afm_cdm_forward(C.byref(w), feat.data_ptr(), x.data_ptr(), t.data_ptr(), text.data_ptr(), out.data_ptr(),
+                                          None, B, N, ws.data_ptr(), ws.numel(), ffi.stream_of(x)), "afm_cdm_forward")
+        return out

@@ -48,6 +48,34 @@ class PtAttentionArgs(C.Structure):
                                       "out_scale", "out_shift")] + [("relu", i32)]
 
 
+class Lin(C.Structure):
+    _fields_ = [("w", c_f32p), ("b", c_f32p)]
+
+
+class Ln(C.Structure):
+    _fields_ = [("g", c_f32p), ("b", c_f32p)]
+
+
+class MhaW(C.Structure):
+    _fields_ = [("q", Lin), ("k", Lin), ("v", Lin), ("o", Lin)]
+
+
+class MlpW(C.Structure):
+    _fields_ = [("norm", Ln), ("fc1", Lin), ("fc2", Lin)]
+
+
+class CdmWeights(C.Structure):
+    _fields_ = [
+        ("contact_dim", i32), ("feat_dim", i32), ("dq", i32), ("dkv", i32), ("enc_heads", i32), ("dec_heads", i32),
+        ("n_self", i32), ("text_dim", i32), ("time_dim", i32), ("n_timesteps", i32), ("time_table", c_f32p),
+        ("language_adapter", Lin), ("time_embedding_adapter", Lin), ("encoder_adapter", Lin), ("decoder_adapter", Lin),
+        ("enc_q_norm", Ln), ("enc_kv_norm", Ln), ("enc_attn", MhaW), ("enc_mlp", MlpW),
+        ("self_norm", Ln * 4), ("self_attn", MhaW * 4), ("self_mlp", MlpW * 4),
+        ("dec_q_norm", Ln), ("dec_kv_norm", Ln), ("dec_attn", MhaW), ("dec_mlp", MlpW),
+        ("contact_layer", Lin),
+    ]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", i64), ("total_ms", C.c_double), ("total_work", C.c_double)]
 
@@ -88,6 +116,9 @@ EXPORTS = {
     "afm_transition_down": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, C.c_void_p, i32, c_f32p, i32, c_f32p, c_f32p, c_f32p,
                                       i32, C.c_void_p]),
     "afm_pt_attention": (C.c_int, [C.POINTER(PtAttentionArgs), C.c_void_p]),
+    "afm_cdm_workspace_bytes": (i64, [C.POINTER(CdmWeights), i32, i32]),
+    "afm_cdm_forward": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, C.POINTER(DdpmArgs),
+                                  i32, i32, C.c_void_p, i64, C.c_void_p]),
     "afm_profile_enable": (C.c_int, [i32]),
     "afm_profile_read": (C.c_int, [C.POINTER(ProfileEntry), i32]),
     "afm_cmdm_workspace_bytes": (i64, [C.POINTER(CmdmWeights), i32, i32]),

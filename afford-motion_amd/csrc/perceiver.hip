@@ -1,0 +1,445 @@
+// CDM / ContactPerceiver denoiser (reference models/cdm.py:155-188,474-513; Perceiver-IO blocks of
+// models/modules.py:234-661).
+//
+// Per sample: N = 8192 points x 256 channels on the key/value side, but only TWO latent queries.
+//   latent_pre   : enc_q0 = [language_adapter(text), time_embedding_adapter(temb[t])], q = q_proj(LN(enc_q0)) and the
+//                  FOLDED queries u[i,h] = W_k[h]^T q[i,h] (16 vectors of 256), c[i,h] = q[i,h].b_k[h]
+//   (afm_linear) : enc_kv = encoder_adapter(feat)                                         [B*N, 256]
+//   enc_reduce   : flash-style reduction over the points: scores = LN_kv(enc_kv).u + c, online softmax,
+//                  s[i,h] = sum_n a_n LN_kv(enc_kv_n)  -> per-wave partials (m, l, s)   (K / V never exist)
+//   latent_post  : combine partials, o = W_v s + b_v, o_proj, residual, MLP, 2 self-attention layers on the 2
+//                  latents, then the decoder's folded keys/values G[j,h] = W_q[h]^T k[j,h], P[j,h] = W_o[:,h] v[j,h]
+//   (afm_linear) : dec_q0 = decoder_adapter(enc_kv)                                        [B*N, 256]
+//   dec_attend   : per point: qn = LN(dec_q0); 16 scores qn.G + cb; softmax over the 2 keys per head; attention
+//                  output = sum a P + b_o; + residual; LN of the MLP -> h1, z
+//   (afm_linear) : t = GELU(fc1 z), h2 = fc2 t + h1, out = contact_layer h2 (+ fused DDPM update)
+// The three dense 256x256 per-point layers are the FLOPs (103 of the 115 GFLOP/step folded work at B = 32)
+// and run on the f32-MFMA GEMM; the kernels here are streaming / latency kernels (one wave per point).
+#include "common.h"
+#include "profile.h"
+
+extern "C" int afm_linear(const afm_linear_args*, void*);
+
+namespace {
+
+constexpr int NSPLIT = 16;          // workgroups per sample in enc_reduce (x4 waves = 64 partials per sample)
+constexpr int NPART = NSPLIT * 4;
+constexpr int MAXD = 512;           // dq upper bound for the latent kernels' LDS vectors
+
+inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+// ---------------------------------------------------------------- small device helpers (latent kernels)
+// out[tok][o] = b[o] + sum_k W[o][k] * in[tok][k]   for 2 tokens; one wave per output row, coalesced row reads
+__device__ void matvec2(const float* __restrict__ W, const float* __restrict__ b, const float* in, float* out, int outd, int ind,
+                        int in_stride, int out_stride) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int o = wave; o < outd; o += nw) {
+        float a0 = 0.f, a1 = 0.f;
+        const float* wr = W + (int64_t)o * ind;
+        for (int k = lane; k < ind; k += 64) {
+            const float w = wr[k];
+            a0 += w * in[k];
+            a1 += w * in[in_stride + k];
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        if (lane == 0) {
+            const float bb = b ? b[o] : 0.f;
+            out[o] = a0 + bb; out[out_stride + o] = a1 + bb;
+        }
+    }
+}
+
+// LayerNorm of 2 tokens (waves 0 and 1), eps 1e-5
+__device__ void ln2(const float* in, float* out, afm_ln p, int dim, int stride) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2) {
+        const float* x = in + wave * stride;
+        float s = 0.f;
+        for (int k = lane; k < dim; k += 64) s += x[k];
+        const float mean = wave_sum(s) / dim;
+        float q = 0.f;
+        for (int k = lane; k < dim; k += 64) { const float d = x[k] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / dim + 1e-5f);
+        for (int k = lane; k < dim; k += 64) out[wave * stride + k] = (x[k] - mean) * rstd * p.g[k] + p.b[k];
+    }
+}
+
+// x <- x + fc2(GELU(fc1(LN(x))))  on 2 tokens (modules.py:651-661 + Residual :222-231); tmp1/tmp2 are [2][dim] scratch
+__device__ void mlp_residual2(float* x, float* tmp1, float* tmp2, const afm_mlp_w& m, int dim) {
+    ln2(x, tmp1, m.norm, dim, MAXD);
+    __syncthreads();
+    matvec2(m.fc1.w, m.fc1.b, tmp1, tmp2, dim, dim, MAXD, MAXD);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x) { float* p = tmp2 + (i / dim) * MAXD + (i % dim); *p = gelu_erf(*p); }
+    __syncthreads();
+    matvec2(m.fc2.w, m.fc2.b, tmp2, tmp1, dim, dim, MAXD, MAXD);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x) { const int o = (i / dim) * MAXD + (i % dim); x[o] += tmp1[o]; }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- latent_pre
+// grid B, block 512.  Outputs: lat0 [B][2][dq] (enc_q0), u [B][2*He][dkv], cu [B][2*He]
+__global__ __launch_bounds__(512) void latent_pre_kernel(const afm_cdm_weights w, const int64_t* __restrict__ t,
+                                                         const float* __restrict__ text_feat, float* __restrict__ lat0,
+                                                         float* __restrict__ u, float* __restrict__ cu) {
+    __shared__ float vin[2][MAXD], q0[2][MAXD], qn[2][MAXD], q[2][MAXD];
+    const int b = blockIdx.x, dq = w.dq, dkv = w.dkv, He = w.enc_heads, hd = dq / He;
+    int64_t ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= w.n_timesteps ? w.n_timesteps - 1 : ti);
+    for (int i = threadIdx.x; i < w.text_dim; i += blockDim.x) vin[0][i] = text_feat[(int64_t)b * w.text_dim + i];
+    for (int i = threadIdx.x; i < w.time_dim; i += blockDim.x) vin[1][i] = w.time_table[ti * w.time_dim + i];
+    __syncthreads();
+    {   // two different adapters for the two latents: one wave per output row, token 0 = text, token 1 = time
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int o = wave; o < dq; o += nw) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int k = lane; k < w.text_dim; k += 64) a0 += w.language_adapter.w[(int64_t)o * w.text_dim + k] * vin[0][k];
+            for (int k = lane; k < w.time_dim; k += 64) a1 += w.time_embedding_adapter.w[(int64_t)o * w.time_dim + k] * vin[1][k];
+            a0 = wave_sum(a0); a1 = wave_sum(a1);
+            if (lane == 0) { q0[0][o] = a0 + w.language_adapter.b[o]; q0[1][o] = a1 + w.time_embedding_adapter.b[o]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) lat0[(int64_t)b * 2 * dq + i] = q0[i / dq][i % dq];
+    ln2(&q0[0][0], &qn[0][0], w.enc_q_norm, dq, MAXD);
+    __syncthreads();
+    matvec2(w.enc_attn.q.w, w.enc_attn.q.b, &qn[0][0], &q[0][0], dq, dq, MAXD, MAXD);
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) q[i / dq][i % dq] *= scale;      // q * dp_scale (modules.py:330)
+    __syncthreads();
+    // folded queries: u[i,h][c] = sum_r W_k[h*hd + r][c] * q[i][h*hd + r]
+    const int nih = 2 * He;
+    for (int e = threadIdx.x; e < nih * dkv; e += blockDim.x) {
+        const int ih = e / dkv, c = e % dkv, i = ih / He, h = ih % He;
+        float acc = 0.f;
+        for (int r = 0; r < hd; ++r) acc += w.enc_attn.k.w[(int64_t)(h * hd + r) * dkv + c] * q[i][h * hd + r];
+        u[((int64_t)b * nih + ih) * dkv + c] = acc;
+    }
+    for (int ih = threadIdx.x; ih < nih; ih += blockDim.x) {
+        const int i = ih / He, h = ih % He;
+        float acc = 0.f;
+        for (int r = 0; r < hd; ++r) acc += w.enc_attn.k.b[h * hd + r] * q[i][h * hd + r];
+        cu[(int64_t)b * nih + ih] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- enc_reduce
+// grid (NSPLIT, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NQ = 16 folded queries.
+template <int NQ>
+__global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u,
+                                                         const float* __restrict__ cu, int N, float* __restrict__ pm,
+                                                         float* __restrict__ pl, float* __restrict__ pacc) {
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = lane * 4;
+    float uq[NQ][4], acc[NQ][4], m[NQ], l[NQ], cq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(u + ((int64_t)b * NQ + q) * 256 + c0);
+        uq[q][0] = v.x; uq[q][1] = v.y; uq[q][2] = v.z; uq[q][3] = v.w;
+        acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+        m[q] = -INFINITY; l[q] = 0.f; cq[q] = cu[(int64_t)b * NQ + q];
+    }
+    const float4 g = *reinterpret_cast<const float4*>(kvn.g + c0), be = *reinterpret_cast<const float4*>(kvn.b + c0);
+    const int per = (N + NSPLIT - 1) / NSPLIT;
+    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    for (int n = n0 + wave; n < n1; n += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + n) * 256 + c0);
+        const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
+        const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+        const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
+        const float y0 = d0 * rstd * g.x + be.x, y1 = d1 * rstd * g.y + be.y, y2 = d2 * rstd * g.z + be.z, y3 = d3 * rstd * g.w + be.w;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float s = wave_sum((y0 * uq[q][0] + y1 * uq[q][1]) + (y2 * uq[q][2] + y3 * uq[q][3])) + cq[q];
+            const float mn = fmaxf(m[q], s);
+            const float alpha = __expf(m[q] - mn), p = __expf(s - mn);
+            l[q] = l[q] * alpha + p;
+            m[q] = mn;
+            acc[q][0] = acc[q][0] * alpha + p * y0; acc[q][1] = acc[q][1] * alpha + p * y1;
+            acc[q][2] = acc[q][2] * alpha + p * y2; acc[q][3] = acc[q][3] * alpha + p * y3;
+        }
+    }
+    const int part = blockIdx.x * 4 + wave;
+    const int64_t base = ((int64_t)b * NPART + part) * NQ;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (lane == 0) { pm[base + q] = m[q]; pl[base + q] = l[q]; }
+        *reinterpret_cast<float4*>(pacc + (base + q) * 256 + c0) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    }
+}
+
+// ---------------------------------------------------------------- latent_post
+// grid B, block 512.  Output dec_lat [B][ G(2*Hd*dkv) | P(2*Hd*dkv) | cb(2*Hd) ]
+__global__ __launch_bounds__(512) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ lat0,
+                                                          const float* __restrict__ pm, const float* __restrict__ pl,
+                                                          const float* __restrict__ pacc, float* __restrict__ dec_lat) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, dq = w.dq, dkv = w.dkv, He = w.enc_heads, Hd = w.dec_heads;
+    const int nih = 2 * He, hd = dq / He, hdd = dkv / Hd;
+    float* s = sm;                          // [nih][dkv]
+    float* x = s + nih * dkv;               // [2][MAXD] latent state
+    float* t1 = x + 2 * MAXD;               // scratch vectors [2][MAXD] each
+    float* t2 = t1 + 2 * MAXD;
+    float* t3 = t2 + 2 * MAXD;
+    float* t4 = t3 + 2 * MAXD;
+    float* wq = t4 + 2 * MAXD;              // [nih][NPART] combine weights, later small scratch
+    // ---- combine the per-wave partials of enc_reduce
+    for (int e = threadIdx.x; e < nih; e += blockDim.x) {
+        float M = -INFINITY;
+        for (int p = 0; p < NPART; ++p) M = fmaxf(M, pm[((int64_t)b * NPART + p) * nih + e]);
+        float L = 0.f;
+        for (int p = 0; p < NPART; ++p) {
+            const float mm = pm[((int64_t)b * NPART + p) * nih + e];
+            const float ww = (mm == -INFINITY) ? 0.f : __expf(mm - M);
+            wq[e * NPART + p] = ww;
+            L += pl[((int64_t)b * NPART + p) * nih + e] * ww;
+        }
+        const float inv = 1.0f / L;
+        for (int p = 0; p < NPART; ++p) wq[e * NPART + p] *= inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nih * dkv; e += blockDim.x) {
+        const int ih = e / dkv, c = e % dkv;
+        float a = 0.f;
+        for (int p = 0; p < NPART; ++p) a += wq[ih * NPART + p] * pacc[(((int64_t)b * NPART + p) * nih + ih) * dkv + c];
+        s[e] = a;
+    }
+    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) x[(i / dq) * MAXD + (i % dq)] = lat0[(int64_t)b * 2 * dq + i];
+    __syncthreads();
+    {   // ---- attention output o[i][h*hd + r] = W_v[h*hd+r] . s[i,h] + b_v   -> t1
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int o = wave; o < dq; o += nw) {
+            const int h = o / hd;
+            float a0 = 0.f, a1 = 0.f;
+            for (int k = lane; k < dkv; k += 64) {
+                const float wv = w.enc_attn.v.w[(int64_t)o * dkv + k];
+                a0 += wv * s[(0 * He + h) * dkv + k];
+                a1 += wv * s[(1 * He + h) * dkv + k];
+            }
+            a0 = wave_sum(a0); a1 = wave_sum(a1);
+            if (lane == 0) { t1[o] = a0 + w.enc_attn.v.b[o]; t1[MAXD + o] = a1 + w.enc_attn.v.b[o]; }
+        }
+    }
+    __syncthreads();
+    matvec2(w.enc_attn.o.w, w.enc_attn.o.b, t1, t2, dq, dq, MAXD, MAXD);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) { const int o = (i / dq) * MAXD + (i % dq); x[o] += t2[o]; }
+    __syncthreads();
+    mlp_residual2(x, t1, t2, w.enc_mlp, dq);
+    // ---- self-attention block on the two latents (modules.py:544-648)
+    const float sc = 1.0f / sqrtf((float)hd);
+    for (int li = 0; li < w.n_self; ++li) {
+        ln2(x, t1, w.self_norm[li], dq, MAXD);
+        __syncthreads();
+        matvec2(w.self_attn[li].q.w, w.self_attn[li].q.b, t1, t2, dq, dq, MAXD, MAXD);
+        matvec2(w.self_attn[li].k.w, w.self_attn[li].k.b, t1, t3, dq, dq, MAXD, MAXD);
+        matvec2(w.self_attn[li].v.w, w.self_attn[li].v.b, t1, t4, dq, dq, MAXD, MAXD);
+        __syncthreads();
+        if (threadIdx.x < He * 4) {                      // (h, i, j) scores
+            const int h = threadIdx.x >> 2, i = (threadIdx.x >> 1) & 1, j = threadIdx.x & 1;
+            float a = 0.f;
+            for (int r = 0; r < hd; ++r) a += (t2[i * MAXD + h * hd + r] * sc) * t3[j * MAXD + h * hd + r];
+            wq[threadIdx.x] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x < He * 2) {                      // softmax over the 2 keys
+            const int base = threadIdx.x * 2;
+            const float a0 = wq[base], a1 = wq[base + 1], mx = fmaxf(a0, a1);
+            const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
+            wq[64 + base] = e0 * inv; wq[64 + base + 1] = e1 * inv;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * dq; e += blockDim.x) {
+            const int i = e / dq, c = e % dq, h = c / hd;
+            t1[i * MAXD + c] = wq[64 + (h * 2 + i) * 2 + 0] * t4[c] + wq[64 + (h * 2 + i) * 2 + 1] * t4[MAXD + c];
+        }
+        __syncthreads();
+        matvec2(w.self_attn[li].o.w, w.self_attn[li].o.b, t1, t2, dq, dq, MAXD, MAXD);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) { const int o = (i / dq) * MAXD + (i % dq); x[o] += t2[o]; }
+        __syncthreads();
+        mlp_residual2(x, t1, t2, w.self_mlp[li], dq);
+    }
+    // ---- decoder keys / values from the two latents, folded through W_q / W_o of the decoder attention
+    ln2(x, t1, w.dec_kv_norm, dq, MAXD);
+    __syncthreads();
+    matvec2(w.dec_attn.k.w, w.dec_attn.k.b, t1, t2, dkv, dq, MAXD, MAXD);      // kd [2][dkv]
+    matvec2(w.dec_attn.v.w, w.dec_attn.v.b, t1, t3, dkv, dq, MAXD, MAXD);      // vd [2][dkv]
+    __syncthreads();
+    const float scd = 1.0f / sqrtf((float)hdd);
+    const int njh = 2 * Hd;
+    float* G = dec_lat + (int64_t)b * (2 * njh * dkv + njh);
+    float* P = G + njh * dkv;
+    float* cb = P + njh * dkv;
+    for (int e = threadIdx.x; e < njh * dkv; e += blockDim.x) {
+        const int jh = e / dkv, c = e % dkv, j = jh / Hd, h = jh % Hd;
+        float a = 0.f, pp = 0.f;
+        for (int r = 0; r < hdd; ++r) {
+            a += w.dec_attn.q.w[(int64_t)(h * hdd + r) * dkv + c] * t2[j * MAXD + h * hdd + r];
+            pp += w.dec_attn.o.w[(int64_t)c * dkv + h * hdd + r] * t3[j * MAXD + h * hdd + r];
+        }
+        G[e] = a * scd;
+        P[e] = pp;
+    }
+    for (int jh = threadIdx.x; jh < njh; jh += blockDim.x) {
+        const int j = jh / Hd, h = jh % Hd;
+        float a = 0.f;
+        for (int r = 0; r < hdd; ++r) a += w.dec_attn.q.b[h * hdd + r] * t2[j * MAXD + h * hdd + r];
+        cb[jh] = a * scd;
+    }
+}
+
+// ---------------------------------------------------------------- dec_attend
+// grid (chunks, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NJH = 2 keys x 8 heads.
+template <int HD>
+__global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat,
+                                                         afm_ln qn, const float* __restrict__ bo, afm_ln mlpn, int N,
+                                                         float* __restrict__ h1, float* __restrict__ z) {
+    constexpr int NJH = 2 * HD;
+    __shared__ __attribute__((aligned(16))) float GP[2 * NJH * 256 + NJH];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane * 4;
+    const float* src = dec_lat + (int64_t)b * (2 * NJH * 256 + NJH);
+    for (int i = threadIdx.x; i < 2 * NJH * 256 + NJH; i += blockDim.x) GP[i] = src[i];
+    const float4 g1 = *reinterpret_cast<const float4*>(qn.g + c0), b1 = *reinterpret_cast<const float4*>(qn.b + c0);
+    const float4 g2 = *reinterpret_cast<const float4*>(mlpn.g + c0), b2 = *reinterpret_cast<const float4*>(mlpn.b + c0);
+    const float4 ob = *reinterpret_cast<const float4*>(bo + c0);
+    __syncthreads();
+    const float* G = GP;
+    const float* P = GP + NJH * 256;
+    const float* cb = P + NJH * 256;
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    for (int n = n0 + wave; n < n1; n += 4) {
+        const int64_t row = ((int64_t)b * N + n) * 256 + c0;
+        const float4 x = *reinterpret_cast<const float4*>(dec_q0 + row);
+        float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
+        float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+        float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
+        const float y0 = d0 * rstd * g1.x + b1.x, y1 = d1 * rstd * g1.y + b1.y, y2 = d2 * rstd * g1.z + b1.z, y3 = d3 * rstd * g1.w + b1.w;
+        float sc[NJH];
+#pragma unroll
+        for (int jh = 0; jh < NJH; ++jh) {
+            const float4 gv = *reinterpret_cast<const float4*>(G + jh * 256 + c0);
+            sc[jh] = wave_sum((y0 * gv.x + y1 * gv.y) + (y2 * gv.z + y3 * gv.w)) + cb[jh];
+        }
+        float o0 = ob.x, o1 = ob.y, o2 = ob.z, o3 = ob.w;
+#pragma unroll
+        for (int h = 0; h < HD; ++h) {                       // softmax over the two keys (j = 0, 1) of head h
+            const float a0 = sc[h], a1 = sc[HD + h], mx = fmaxf(a0, a1);
+            const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
+            const float4 p0 = *reinterpret_cast<const float4*>(P + h * 256 + c0);
+            const float4 p1 = *reinterpret_cast<const float4*>(P + (HD + h) * 256 + c0);
+            const float w0 = e0 * inv, w1 = e1 * inv;
+            o0 += w0 * p0.x + w1 * p1.x; o1 += w0 * p0.y + w1 * p1.y; o2 += w0 * p0.z + w1 * p1.z; o3 += w0 * p0.w + w1 * p1.w;
+        }
+        const float r0 = o0 + x.x, r1 = o1 + x.y, r2 = o2 + x.z, r3 = o3 + x.w;            // Residual adds the raw query
+        *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
+        mean = wave_sum((r0 + r1) + (r2 + r3)) * (1.0f / 256.0f);
+        d0 = r0 - mean; d1 = r1 - mean; d2 = r2 - mean; d3 = r3 - mean;
+        rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
+        *reinterpret_cast<float4*>(z + row) =
+            make_float4(d0 * rstd * g2.x + b2.x, d1 * rstd * g2.y + b2.y, d2 * rstd * g2.z + b2.z, d3 * rstd * g2.w + b2.w);
+    }
+}
+
+struct CdmWs {
+    float *enc_kv, *bufB, *h1, *z, *lat0, *u, *cu, *pm, *pl, *pacc, *dec_lat;
+    int64_t bytes;
+};
+
+CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
+    char* p = (char*)base;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { char* r = p ? p + off : nullptr; off += align256(n); return (float*)r; };
+    const int64_t M = (int64_t)B * N, nih = 2 * w.enc_heads, njh = 2 * w.dec_heads;
+    CdmWs s;
+    s.enc_kv = take(M * w.dkv * 4); s.bufB = take(M * w.dkv * 4); s.h1 = take(M * w.dkv * 4); s.z = take(M * w.dkv * 4);
+    s.lat0 = take((int64_t)B * 2 * w.dq * 4); s.u = take((int64_t)B * nih * w.dkv * 4); s.cu = take((int64_t)B * nih * 4);
+    s.pm = take((int64_t)B * NPART * nih * 4); s.pl = take((int64_t)B * NPART * nih * 4);
+    s.pacc = take((int64_t)B * NPART * nih * w.dkv * 4);
+    s.dec_lat = take((int64_t)B * (2 * njh * w.dkv + njh) * 4);
+    s.bytes = off;
+    return s;
+}
+
+int validate(const afm_cdm_weights* w, int B, int N) {
+    if (!w || B < 0 || N <= 0) return AFM_E_BADARG;
+    if (w->dkv != 256 || w->dq <= 0 || w->dq > MAXD || (w->dq & 3) || w->text_dim > MAXD || w->time_dim > MAXD) return AFM_E_UNSUPPORTED;
+    if (w->enc_heads != 8 || w->dec_heads != 8 || w->n_self < 0 || w->n_self > 4) return AFM_E_UNSUPPORTED;
+    if (w->feat_dim <= 0 || w->contact_dim <= 0 || !w->time_table || w->n_timesteps <= 0) return AFM_E_BADARG;
+    return 0;
+}
+
+#define AFM_TRY(expr) do { int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
+
+}  // namespace
+
+extern "C" int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N) {
+    if (validate(w, B, N) != 0) return AFM_E_BADARG;
+    return carve(*w, B, N, nullptr).bytes;
+}
+
+extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
+                               const float* text_feat, float* x0_out, const afm_ddpm_args* ddpm, int32_t B, int32_t N,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    AFM_TRY(validate(wp, B, N));
+    if (!feat || !t || !text_feat || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
+    if (ddpm && (!ddpm->x_next || !ddpm->c1 || !ddpm->c2 || !ddpm->sigma || !ddpm->noise || !x_t)) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    const afm_cdm_weights& w = *wp;
+    hipStream_t s = (hipStream_t)stream;
+    const CdmWs ws = carve(w, B, N, workspace);
+    if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
+    const int M = B * N, dkv = w.dkv;
+
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        hipLaunchKernelGGL(latent_pre_kernel, dim3(B), dim3(512), 0, s, w, t, text_feat, ws.lat0, ws.u, ws.cu);
+        AFM_CHECK_LAUNCH();
+    }
+    afm_linear_args a = {};
+    a.A = feat; a.lda = w.feat_dim; a.W = w.encoder_adapter.w; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
+    a.M = M; a.N = dkv; a.K = w.feat_dim; a.bias = w.encoder_adapter.b;
+    AFM_TRY(afm_linear(&a, s));
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        hipLaunchKernelGGL(enc_reduce_kernel<16>, dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, ws.u, ws.cu, N, ws.pm,
+                           ws.pl, ws.pacc);
+        AFM_CHECK_LAUNCH();
+        const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(512), lds, s, w, ws.lat0, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
+        AFM_CHECK_LAUNCH();
+    }
+    a = {};
+    a.A = ws.enc_kv; a.lda = dkv; a.W = w.decoder_adapter.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
+    a.M = M; a.N = dkv; a.K = dkv; a.bias = w.decoder_adapter.b;
+    AFM_TRY(afm_linear(&a, s));
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        int chunks = (N + 255) / 256;
+        if (chunks > 64) chunks = 64;
+        hipLaunchKernelGGL(dec_attend_kernel<8>, dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b,
+                           w.dec_mlp.norm, N, ws.h1, ws.z);
+        AFM_CHECK_LAUNCH();
+    }
+    a = {};
+    a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
+    a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
+    AFM_TRY(afm_linear(&a, s));
+    a = {};
+    a.A = ws.bufB; a.lda = dkv; a.W = w.dec_mlp.fc2.w; a.ldw = dkv; a.C = ws.z; a.ldc = dkv;
+    a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc2.b; a.residual = ws.h1; a.ldr = dkv;
+    AFM_TRY(afm_linear(&a, s));
+    a = {};
+    a.A = ws.z; a.lda = dkv; a.W = w.contact_layer.w; a.ldw = dkv; a.C = x0_out; a.ldc = w.contact_dim;
+    a.M = M; a.N = w.contact_dim; a.K = dkv; a.bias = w.contact_layer.b;
+    if (ddpm) {
+        a.ddpm_xt = x_t; a.ddpm_noise = ddpm->noise; a.ddpm_out = ddpm->x_next; a.ldx = w.contact_dim;
+        a.ddpm_c1 = ddpm->c1; a.ddpm_c2 = ddpm->c2; a.ddpm_sigma = ddpm->sigma; a.rows_per_sample = N;
+    }
+    AFM_TRY(afm_linear(&a, s));
+    return 0;
+}

@@ -239,6 +239,46 @@ int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_
                          int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CDM (`Perceiver`) denoiser forward.  Replaces CDM.forward + ContactPerceiver.forward
+ * (models/cdm.py:474-513,155-188) and the Perceiver-IO blocks it uses (models/modules.py:234-661:
+ * CrossAttentionLayer, SelfAttentionBlock, MLP, Residual; pad mask / rotary / kv-cache never used).
+ *
+ * The encoder has only TWO latent queries (text, time), so its cross-attention over the N points is
+ * evaluated without materialising K/V: q.(W_k x + b_k) = (W_k^T q).x + q.b_k and
+ * sum_n a_n (W_v x_n + b_v) = W_v (sum_n a_n x_n) + b_v (fp re-association only); the decoder's
+ * two-key attention folds the same way.  The dense per-point layers (decoder adapter, MLP) run on afm_linear.
+ *
+ * All weights are the reference's tensors (state-dict names in the comments, prefix `contact_model.`).
+ */
+typedef struct { const float* w; const float* b; } afm_lin;                 /* nn.Linear weight [out,in], bias [out] */
+typedef struct { const float* g; const float* b; } afm_ln;                  /* nn.LayerNorm weight, bias             */
+typedef struct { afm_lin q, k, v, o; } afm_mha_w;                          /* attention.{q,k,v,o}_proj               */
+typedef struct { afm_ln norm; afm_lin fc1, fc2; } afm_mlp_w;               /* MLP: module.0 (LN), .1, .3              */
+typedef struct {
+    int32_t contact_dim;       /* input_feats (6)                                                  */
+    int32_t feat_dim;          /* encoder_adapter in_features = contact_dim + point_feat_dim + 3   */
+    int32_t dq, dkv;           /* encoder_q_input_channels (512), encoder_kv_input_channels (256)  */
+    int32_t enc_heads, dec_heads, n_self;   /* 8, 8, encoder_self_attn_num_layers (2)              */
+    int32_t text_dim, time_dim, n_timesteps;
+    const float* time_table;   /* [n_timesteps, time_dim]: TimestepEmbedder output for every t     */
+    afm_lin language_adapter, time_embedding_adapter, encoder_adapter, decoder_adapter;
+    afm_ln enc_q_norm, enc_kv_norm; afm_mha_w enc_attn; afm_mlp_w enc_mlp;          /* encoder_cross_attn.{0,1}.module */
+    afm_ln self_norm[4]; afm_mha_w self_attn[4]; afm_mlp_w self_mlp[4];             /* encoder_self_attn.{l}.{0,1}.module */
+    afm_ln dec_q_norm, dec_kv_norm; afm_mha_w dec_attn; afm_mlp_w dec_mlp;          /* decoder_cross_attn.{0,1}.module */
+    afm_lin contact_layer;     /* [contact_dim, dkv]                                               */
+} afm_cdm_weights;
+
+int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
+
+/* One denoiser evaluation (+ optional fused DDPM update, same afm_ddpm_args as the CMDM).
+ *   feat [B,N,feat_dim] = cat(x_t, (point features), xyz) as cdm.py:167-171 builds it; x_t itself is feat[..., :contact_dim]
+ *   (needed separately, contiguous [B,N,contact_dim], only for the DDPM update); t [B] int64; text_feat [B,text_dim];
+ *   x0_out [B,N,contact_dim] (may be NULL when ddpm != NULL). */
+int afm_cdm_forward(const afm_cdm_weights* w, const float* feat, const float* x_t, const int64_t* t,
+                    const float* text_feat, float* x0_out, const afm_ddpm_args* ddpm, int32_t B, int32_t N,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Opt-in profiler (measurement only, no reference counterpart): when enabled, every kernel launch of
  * this library is bracketed by HIP events on its own stream.  afm_profile_read synchronises, returns
  * per-kernel totals since the last read (work = algorithmic FLOPs, or bytes for streaming kernels) and

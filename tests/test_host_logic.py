@@ -97,6 +97,23 @@ def test_cmdm_state_dict_keys_match_reference():
     assert sum(p.numel() for p in model.parameters()) == 12204111
 
 
+def test_cdm_state_dict_keys_match_reference():
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.scene_model.use_scene_model=False",
+                                                           "model.input_feats=6"])
+    model = base.create_model(cfg, device="cpu")
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    want = {}
+    for line in open(os.path.join(GOLDEN, "cdm_state_dict_keys.txt")):
+        k, shp = line.strip().split(" ", 1)
+        want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
+    assert have == want
+    assert sum(p.numel() for p in model.parameters()) == 5431814
+    for bad in (["model.arch=MLP"], ["model.scene_model.use_scene_model=True", "task.dataset.use_openscene=False"]):
+        with pytest.raises(NotImplementedError):                             # unbuilt variants fail loudly
+            base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver"] + bad),
+                              device="cpu")
+
+
 def test_product_path_refuses_cpu_tensors():
     model = base.create_model(_cmdm_cfg(), device="cpu").eval()
     with pytest.raises(ffi.AfmError):
