@@ -28,6 +28,47 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Reduce NV per-lane values over the 64 lanes with a halving butterfly: NV/2 + NV/4 + ... + 1 exchanges, then
+// log2(64/NV) plain steps (17 cross-lane ops for NV = 16 instead of 96).  On return v[0] of lane l holds the wave
+// total of value index  owner(l) = sum_b bit(l, 5-b) * (NV >> (b+1))  (NV = 16: bits 5,4,3,2 -> 8,4,2,1).
+template <int N>
+__device__ __forceinline__ void halve_step(float* v, int lane, int mask) {
+    const bool up = (lane & mask) != 0;
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) {
+        const float keep = up ? v[q + N / 2] : v[q];
+        const float send = up ? v[q] : v[q + N / 2];
+        v[q] = keep + __shfl_xor(send, mask);
+    }
+}
+template <int NV>
+__device__ __forceinline__ float wave_reduce_multi(float (&v)[NV], int lane) {
+    static_assert(NV == 16 || NV == 8 || NV == 4, "NV");
+    if (NV == 16) { halve_step<16>(v, lane, 32); halve_step<8>(v, lane, 16); halve_step<4>(v, lane, 8); halve_step<2>(v, lane, 4);
+                    v[0] += __shfl_xor(v[0], 2); v[0] += __shfl_xor(v[0], 1); }
+    if (NV == 8) { halve_step<8>(v, lane, 32); halve_step<4>(v, lane, 16); halve_step<2>(v, lane, 8);
+                   v[0] += __shfl_xor(v[0], 4); v[0] += __shfl_xor(v[0], 2); v[0] += __shfl_xor(v[0], 1); }
+    if (NV == 4) { halve_step<4>(v, lane, 32); halve_step<2>(v, lane, 16);
+                   v[0] += __shfl_xor(v[0], 8); v[0] += __shfl_xor(v[0], 4); v[0] += __shfl_xor(v[0], 2); v[0] += __shfl_xor(v[0], 1); }
+    return v[0];
+}
+// lane that owns value index q after wave_reduce_multi<NV> (its low bits are free: use the lowest such lane)
+template <int NV>
+__device__ __forceinline__ constexpr int multi_owner_lane(int q) {
+    return NV == 16 ? ((q >> 3) & 1) * 32 + ((q >> 2) & 1) * 16 + ((q >> 1) & 1) * 8 + (q & 1) * 4
+         : NV == 8  ? ((q >> 2) & 1) * 32 + ((q >> 1) & 1) * 16 + (q & 1) * 8
+                    : ((q >> 1) & 1) * 32 + (q & 1) * 16;
+}
+template <int NV>
+__device__ __forceinline__ int multi_owned_index(int lane) {
+    return NV == 16 ? ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
+         : NV == 8  ? ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)
+                    : ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
+}
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {      // src_lane must be wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -29,22 +29,31 @@ constexpr int MAXD = 512;           // dq upper bound for the latent kernels' LD
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 // ---------------------------------------------------------------- small device helpers (latent kernels)
-// out[tok][o] = b[o] + sum_k W[o][k] * in[tok][k]   for 2 tokens; one wave per output row, coalesced row reads
+// out[tok][o] = b[o] + sum_k W[o][k] * in[tok][k]   for 2 tokens.  Each wave takes 4 output rows at a time
+// (8 independent accumulators, float4 weight loads in flight for all 4 rows) and finishes them with ONE
+// 8-value halving reduction.  ind must be a multiple of 4; W rows 16-byte aligned.
 __device__ void matvec2(const float* __restrict__ W, const float* __restrict__ b, const float* in, float* out, int outd, int ind,
                         int in_stride, int out_stride) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int o = wave; o < outd; o += nw) {
-        float a0 = 0.f, a1 = 0.f;
-        const float* wr = W + (int64_t)o * ind;
-        for (int k = lane; k < ind; k += 64) {
-            const float w = wr[k];
-            a0 += w * in[k];
-            a1 += w * in[in_stride + k];
+    for (int o0 = wave * 4; o0 < outd; o0 += nw * 4) {
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = 0.f;
+        for (int k = lane * 4; k < ind; k += 256) {
+            const float4 x0 = *reinterpret_cast<const float4*>(in + k);
+            const float4 x1 = *reinterpret_cast<const float4*>(in + in_stride + k);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = min(o0 + r, outd - 1);
+                const float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)o * ind + k);
+                a[r] += (wv.x * x0.x + wv.y * x0.y) + (wv.z * x0.z + wv.w * x0.w);
+                a[4 + r] += (wv.x * x1.x + wv.y * x1.y) + (wv.z * x1.z + wv.w * x1.w);
+            }
         }
-        a0 = wave_sum(a0); a1 = wave_sum(a1);
-        if (lane == 0) {
-            const float bb = b ? b[o] : 0.f;
-            out[o] = a0 + bb; out[out_stride + o] = a1 + bb;
+        const float tot = wave_reduce_multi<8>(a, lane);
+        if ((lane & 7) == 0) {                       // one lane per owned index: idx = tok * 4 + r
+            const int idx = multi_owned_index<8>(lane), tok = idx >> 2, o = o0 + (idx & 3);
+            if (o < outd) out[tok * out_stride + o] = tot + (b ? b[o] : 0.f);
         }
     }
 }
@@ -79,8 +88,8 @@ __device__ void mlp_residual2(float* x, float* tmp1, float* tmp2, const afm_mlp_
 }
 
 // ---------------------------------------------------------------- latent_pre
-// grid B, block 512.  Outputs: lat0 [B][2][dq] (enc_q0), u [B][2*He][dkv], cu [B][2*He]
-__global__ __launch_bounds__(512) void latent_pre_kernel(const afm_cdm_weights w, const int64_t* __restrict__ t,
+// grid B, block 1024.  Outputs: lat0 [B][2][dq] (enc_q0), u [B][2*He][dkv], cu [B][2*He]
+__global__ __launch_bounds__(1024) void latent_pre_kernel(const afm_cdm_weights w, const int64_t* __restrict__ t,
                                                          const float* __restrict__ text_feat, float* __restrict__ lat0,
                                                          float* __restrict__ u, float* __restrict__ cu) {
     __shared__ float vin[2][MAXD], q0[2][MAXD], qn[2][MAXD], q[2][MAXD];
@@ -133,34 +142,44 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
                                                          float* __restrict__ pl, float* __restrict__ pacc) {
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0 = lane * 4;
-    float uq[NQ][4], acc[NQ][4], m[NQ], l[NQ], cq[NQ];
+    float uq[NQ][4], acc[NQ][4], m[NQ], l[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(u + ((int64_t)b * NQ + q) * 256 + c0);
         uq[q][0] = v.x; uq[q][1] = v.y; uq[q][2] = v.z; uq[q][3] = v.w;
         acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
-        m[q] = -INFINITY; l[q] = 0.f; cq[q] = cu[(int64_t)b * NQ + q];
+        m[q] = -INFINITY; l[q] = 0.f;
     }
     const float4 g = *reinterpret_cast<const float4*>(kvn.g + c0), be = *reinterpret_cast<const float4*>(kvn.b + c0);
     const int per = (N + NSPLIT - 1) / NSPLIT;
     const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    // each lane OWNS one folded query (index multi_owned_index<16>(lane)) for the online-softmax state;
+    // the per-point (alpha, p) of all 16 queries are then broadcast with v_readlane
+    const int own = multi_owned_index<NQ>(lane);
+    float m_own = -INFINITY, l_own = 0.f, c_own = cu[(int64_t)b * NQ + own];
     for (int n = n0 + wave; n < n1; n += 4) {
         const float4 x = *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + n) * 256 + c0);
         const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
         const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
         const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
         const float y0 = d0 * rstd * g.x + be.x, y1 = d1 * rstd * g.y + be.y, y2 = d2 * rstd * g.z + be.z, y3 = d3 * rstd * g.w + be.w;
+        float d[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) d[q] = (y0 * uq[q][0] + y1 * uq[q][1]) + (y2 * uq[q][2] + y3 * uq[q][3]);
+        const float sown = wave_reduce_multi<NQ>(d, lane) + c_own;
+        const float mn = fmaxf(m_own, sown);
+        const float alpha = __expf(m_own - mn), pw = __expf(sown - mn);
+        l_own = l_own * alpha + pw;
+        m_own = mn;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const float s = wave_sum((y0 * uq[q][0] + y1 * uq[q][1]) + (y2 * uq[q][2] + y3 * uq[q][3])) + cq[q];
-            const float mn = fmaxf(m[q], s);
-            const float alpha = __expf(m[q] - mn), p = __expf(s - mn);
-            l[q] = l[q] * alpha + p;
-            m[q] = mn;
-            acc[q][0] = acc[q][0] * alpha + p * y0; acc[q][1] = acc[q][1] * alpha + p * y1;
-            acc[q][2] = acc[q][2] * alpha + p * y2; acc[q][3] = acc[q][3] * alpha + p * y3;
+            const float aq = lane_bcast(alpha, multi_owner_lane<NQ>(q)), pq = lane_bcast(pw, multi_owner_lane<NQ>(q));
+            acc[q][0] = acc[q][0] * aq + pq * y0; acc[q][1] = acc[q][1] * aq + pq * y1;
+            acc[q][2] = acc[q][2] * aq + pq * y2; acc[q][3] = acc[q][3] * aq + pq * y3;
         }
     }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { m[q] = lane_bcast(m_own, multi_owner_lane<NQ>(q)); l[q] = lane_bcast(l_own, multi_owner_lane<NQ>(q)); }
     const int part = blockIdx.x * 4 + wave;
     const int64_t base = ((int64_t)b * NPART + part) * NQ;
 #pragma unroll
@@ -171,8 +190,8 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- latent_post
-// grid B, block 512.  Output dec_lat [B][ G(2*Hd*dkv) | P(2*Hd*dkv) | cb(2*Hd) ]
-__global__ __launch_bounds__(512) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ lat0,
+// grid B, block 1024.  Output dec_lat [B][ G(2*Hd*dkv) | P(2*Hd*dkv) | cb(2*Hd) ]
+__global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ lat0,
                                                           const float* __restrict__ pm, const float* __restrict__ pl,
                                                           const float* __restrict__ pacc, float* __restrict__ dec_lat) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(512) void latent_post_kernel(const afm_cdm_weights 
 
 // ---------------------------------------------------------------- dec_attend
 // grid (chunks, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NJH = 2 keys x 8 heads.
-template <int HD>
+template <int HD>      // HD must be 8 (NJH = 16 scores per point)
 __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat,
                                                          afm_ln qn, const float* __restrict__ bo, afm_ln mlpn, int N,
                                                          float* __restrict__ h1, float* __restrict__ z) {
@@ -322,17 +341,20 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
             const float4 gv = *reinterpret_cast<const float4*>(G + jh * 256 + c0);
-            sc[jh] = wave_sum((y0 * gv.x + y1 * gv.y) + (y2 * gv.z + y3 * gv.w)) + cb[jh];
+            sc[jh] = (y0 * gv.x + y1 * gv.y) + (y2 * gv.z + y3 * gv.w);
         }
+        // lane owns score jh = j*HD + h (j <-> lane bit 5); its softmax partner (other key, same head) is lane ^ 32
+        const float s_own = wave_reduce_multi<NJH>(sc, lane) + cb[multi_owned_index<NJH>(lane)];
+        const float s_oth = __shfl_xor(s_own, 32);
+        const float mx = fmaxf(s_own, s_oth);
+        const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
+        const float w_own = e_own / (e_own + e_oth);
         float o0 = ob.x, o1 = ob.y, o2 = ob.z, o3 = ob.w;
 #pragma unroll
-        for (int h = 0; h < HD; ++h) {                       // softmax over the two keys (j = 0, 1) of head h
-            const float a0 = sc[h], a1 = sc[HD + h], mx = fmaxf(a0, a1);
-            const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
-            const float4 p0 = *reinterpret_cast<const float4*>(P + h * 256 + c0);
-            const float4 p1 = *reinterpret_cast<const float4*>(P + (HD + h) * 256 + c0);
-            const float w0 = e0 * inv, w1 = e1 * inv;
-            o0 += w0 * p0.x + w1 * p1.x; o1 += w0 * p0.y + w1 * p1.y; o2 += w0 * p0.z + w1 * p1.z; o3 += w0 * p0.w + w1 * p1.w;
+        for (int jh = 0; jh < NJH; ++jh) {
+            const float wj = lane_bcast(w_own, multi_owner_lane<NJH>(jh));
+            const float4 pv = *reinterpret_cast<const float4*>(P + jh * 256 + c0);
+            o0 += wj * pv.x; o1 += wj * pv.y; o2 += wj * pv.z; o3 += wj * pv.w;
         }
         const float r0 = o0 + x.x, r1 = o1 + x.y, r2 = o2 + x.z, r3 = o3 + x.w;            // Residual adds the raw query
         *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
@@ -396,7 +418,7 @@ extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, con
 
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        hipLaunchKernelGGL(latent_pre_kernel, dim3(B), dim3(512), 0, s, w, t, text_feat, ws.lat0, ws.u, ws.cu);
+        hipLaunchKernelGGL(latent_pre_kernel, dim3(B), dim3(1024), 0, s, w, t, text_feat, ws.lat0, ws.u, ws.cu);
         AFM_CHECK_LAUNCH();
     }
     afm_linear_args a = {};
@@ -410,7 +432,7 @@ extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, con
         AFM_CHECK_LAUNCH();
         const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(512), lds, s, w, ws.lat0, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
+        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, ws.lat0, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
         AFM_CHECK_LAUNCH();
     }
     a = {};
