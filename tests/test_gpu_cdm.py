@@ -72,3 +72,31 @@ def test_full_size_vs_oracle():
     want = dr.cdm_forward(sh.weights(sh.cdm()), x, t, text, xyz)
     got = m(x.to(dev()), t.to(dev()), c_text_feat=text.to(dev()), c_pc_xyz=xyz.to(dev()))
     report("CDM forward N=8192 vs oracle", got, want, 2e-4)
+
+
+def test_two_stage_adm_to_amdm_pipeline_vs_oracle():
+    """BASELINE configs[4] in miniature: ADM loop -> in-HBM glue -> AMDM loop (contact encoder included),
+    explicit noise, vs the CPU oracle doing the same two loops."""
+    from afm.pipeline import two_stage_sample
+    from oracle import denoiser_ref as dr, diffusion_ref as df, shapes as sh
+    from test_gpu_cmdm import cmdm_cfg
+    B, N, L = 2, 1024, 12
+    adm = create_model(cdm_cfg(num_points=N), device=dev()); load_named_weights(adm); adm = adm.to(dev()).eval()
+    amdm = create_model(cmdm_cfg(num_points=N), device=dev()); load_named_weights(amdm); amdm = amdm.to(dev()).eval()
+    d_adm = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="3"))
+    d_amdm = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="3"))
+    text, xyz = synth.text_feature(B), synth.scene_cloud(B, N, seed=61)
+    a_xT, a_nz = synth.gaussian("p_axT", (B, N, 6)) * 0.3 + 0.5, [synth.gaussian(f"p_anz{j}", (B, N, 6)) * 0.1 for j in range(3)]
+    m_xT, m_nz = synth.gaussian("p_mxT", (B, L, 263)), [synth.gaussian(f"p_mnz{j}", (B, L, 263)) for j in range(3)]
+    out = two_stage_sample(adm, d_adm, amdm, d_amdm, text_feat=text.to(dev()), xyz=xyz.to(dev()), frames=L, sigma=0.8,
+                           adm_noise=dict(x_T=a_xT.to(dev()), steps=torch.stack(a_nz).to(dev())),
+                           amdm_noise=dict(x_T=m_xT.to(dev()), steps=torch.stack(m_nz).to(dev())))
+    sd_a, sd_m = sh.weights(sh.cdm()), sh.weights(sh.cmdm())
+    c_ref = df.p_sample_loop(df.Schedule(500, "cosine", "3"), lambda x, t, **k: dr.cdm_forward(sd_a, x, t, text, xyz), a_xT, a_nz)
+    cond_ref = torch.exp(-0.5 * (torch.sqrt(-2 * torch.log(c_ref.clamp(1e-20, 1.0)) * 0.8 ** 2)) ** 2 / 0.8 ** 2)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    m_ref = df.p_sample_loop(df.Schedule(1000, "cosine", "3"),
+                             lambda x, t, **k: dr.cmdm_forward(sd_m, x, t, text, xyz, cond_ref, mask), m_xT, m_nz)
+    report("two-stage: ADM contact", out["contact"], c_ref, 1e-4)
+    report("two-stage: glue", out["cond"], cond_ref, 1e-4)
+    report("two-stage: AMDM motion", out["motion"], m_ref, 1e-3)
