@@ -29,33 +29,34 @@ struct RowMap {
     }
 };
 
-// One thread stages ROWS/32 rows x 4 consecutive k of a [ROWS x 32] tile.  Row base pointers are
-// computed ONCE (row remap / clamping out of the K loop); rows past the matrix edge are clamped to the
-// last valid row (their products are never stored), only the K tail is zero-filled.
+// One thread stages ROWS/32 rows x 4 consecutive k of a [ROWS x 32] tile.  Row base pointers are computed ONCE
+// (row remap / clamping out of the K loop); rows past the matrix edge are clamped to the last valid row (their
+// products are never stored).  Loads are UNCONDITIONAL (k clamped into the row) so the compiler emits no
+// zero-init + branch + `s_waitcnt vmcnt(0)` in front of them; the K tail is zero-filled when the tile is
+// written to LDS (store_tile), i.e. after the wait that the data needs anyway.
 template <int ROWS, bool VEC>
 __device__ __forceinline__ void load_tile(const float* const (&rowp)[ROWS / 32], int k, int K, float4 (&reg)[ROWS / 32]) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* p = rowp[i] + k;
         if (VEC) {
-            if (k < K) v = *reinterpret_cast<const float4*>(p);
+            reg[i] = *reinterpret_cast<const float4*>(rowp[i] + min(k, K - 4));
         } else {
-            if (k + 0 < K) v.x = p[0];
-            if (k + 1 < K) v.y = p[1];
-            if (k + 2 < K) v.z = p[2];
-            if (k + 3 < K) v.w = p[3];
+            const float* p = rowp[i];
+            reg[i] = make_float4(p[min(k, K - 1)], p[min(k + 1, K - 1)], p[min(k + 2, K - 1)], p[min(k + 3, K - 1)]);
         }
-        reg[i] = v;
     }
 }
 
 template <int ROWS>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const float4 (&reg)[ROWS / 32]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const float4 (&reg)[ROWS / 32], int k, int K) {
     const int c4 = tid & 7, r0 = tid >> 3;
+    const bool k0 = k < K, k1 = k + 1 < K, k2 = k + 2 < K, k3 = k + 3 < K;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i)
-        *reinterpret_cast<float4*>(lds + (r0 + 32 * i) * LDK + c4 * 4) = reg[i];
+    for (int i = 0; i < ROWS / 32; ++i) {
+        float4 v = reg[i];
+        v.x = k0 ? v.x : 0.f; v.y = k1 ? v.y : 0.f; v.z = k2 ? v.z : 0.f; v.w = k3 ? v.w : 0.f;
+        *reinterpret_cast<float4*>(lds + (r0 + 32 * i) * LDK + c4 * 4) = v;
+    }
 }
 
 // epilogue math for one output element (compact: instantiated once, looped over, never unrolled 64x)
@@ -67,6 +68,46 @@ __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int
     if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
     if (p.act_post) v = apply_act(v, p.act_post);
     return v;
+}
+
+// Shared epilogue: the accumulators were staged in `lds` as a [BM][BN + 4] tile; stream rows out with 16-byte accesses.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const float* lds, int bm, int bn, int tid) {
+    constexpr int LDC = BN + 4;
+    const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
+    const int col0 = bn * BN;
+    const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && !p.ddpm_out &&
+                         ((((uintptr_t)p.C) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) | ((uintptr_t)p.scale) | ((uintptr_t)p.rowtab)) & 15) == 0;
+    if (vec_out) {
+        for (int e = tid; e < BM * (BN / 4); e += 256) {
+            const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
+            const int grow = bm * BM + row, gcol = col0 + cq;
+            if (grow >= p.M || gcol >= p.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(lds + row * LDC + cq);
+            const int64_t orow = cmap(grow);
+            if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + gcol); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+            if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+            if (p.residual) { const float4 t = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.rowtab) { const float4 t = *reinterpret_cast<const float4*>(p.rowtab + (int64_t)(grow % p.rowtab_period) * p.N + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.act_post) { v.x = apply_act(v.x, p.act_post); v.y = apply_act(v.y, p.act_post); v.z = apply_act(v.z, p.act_post); v.w = apply_act(v.w, p.act_post); }
+            *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
+        }
+    } else {
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int row = e / BN, c = e % BN;
+            const int grow = bm * BM + row, gcol = col0 + c;
+            if (grow >= p.M || gcol >= p.N) continue;
+            const int64_t orow = cmap(grow);
+            const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol);
+            if (p.C) p.C[orow * p.ldc + gcol] = v;
+            if (p.ddpm_out) {
+                const int b = grow / p.rows_per_sample;
+                const int64_t ix = orow * p.ldx + gcol;
+                p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
+            }
+        }
+    }
 }
 
 template <int BM, int BN, bool VEC>
@@ -107,20 +148,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM / 32], rw[BN / 32];
+    // Register ring of depth 2: the loads of K-tile kt+2 are issued before the MFMAs of tile kt, so a load has
+    // TWO tiles of MFMA time (>= 2 x 1024 cycles per resident wave) to land before its s_waitcnt (one tile was not
+    // enough under load: SQ_WAIT_ANY 23 %).  The loop is unrolled by two so both register sets keep static names.
+    float4 ra0[BM / 32], rw0[BN / 32], ra1[BM / 32], rw1[BN / 32];
     const int nk = (p.K + BK - 1) / BK;
-    load_tile<BM, VEC>(arow, c4 * 4, p.K, ra);
-    load_tile<BN, VEC>(wrow, c4 * 4, p.K, rw);
-    store_tile<BM>(lds, tid, ra);
-    store_tile<BN>(lds + BM * LDK, tid, rw);
+    const int kc = c4 * 4;
+    load_tile<BM, VEC>(arow, kc, p.K, ra0);
+    load_tile<BN, VEC>(wrow, kc, p.K, rw0);
+    if (nk > 1) {
+        load_tile<BM, VEC>(arow, BK + kc, p.K, ra1);
+        load_tile<BN, VEC>(wrow, BK + kc, p.K, rw1);
+    }
+    store_tile<BM>(lds, tid, ra0, kc, p.K);
+    store_tile<BN>(lds + BM * LDK, tid, rw0, kc, p.K);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            load_tile<BM, VEC>(arow, (kt + 1) * BK + c4 * 4, p.K, ra);
-            load_tile<BN, VEC>(wrow, (kt + 1) * BK + c4 * 4, p.K, rw);
-        }
+    auto compute = [&](int cur) {
         const float* a_base = lds + cur * STAGE + (wm * (BM / 2) + r32) * LDK + hh * 16;
         const float* w_base = lds + cur * STAGE + BM * LDK + (wn * (BN / 2) + r32) * LDK + hh * 16;
 #pragma unroll
@@ -144,9 +188,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(af[tm][e], bf[tn][e], acc[tm][tn]);
         }
+    };
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        // ---- even tile kt: reads stage 0; set 0 is free (stored), refill it with tile kt+2; then store set 1 (tile kt+1)
+        if (kt + 2 < nk) {
+            load_tile<BM, VEC>(arow, (kt + 2) * BK + kc, p.K, ra0);
+            load_tile<BN, VEC>(wrow, (kt + 2) * BK + kc, p.K, rw0);
+        }
+        compute(0);
         if (kt + 1 < nk) {
-            store_tile<BM>(lds + (cur ^ 1) * STAGE, tid, ra);
-            store_tile<BN>(lds + (cur ^ 1) * STAGE + BM * LDK, tid, rw);
+            store_tile<BM>(lds + STAGE, tid, ra1, (kt + 1) * BK + kc, p.K);
+            store_tile<BN>(lds + STAGE + BM * LDK, tid, rw1, (kt + 1) * BK + kc, p.K);
+        }
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // ---- odd tile kt+1: reads stage 1; refill set 1 with tile kt+3; then store set 0 (tile kt+2)
+        if (kt + 3 < nk) {
+            load_tile<BM, VEC>(arow, (kt + 3) * BK + kc, p.K, ra1);
+            load_tile<BN, VEC>(wrow, (kt + 3) * BK + kc, p.K, rw1);
+        }
+        compute(1);
+        if (kt + 2 < nk) {
+            store_tile<BM>(lds, tid, ra0, (kt + 2) * BK + kc, p.K);
+            store_tile<BN>(lds + BM * LDK, tid, rw0, (kt + 2) * BK + kc, p.K);
         }
         __syncthreads();
     }
@@ -164,40 +229,135 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
                 lds[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
     __syncthreads();
 
-    const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
-    const int col0 = bn * BN;
-    const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && !p.ddpm_out &&
-                         ((((uintptr_t)p.C) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) | ((uintptr_t)p.scale) | ((uintptr_t)p.rowtab)) & 15) == 0;
-    if (vec_out) {
-        for (int e = tid; e < BM * (BN / 4); e += 256) {
-            const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
-            const int grow = bm * BM + row, gcol = col0 + cq;
-            if (grow >= p.M || gcol >= p.N) continue;
-            float4 v = *reinterpret_cast<const float4*>(lds + row * LDC + cq);
-            const int64_t orow = cmap(grow);
-            if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + gcol); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
-            if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
-            if (p.residual) { const float4 t = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            if (p.rowtab) { const float4 t = *reinterpret_cast<const float4*>(p.rowtab + (int64_t)(grow % p.rowtab_period) * p.N + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            if (p.act_post) { v.x = apply_act(v.x, p.act_post); v.y = apply_act(v.y, p.act_post); v.z = apply_act(v.z, p.act_post); v.w = apply_act(v.w, p.act_post); }
-            *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
-        }
-    } else {
-        for (int e = tid; e < BM * BN; e += 256) {
-            const int row = e / BN, c = e % BN;
-            const int grow = bm * BM + row, gcol = col0 + c;
-            if (grow >= p.M || gcol >= p.N) continue;
-            const int64_t orow = cmap(grow);
-            const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol);
-            if (p.C) p.C[orow * p.ldc + gcol] = v;
-            if (p.ddpm_out) {
-                const int b = grow / p.rows_per_sample;
-                const int64_t ix = orow * p.ldx + gcol;
-                p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
-            }
-        }
+    gemm_epilogue<BM, BN>(p, lds, bm, bn, tid);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// DMA variant (K % 32 == 0, 16-byte aligned operands): operands go global -> LDS directly (global_load_lds_dwordx4),
+// no staging VGPRs, no ds_write, no K-tail select; a 3-stage LDS ring gives a true prefetch distance of two K-tiles
+// with hand-counted `s_waitcnt vmcnt(N)` and ONE raw s_barrier per K-tile (the compiler's own waits cannot express
+// "all but the newest tile").  Measured on the ingredient microbenchmark (tools/mfma_ingredients.hip): register-staged
+// loads cost 150 -> 125-130 TF and the K-tail select another 8 %.
+// LDS image: [row][8 chunks of 16 B] UNPADDED (the DMA destination is wave-uniform base + lane*16, so the image must be
+// lane-linear); bank conflicts are removed by an XOR swizzle applied on the SOURCE address: LDS slot (row, c) holds
+// logical chunk c ^ (row & 7), and a reader of logical chunk q reads slot q ^ (row & 7) (same involution both sides).
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p, int nbm, int nbn) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int STAGE = (BM + BN) * BK;            // floats per stage: A tile then W tile, 32 floats per row
+    constexpr int LDC = BN + 4;
+    constexpr int LDS_FLOATS = (3 * STAGE > BM * LDC) ? 3 * STAGE : BM * LDC;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int nblk = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int c8 = tid & 7, r0 = tid >> 3;           // this thread's (row-in-pass, 16-byte slot) of every DMA pass
+
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off};
+    // per-pass source pointers with the swizzle folded in: slot c8 of row r receives logical chunk c8 ^ (r & 7)
+    const float* asrc[BM / 32];
+    const float* wsrc[BN / 32];
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+        const int r = r0 + 32 * i;
+        asrc[i] = p.A + amap(min(bm * BM + r, p.M - 1)) * p.lda + ((c8 ^ (r & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+        const int r = r0 + 32 * i;
+        wsrc[i] = p.W + (int64_t)min(bn * BN + r, p.N - 1) * p.ldw + ((c8 ^ (r & 7)) << 2);
+    }
+    const int wave_off = __builtin_amdgcn_readfirstlane(wave) * 256;     // floats: 8 rows x 32 per wave per pass
+    auto issue = [&](int kt, int stage) {
+        float* a_dst = lds + stage * STAGE + wave_off;
+        float* w_dst = lds + stage * STAGE + BM * BK + wave_off;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) glds16(asrc[i] + kt * BK, a_dst + i * 32 * BK);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) glds16(wsrc[i] + kt * BK, w_dst + i * 32 * BK);
+    };
+    constexpr int PER_TILE = BM / 32 + BN / 32;      // DMA instructions per thread per K-tile
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    const int swz = r32 & 7;
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's part of tile kt has landed once at most one newer tile (kt+1) is still in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // every wave's part landed; every wave is done with tile kt-1
+        if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);       // (kt+2) % 3 == (stage + 2) % 3
+        // LDS operand reads are issued through inline asm: with an LDS-DMA in flight hipcc otherwise guards every
+        // ds_read with `s_waitcnt vmcnt(0)` (it cannot prove the DMA target does not alias), which drains the ring.
+        // All reads of the K-tile are issued up front (they return in order), then each MFMA group waits for exactly
+        // the reads it needs (counted lgkmcnt) - guide section 5.7 forms (ii)/(iii), rule 18 (sched_barrier after a wait).
+        const unsigned a_addr = (unsigned)((stage * STAGE + (wm * (BM / 2) + r32) * BK) * 4);
+        const unsigned w_addr = (unsigned)((stage * STAGE + BM * BK + (wn * (BN / 2) + r32) * BK) * 4);
+        f32x4 af[4][TM], bf[4][TN];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned slot = (unsigned)((((hh * 4 + j) ^ swz) << 2) * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[j][i]) : "v"(a_addr + slot + (unsigned)(i * 32 * BK * 4)));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bf[j][i]) : "v"(w_addr + slot + (unsigned)(i * 32 * BK * 4)));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // reads still allowed in flight after group j's operands arrived: (3 - j) * (TM + TN)
+            if (j == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * (TM + TN)) : "memory");
+            if (j == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+            if (j == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(1 * (TM + TN)) : "memory");
+            if (j == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[j][i]));
+#pragma unroll
+            for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(bf[j][i]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(af[j][tm][e], bf[j][tn][e], acc[tm][tn]);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    __syncthreads();                                  // all waves done reading the last stage before it is reused
+
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
+    __syncthreads();
+    gemm_epilogue<BM, BN>(p, lds, bm, bn, tid);
 }
 
 template <int BM, int BN>
@@ -205,7 +365,10 @@ int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     dim3 grid(nbm * nbn), block(256);
     AfmProf prof(BM == 128 ? AFM_PROF_GEMM128 : (BN == 128 ? AFM_PROF_GEMM64x128 : AFM_PROF_GEMM64), 2.0 * a.M * a.N * a.K, s);
-    if (vec)
+    static const bool no_dma = getenv("AFM_GEMM_NO_DMA") != nullptr;      // tuning knob
+    if (vec && (a.K % BK) == 0 && !no_dma)
+        hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN>), grid, block, 0, s, a, nbm, nbn);
+    else if (vec)
         hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, true>), grid, block, 0, s, a, nbm, nbn);
     else
         hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, false>), grid, block, 0, s, a, nbm, nbn);
