@@ -15,6 +15,7 @@
 extern "C" int afm_linear(const afm_linear_args*, void*);
 extern "C" int afm_mha_fwd(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_layernorm(const float*, const float*, const float*, float*, int64_t, int32_t, float, void*);
+extern "C" int afm_layernorm_rows(const float*, const float*, const float*, float*, int64_t, int32_t, float, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_randn(float*, int32_t, int64_t, uint64_t, int64_t, int32_t, void*);
 
 namespace {
@@ -116,20 +117,29 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.M = M; a.N = 3 * d; a.K = d; a.bias = lw.in_proj_b;
         AFM_TRY(afm_linear(&a, s));
         AFM_TRY(afm_mha_fwd(ws.qkv, keymask, ws.att, B, T, w.heads, d / w.heads, s));
+        // After the LAST layer only the L motion tokens of each sample are read (motion_layer, cmdm.py:169,195), and
+        // everything after the attention is row-local: run it on the B*L motion rows only (token rows gathered /
+        // scattered by the row maps; the other rows of tmp/x1/y keep stale values nobody reads).
+        const bool last = (li == w.n_layers - 1);
+        const int rows = last ? B * L : M;
+        const int g = last ? L : 0, gs = last ? T : 0, go = last ? 1 + w.n_cond : 0;
         a = {};
         a.A = ws.att; a.lda = d; a.W = lw.out_proj_w; a.ldw = d; a.C = ws.tmp; a.ldc = d;
-        a.M = M; a.N = d; a.K = d; a.bias = lw.out_proj_b; a.residual = X; a.ldr = d;
+        a.M = rows; a.N = d; a.K = d; a.bias = lw.out_proj_b; a.residual = X; a.ldr = d;
+        a.a_grp = g; a.a_stride = gs; a.a_off = go; a.c_grp = g; a.c_stride = gs; a.c_off = go;
         AFM_TRY(afm_linear(&a, s));
-        AFM_TRY(afm_layernorm(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, M, d, 1e-5f, s));
+        AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, rows, d, 1e-5f, g, gs, go, s));
         a = {};
         a.A = ws.x1; a.lda = d; a.W = lw.lin1_w; a.ldw = d; a.C = ws.hid; a.ldc = w.ff;
-        a.M = M; a.N = w.ff; a.K = d; a.bias = lw.lin1_b; a.act = AFM_ACT_GELU;
+        a.M = rows; a.N = w.ff; a.K = d; a.bias = lw.lin1_b; a.act = AFM_ACT_GELU;
+        a.a_grp = g; a.a_stride = gs; a.a_off = go;                       // hid is written compactly [rows, ff]
         AFM_TRY(afm_linear(&a, s));
         a = {};
         a.A = ws.hid; a.lda = w.ff; a.W = lw.lin2_w; a.ldw = w.ff; a.C = ws.tmp; a.ldc = d;
-        a.M = M; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.x1; a.ldr = d;
+        a.M = rows; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.x1; a.ldr = d;
+        a.c_grp = g; a.c_stride = gs; a.c_off = go;
         AFM_TRY(afm_linear(&a, s));
-        AFM_TRY(afm_layernorm(ws.tmp, lw.norm2_w, lw.norm2_b, ws.y, M, d, 1e-5f, s));
+        AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm2_w, lw.norm2_b, ws.y, rows, d, 1e-5f, g, gs, go, s));
         X = ws.y;
     }
 

@@ -9,10 +9,11 @@ namespace {
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        int64_t rows, int dim, float eps) {
+                                                        int64_t rows, int dim, float eps, int grp, int stride, int off) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (grp) row = (row / grp) * stride + off + row % grp;          // logical row -> strided token row
     const float* xp = x + row * dim;
     float4 v[MAXV];
     float sum = 0.f;
@@ -128,18 +129,26 @@ extern "C" int afm_masked_mse(const float* target, const float* pred, const uint
     return 0;
 }
 
+extern "C" int afm_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
+                                  float eps, int32_t grp, int32_t stride, int32_t off, void* stream);
+
 extern "C" int afm_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
                              float eps, void* stream) {
+    return afm_layernorm_rows(x, gamma, beta, y, rows, dim, eps, 0, 0, 0, stream);
+}
+
+extern "C" int afm_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
+                                  float eps, int32_t grp, int32_t stride, int32_t off, void* stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || dim <= 0 || (dim & 3)) return AFM_E_BADARG;
     if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return AFM_E_BADARG;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256), grid((unsigned)((rows + 3) / 4));
     AfmProf prof(AFM_PROF_LN, 8.0 * rows * dim, s);
-    if (dim <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
-    else if (dim <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
-    else if (dim <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
-    else if (dim <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps);
+    if (dim <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps, grp, stride, off);
+    else if (dim <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps, grp, stride, off);
+    else if (dim <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps, grp, stride, off);
+    else if (dim <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, rows, dim, eps, grp, stride, off);
     else return AFM_E_UNSUPPORTED;
     AFM_CHECK_LAUNCH();
     return 0;

@@ -90,6 +90,10 @@ int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out,
  * (norm1 / norm2 of the encoder layer, modules.py:399-400,459,653).  In-place allowed. */
 int afm_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                   int64_t rows, int32_t dim, float eps, void* stream);
+/* Same, on a strided subset of token rows: logical row r -> (r / grp) * stride + off + r % grp of both x and y
+ * (grp == 0: identity).  Used to normalise only the L motion tokens of each sample in the last encoder layer. */
+int afm_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
+                       float eps, int32_t grp, int32_t stride, int32_t off, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * afm_ddpm_step: x_next = (c1[b] * x0 + c2[b] * x_t) + sigma[b] * noise, evaluated WITHOUT fma
