@@ -110,6 +110,7 @@ class CDM(TextEncoderMixin, nn.Module):
                                               text_feat_dim=self.text_feat_dim, time_emb_dim=self.time_emb_dim)
         self.contact_layer = nn.Linear(self.arch_cfg.last_dim, self.contact_dim, bias=True)
         self._pack = None
+        self._text_cache = None
         self._ws = {}
 
     # ------------------------------------------------------------------ weight pack
@@ -143,7 +144,6 @@ class CDM(TextEncoderMixin, nn.Module):
         w.contact_dim, w.feat_dim, w.dq, w.dkv = self.contact_dim, cm.feat_dim, cm.dq, cm.dkv
         w.enc_heads, w.dec_heads, w.n_self = cm.enc_heads, cm.dec_heads, cm.n_self
         w.text_dim, w.time_dim, w.n_timesteps = self.text_feat_dim, self.time_emb_dim, self.timestep_embedder.pe.shape[0]
-        w.time_table = P(self.timestep_embedder.table())
         lin(w.language_adapter, cm.language_adapter); lin(w.time_embedding_adapter, cm.time_embedding_adapter)
         lin(w.encoder_adapter, cm.encoder_adapter); lin(w.decoder_adapter, cm.decoder_adapter)
         ca = cm.encoder_cross_attn[0].module
@@ -156,8 +156,34 @@ class CDM(TextEncoderMixin, nn.Module):
         ln(w.dec_q_norm, da.q_norm); ln(w.dec_kv_norm, da.kv_norm); mha(w.dec_attn, da.attention)
         mlp(w.dec_mlp, cm.decoder_cross_attn[1].module)
         lin(w.contact_layer, self.contact_layer)
+        # time latent of EVERY timestep (depends on t only): off the per-step path
+        table = ffi.f32c(self.timestep_embedder.table())
+        q0, u, cu = self._latent_tokens(w, 1, table)
+        keep += [table, q0, u, cu]
+        w.time_q0, w.time_u, w.time_cu = q0.data_ptr(), u.data_ptr(), cu.data_ptr()
         self._pack = (ver, w, keep)
+        self._text_cache = None
         return w
+
+    def _latent_tokens(self, w, which: int, rows: torch.Tensor):
+        """afm_cdm_latent_tokens: rows [n, in_dim] -> (q0 [n,dq], u [n,He,dkv], cu [n,He])."""
+        n, cm = rows.shape[0], self.contact_model
+        q0 = torch.empty(n, cm.dq, device=rows.device); u = torch.empty(n, cm.enc_heads, cm.dkv, device=rows.device)
+        cu = torch.empty(n, cm.enc_heads, device=rows.device)
+        ffi.check(ffi.load().afm_cdm_latent_tokens(C.byref(w), which, rows.data_ptr(), n, q0.data_ptr(), u.data_ptr(), cu.data_ptr(),
+                                                   ffi.stream_of(rows)), "afm_cdm_latent_tokens")
+        return q0, u, cu
+
+    def _text_latent(self, w, kwargs, device):
+        """Text latent of every sample; cached while the same text tensor / strings are passed (the sampling loop)."""
+        tf = kwargs.get("c_text_feat")
+        key = (tf.data_ptr(), tf._version, tuple(tf.shape)) if isinstance(tf, torch.Tensor) else tuple(kwargs["c_text"])
+        if getattr(self, "_text_cache", None) is not None and self._text_cache[0] == key:
+            return self._text_cache[1]
+        text = ffi.f32c(self.encode_text(kwargs).to(device))
+        lat = self._latent_tokens(w, 0, text)
+        self._text_cache = (key, lat, text)
+        return lat
 
     def _features(self, x, kwargs) -> torch.Tensor:
         """cat(x_t, per-point features, xyz) exactly as cdm.py:495-505 + ContactPerceiver.forward :167-171."""
@@ -182,7 +208,7 @@ class CDM(TextEncoderMixin, nn.Module):
             B, N, _ = x.shape
             w = self._weights()
             feat = self._features(x, kwargs)
-            text = ffi.f32c(self.encode_text(kwargs).to(x.device))
+            tq0, tu, tcu = self._text_latent(w, kwargs, x.device)
             t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
             key = (B, N, str(x.device))
             if key not in self._ws:
@@ -192,6 +218,7 @@ class CDM(TextEncoderMixin, nn.Module):
                 self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=x.device)}
             ws = self._ws[key]
             out = torch.empty_like(x)
-            ffi.check(lib.afm_cdm_forward(C.byref(w), feat.data_ptr(), x.data_ptr(), t.data_ptr(), text.data_ptr(), out.data_ptr(),
-                                          None, B, N, ws.data_ptr(), ws.numel(), ffi.stream_of(x)), "afm_cdm_forward")
+            ffi.check(lib.afm_cdm_forward(C.byref(w), feat.data_ptr(), x.data_ptr(), t.data_ptr(), tq0.data_ptr(), tu.data_ptr(),
+                                          tcu.data_ptr(), out.data_ptr(), None, B, N, ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
+                      "afm_cdm_forward")
         return out

@@ -67,7 +67,8 @@ class MlpW(C.Structure):
 class CdmWeights(C.Structure):
     _fields_ = [
         ("contact_dim", i32), ("feat_dim", i32), ("dq", i32), ("dkv", i32), ("enc_heads", i32), ("dec_heads", i32),
-        ("n_self", i32), ("text_dim", i32), ("time_dim", i32), ("n_timesteps", i32), ("time_table", c_f32p),
+        ("n_self", i32), ("text_dim", i32), ("time_dim", i32), ("n_timesteps", i32),
+        ("time_q0", c_f32p), ("time_u", c_f32p), ("time_cu", c_f32p),
         ("language_adapter", Lin), ("time_embedding_adapter", Lin), ("encoder_adapter", Lin), ("decoder_adapter", Lin),
         ("enc_q_norm", Ln), ("enc_kv_norm", Ln), ("enc_attn", MhaW), ("enc_mlp", MlpW),
         ("self_norm", Ln * 4), ("self_attn", MhaW * 4), ("self_mlp", MlpW * 4),
@@ -118,8 +119,9 @@ EXPORTS = {
                                       i32, C.c_void_p]),
     "afm_pt_attention": (C.c_int, [C.POINTER(PtAttentionArgs), C.c_void_p]),
     "afm_cdm_workspace_bytes": (i64, [C.POINTER(CdmWeights), i32, i32]),
-    "afm_cdm_forward": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, C.POINTER(DdpmArgs),
-                                  i32, i32, C.c_void_p, i64, C.c_void_p]),
+    "afm_cdm_forward": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                  C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p]),
+    "afm_cdm_latent_tokens": (C.c_int, [C.POINTER(CdmWeights), i32, c_f32p, i32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "afm_profile_enable": (C.c_int, [i32]),
     "afm_profile_read": (C.c_int, [C.POINTER(ProfileEntry), i32]),
     "afm_cmdm_workspace_bytes": (i64, [C.POINTER(CmdmWeights), i32, i32]),

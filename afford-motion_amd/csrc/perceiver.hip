@@ -2,8 +2,8 @@
 // models/modules.py:234-661).
 //
 // Per sample: N = 8192 points x 256 channels on the key/value side, but only TWO latent queries.
-//   latent_pre   : enc_q0 = [language_adapter(text), time_embedding_adapter(temb[t])], q = q_proj(LN(enc_q0)) and the
-//                  FOLDED queries u[i,h] = W_k[h]^T q[i,h] (16 vectors of 256), c[i,h] = q[i,h].b_k[h]
+//   latent_token : (hoisted: once per text / once per timestep) enc_q0 row = adapter(input), q = q_proj(LN(enc_q0)) and the
+//                  FOLDED queries u[h] = W_k[h]^T q[h] (8 vectors of 256 per latent), c[h] = q[h].b_k[h]
 //   (afm_linear) : enc_kv = encoder_adapter(feat)                                         [B*N, 256]
 //   enc_reduce   : flash-style reduction over the points: scores = LN_kv(enc_kv).u + c, online softmax,
 //                  s[i,h] = sum_n a_n LN_kv(enc_kv_n)  -> per-wave partials (m, l, s)   (K / V never exist)
@@ -87,65 +87,59 @@ __device__ void mlp_residual2(float* x, float* tmp1, float* tmp2, const afm_mlp_
     __syncthreads();
 }
 
-// ---------------------------------------------------------------- latent_pre
-// grid B, block 1024.  Outputs: lat0 [B][2][dq] (enc_q0), u [B][2*He][dkv], cu [B][2*He]
-__global__ __launch_bounds__(1024) void latent_pre_kernel(const afm_cdm_weights w, const int64_t* __restrict__ t,
-                                                         const float* __restrict__ text_feat, float* __restrict__ lat0,
-                                                         float* __restrict__ u, float* __restrict__ cu) {
-    __shared__ float vin[2][MAXD], q0[2][MAXD], qn[2][MAXD], q[2][MAXD];
-    const int b = blockIdx.x, dq = w.dq, dkv = w.dkv, He = w.enc_heads, hd = dq / He;
-    int64_t ti = t[b];
-    ti = ti < 0 ? 0 : (ti >= w.n_timesteps ? w.n_timesteps - 1 : ti);
-    for (int i = threadIdx.x; i < w.text_dim; i += blockDim.x) vin[0][i] = text_feat[(int64_t)b * w.text_dim + i];
-    for (int i = threadIdx.x; i < w.time_dim; i += blockDim.x) vin[1][i] = w.time_table[ti * w.time_dim + i];
+// ---------------------------------------------------------------- latent_token
+// One latent token per workgroup (grid = number of tokens, block 1024): adapter -> enc_q0 row, LN_q, q_proj, dp_scale,
+// and the folded queries u[h][c] = sum_r W_k[h*hd + r][c] q[h*hd + r], cu[h] = q_h . b_k[h].
+// Both latents are per-step invariant given their input: the text token depends on the sample's text only (once per
+// sampling run) and the time token on t only (tabulated for every timestep when the weights are packed), so this
+// kernel is OFF the per-step path; the per-step kernels gather its outputs.
+__global__ __launch_bounds__(1024) void latent_token_kernel(const afm_cdm_weights w, const float* __restrict__ in, int in_dim,
+                                                           afm_lin adapter, float* __restrict__ q0_out, float* __restrict__ u_out,
+                                                           float* __restrict__ cu_out) {
+    __shared__ __attribute__((aligned(16))) float vin[2][MAXD], q0[2][MAXD], qn[2][MAXD], q[2][MAXD];
+    const int tok = blockIdx.x, dq = w.dq, dkv = w.dkv, He = w.enc_heads, hd = dq / He;
+    for (int i = threadIdx.x; i < MAXD; i += blockDim.x) { vin[0][i] = i < in_dim ? in[(int64_t)tok * in_dim + i] : 0.f; vin[1][i] = 0.f; }
     __syncthreads();
-    {   // two different adapters for the two latents: one wave per output row, token 0 = text, token 1 = time
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int o = wave; o < dq; o += nw) {
-            float a0 = 0.f, a1 = 0.f;
-            for (int k = lane; k < w.text_dim; k += 64) a0 += w.language_adapter.w[(int64_t)o * w.text_dim + k] * vin[0][k];
-            for (int k = lane; k < w.time_dim; k += 64) a1 += w.time_embedding_adapter.w[(int64_t)o * w.time_dim + k] * vin[1][k];
-            a0 = wave_sum(a0); a1 = wave_sum(a1);
-            if (lane == 0) { q0[0][o] = a0 + w.language_adapter.b[o]; q0[1][o] = a1 + w.time_embedding_adapter.b[o]; }
-        }
-    }
+    matvec2(adapter.w, adapter.b, &vin[0][0], &q0[0][0], dq, in_dim, MAXD, MAXD);      // row 1 is a dummy token
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) lat0[(int64_t)b * 2 * dq + i] = q0[i / dq][i % dq];
+    for (int i = threadIdx.x; i < dq; i += blockDim.x) q0_out[(int64_t)tok * dq + i] = q0[0][i];
     ln2(&q0[0][0], &qn[0][0], w.enc_q_norm, dq, MAXD);
     __syncthreads();
     matvec2(w.enc_attn.q.w, w.enc_attn.q.b, &qn[0][0], &q[0][0], dq, dq, MAXD, MAXD);
     __syncthreads();
-    const float scale = 1.0f / sqrtf((float)hd);
-    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) q[i / dq][i % dq] *= scale;      // q * dp_scale (modules.py:330)
-    __syncthreads();
-    // folded queries: u[i,h][c] = sum_r W_k[h*hd + r][c] * q[i][h*hd + r]
-    const int nih = 2 * He;
-    for (int e = threadIdx.x; e < nih * dkv; e += blockDim.x) {
-        const int ih = e / dkv, c = e % dkv, i = ih / He, h = ih % He;
+    const float scale = 1.0f / sqrtf((float)hd);                                          // q * dp_scale (modules.py:330)
+    for (int e = threadIdx.x; e < He * dkv; e += blockDim.x) {
+        const int h = e / dkv, c = e % dkv;
         float acc = 0.f;
-        for (int r = 0; r < hd; ++r) acc += w.enc_attn.k.w[(int64_t)(h * hd + r) * dkv + c] * q[i][h * hd + r];
-        u[((int64_t)b * nih + ih) * dkv + c] = acc;
+        for (int r = 0; r < hd; ++r) acc += w.enc_attn.k.w[(int64_t)(h * hd + r) * dkv + c] * (q[0][h * hd + r] * scale);
+        u_out[((int64_t)tok * He + h) * dkv + c] = acc;
     }
-    for (int ih = threadIdx.x; ih < nih; ih += blockDim.x) {
-        const int i = ih / He, h = ih % He;
+    for (int h = threadIdx.x; h < He; h += blockDim.x) {
         float acc = 0.f;
-        for (int r = 0; r < hd; ++r) acc += w.enc_attn.k.b[h * hd + r] * q[i][h * hd + r];
-        cu[(int64_t)b * nih + ih] = acc;
+        for (int r = 0; r < hd; ++r) acc += w.enc_attn.k.b[h * hd + r] * (q[0][h * hd + r] * scale);
+        cu_out[(int64_t)tok * He + h] = acc;
     }
 }
 
 // ---------------------------------------------------------------- enc_reduce
 // grid (NSPLIT, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NQ = 16 folded queries.
 template <int NQ>
-__global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u,
-                                                         const float* __restrict__ cu, int N, float* __restrict__ pm,
-                                                         float* __restrict__ pl, float* __restrict__ pacc) {
+__global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
+                                                         const float* __restrict__ cu_text, const float* __restrict__ u_time,
+                                                         const float* __restrict__ cu_time, const int64_t* __restrict__ t, int n_t,
+                                                         int N, float* __restrict__ pm, float* __restrict__ pl,
+                                                         float* __restrict__ pacc) {
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0 = lane * 4;
+    int64_t ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
+    // folded query q < NQ/2: text latent of this sample; q >= NQ/2: time latent of timestep t[b]
+    auto uptr = [&](int q) { return q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256; };
+    auto cval = [&](int q) { return q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]; };
     float uq[NQ][4], acc[NQ][4], m[NQ], l[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(u + ((int64_t)b * NQ + q) * 256 + c0);
+        const float4 v = *reinterpret_cast<const float4*>(uptr(q) + c0);
         uq[q][0] = v.x; uq[q][1] = v.y; uq[q][2] = v.z; uq[q][3] = v.w;
         acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
         m[q] = -INFINITY; l[q] = 0.f;
@@ -156,7 +150,7 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
     // each lane OWNS one folded query (index multi_owned_index<16>(lane)) for the online-softmax state;
     // the per-point (alpha, p) of all 16 queries are then broadcast with v_readlane
     const int own = multi_owned_index<NQ>(lane);
-    float m_own = -INFINITY, l_own = 0.f, c_own = cu[(int64_t)b * NQ + own];
+    float m_own = -INFINITY, l_own = 0.f, c_own = cval(own);
     for (int n = n0 + wave; n < n1; n += 4) {
         const float4 x = *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + n) * 256 + c0);
         const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
@@ -191,7 +185,8 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
 
 // ---------------------------------------------------------------- latent_post
 // grid B, block 1024.  Output dec_lat [B][ G(2*Hd*dkv) | P(2*Hd*dkv) | cb(2*Hd) ]
-__global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ lat0,
+__global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ q0_text,
+                                                          const float* __restrict__ q0_time, const int64_t* __restrict__ t,
                                                           const float* __restrict__ pm, const float* __restrict__ pl,
                                                           const float* __restrict__ pacc, float* __restrict__ dec_lat) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -225,7 +220,11 @@ __global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights
         for (int p = 0; p < NPART; ++p) a += wq[ih * NPART + p] * pacc[(((int64_t)b * NPART + p) * nih + ih) * dkv + c];
         s[e] = a;
     }
-    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) x[(i / dq) * MAXD + (i % dq)] = lat0[(int64_t)b * 2 * dq + i];
+    {
+        int64_t ti = t[b];
+        ti = ti < 0 ? 0 : (ti >= w.n_timesteps ? w.n_timesteps - 1 : ti);
+        for (int i = threadIdx.x; i < dq; i += blockDim.x) { x[i] = q0_text[(int64_t)b * dq + i]; x[MAXD + i] = q0_time[ti * dq + i]; }
+    }
     __syncthreads();
     {   // ---- attention output o[i][h*hd + r] = W_v[h*hd+r] . s[i,h] + b_v   -> t1
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 }
 
 struct CdmWs {
-    float *enc_kv, *bufB, *h1, *z, *lat0, *u, *cu, *pm, *pl, *pacc, *dec_lat;
+    float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat;
     int64_t bytes;
 };
 
@@ -378,7 +377,6 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     const int64_t M = (int64_t)B * N, nih = 2 * w.enc_heads, njh = 2 * w.dec_heads;
     CdmWs s;
     s.enc_kv = take(M * w.dkv * 4); s.bufB = take(M * w.dkv * 4); s.h1 = take(M * w.dkv * 4); s.z = take(M * w.dkv * 4);
-    s.lat0 = take((int64_t)B * 2 * w.dq * 4); s.u = take((int64_t)B * nih * w.dkv * 4); s.cu = take((int64_t)B * nih * 4);
     s.pm = take((int64_t)B * NPART * nih * 4); s.pl = take((int64_t)B * NPART * nih * 4);
     s.pacc = take((int64_t)B * NPART * nih * w.dkv * 4);
     s.dec_lat = take((int64_t)B * (2 * njh * w.dkv + njh) * 4);
@@ -390,7 +388,7 @@ int validate(const afm_cdm_weights* w, int B, int N) {
     if (!w || B < 0 || N <= 0) return AFM_E_BADARG;
     if (w->dkv != 256 || w->dq <= 0 || w->dq > MAXD || (w->dq & 3) || w->text_dim > MAXD || w->time_dim > MAXD) return AFM_E_UNSUPPORTED;
     if (w->enc_heads != 8 || w->dec_heads != 8 || w->n_self < 0 || w->n_self > 4) return AFM_E_UNSUPPORTED;
-    if (w->feat_dim <= 0 || w->contact_dim <= 0 || !w->time_table || w->n_timesteps <= 0) return AFM_E_BADARG;
+    if (w->feat_dim <= 0 || w->contact_dim <= 0 || w->n_timesteps <= 0) return AFM_E_BADARG;
     return 0;
 }
 
@@ -403,11 +401,28 @@ extern "C" int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, 
     return carve(*w, B, N, nullptr).bytes;
 }
 
+extern "C" int afm_cdm_latent_tokens(const afm_cdm_weights* wp, int32_t which, const float* in, int32_t n, float* q0_out,
+                                     float* u_out, float* cu_out, void* stream) {
+    AFM_TRY(validate(wp, 0, 1));
+    if (!in || !q0_out || !u_out || !cu_out || n < 0 || (which != 0 && which != 1)) return AFM_E_BADARG;
+    if (n == 0) return 0;
+    const afm_cdm_weights& w = *wp;
+    const int in_dim = which == 0 ? w.text_dim : w.time_dim;
+    if (in_dim & 3) return AFM_E_UNSUPPORTED;
+    AfmProf prof(AFM_PROF_CDM, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(latent_token_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, w, in, in_dim,
+                       which == 0 ? w.language_adapter : w.time_embedding_adapter, q0_out, u_out, cu_out);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
-                               const float* text_feat, float* x0_out, const afm_ddpm_args* ddpm, int32_t B, int32_t N,
-                               void* workspace, int64_t workspace_bytes, void* stream) {
+                               const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
+                               const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
     AFM_TRY(validate(wp, B, N));
-    if (!feat || !t || !text_feat || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
+    if (!feat || !t || !text_q0 || !text_u || !text_cu || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
+    if (!wp->time_q0 || !wp->time_u || !wp->time_cu) return AFM_E_BADARG;
     if (ddpm && (!ddpm->x_next || !ddpm->c1 || !ddpm->c2 || !ddpm->sigma || !ddpm->noise || !x_t)) return AFM_E_BADARG;
     if (B == 0) return 0;
     const afm_cdm_weights& w = *wp;
@@ -416,23 +431,18 @@ extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, con
     if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
     const int M = B * N, dkv = w.dkv;
 
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        hipLaunchKernelGGL(latent_pre_kernel, dim3(B), dim3(1024), 0, s, w, t, text_feat, ws.lat0, ws.u, ws.cu);
-        AFM_CHECK_LAUNCH();
-    }
     afm_linear_args a = {};
     a.A = feat; a.lda = w.feat_dim; a.W = w.encoder_adapter.w; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = w.feat_dim; a.bias = w.encoder_adapter.b;
     AFM_TRY(afm_linear(&a, s));
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        hipLaunchKernelGGL(enc_reduce_kernel<16>, dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, ws.u, ws.cu, N, ws.pm,
-                           ws.pl, ws.pacc);
+        hipLaunchKernelGGL(enc_reduce_kernel<16>, dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
+                           w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc);
         AFM_CHECK_LAUNCH();
         const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, ws.lat0, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
+        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
         AFM_CHECK_LAUNCH();
     }
     a = {};

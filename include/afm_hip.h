@@ -264,7 +264,11 @@ typedef struct {
     int32_t dq, dkv;           /* encoder_q_input_channels (512), encoder_kv_input_channels (256)  */
     int32_t enc_heads, dec_heads, n_self;   /* 8, 8, encoder_self_attn_num_layers (2)              */
     int32_t text_dim, time_dim, n_timesteps;
-    const float* time_table;   /* [n_timesteps, time_dim]: TimestepEmbedder output for every t     */
+    /* per-timestep tables of the TIME latent, built once per weight version with afm_cdm_latent_tokens(which = 1) on
+     * the TimestepEmbedder output of every t (modules.py:38-53): enc_q0 row, folded queries, folded key-bias terms */
+    const float* time_q0;      /* [n_timesteps, dq]                 */
+    const float* time_u;       /* [n_timesteps, enc_heads, dkv]     */
+    const float* time_cu;      /* [n_timesteps, enc_heads]          */
     afm_lin language_adapter, time_embedding_adapter, encoder_adapter, decoder_adapter;
     afm_ln enc_q_norm, enc_kv_norm; afm_mha_w enc_attn; afm_mlp_w enc_mlp;          /* encoder_cross_attn.{0,1}.module */
     afm_ln self_norm[4]; afm_mha_w self_attn[4]; afm_mlp_w self_mlp[4];             /* encoder_self_attn.{l}.{0,1}.module */
@@ -276,11 +280,18 @@ int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
 
 /* One denoiser evaluation (+ optional fused DDPM update, same afm_ddpm_args as the CMDM).
  *   feat [B,N,feat_dim] = cat(x_t, (point features), xyz) as cdm.py:167-171 builds it; x_t itself is feat[..., :contact_dim]
- *   (needed separately, contiguous [B,N,contact_dim], only for the DDPM update); t [B] int64; text_feat [B,text_dim];
+ *   (needed separately, contiguous [B,N,contact_dim], only for the DDPM update); t [B] int64;
+ *   text_q0 / text_u / text_cu: the TEXT latent of every sample from afm_cdm_latent_tokens(which = 0) on text_feat [B,text_dim];
  *   x0_out [B,N,contact_dim] (may be NULL when ddpm != NULL). */
 int afm_cdm_forward(const afm_cdm_weights* w, const float* feat, const float* x_t, const int64_t* t,
-                    const float* text_feat, float* x0_out, const afm_ddpm_args* ddpm, int32_t B, int32_t N,
-                    void* workspace, int64_t workspace_bytes, void* stream);
+                    const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
+                    const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Latent-token precomputation (step-invariant, off the per-step path): for n input rows `in` [n, text_dim] (which = 0,
+ * language_adapter) or [n, time_dim] (which = 1, time_embedding_adapter) compute the latent's enc_q0 row
+ * q0_out [n, dq], q = dp_scale * q_proj(LN_q(q0)) folded through k_proj: u_out [n, enc_heads, dkv], cu_out [n, enc_heads]. */
+int afm_cdm_latent_tokens(const afm_cdm_weights* w, int32_t which, const float* in, int32_t n,
+                          float* q0_out, float* u_out, float* cu_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Opt-in profiler (measurement only, no reference counterpart): when enabled, every kernel launch of
