@@ -174,8 +174,9 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_fwd_kernel(const float* __
 
 extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
                            int32_t dh, void* stream) {
-    if (!qkv || !out || B < 0 || T <= 0 || H <= 0) return AFM_E_BADARG;
     if (dh != DH) return AFM_E_UNSUPPORTED;
+    if (B == 0) return 0;                                     // empty batch (pointers may be null)
+    if (!qkv || !out || B < 0 || T <= 0 || H <= 0) return AFM_E_BADARG;
     if ((((uintptr_t)qkv) & 15) || (((uintptr_t)out) & 15)) return AFM_E_BADARG;
     if (B == 0) return 0;
     const int nqb = (T + 31) / 32;

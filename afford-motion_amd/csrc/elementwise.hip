@@ -139,7 +139,9 @@ extern "C" int afm_layernorm(const float* x, const float* gamma, const float* be
 
 extern "C" int afm_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
                                   float eps, int32_t grp, int32_t stride, int32_t off, void* stream) {
-    if (!x || !gamma || !beta || !y || rows < 0 || dim <= 0 || (dim & 3)) return AFM_E_BADARG;
+    if (dim <= 0 || (dim & 3)) return AFM_E_BADARG;
+    if (rows == 0) return 0;                                  // empty batch (pointers may be null)
+    if (!x || !gamma || !beta || !y || rows < 0) return AFM_E_BADARG;
     if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return AFM_E_BADARG;
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -381,6 +381,7 @@ int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
 extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (!args) return AFM_E_BADARG;
     const afm_linear_args& a = *args;
+    if (a.M == 0) return 0;                                   // empty batch: nothing to do (pointers may be null)
     if (!a.A || !a.W || a.M < 0 || a.N <= 0 || a.K <= 0) return AFM_E_BADARG;
     if (!a.C && !a.ddpm_out) return AFM_E_BADARG;
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))

@@ -142,3 +142,50 @@ def test_sub_batch_streams_are_bit_identical(cmdm):
         outs.append(diff.p_sample_loop(model, (2, 16, 263), clip_denoised=False, model_kwargs=kw, seed=5).cpu())
     model.loop_streams = 2
     assert torch.equal(outs[0], outs[1])
+
+
+def test_config0_100_step_loop_vs_oracle():
+    """BASELINE configs[0]: CMDM t2m_contact_motion config, synthetic B=4, L=60, D=263, 100 DDPM steps,
+    shared explicit noise, HIP native loop vs the CPU oracle loop (drift over 100 sequential steps)."""
+    from oracle import denoiser_ref as dr, diffusion_ref as df, shapes as sh
+    cfg = cmdm_cfg(num_points=8192, steps=100)
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    B, L = 4, 60
+    text, cont = synth.text_feature(B), synth.gaussian("c0_cont", (B, 128, 256))
+    mask = synth.frame_mask(B, L, seed=9)
+    xT = synth.gaussian("c0_xT", (B, L, 263))
+    nz = [synth.gaussian(f"c0_nz{j}", (B, L, 263)) for j in range(100)]
+    sd = sh.weights(sh.cmdm())
+    want = df.p_sample_loop(df.Schedule(100), lambda x, t, **k: dr.cmdm_forward(sd, x, t, text, x_mask=mask, cont_emb=cont), xT, nz)
+    got = diff.p_sample_loop(model, (B, L, 263), noise=xT.to(dev()), clip_denoised=False, step_noise=torch.stack(nz).to(dev()),
+                             model_kwargs=dict(c_text_feat=text.to(dev()), c_cont_emb=cont.to(dev()), x_mask=mask.to(dev())))
+    report("config[0] 100-step loop vs oracle", got, want, 1e-3)
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] size (B=32, L=196, T=326), where the oracle is too slow to run in a test: size-independent
+    properties of the denoiser - determinism, batch-permutation equivariance (samples are independent), and padded
+    frames cannot influence the valid frames of the same sample."""
+    cfg = cmdm_cfg(num_points=8192)
+    model, _ = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    B, L = 32, 196
+    x = synth.gaussian("fp_x", (B, L, 263)).to(dev()); t = torch.arange(B, device=dev()) * 31
+    text, cont = synth.text_feature(B).to(dev()), synth.gaussian("fp_cont", (B, 128, 256)).to(dev())
+    mask = synth.frame_mask(B, L, seed=4).to(dev())
+    kw = dict(c_text_feat=text, c_cont_emb=cont, x_mask=mask)
+    out = model(x, t, **kw)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, model(x, t, **kw))                                        # deterministic
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(dev())
+    outp = model(x[perm].contiguous(), t[perm].contiguous(), c_text_feat=text[perm].contiguous(),
+                 c_cont_emb=cont[perm].contiguous(), x_mask=mask[perm].contiguous())
+    assert torch.equal(outp, out[perm])                                                # sample independence, bit-exact
+    x2 = x.clone()
+    x2[mask] = 1234.5                                                                  # garbage in the padded frames
+    out2 = model(x2, t, **kw)
+    valid = ~mask
+    assert torch.equal(out2[valid], out[valid])                                        # masked keys carry exactly zero weight

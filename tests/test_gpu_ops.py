@@ -153,3 +153,20 @@ def test_masked_mse():
     want = (((a - b) ** 2) * keep).sum((1, 2)) / (keep.sum((1, 2)) * D)
     report("masked mse", ops.masked_mse(a.to(dev()), b.to(dev()), m.to(dev())), want, 1e-5)
     report("unmasked mse", ops.masked_mse(a.to(dev()), b.to(dev()), None), ((a - b) ** 2).mean((1, 2)), 1e-5)
+
+
+def test_empty_and_degenerate_inputs():
+    """Empty batches are no-ops; bad arguments are rejected with AfmError instead of launching."""
+    d = dev()
+    assert ops.linear(torch.zeros(0, 64, device=d), torch.zeros(32, 64, device=d)).shape == (0, 32)
+    assert ops.mha(torch.zeros(0, 8, 3 * 512, device=d), None, 8).shape == (0, 8, 512)
+    assert ops.layernorm(torch.zeros(0, 512, device=d), torch.ones(512, device=d), torch.zeros(512, device=d)).shape == (0, 512)
+    with pytest.raises(ffi.AfmError):                      # head dim other than 64 is unsupported, loudly
+        ops.mha(torch.zeros(1, 8, 3 * 256, device=d), None, 8)
+    with pytest.raises(ffi.AfmError):                      # LayerNorm dim must be a multiple of 4
+        ops.layernorm(torch.zeros(2, 6, device=d), torch.ones(6, device=d), torch.zeros(6, device=d))
+    with pytest.raises(ffi.AfmError):                      # CPU tensors never reach a kernel
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    # a single token / single key attention is the identity on V
+    qkv = synth.gaussian("deg_qkv", (2, 1, 3 * 512)).to(d)
+    report("mha T=1", ops.mha(qkv, None, 8), qkv[..., 1024:].cpu(), 1e-6)
