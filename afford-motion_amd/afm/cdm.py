@@ -100,8 +100,22 @@ class CDM(TextEncoderMixin, nn.Module):
         elif sm.use_openscene:
             self.point_feat_dim = sm.point_feat_dim
         else:
-            raise NotImplementedError("frozen PointTransformerSeg scene backbone (cdm.py:444-446,508) is a later row "
-                                      "(SURVEY.md section 8f-2); supply per-point features via use_openscene / c_pc_feat")
+            # frozen scene backbone (cdm.py:444-446): PointTransformerSeg over (xyz, colour); weights are excluded from
+            # checkpoints by the reference's _save (keys containing 'scene_model', utils/training.py:97)
+            if sm.name != "PointTransformerSeg":
+                raise NotImplementedError(sm.name)
+            from .scene import PointTransformerSeg
+            self.scene_model_dim = 3 + int(sm.use_color) * 3
+            self.scene_model = PointTransformerSeg(c=self.scene_model_dim, num_points=sm.num_points)
+            pw = getattr(sm, "pretrained_weight", None)
+            if pw:
+                import os
+                if os.path.exists(pw):
+                    sd = torch.load(pw, map_location="cpu")
+                    self.scene_model.load_state_dict({k: v for k, v in sd.items() if "enc" in k or "dec" in k})
+            self.scene_model.eval().requires_grad_(False)
+            self.point_feat_dim = sm.point_feat_dim
+            self._scene_cache = None
         self.arch = cfg.arch
         if self.arch != "Perceiver":
             raise NotImplementedError(f"arch={self.arch!r}: only 'Perceiver' is selected by the reference's scripts")
@@ -188,7 +202,14 @@ class CDM(TextEncoderMixin, nn.Module):
     def _features(self, x, kwargs) -> torch.Tensor:
         """cat(x_t, per-point features, xyz) exactly as cdm.py:495-505 + ContactPerceiver.forward :167-171."""
         parts = [x]
-        if self.point_feat_dim > 0:
+        if hasattr(self, "scene_model"):
+            # step-invariant: the reference re-runs the frozen backbone in every step (cdm.py:508); cache per scene batch
+            xyz, col = kwargs["c_pc_xyz"], kwargs.get("c_pc_feat")
+            key = (xyz.data_ptr(), xyz._version, None if col is None else (col.data_ptr(), col._version), tuple(xyz.shape))
+            if self._scene_cache is None or self._scene_cache[0] != key:
+                self._scene_cache = (key, self.scene_model((xyz.to(x), None if col is None else col.to(x))))
+            parts.append(self._scene_cache[1])
+        elif self.point_feat_dim > 0:
             pf = kwargs["c_pc_feat"]
             if self.point_feat_dim == 1 and pf.shape[-1] != 1:
                 raise NotImplementedError("openscene text-similarity feature (cdm.py:500-503)")

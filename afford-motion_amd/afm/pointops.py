@@ -90,3 +90,25 @@ def pt_attention(p, qkv, knn_idx, channels: int, share_planes: int, lp0_w, lp0_b
     a.relu = 1 if relu else 0
     ffi.check(lib.afm_pt_attention(C.byref(a), ffi.stream_of(p)), "afm_pt_attention")
     return out
+
+
+def interpolate(xyz_src, xyz_dst, feat, batch: int, m: int, n: int, base=None, k: int = 3) -> torch.Tensor:
+    """k-NN inverse-distance upsampling of ``feat`` [batch*m, c] from xyz_src to the batch*n points xyz_dst
+    (+ ``base`` [batch*n, c] if given) - pointops.interpolation of the reference."""
+    lib = ffi.load()
+    idx, d2 = knn(k, xyz_src, xyz_dst, batch, m, n)
+    feat = ffi.f32c(feat)
+    out = torch.empty(batch * n, feat.shape[1], dtype=torch.float32, device=feat.device)
+    b = None if base is None else ffi.f32c(base)
+    ffi.check(lib.afm_interpolate(feat.data_ptr(), idx.data_ptr(), d2.data_ptr(), ffi.ptr(b), out.data_ptr(), batch * n,
+                                  feat.shape[1], k, ffi.stream_of(feat)), "afm_interpolate")
+    return out
+
+
+def segment_mean(x: torch.Tensor, batch: int, n: int) -> torch.Tensor:
+    lib = ffi.load()
+    ffi.require_gpu(x)
+    x = ffi.f32c(x)
+    out = torch.empty(batch, x.shape[1], dtype=torch.float32, device=x.device)
+    ffi.check(lib.afm_segment_mean(x.data_ptr(), out.data_ptr(), batch, n, x.shape[1], ffi.stream_of(x)), "afm_segment_mean")
+    return out

@@ -145,3 +145,88 @@ class SceneMapEncoder(nn.Module):
                     for blk in list(enc)[1:]:
                         x0 = blk.run(p0, x0, knn_idx)
             return x0.view(B, -1, x0.shape[-1])
+
+
+class TransitionUp(nn.Module):
+    """Decoder stage (reference pointtransformer.py:72-99).  Head mode (out_planes None): every point is concatenated with
+    ReLU(linear2(mean of its sample)), then Linear+BN+ReLU.  Fusion mode: Linear+BN+ReLU of the fine level plus the 3-NN
+    inverse-distance interpolation of Linear+BN+ReLU of the coarse level."""
+
+    def __init__(self, in_planes, out_planes=None):
+        super().__init__()
+        if out_planes is None:
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+        else:
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+
+    @staticmethod
+    def _lin_bn_relu(x, lin: nn.Linear, bn: nn.BatchNorm1d):
+        s, b = _bn_fold(bn)
+        return ops.linear(x, lin.weight, lin.bias * s + b, scale=s, act=ffi.ACT_RELU)       # BN(Wx + bias) = s*Wx + (s*bias + shift)
+
+    def run_head(self, x: torch.Tensor, batch: int):
+        n = x.shape[0] // batch
+        g = ops.linear(pointops.segment_mean(x, batch, n), self.linear2[0].weight, self.linear2[0].bias, act=ffi.ACT_RELU)   # [B, c]
+        cat = torch.cat((x, g.repeat_interleave(n, dim=0)), 1)
+        return self._lin_bn_relu(cat, self.linear1[0], self.linear1[1])
+
+    def run_fuse(self, p1, x1, p2, x2, batch: int):
+        n1, n2 = p1.shape[0] // batch, p2.shape[0] // batch
+        a = self._lin_bn_relu(x1, self.linear1[0], self.linear1[1])
+        b = self._lin_bn_relu(x2, self.linear2[0], self.linear2[1])
+        return pointops.interpolate(p2, p1, b, batch, n2, n1, base=a)
+
+
+class PointTransformerSeg(nn.Module):
+    """Frozen scene backbone of the HUMANISE / novel ADM (reference pointtransformer.py:126-213,
+    `pointtransformer_seg_repro`: blocks [2,3,4,6,3]): (xyz [B,N,3], colour [B,N,c-3]) -> per-point features [B,N,32].
+    Step-invariant in sampling, so the CDM evaluates it once per scene batch."""
+
+    def __init__(self, blocks=(2, 3, 4, 6, 3), c: int = 6, num_points: int = 8192):
+        super().__init__()
+        self.num_points, self.c = num_points, c
+        self.in_planes = c
+        planes, share = [32, 64, 128, 256, 512], 8
+        self.strides, self.nsamples = [1, 4, 4, 4, 4], [8, 16, 16, 16, 16]
+        for i in range(5):
+            setattr(self, f"enc{i + 1}", self._make_enc(planes[i], blocks[i], share, self.strides[i], self.nsamples[i]))
+        for i in (4, 3, 2, 1, 0):
+            setattr(self, f"dec{i + 1}", self._make_dec(planes[i], share, self.nsamples[i], is_head=(i == 4)))
+
+    def _make_enc(self, planes, blocks, share, stride, nsample):
+        layers = [TransitionDown(self.in_planes, planes, stride, nsample)]
+        self.in_planes = planes
+        layers += [PointTransformerBlock(planes, planes, share, nsample=nsample) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def _make_dec(self, planes, share, nsample, is_head=False):
+        layers = [TransitionUp(self.in_planes, None if is_head else planes)]
+        self.in_planes = planes
+        layers.append(PointTransformerBlock(planes, planes, share, nsample=nsample))
+        return nn.Sequential(*layers)
+
+    def forward(self, pxo):
+        p, x = pxo
+        ffi.require_gpu(p)
+        with torch.no_grad():
+            B, N = p.shape[0], p.shape[1]
+            p0 = ffi.f32c(p).reshape(B * N, 3)
+            x0 = p0 if self.c == 3 else torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+            ps, xs, knns = [], [], []
+            for lvl in range(5):
+                enc = getattr(self, f"enc{lvl + 1}")
+                p0, x0 = enc[0].run(p0, x0, B)
+                n = p0.shape[0] // B
+                ki, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
+                for blk in list(enc)[1:]:
+                    x0 = blk.run(p0, x0, ki)
+                ps.append(p0); xs.append(x0); knns.append(ki)
+            y = self.dec5[0].run_head(xs[4], B)
+            y = self.dec5[1].run(ps[4], y, knns[4])
+            for lvl in (3, 2, 1, 0):
+                dec = getattr(self, f"dec{lvl + 1}")
+                y = dec[0].run_fuse(ps[lvl], xs[lvl], ps[lvl + 1], y, B)
+                y = dec[1].run(ps[lvl], y, knns[lvl])
+            return y.view(B, N, -1)

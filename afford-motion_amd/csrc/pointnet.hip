@@ -139,20 +139,22 @@ struct PtAttnArgs {
     const float *w0_s, *w0_t, *w2_w, *w2_b, *w3_s, *w3_t, *w5_w, *w5_b;
     const float *out_s, *out_t;
     int relu;
+    int w2_lds;      // 1: linear_w.2 weight transposed into LDS (C <= 256); 0: read from global (C = 512, few points)
 };
 
 template <int CPL, int KN, int NE>
 __global__ __launch_bounds__(256) void pt_attention_kernel(const PtAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = a.C, CS = a.CS, LW = C + 1;
-    float* W2T = smem;                               // [C][CS]
-    float* W5T = W2T + C * CS;                       // [CS][CS]  (W5T[t'][t] = W5[t][t'])
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* W2T = smem;                               // [C][CS] (only when a.w2_lds)
+    float* W5T = W2T + (a.w2_lds ? C * CS : 0);      // [CS][CS]  (W5T[t'][t] = W5[t][t'])
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
     float* w1 = W5T + CS * CS + wave * (KN * LW + 2 * KN * CS);   // [KN][C+1]
     float* u = w1 + KN * LW;                         // [KN][CS]
     float* att = u + KN * CS;                        // [KN][CS]
 
-    for (int i = threadIdx.x; i < C * CS; i += blockDim.x) { const int t = i / C, ch = i % C; W2T[ch * CS + t] = a.w2_w[i]; }
+    if (a.w2_lds)
+        for (int i = threadIdx.x; i < C * CS; i += blockDim.x) { const int t = i / C, ch = i % C; W2T[ch * CS + t] = a.w2_w[i]; }
     for (int i = threadIdx.x; i < CS * CS; i += blockDim.x) { const int t = i / CS, t2 = i % CS; W5T[t2 * CS + t] = a.w5_w[i]; }
 
     // position-MLP constants (3x3 + BN fold), identical in every lane
@@ -174,9 +176,9 @@ __global__ __launch_bounds__(256) void pt_attention_kernel(const PtAttnArgs a) {
     const float b2 = a.w2_b[tt], s3 = a.w3_s[tt], t3 = a.w3_t[tt], b5 = a.w5_b[tt];
     __syncthreads();
 
-    const int quads = (a.n + 3) / 4;
+    const int quads = (a.n + nwv - 1) / nwv;
     for (int qd = blockIdx.x; qd < quads; qd += gridDim.x) {
-        const int pt = qd * 4 + wave;
+        const int pt = qd * nwv + wave;
         const bool live = pt < a.n;
         const int pi = live ? pt : a.n - 1;
         float vp[KN][CPL];
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void pt_attention_kernel(const PtAttnArgs a) {
 #pragma unroll
             for (int e = 0; e < NE; ++e) accu[e] = b2;
             for (int ch = 0; ch < C; ++ch) {
-                const float wv = W2T[ch * CS + tt];
+                const float wv = a.w2_lds ? W2T[ch * CS + tt] : a.w2_w[(int64_t)tt * C + ch];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
                     const int j = jb + e * jstep;
@@ -299,7 +301,7 @@ extern "C" int afm_pt_attention(const afm_pt_attention_args* g, void* stream) {
     const int C = g->channels, KN = g->nsample, S = g->share_planes;
     if (C <= 0 || S <= 0 || C % S) return AFM_E_BADARG;
     const int CS = C / S;
-    if (C > 256 || (KN != 8 && KN != 16) || CS > 64 || (64 % CS) != 0) return AFM_E_UNSUPPORTED;
+    if (C > 512 || (KN != 8 && KN != 16) || CS > 64 || (64 % CS) != 0) return AFM_E_UNSUPPORTED;
     if (g->n == 0) return 0;
     PtAttnArgs a;
     a.p = g->p; a.qkv = g->qkv; a.knn = g->knn_idx; a.out = g->out; a.n = g->n; a.C = C; a.KN = KN; a.CS = CS;
@@ -309,9 +311,11 @@ extern "C" int afm_pt_attention(const afm_pt_attention_args* g, void* stream) {
     a.out_s = g->out_scale; a.out_t = g->out_shift; a.relu = g->relu;
     const int cpl = (C + 63) / 64;
     const int ne = (KN + (64 / CS) - 1) / (64 / CS);
-    const size_t lds = (size_t)(C * CS + CS * CS + 4 * (KN * (C + 1) + 2 * KN * CS)) * sizeof(float);
-    int quads = (g->n + 3) / 4;
-    const dim3 grid(quads < 2048 ? quads : 2048), block(256);
+    a.w2_lds = C <= 256 ? 1 : 0;
+    const int nwv = C <= 256 ? 4 : 1;                // the 512-channel level has N/256 points per sample: one wave per block
+    const size_t lds = (size_t)((a.w2_lds ? C * CS : 0) + CS * CS + nwv * (KN * (C + 1) + 2 * KN * CS)) * sizeof(float);
+    int quads = (g->n + nwv - 1) / nwv;
+    const dim3 grid(quads < 2048 ? quads : 2048), block(64 * nwv);
     hipStream_t s = (hipStream_t)stream;
     AfmProf prof(AFM_PROF_PTATTN, 2.0 * g->n * KN * ((double)C * CS + CS * CS + 5.0 * C), s);
 #define AFM_PT(CPL_, KN_, NE_)                                                                                             \
@@ -322,15 +326,16 @@ extern "C" int afm_pt_attention(const afm_pt_attention_args* g, void* stream) {
         hipLaunchKernelGGL((pt_attention_kernel<CPL_, KN_, NE_>), grid, block, lds, s, a);                                 \
     } while (0)
     if (KN == 8) {
-        if (ne > 4 || cpl > 4) return AFM_E_UNSUPPORTED;
+        if (ne > 4 || cpl > 4 || !a.w2_lds) return AFM_E_UNSUPPORTED;
         if (cpl == 1 && ne <= 1) AFM_PT(1, 8, 1);
         else if (cpl <= 2 && ne <= 2) AFM_PT(2, 8, 2);
         else AFM_PT(4, 8, 4);
     } else {
-        if (ne > 8 || cpl > 4) return AFM_E_UNSUPPORTED;
+        if (ne > 16 || cpl > 8) return AFM_E_UNSUPPORTED;
         if (cpl == 1 && ne <= 2) AFM_PT(1, 16, 2);
         else if (cpl <= 2 && ne <= 4) AFM_PT(2, 16, 4);
-        else AFM_PT(4, 16, 8);
+        else if (cpl <= 4 && ne <= 8) AFM_PT(4, 16, 8);
+        else AFM_PT(8, 16, 16);
     }
 #undef AFM_PT
     AFM_CHECK_LAUNCH();

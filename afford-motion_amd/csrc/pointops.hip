@@ -124,7 +124,60 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+// out[i,:] = base[i,:] + sum_j w_ij * feat[idx[i,j],:],  w_ij = (1 / (sqrt(d2_ij) + 1e-8)) / sum_j (...)   (k neighbours)
+__global__ __launch_bounds__(256) void interpolate_kernel(const float* __restrict__ feat, const int* __restrict__ idx,
+                                                          const float* __restrict__ d2, const float* __restrict__ base,
+                                                          float* __restrict__ out, int64_t n, int c, int k) {
+    const int c4n = c >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * c4n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / c4n;
+        const int cc = (int)(e - i * c4n) * 4;
+        float w[8], norm = 0.f;
+        for (int j = 0; j < k; ++j) { w[j] = 1.0f / (sqrtf(d2[i * k + j]) + 1e-8f); norm += w[j]; }
+        float4 acc = base ? *reinterpret_cast<const float4*>(base + i * c + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 up = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < k; ++j) {
+            const float4 f = *reinterpret_cast<const float4*>(feat + (int64_t)idx[i * k + j] * c + cc);
+            const float wj = w[j] / norm;
+            up.x += f.x * wj; up.y += f.y * wj; up.z += f.z * wj; up.w += f.w * wj;
+        }
+        *reinterpret_cast<float4*>(out + i * c + cc) = make_float4(acc.x + up.x, acc.y + up.y, acc.z + up.z, acc.w + up.w);
+    }
+}
+
+// out[b,:] = mean over the n rows of sample b  (grid B, block 256; c <= 4096)
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int c) {
+    const int b = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += x[((int64_t)b * n + i) * c + ch];
+        out[(int64_t)b * c + ch] = s / (float)n;
+    }
+}
+
 }  // namespace
+
+extern "C" int afm_interpolate(const float* feat, const int32_t* idx, const float* dist2, const float* base, float* out,
+                               int64_t n, int32_t c, int32_t k, void* stream) {
+    if (c <= 0 || (c & 3) || k <= 0 || k > 8 || n < 0) return AFM_E_BADARG;
+    if (n == 0) return 0;
+    if (!feat || !idx || !dist2 || !out) return AFM_E_BADARG;
+    const int64_t total = n * (c >> 2);
+    unsigned g = (unsigned)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(interpolate_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, feat, idx, dist2, base, out, n, c, k);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_segment_mean(const float* x, float* out, int32_t B, int32_t n, int32_t c, void* stream) {
+    if (B < 0 || n <= 0 || c <= 0) return AFM_E_BADARG;
+    if (B == 0) return 0;
+    if (!x || !out) return AFM_E_BADARG;
+    hipLaunchKernelGGL(segment_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, n, c);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream) {
     if (!xyz || !idx_out || B < 0 || n <= 0 || m < 0 || m > n) return AFM_E_BADARG;

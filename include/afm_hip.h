@@ -137,6 +137,14 @@ int afm_knn(int32_t k, const float* xyz, const float* new_xyz, int32_t B, int32_
 /* out[r, :] = src[idx[r], :]  (the `p[idx.long(), :]` of pointtransformer.py:62) */
 int afm_gather_rows(const float* src, const int32_t* idx, float* out, int64_t rows, int32_t c, void* stream);
 
+/* afm_interpolate: inverse-distance-weighted feature upsampling of pointops.interpolation (pointops.py:164-178):
+ *   out[i,:] = base[i,:] + sum_j w_ij feat[idx[i,j],:],  w_ij = r_ij / sum_j r_ij,  r_ij = 1 / (sqrt(dist2[i,j]) + 1e-8)
+ * idx / dist2 [n,k] come from afm_knn (k = 3); base may be NULL.  Fuses the `linear1(x1) +` of TransitionUp
+ * (pointtransformer.py:98).  afm_segment_mean: per-sample mean over n rows (TransitionUp head mode, :90). */
+int afm_interpolate(const float* feat, const int32_t* idx, const float* dist2, const float* base, float* out,
+                    int64_t n, int32_t c, int32_t k, void* stream);
+int afm_segment_mean(const float* x, float* out, int32_t B, int32_t n, int32_t c, void* stream);
+
 /* afm_transition_down: fused "set abstraction" of TransitionDown.forward (pointtransformer.py:53-69,
  * stride != 1, eval-mode BN folded to scale/shift):
  *   out[i, o] = max_j ReLU(scale[o] * (W[o,:] . [p[knn[i,j]] - new_p[i] ; x[knn[i,j]]]) + shift[o])

@@ -149,6 +149,19 @@ def main():
     with torch.no_grad():
         save("scene_map_encoder_N1024", xyz=xyz, contact=con, out=sme(xyz, con))
 
+    # frozen scene backbone (HUMANISE / novel ADM, cdm.py:444-446,508): PointTransformerSeg(c=6), N=4096 -> 16 points at level 5
+    Ns = 4096
+    seg = rpt.pointtransformer_seg_repro(c=6, num_points=Ns).eval()
+    synth.fill_module_(seg)
+    sxyz, scol = synth.scene_cloud(1, Ns, seed=15), synth.contact_map(1, Ns, joints=3, seed=15)
+    with torch.no_grad():
+        so = seg((sxyz, scol))
+    keys = sorted(seg.state_dict().keys())
+    with open(os.path.join(GOLD, "seg_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(f"{k} {tuple(seg.state_dict()[k].shape)}" for k in keys) + "\n")
+    sel = torch.arange(0, Ns, 8)
+    save("point_transformer_seg_N4096", xyz=sxyz, color=scol, rows=sel, out_rows=so[0, sel], out_sum=so.double().sum(), out_abs_sum=so.double().abs().sum())
+
     # reduced CMDM / CDM ---------------------------------------------------------------
     L = 16
     cfg = to_attr(dict(model=cmdm_cfg(num_points=N), diffusion=diffusion_cfg(1000, "")))

@@ -115,3 +115,58 @@ def scene_map_encoder(sd: SD, pre: str, p: torch.Tensor, x: torch.Tensor, blocks
         aux_all.append(aux)
     out = x0.view(B, -1, x0.shape[-1])
     return (out, aux_all) if return_aux else out
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k: int = 3):
+    """scene_models/pointops.py:164-178: k-NN inverse-distance weighted feature upsampling (dist = sqrt(d2))."""
+    idx, d2 = po.knn_query(k, xyz, new_xyz, offset, new_offset)
+    dist_recip = 1.0 / (torch.sqrt(d2) + 1e-8)
+    weight = dist_recip / dist_recip.sum(dim=1, keepdim=True)
+    out = torch.zeros(new_xyz.shape[0], feat.shape[1])
+    for i in range(k):
+        out += feat[idx[:, i].long(), :] * weight[:, i].unsqueeze(-1)
+    return out
+
+
+def transition_up(sd: SD, pre: str, p1, x1, o1, p2=None, x2=None, o2=None):
+    """scene_models/pointtransformer.py:72-99.  Head mode (pxo2 is None): concat every point with the linear2-transformed
+    mean of its sample, then linear1+BN+ReLU.  Fusion mode: linear1(x1) + interpolate(linear2(x2)) from the coarser level."""
+    if p2 is None:
+        parts, s_i = [], 0
+        for e_i in [int(v) for v in o1]:
+            xb = x1[s_i:e_i]
+            g = F.relu(_lin(sd, pre + ".linear2.0", xb.sum(0, True) / (e_i - s_i)))
+            parts.append(torch.cat((xb, g.repeat(e_i - s_i, 1)), 1))
+            s_i = e_i
+        x = torch.cat(parts, 0)
+        return F.relu(_bn(sd, pre + ".linear1.1", _lin(sd, pre + ".linear1.0", x)))
+    a = F.relu(_bn(sd, pre + ".linear1.1", _lin(sd, pre + ".linear1.0", x1)))
+    b = F.relu(_bn(sd, pre + ".linear2.1", _lin(sd, pre + ".linear2.0", x2)))
+    return a + interpolation(p2, p1, b, o2, o1)
+
+
+def point_transformer_seg(sd: SD, pre: str, p: torch.Tensor, x: torch.Tensor, blocks=(2, 3, 4, 6, 3),
+                          stride=(1, 4, 4, 4, 4), nsample=(8, 16, 16, 16, 16)):
+    """scene_models/pointtransformer.py:126-213 (`pointtransformer_seg_repro`): 5-level encoder + FPN-style decoder.
+    p [B,N,3], x [B,N,c-3] -> per-point features [B,N,32]."""
+    B, N = p.shape[:2]
+    P = lambda n: f"{pre}.{n}" if pre else n
+    o = torch.arange(1, B + 1, dtype=torch.int32) * N
+    p0 = p.reshape(B * N, 3).contiguous()
+    x0 = torch.cat((p0, x.reshape(B * N, -1)), 1) if x is not None and x.shape[-1] > 0 else p0
+    ps, xs, os_, knn = [], [], [], []
+    for lvl in range(5):
+        e = P(f"enc{lvl + 1}")
+        p0, x0, o, _ = transition_down(sd, e + ".0", p0, x0, o, stride[lvl], nsample[lvl])
+        ki, _ = po.knn_query(nsample[lvl], p0, p0, o, o)
+        for j in range(1, blocks[lvl]):
+            x0 = point_transformer_block(sd, f"{e}.{j}", p0, x0, o, nsample[lvl], 8, ki)
+        ps.append(p0); xs.append(x0); os_.append(o); knn.append(ki)
+    # decoders: every dec level = TransitionUp + (2 - 1) PointTransformerBlock
+    y = transition_up(sd, P("dec5.0"), ps[4], xs[4], os_[4])
+    y = point_transformer_block(sd, P("dec5.1"), ps[4], y, os_[4], nsample[4], 8, knn[4])
+    for lvl in (3, 2, 1, 0):
+        d = P(f"dec{lvl + 1}")
+        y = transition_up(sd, d + ".0", ps[lvl], xs[lvl], os_[lvl], ps[lvl + 1], y, os_[lvl + 1])
+        y = point_transformer_block(sd, d + ".1", ps[lvl], y, os_[lvl], nsample[lvl], 8, knn[lvl])
+    return y.view(B, N, -1)

@@ -72,6 +72,31 @@ def scene_map_encoder(pre, cin=9, planes=(32, 64, 128, 256), blocks=(2, 2, 2, 2)
     return s
 
 
+def transition_up(pre, cin, cout=None) -> Shapes:
+    if cout is None:        # head: linear1 = Linear(2c, c)+BN, linear2 = Linear(c, c)
+        return {**_lin(_p(pre, "linear1.0"), 2 * cin, cin), **_bn(_p(pre, "linear1.1"), cin), **_lin(_p(pre, "linear2.0"), cin, cin)}
+    return {**_lin(_p(pre, "linear1.0"), cout, cout), **_bn(_p(pre, "linear1.1"), cout),
+            **_lin(_p(pre, "linear2.0"), cin, cout), **_bn(_p(pre, "linear2.1"), cout)}
+
+
+def point_transformer_seg(pre, c=6, blocks=(2, 3, 4, 6, 3)) -> Shapes:
+    planes, stride = (32, 64, 128, 256, 512), (1, 4, 4, 4, 4)
+    s: Shapes = {}
+    cin = c
+    for l in range(5):
+        e = _p(pre, f"enc{l + 1}")
+        s.update(transition_down(f"{e}.0", cin, planes[l], stride[l]))
+        cin = planes[l]
+        for j in range(1, blocks[l]):
+            s.update(pt_block(f"{e}.{j}", cin))
+    for l in (4, 3, 2, 1, 0):
+        d = _p(pre, f"dec{l + 1}")
+        s.update(transition_up(f"{d}.0", cin, None if l == 4 else planes[l]))
+        cin = planes[l]
+        s.update(pt_block(f"{d}.1", cin))
+    return s
+
+
 def cmdm(input_feats=263, d=512, te=512, ff=1024, layers=5, text_dim=512, contact_dim=6,
          planes=(32, 64, 128, 256), blocks=(2, 2, 2, 2)) -> Shapes:
     s = timestep_embedder("timestep_embedder", d, te)

@@ -103,3 +103,33 @@ def test_set_abstraction_full_size_vs_oracle():
         n_p, y = td.run(p.to(dev()), x.to(dev()), B)
         assert torch.equal(n_p.cpu(), wp)
         report(f"set abstraction 8192->{n // stride}", y, wy, 2e-4)
+
+
+def test_point_transformer_seg_vs_reference_golden():
+    """Frozen scene backbone of the HUMANISE / novel ADM: 5-level encoder + FPN decoder (TransitionUp, 3-NN interpolation)."""
+    g = golden("point_transformer_seg_N4096")
+    seg = load_named_weights(S.PointTransformerSeg(c=6, num_points=4096)).to(dev()).eval()
+    out = seg((g["xyz"].to(dev()), g["color"].to(dev())))[0].cpu()
+    report("PointTransformerSeg N=4096 (sampled rows)", out[g["rows"].long()], g["out_rows"], 3e-4)
+    assert abs(out.double().sum().item() - float(g["out_sum"])) < 1e-2 * max(1.0, abs(float(g["out_abs_sum"])) * 1e-3)
+
+
+def test_cdm_with_scene_backbone_vs_oracle():
+    """ts2m_contact-style CDM: frozen PointTransformerSeg(c=6) features (32-d) feed the Perceiver (41 input channels)."""
+    from afm.base import create_model
+    from oracle import denoiser_ref as dr, scene_ref as sr, shapes as sh
+    from test_gpu_cdm import cdm_cfg
+    cfg = cdm_cfg(num_points=4096, point_feats=True)
+    cfg.model.scene_model.use_openscene = False
+    cfg.model.scene_model.use_color = True
+    m = create_model(cfg, device=dev())
+    load_named_weights(m)
+    m = m.to(dev()).eval()
+    B, N = 1, 4096
+    x = synth.gaussian("cdmseg_x", (B, N, 6)); xyz = synth.scene_cloud(B, N, seed=71); col = synth.contact_map(B, N, joints=3, seed=71)
+    text = synth.text_feature(B); t = torch.tensor([123])
+    sd_seg = {k[len("scene_model."):]: v for k, v in sh.weights({"scene_model." + k: v for k, v in sh.point_transformer_seg("", c=6).items()}).items()}
+    emb = sr.point_transformer_seg(sd_seg, "", xyz, col)
+    want = dr.cdm_forward(sh.weights(sh.cdm(point_feat_dim=32)), x, t, text, xyz, pc_emb=emb)
+    got = m(x.to(dev()), t.to(dev()), c_text_feat=text.to(dev()), c_pc_xyz=xyz.to(dev()), c_pc_feat=col.to(dev()))
+    report("CDM + frozen scene backbone vs oracle", got, want, 3e-4)

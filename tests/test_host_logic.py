@@ -108,7 +108,15 @@ def test_cdm_state_dict_keys_match_reference():
         want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
     assert have == want
     assert sum(p.numel() for p in model.parameters()) == 5431814
-    for bad in (["model.arch=MLP"], ["model.scene_model.use_scene_model=True", "task.dataset.use_openscene=False"]):
+    seg = base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver",
+                                        "model.scene_model.pretrained_weight=''", "task.dataset.use_color=True"]), device="cpu")
+    have = {k[len("scene_model."):]: tuple(v.shape) for k, v in seg.state_dict().items() if k.startswith("scene_model.")}
+    want = {}
+    for line in open(os.path.join(GOLDEN, "seg_state_dict_keys.txt")):
+        k, shp = line.strip().split(" ", 1)
+        want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
+    assert have == want                                                      # frozen scene backbone: reference key names
+    for bad in (["model.arch=MLP"],):
         with pytest.raises(NotImplementedError):                             # unbuilt variants fail loudly
             base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver"] + bad),
                               device="cpu")
