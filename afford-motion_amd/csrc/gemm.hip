@@ -364,9 +364,12 @@ template <int BM, int BN>
 int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     dim3 grid(nbm * nbn), block(256);
-    AfmProf prof(BM == 128 ? AFM_PROF_GEMM128 : (BN == 128 ? AFM_PROF_GEMM64x128 : AFM_PROF_GEMM64), 2.0 * a.M * a.N * a.K, s);
     static const bool no_dma = getenv("AFM_GEMM_NO_DMA") != nullptr;      // tuning knob
-    if (vec && (a.K % BK) == 0 && !no_dma)
+    const bool dma = vec && (a.K % BK) == 0 && !no_dma;
+    const int tag = BM == 128 ? (dma ? AFM_PROF_GEMM128_DMA : AFM_PROF_GEMM128)
+                              : (BN == 128 ? (dma ? AFM_PROF_GEMM64x128_DMA : AFM_PROF_GEMM64x128) : (dma ? AFM_PROF_GEMM64_DMA : AFM_PROF_GEMM64));
+    AfmProf prof(tag, 2.0 * a.M * a.N * a.K, s);
+    if (dma)
         hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN>), grid, block, 0, s, a, nbm, nbn);
     else if (vec)
         hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, true>), grid, block, 0, s, a, nbm, nbn);

@@ -2,7 +2,8 @@
 #include <hip/hip_runtime.h>
 enum {
     AFM_PROF_GEMM128 = 0, AFM_PROF_GEMM64x128, AFM_PROF_GEMM64, AFM_PROF_MHA, AFM_PROF_LN, AFM_PROF_MISC, AFM_PROF_FPS,
-    AFM_PROF_KNN, AFM_PROF_TD, AFM_PROF_PTATTN, AFM_PROF_CDM, AFM_PROF_NTAGS
+    AFM_PROF_KNN, AFM_PROF_TD, AFM_PROF_PTATTN, AFM_PROF_CDM, AFM_PROF_GEMM128_DMA, AFM_PROF_GEMM64x128_DMA, AFM_PROF_GEMM64_DMA,
+    AFM_PROF_NTAGS
 };
 bool afm_prof_on();
 void afm_prof_begin(int tag, double work, hipStream_t s, void** handle);

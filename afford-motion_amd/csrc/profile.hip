@@ -15,7 +15,8 @@ std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_free;
 const char* kNames[AFM_PROF_NTAGS] = {"gemm_f32_mfma<128,128>", "gemm_f32_mfma<64,128>", "gemm_f32_mfma<64,64>", "mha_fwd_kernel",
                                       "layernorm_kernel", "ddpm_randn_misc", "fps_kernel", "knn_kernel",
-                                      "transition_down_kernel", "pt_attention_kernel", "cdm_perceiver"};
+                                      "transition_down_kernel", "pt_attention_kernel", "cdm_perceiver", "gemm_f32_mfma_dma<128,128>",
+                                      "gemm_f32_mfma_dma<64,128>", "gemm_f32_mfma_dma<64,64>"};
 }  // namespace
 
 bool afm_prof_on() { return g_on; }

@@ -28,13 +28,24 @@ import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, L, D, NPTS = 32, 196, 263, 8192
 F32_MFMA_PEAK_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-DOMINANT = "gemm_f32_mfma<64,64>"
+DOMINANT = "gemm_f32_mfma_dma<64,64>"
 
 
 def step_flops(batch: int, frames: int = L, groups: int = NPTS // 64) -> float:
     """Algorithmic FLOPs of one CMDM step: 5 encoder layers + motion adapters + time MLP."""
     T = 2 + groups + frames
     return batch * (5 * T * (4194304 + 2048 * T) + 2 * (2 * 263 * 512 * frames) + 2 * 2 * 512 * 512)
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes and calibrated on layernorm_kernel): written by tools/summarize_profiles.py into
+    profiles/traffic.json on the GPU box; counters cannot be read from inside the process, so null when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def build(dev, steps_cfg: str):
@@ -167,7 +178,7 @@ def main():
         if g:
             ach = g["total_work"] / (g["total_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                     "avg_launch_us": round(1e3 * g["total_ms"] / g["launches"], 2), "launches": g["launches"],
                     "flops_per_launch": g["total_work"] / g["launches"],
                     "all_kernels_ms_per_step": {k: round(v["total_ms"] / K, 4) for k, v in prof.items()}}
