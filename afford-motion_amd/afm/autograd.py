@@ -1,0 +1,309 @@
+"""Training path: torch.autograd Functions whose forward AND backward are the HIP kernels of libafm_hip.so.
+
+torch.autograd is only the tape (it orders the backward calls and accumulates ``.grad`` so that the reference's
+``loss.backward(); optimizer.step()`` of utils/training.py:140-155 works unchanged); every tensor operation on the
+path is a C-ABI call.  Two granularities:
+
+* ``encoder_layer`` - one post-LN nn.TransformerEncoderLayer (cmdm.py:66-77, train mode incl. its four dropouts) as a
+  single Function with a hand-scheduled backward: LayerNorm backward emits the dropout-masked branch gradient,
+  the input-gradient GEMMs fuse GELU' / dropout / residual-add in their epilogues, weight gradients run on the
+  reduction-major MFMA kernel, attention backward is flash-style from the saved log-sum-exp.
+* ``linear`` / ``posenc_dropout`` / ``masked_mse`` - the small stand-alone pieces around the layers (adapters,
+  TimestepEmbedder MLP, PositionalEncoding, output projection, loss).
+
+Dropout masks are never stored: forward and backward regenerate them from (seed, mask id, row, col).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import ffi
+
+RowMap = Tuple[int, int, int]
+
+
+def _st(t: torch.Tensor) -> int:
+    return ffi.stream_of(t)
+
+
+def _gemm(A, W, out, M, N, K, *, lda=None, bias=None, residual=None, act=0, preact=None, dact=0, dact_z=None, drop=None,
+          drop_after=0, a_map=None, c_map=None, rowtab=None):
+    """Raw afm_linear call: out[M,N] = epilogue(A[M,K] @ W[N,K]^T)."""
+    a = ffi.LinearArgs()
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc = A.data_ptr(), (K if lda is None else lda), W.data_ptr(), K, out.data_ptr(), N
+    a.M, a.N, a.K = M, N, K
+    if bias is not None:
+        a.bias = bias.data_ptr()
+    if residual is not None:
+        a.residual, a.ldr = residual.data_ptr(), N
+    if rowtab is not None:
+        a.rowtab, a.rowtab_period = rowtab.data_ptr(), rowtab.shape[0]
+    a.act = act
+    if preact is not None:
+        a.preact, a.ldp = preact.data_ptr(), N
+    if dact:
+        a.dact, a.dact_z, a.ldz = dact, dact_z.data_ptr(), N
+    if drop is not None and drop[0] > 0.0:
+        a.drop_p, a.drop_seed, a.drop_id, a.drop_after = drop[0], drop[1], drop[2], drop_after
+    if a_map:
+        a.a_grp, a.a_stride, a.a_off = a_map
+    if c_map:
+        a.c_grp, a.c_stride, a.c_off = c_map
+    ffi.check(ffi.load().afm_linear(C.byref(a), _st(out)), "afm_linear")
+    return out
+
+
+def _transpose(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] -> [K,N] on the device (operand of the input-gradient GEMM dX = dY @ W)."""
+    out = torch.empty(w.shape[1], w.shape[0], device=w.device, dtype=torch.float32)
+    ffi.check(ffi.load().afm_transpose(w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1], _st(w)), "afm_transpose")
+    return out
+
+
+def _wgrad(dY, X, M, N, K, *, want_bias=True, dy_map: Optional[RowMap] = None, x_map: Optional[RowMap] = None, lddy=None, ldx=None):
+    lib = ffi.load()
+    dW = torch.empty(N, K, device=dY.device, dtype=torch.float32)
+    db = torch.empty(N, device=dY.device, dtype=torch.float32) if want_bias else None
+    nbytes = lib.afm_linear_wgrad_workspace_bytes(M, N, K)
+    if nbytes < 0:
+        ffi.check(int(nbytes), "afm_linear_wgrad_workspace_bytes")
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dY.device)
+    a = ffi.WgradArgs()
+    a.dY, a.lddy, a.X, a.ldx, a.dW, a.lddw = dY.data_ptr(), (N if lddy is None else lddy), X.data_ptr(), (K if ldx is None else ldx), dW.data_ptr(), K
+    a.db = ffi.ptr(db)
+    a.M, a.N, a.K = M, N, K
+    if dy_map:
+        a.dy_grp, a.dy_stride, a.dy_off = dy_map
+    if x_map:
+        a.x_grp, a.x_stride, a.x_off = x_map
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    ffi.check(lib.afm_linear_wgrad(C.byref(a), _st(dY)), "afm_linear_wgrad")
+    return dW, db
+
+
+def _layernorm(x, g, b, eps=1e-5):
+    out = torch.empty_like(x)
+    dim = x.shape[-1]
+    ffi.check(ffi.load().afm_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), x.numel() // dim, dim, eps, _st(x)),
+              "afm_layernorm")
+    return out
+
+
+def _layernorm_bwd(x, g, dy, drop=None, eps=1e-5):
+    """-> (dx, dx_dropmasked or dx, dgamma, dbeta)."""
+    lib = ffi.load()
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    dx = torch.empty_like(x)
+    use_drop = drop is not None and drop[0] > 0.0
+    dxd = torch.empty_like(x) if use_drop else None
+    dg = torch.empty(dim, device=x.device, dtype=torch.float32)
+    db = torch.empty(dim, device=x.device, dtype=torch.float32)
+    nbytes = lib.afm_layernorm_bwd_workspace_bytes(rows, dim)
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=x.device)
+    p, seed, did = drop if use_drop else (0.0, 0, 0)
+    ffi.check(lib.afm_layernorm_bwd(x.data_ptr(), g.data_ptr(), dy.data_ptr(), dx.data_ptr(), ffi.ptr(dxd), dg.data_ptr(), db.data_ptr(),
+                                    rows, dim, eps, p, seed, did, ws.data_ptr(), ws.numel(), _st(x)), "afm_layernorm_bwd")
+    return dx, (dxd if use_drop else dx), dg, db
+
+
+def _rowop(x, *, rowtab=None, z=None, act=0, drop=None, out=None):
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    out = torch.empty_like(x) if out is None else out
+    p, seed, did = drop if (drop is not None and drop[0] > 0.0) else (0.0, 0, 0)
+    ffi.check(ffi.load().afm_rowop(x.data_ptr(), ffi.ptr(rowtab), 0 if rowtab is None else rowtab.shape[0], ffi.ptr(z), act, out.data_ptr(),
+                                   rows, cols, p, seed, did, _st(x)), "afm_rowop")
+    return out
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    ffi.require_gpu(t)
+    return ffi.f32c(t.detach())
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone linear
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, a_map, rows):
+        xc, w = _c(x), _c(weight)
+        b = None if bias is None else _c(bias)
+        K, N = w.shape[1], w.shape[0]
+        M = rows if rows is not None else xc.numel() // K
+        out = torch.empty(M, N, device=xc.device, dtype=torch.float32)
+        z = torch.empty_like(out) if act else None
+        _gemm(xc.view(-1, K), w, out, M, N, K, bias=b, act=act, preact=z, a_map=a_map)
+        ctx.save_for_backward(xc, w, z)
+        ctx.cfg = (act, a_map, M, N, K, tuple(x.shape), bias is not None)
+        return out if rows is not None or a_map else out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w, z = ctx.saved_tensors
+        act, a_map, M, N, K, xshape, has_bias = ctx.cfg
+        dy = _c(dy).view(M, N)
+        if act:
+            dy = _rowop(dy, z=z, act=act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = _wgrad(dy, xc.view(-1, K), M, N, K, want_bias=has_bias, x_map=a_map)
+        if ctx.needs_input_grad[0]:
+            if a_map:
+                dx = torch.zeros(xc.numel() // K, K, device=dy.device, dtype=torch.float32)   # rows outside the gather get 0
+            else:
+                dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            _gemm(dy, _transpose(w), dx, M, K, N, c_map=a_map)
+            dx = dx.view(xshape)
+        return dx, dw, db, None, None, None
+
+
+def linear(x, weight, bias=None, *, act: int = ffi.ACT_NONE, a_map: Optional[RowMap] = None, rows: Optional[int] = None):
+    """act(x @ weight.T + bias) with a HIP backward.  ``a_map`` + ``rows`` gather a strided subset of x's rows
+    (the motion tokens of every sample, cmdm.py:169)."""
+    return _LinearFn.apply(x, weight, bias, act, a_map, rows)
+
+
+# ------------------------------------------------------------------------------------------------ PositionalEncoding
+class _PosEncDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pe, drop):
+        xc = _c(x)
+        ctx.drop = drop
+        return _rowop(xc, rowtab=_c(pe), drop=drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        return (_rowop(dy, drop=ctx.drop) if ctx.drop[0] > 0.0 else dy), None, None
+
+
+def posenc_dropout(x, pe, drop):
+    """dropout(x + pe[:T]) over [B, T, d] (modules.py:43-45); pe [T, d]."""
+    return _PosEncDropoutFn.apply(x, pe, drop)
+
+
+# ------------------------------------------------------------------------------------------------ encoder layer
+class _EncoderLayerFn(torch.autograd.Function):
+    """x [B, T, d] -> post-LN TransformerEncoderLayer(x) with key padding mask; drops = (p, seed, id0): ids id0..id0+3 are
+    the attention-probability, dropout1, FFN and dropout2 masks."""
+
+    @staticmethod
+    def forward(ctx, x, key_mask, heads, drops, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b):
+        lib = ffi.load()
+        xc = _c(x)
+        B, T, d = xc.shape
+        M, ff = B * T, l1_w.shape[0]
+        P = [_c(t) for t in (in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b)]
+        in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b = P
+        p, seed, id0 = drops
+        dev = xc.device
+        km = None if key_mask is None else key_mask.to(torch.uint8).contiguous()
+        qkv = torch.empty(M, 3 * d, device=dev, dtype=torch.float32)
+        _gemm(xc, in_w, qkv, M, 3 * d, d, bias=in_b)
+        att = torch.empty(M, d, device=dev, dtype=torch.float32)
+        lse = torch.empty(B * heads * T, device=dev, dtype=torch.float32)
+        ffi.check(lib.afm_mha_fwd_train(qkv.data_ptr(), ffi.ptr(km), att.data_ptr(), lse.data_ptr(), B, T, heads, d // heads, p, seed, id0,
+                                        _st(xc)), "afm_mha_fwd_train")
+        s1 = torch.empty(M, d, device=dev, dtype=torch.float32)
+        _gemm(att, out_w, s1, M, d, d, bias=out_b, residual=xc, drop=(p, seed, id0 + 1))
+        x1 = _layernorm(s1, n1_w, n1_b)
+        z = torch.empty(M, ff, device=dev, dtype=torch.float32)
+        h = torch.empty(M, ff, device=dev, dtype=torch.float32)
+        _gemm(x1, l1_w, h, M, ff, d, bias=l1_b, act=ffi.ACT_GELU, preact=z, drop=(p, seed, id0 + 2))
+        s2 = torch.empty(M, d, device=dev, dtype=torch.float32)
+        _gemm(h, l2_w, s2, M, d, ff, bias=l2_b, residual=x1, drop=(p, seed, id0 + 3))
+        x2 = _layernorm(s2, n2_w, n2_b)
+        ctx.save_for_backward(xc, km, qkv, att, lse, s1, x1, z, h, s2, *P)
+        ctx.cfg = (B, T, d, ff, heads, drops)
+        return x2.view(B, T, d)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        lib = ffi.load()
+        xc, km, qkv, att, lse, s1, x1, z, h, s2, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b = ctx.saved_tensors
+        B, T, d, ff, heads, (p, seed, id0) = ctx.cfg
+        M = B * T
+        dev = xc.device
+        dx2 = _c(dx2).view(M, d)
+        # ---- FFN half:  x2 = LN2(s2), s2 = x1 + drop3(h W2^T + b2), h = drop2(gelu(z)), z = x1 W1^T + b1
+        ds2, ds2d, dn2w, dn2b = _layernorm_bwd(s2, n2_w, dx2, drop=(p, seed, id0 + 3))
+        dl2w, dl2b = _wgrad(ds2d, h, M, d, ff)
+        dz = torch.empty(M, ff, device=dev, dtype=torch.float32)
+        _gemm(ds2d, _transpose(l2_w), dz, M, ff, d, drop=(p, seed, id0 + 2), dact=ffi.ACT_GELU, dact_z=z)     # dh o mask o gelu'(z)
+        dl1w, dl1b = _wgrad(dz, x1, M, ff, d)
+        dx1 = torch.empty(M, d, device=dev, dtype=torch.float32)
+        _gemm(dz, _transpose(l1_w), dx1, M, d, ff, residual=ds2)                                           # + residual path of s2
+        # ---- attention half:  x1 = LN1(s1), s1 = x + drop1(att Wo^T + bo), att = MHA(qkv), qkv = x Win^T + bin
+        ds1, ds1d, dn1w, dn1b = _layernorm_bwd(s1, n1_w, dx1, drop=(p, seed, id0 + 1))
+        dow, dob = _wgrad(ds1d, att, M, d, d)
+        datt = torch.empty(M, d, device=dev, dtype=torch.float32)
+        _gemm(ds1d, _transpose(out_w), datt, M, d, d)
+        dqkv = torch.empty(M, 3 * d, device=dev, dtype=torch.float32)
+        ws = torch.empty(B * heads * T, device=dev, dtype=torch.float32)
+        ffi.check(lib.afm_mha_bwd(qkv.data_ptr(), ffi.ptr(km), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, T, heads,
+                                  d // heads, p, seed, id0, ws.data_ptr(), ws.numel() * 4, _st(xc)), "afm_mha_bwd")
+        diw, dib = _wgrad(dqkv, xc.view(M, d), M, 3 * d, d)
+        dx = torch.empty(M, d, device=dev, dtype=torch.float32)
+        _gemm(dqkv, _transpose(in_w), dx, M, d, 3 * d, residual=ds1)
+        return (dx.view(B, T, d), None, None, None, diw, dib, dow, dob, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b)
+
+
+def encoder_layer(x, layer: torch.nn.TransformerEncoderLayer, key_mask, heads: int, drops):
+    """One nn.TransformerEncoderLayer (post-LN, GELU, batch_first) forward with the HIP backward attached."""
+    return _EncoderLayerFn.apply(x, key_mask, heads, drops, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
+                                 layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
+                                 layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
+                                 layer.norm2.bias)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _MaskedMseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, pred, frame_mask):
+        t, p = _c(target), _c(pred)
+        B, D = t.shape[0], t.shape[-1]
+        L = t.numel() // max(B * D, 1)
+        km = None if frame_mask is None else frame_mask.reshape(B, L).to(torch.uint8).contiguous()
+        out = torch.empty(B, device=t.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_masked_mse(t.data_ptr(), p.data_ptr(), ffi.ptr(km), out.data_ptr(), B, L, D, _st(t)), "afm_masked_mse")
+        ctx.save_for_backward(t, p, km)
+        ctx.dims = (B, L, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dloss):
+        t, p, km = ctx.saved_tensors
+        B, L, D = ctx.dims
+        dpred = torch.empty_like(p)
+        dl = _c(dloss)
+        ffi.check(ffi.load().afm_masked_mse_bwd(t.data_ptr(), p.data_ptr(), ffi.ptr(km), dl.data_ptr(), dpred.data_ptr(), B, L, D, _st(t)),
+                  "afm_masked_mse_bwd")
+        return None, dpred, None
+
+
+def masked_mse(target, pred, frame_mask):
+    """Per-sample masked MSE [B] (gaussian_diffusion.py:815-818) with gradient to ``pred``."""
+    return _MaskedMseFn.apply(target, pred, frame_mask)
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def adamw_step(params, state: dict, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+    """torch.optim.AdamW semantics (utils/training.py:48-53) as one fused kernel per parameter tensor; ``state`` maps
+    parameter -> (step, exp_avg, exp_avg_sq) and is created on first use."""
+    lib = ffi.load()
+    for p in params:
+        if p.grad is None:
+            continue
+        ffi.require_gpu(p)
+        st = state.get(p)
+        if st is None:
+            st = [0, torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format)]
+            state[p] = st
+        st[0] += 1
+        g = ffi.f32c(p.grad)
+        assert p.is_contiguous() and p.dtype == torch.float32
+        ffi.check(lib.afm_adamw(p.data_ptr(), g.data_ptr(), st[1].data_ptr(), st[2].data_ptr(), p.numel(), lr, betas[0], betas[1], eps,
+                                weight_decay, st[0], _st(p)), "afm_adamw")

@@ -21,6 +21,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ffi, ops
 from .base import Model
 from .scene import SceneMapEncoder
@@ -121,6 +122,8 @@ class CMDM(TextEncoderMixin, nn.Module):
             enable_nested_tensor=False, num_layers=sum(self.num_layers))
         self.motion_layer = nn.Linear(self.latent_dim, self.motion_dim, bias=True)
 
+        self.dropout_p = float(cfg.dropout)
+        self._drop_calls = 0       # forward passes with dropout so far: every pass draws fresh masks
         self.hoist_conditions = True
         # sub-batches of the native sampling loop, each on its own HIP stream (AFM_LOOP_STREAMS overrides)
         self.loop_streams = int(os.environ.get("AFM_LOOP_STREAMS", "2"))
@@ -201,9 +204,8 @@ class CMDM(TextEncoderMixin, nn.Module):
     def forward(self, x, timesteps, **kwargs):
         """x [B, L, motion_dim], timesteps [B] int64, kwargs = batch dict (x_mask, c_text | c_text_feat,
         c_pc_xyz, c_pc_contact, info_* ignored) -> predicted x_0, same shape as x."""
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("CMDM backward is a later row (SURVEY.md section 8f-3); "
-                                      "call under torch.no_grad() / model.eval()")
+        if torch.is_grad_enabled() and (self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_train(x, timesteps, **kwargs)
         ffi.require_gpu(x)
         with torch.no_grad():
             lib = ffi.load()
@@ -221,6 +223,67 @@ class CMDM(TextEncoderMixin, nn.Module):
                                            out.data_ptr(), None, B, L, ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
                       "afm_cmdm_forward")
         return out
+
+    # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
+    def forward_train(self, x, timesteps, **kwargs):
+        """Same function as `forward`, composed from differentiable HIP ops (afm.autograd) so that
+        `diffusion.training_losses(...)['loss'].mean().backward()` (utils/training.py:140-152) fills `.grad` of the
+        transformer trunk, the adapters and the TimestepEmbedder.  Train mode applies the reference's dropouts
+        (PositionalEncoding 0.1, cfg.dropout inside every encoder layer incl. attention probabilities) with
+        counter-hash masks.  The SceneMapEncoder runs frozen on running BatchNorm statistics: its backward
+        (batch-statistics BatchNorm through the fused set-abstraction kernels) is the next row."""
+        frozen = not any(p.requires_grad for p in self.contact_encoder.parameters())
+        if not frozen:
+            raise NotImplementedError("the SceneMapEncoder backward is not built yet: freeze it with "
+                                      "`model.contact_encoder.requires_grad_(False)` to train the denoiser trunk")
+        ffi.require_gpu(x)
+        x = ffi.f32c(x)
+        B, L, _ = x.shape
+        d, dev = self.latent_dim, x.device
+        p_drop = self.dropout_p if self.training else 0.0
+        p_pe = float(self.positional_encoder.dropout.p) if self.training else 0.0
+        self._drop_calls += 1
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls) & (2**64 - 1)
+
+        # time token: pe[t] -> Linear -> SiLU -> Linear (modules.py:48-53)
+        te = self.timestep_embedder
+        t_idx = timesteps.to(device=dev, dtype=torch.int64)
+        time_emb = AG.linear(AG.linear(te.pe[t_idx, 0, :], te.time_embed[0].weight, te.time_embed[0].bias, act=ffi.ACT_SILU),
+                             te.time_embed[2].weight, te.time_embed[2].bias).view(B, 1, d)
+        masks = [torch.zeros(B, 1, dtype=torch.bool, device=dev)]
+        # text token (cmdm.py:134-146)
+        text_feat = self.encode_text(kwargs)
+        text_mask = torch.zeros(B, 1, dtype=torch.bool, device=dev)
+        if "c_text_mask" in kwargs:
+            text_mask = text_mask | kwargs["c_text_mask"].to(dev).bool().reshape(B, 1)
+        if "c_text_erase" in kwargs:
+            text_feat = text_feat * (1.0 - kwargs["c_text_erase"].to(dev).float().reshape(B, 1))
+        text_emb = AG.linear(text_feat, self.language_adapter.weight, self.language_adapter.bias).view(B, 1, d)
+        masks.append(text_mask)
+        # contact tokens (cmdm.py:148-156)
+        with torch.no_grad():
+            cont = kwargs["c_cont_emb"] if "c_cont_emb" in kwargs else self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])
+        G = cont.shape[1]
+        cont_mask = torch.zeros(B, G, dtype=torch.bool, device=dev)
+        if "c_pc_mask" in kwargs:
+            cont_mask = cont_mask | kwargs["c_pc_mask"].to(dev).bool().reshape(B, 1)
+        if "c_pc_erase" in kwargs:
+            cont = cont * (1.0 - kwargs["c_pc_erase"].to(dev).float().reshape(B, 1, 1))
+        cont_emb = AG.linear(cont, self.contact_adapter.weight, self.contact_adapter.bias)
+        masks.append(cont_mask)
+        # motion tokens, concatenation, positional encoding + dropout (cmdm.py:159-162)
+        h = AG.linear(x, self.motion_adapter.weight, self.motion_adapter.bias)
+        T = 2 + G + L
+        tok = torch.cat([time_emb, text_emb, cont_emb, h], dim=1)
+        tok = AG.posenc_dropout(tok, self.positional_encoder.pe[:T, 0, :], (p_pe, seed, 1))
+        key_mask = None
+        if self.mask_motion:
+            key_mask = torch.cat(masks + [kwargs["x_mask"].to(dev).bool().reshape(B, L)], dim=1)
+        for i, layer in enumerate(self.self_attn_layer.layers):
+            tok = AG.encoder_layer(tok, layer, key_mask, self.num_heads, (p_drop, seed, 16 + 4 * i))
+        # output projection on the motion tokens only (cmdm.py:169,195)
+        out = AG.linear(tok.view(B * T, d), self.motion_layer.weight, self.motion_layer.bias, a_map=(L, T, T - L), rows=B * L)
+        return out.view(B, L, self.motion_dim)
 
     # ------------------------------------------------------------------ native sampling loop
     def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0):

@@ -221,18 +221,26 @@ class GaussianDiffusion:
     def training_losses(self, model, x_start, t, model_kwargs=None, noise=None, **kwargs):
         """Masked MSE against x_0 (reference gaussian_diffusion.py:745-826, START_X target).
 
-        Forward-only in this round: the denoiser kernels have no backward yet, so calling this
-        with autograd enabled on a training-mode model raises."""
+        With autograd enabled and a model that has trainable parameters the denoiser runs its differentiable HIP path
+        (afm.autograd) and the returned per-sample loss carries the tape, so utils/training.py:140-152's
+        ``terms['loss'].mean().backward()`` works unchanged; otherwise everything runs forward-only."""
         model_kwargs = model_kwargs or {}
         tab = self.tables(x_start.device)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in getattr(model, "parameters", lambda: [])()) \
-                and getattr(model, "training", False):
-            raise NotImplementedError("training (backward through the HIP denoiser) is a later row; "
-                                      "evaluate losses under torch.no_grad() with model.eval()")
+        seed = kwargs.get("seed")
+        if seed is None:       # th.randn_like of the reference: fresh noise on every call, reproducible from torch's seed
+            self._loss_calls = getattr(self, "_loss_calls", 0) + 1
+            seed = (torch.initial_seed() * 6364136223846793005 + self._loss_calls) & (2**63 - 1)
         with torch.no_grad():
-            x_t = self.q_sample(x_start, t, noise=noise)
+            x_t = self.q_sample(x_start, t, noise=noise, seed=seed)
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in getattr(model, "parameters", lambda: [])())
+        if train:
+            from . import autograd as AG
             out = model(x_t, self._model_timesteps(t, tab), **model_kwargs)
-            mse = ops.masked_mse(x_start, out, model_kwargs.get("x_mask"))
+            mse = AG.masked_mse(x_start, out, model_kwargs.get("x_mask"))
+        else:
+            with torch.no_grad():
+                out = model(x_t, self._model_timesteps(t, tab), **model_kwargs)
+                mse = ops.masked_mse(x_start, out, model_kwargs.get("x_mask"))
         return {"mse": mse, "loss": mse}
 
 

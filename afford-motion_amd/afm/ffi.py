@@ -37,6 +37,18 @@ class LinearArgs(C.Structure):
         ("c_grp", i32), ("c_stride", i32), ("c_off", i32),
         ("ddpm_xt", c_f32p), ("ddpm_noise", c_f32p), ("ddpm_out", c_f32p), ("ldx", i64),
         ("ddpm_c1", c_f32p), ("ddpm_c2", c_f32p), ("ddpm_sigma", c_f32p), ("rows_per_sample", i32),
+        # training hooks (ABI v2)
+        ("preact", c_f32p), ("ldp", i64), ("dact_z", c_f32p), ("ldz", i64), ("dact", i32),
+        ("drop_p", C.c_float), ("drop_seed", u64), ("drop_id", C.c_uint32), ("drop_after", i32),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("dY", c_f32p), ("lddy", i64), ("X", c_f32p), ("ldx", i64), ("dW", c_f32p), ("lddw", i64), ("db", c_f32p),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("dy_grp", i32), ("dy_stride", i32), ("dy_off", i32), ("x_grp", i32), ("x_stride", i32), ("x_off", i32),
+        ("accumulate", i32), ("ws", C.c_void_p), ("ws_bytes", i64),
     ]
 
 
@@ -112,6 +124,18 @@ EXPORTS = {
     "afm_ddpm_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
     "afm_randn": (C.c_int, [c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
     "afm_masked_mse": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, C.c_void_p]),
+    "afm_transpose": (C.c_int, [c_f32p, c_f32p, i32, i32, C.c_void_p]),
+    "afm_linear_wgrad_workspace_bytes": (i64, [i32, i32, i32]),
+    "afm_linear_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
+    "afm_layernorm_bwd_workspace_bytes": (i64, [i64, i32]),
+    "afm_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, C.c_float, u64,
+                                    C.c_uint32, C.c_void_p, i64, C.c_void_p]),
+    "afm_mha_fwd_train": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
+    "afm_mha_bwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32,
+                              C.c_void_p, i64, C.c_void_p]),
+    "afm_masked_mse_bwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, i32, i32, i32, C.c_void_p]),
+    "afm_rowop": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, i32, c_f32p, i64, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
+    "afm_adamw": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_void_p]),
     "afm_fps": (C.c_int, [c_f32p, i32, i32, i32, C.c_void_p, C.c_void_p]),
     "afm_knn": (C.c_int, [i32, c_f32p, c_f32p, i32, i32, i32, C.c_void_p, c_f32p, C.c_void_p]),
     "afm_gather_rows": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),

@@ -23,9 +23,12 @@ constexpr int KB = 32;           // keys per block
 constexpr int LDKK = 68;         // padded K row (floats)
 constexpr int MAX_WAVES = 12;      // 3 waves per SIMD -> 168 VGPRs each, no spills
 
-template <int NST>
-__global__ __launch_bounds__(64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
-                                                       float* __restrict__ out, int T, int H, float scale) {
+// TRAIN: also writes lse[b,h,q] = log-sum-exp of the scaled, masked logits (saved for afm_mha_bwd) and applies
+// attention-probability dropout to the P used in P V (the softmax normaliser uses the undropped P, as in torch).
+template <int NST, bool TRAIN>
+__global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
+                                                       float* __restrict__ out, int T, int H, float scale,
+                                                       float* __restrict__ lse, float drop_p, uint64_t drop_seed, uint32_t drop_id) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                               // [2][KB][LDKK]
     float* Vs = smem + 2 * KB * LDKK;               // [2][KB][DH]
@@ -140,6 +143,12 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_fwd_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
                 // ---- O^T += V^T P^T : step r multiplies key (r&3) + 8*(r>>2) + 4*hh
+                if (TRAIN && drop_p > 0.0f) {
+                    const DropKey dk(drop_p, drop_seed, drop_id);
+                    const uint32_t row_ix = blockIdx.x * T + min(qb * 32 + r32, T - 1), col0 = kb * KB + 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] *= dk(row_ix, col0 + (r & 3) + 8 * (r >> 2));
+                }
                 const float* vp = Vs + buf * KB * DH + r32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_fwd_kernel(const float* __
         if (active) {
             const int qrow = qb * 32 + r32;
             if (qrow < T) {
+                if (TRAIN && hh == 0) lse[(int64_t)blockIdx.x * T + qrow] = m_run + __logf(l_run);
                 const float inv = 1.0f / l_run;
                 float* op = out + ((int64_t)b * T + qrow) * D + h * DH + 4 * hh;
 #pragma unroll
@@ -170,25 +180,36 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_fwd_kernel(const float* __
     }
 }
 
-}  // namespace
-
-extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
-                           int32_t dh, void* stream) {
+int mha_fwd_launch(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t T, int32_t H, int32_t dh,
+                          float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, void* stream) {
     if (dh != DH) return AFM_E_UNSUPPORTED;
     if (B == 0) return 0;                                     // empty batch (pointers may be null)
     if (!qkv || !out || B < 0 || T <= 0 || H <= 0) return AFM_E_BADARG;
     if ((((uintptr_t)qkv) & 15) || (((uintptr_t)out) & 15)) return AFM_E_BADARG;
-    if (B == 0) return 0;
+    if (train && (!lse || drop_p < 0.0f || drop_p >= 1.0f)) return AFM_E_BADARG;
     const int nqb = (T + 31) / 32;
     int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
     const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nqb * KB) * sizeof(float) + (size_t)nqb * sizeof(int);
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;
     const float scale = 1.0f / sqrtf((float)dh);
-    AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)T * T * dh, (hipStream_t)stream);
-    if (nw >= 8)
-        hipLaunchKernelGGL(mha_fwd_kernel<2>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, qkv, key_mask, out, T, H, scale);
-    else
-        hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, qkv, key_mask, out, T, H, scale);
+    hipStream_t s = (hipStream_t)stream;
+    AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)T * T * dh, s);
+#define AFM_MHA(NST, TR) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR>), dim3(B * H), dim3(nw * 64), lds, s, qkv, key_mask, out, T, H, scale, lse, drop_p, drop_seed, drop_id)
+    if (train) { if (nw >= 8) AFM_MHA(2, true); else AFM_MHA(4, true); }
+    else { if (nw >= 8) AFM_MHA(2, false); else AFM_MHA(4, false); }
+#undef AFM_MHA
     AFM_CHECK_LAUNCH();
     return 0;
+}
+
+}  // namespace
+
+extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
+                           int32_t dh, void* stream) {
+    return mha_fwd_launch(qkv, key_mask, out, nullptr, B, T, H, dh, 0.0f, 0, 0, false, stream);
+}
+
+extern "C" int afm_mha_fwd_train(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t T, int32_t H,
+                                 int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream) {
+    return mha_fwd_launch(qkv, key_mask, out, lse, B, T, H, dh, drop_p, drop_seed, drop_id, true, stream);
 }

@@ -81,6 +81,39 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// derivative of AFM_ACT_* at the pre-activation z (backward of the fused activations)
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case AFM_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+        case AFM_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
+        case AFM_ACT_SILU: { const float s = 1.0f / (1.0f + __expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+        default: return 1.0f;
+    }
+}
+
+// ---- dropout keep-mask: a counter hash of (seed, mask id, row, column), one 32-bit draw per element so that
+// the forward and the backward kernels regenerate the same mask whatever their register layout is (two rounds of
+// the murmur3 finaliser; keep when the draw >= p * 2^32).  Returns 0 or 1/(1-p).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+struct DropKey {
+    uint32_t k0, k1, thresh; float inv_keep;
+    __device__ __forceinline__ DropKey(float p, uint64_t seed, uint32_t id) {
+        k0 = (uint32_t)seed ^ (id * 0x9E3779B1u);
+        k1 = (uint32_t)(seed >> 32) + id * 0x7FEB352Du + 0x632BE5ABu;
+        const float t = p * 4294967296.0f;
+        thresh = t >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)t;
+        inv_keep = 1.0f / (1.0f - p);
+    }
+    // element (row, col) of the logical matrix the mask belongs to (attention: row = (b*H+h)*T + query, col = key)
+    __device__ __forceinline__ float operator()(uint32_t row, uint32_t col) const {
+        const uint32_t h = mix32(mix32(col ^ k0) + row * 0x9E3779B1u + k1);
+        return h >= thresh ? inv_keep : 0.0f;
+    }
+};
+
 // ---- Philox4x32-10 counter-based generator (Salmon et al. 2011), Box-Muller normals.
 // counter = (element/4 low, element/4 high, step, 0), key = seed ^ hash(global sample index).
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {

@@ -63,10 +63,14 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, con
 __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int grow, int64_t orow, int gcol) {
     if (p.scale) v *= p.scale[gcol];
     if (p.bias) v += p.bias[gcol];
+    if (p.preact) p.preact[orow * p.ldp + gcol] = v;
     if (p.act) v = apply_act(v, p.act);
+    if (p.drop_p > 0.0f && !p.drop_after) v *= DropKey(p.drop_p, p.drop_seed, p.drop_id)((uint32_t)orow, (uint32_t)gcol);
+    if (p.dact) v *= act_grad(p.dact_z[orow * p.ldz + gcol], p.dact);
     if (p.residual) v += p.residual[orow * p.ldr + gcol];
     if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
     if (p.act_post) v = apply_act(v, p.act_post);
+    if (p.drop_p > 0.0f && p.drop_after) v *= DropKey(p.drop_p, p.drop_seed, p.drop_id)((uint32_t)orow, (uint32_t)gcol);
     return v;
 }
 
@@ -76,8 +80,11 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
     constexpr int LDC = BN + 4;
     const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
     const int col0 = bn * BN;
-    const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && !p.ddpm_out &&
-                         ((((uintptr_t)p.C) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) | ((uintptr_t)p.scale) | ((uintptr_t)p.rowtab)) & 15) == 0;
+    const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && ((p.ldp & 3) == 0) && ((p.ldz & 3) == 0) && !p.ddpm_out &&
+                         ((((uintptr_t)p.C) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) | ((uintptr_t)p.scale) | ((uintptr_t)p.rowtab) |
+                           ((uintptr_t)p.preact) | ((uintptr_t)p.dact_z)) & 15) == 0;
+    const bool drop = p.drop_p > 0.0f;
+    const DropKey dk(drop ? p.drop_p : 0.0f, p.drop_seed, p.drop_id);
     if (vec_out) {
         for (int e = tid; e < BM * (BN / 4); e += 256) {
             const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
@@ -87,10 +94,15 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             const int64_t orow = cmap(grow);
             if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + gcol); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
             if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (p.preact) *reinterpret_cast<float4*>(p.preact + orow * p.ldp + gcol) = v;
             if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+            if (drop && !p.drop_after) { const uint32_t ro = (uint32_t)orow, co = (uint32_t)gcol; v.x *= dk(ro, co); v.y *= dk(ro, co + 1); v.z *= dk(ro, co + 2); v.w *= dk(ro, co + 3); }
+            if (p.dact) { const float4 t = *reinterpret_cast<const float4*>(p.dact_z + orow * p.ldz + gcol);
+                          v.x *= act_grad(t.x, p.dact); v.y *= act_grad(t.y, p.dact); v.z *= act_grad(t.z, p.dact); v.w *= act_grad(t.w, p.dact); }
             if (p.residual) { const float4 t = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             if (p.rowtab) { const float4 t = *reinterpret_cast<const float4*>(p.rowtab + (int64_t)(grow % p.rowtab_period) * p.N + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             if (p.act_post) { v.x = apply_act(v.x, p.act_post); v.y = apply_act(v.y, p.act_post); v.z = apply_act(v.z, p.act_post); v.w = apply_act(v.w, p.act_post); }
+            if (drop && p.drop_after) { const uint32_t ro = (uint32_t)orow, co = (uint32_t)gcol; v.x *= dk(ro, co); v.y *= dk(ro, co + 1); v.z *= dk(ro, co + 2); v.w *= dk(ro, co + 3); }
             *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
         }
     } else {

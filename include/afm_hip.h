@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 1
+#define AFM_ABI_VERSION 2
 
 #define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
 #define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
@@ -71,6 +71,17 @@ typedef struct {
      * (all [M,N] with row stride ldx).  C itself (pred_xstart) is still written if C != NULL. */
     const float* ddpm_xt; const float* ddpm_noise; float* ddpm_out; int64_t ldx;
     const float* ddpm_c1; const float* ddpm_c2; const float* ddpm_sigma; int32_t rows_per_sample;
+    /* ---- training hooks (all optional, zero = off; ABI v2).  Order inside the epilogue:
+     *   v = scale*acc + bias; preact <- v; v = act(v); v = dropout(v) [drop_after == 0]; v *= act'(dact_z) [dact];
+     *   v += residual + rowtab; v = act_post(v); v = dropout(v) [drop_after == 1]; C <- v
+     * preact [M,N] (stride ldp): the pre-activation saved for the backward pass (linear1 of the encoder layer,
+     *   time_embed.0).  dact / dact_z [M,N] (stride ldz): multiply by the derivative of AFM_ACT_* at the saved
+     *   pre-activation - the input-gradient GEMM of the NEXT linear produces dz directly (GELU/SiLU backward fused).
+     * dropout: keep-mask from a counter hash of (drop_seed, drop_id, output_row * N + col), scaled by 1/(1-p)
+     *   (nn.Dropout of the encoder layer / PositionalEncoding, modules.py:43-45; regenerated, never stored). */
+    float* preact; int64_t ldp;
+    const float* dact_z; int64_t ldz; int32_t dact;
+    float drop_p; uint64_t drop_seed; uint32_t drop_id; int32_t drop_after;
 } afm_linear_args;
 
 int afm_linear(const afm_linear_args* args, void* stream);
@@ -118,6 +129,72 @@ int afm_randn(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t 
  * Replaces the loss reduction of training_losses (gaussian_diffusion.py:815-818, sum_flat nn.py:93-97). */
 int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_mask, float* out,
                    int32_t B, int32_t L, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training (backward) entry points - the kernels behind `loss.backward()` of training_losses
+ * (gaussian_diffusion.py:757-823 called from utils/training.py:140-152).  Gradients are
+ * deterministic (fixed-order split reductions, no atomics).
+ */
+
+/* out[c][r] = in[r][c] (rows x cols -> cols x rows).  The input-gradient GEMM dX = dY @ W is run as
+ * afm_linear(A = dY, W = W^T), so the [N,K] nn.Linear weights are transposed once per optimiser step. */
+int afm_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream);
+
+/* Weight / bias gradient of y = x @ W^T + b:  dW[N,K] = dY^T @ X,  db[N] = colsum(dY)  (db may be NULL).
+ * dY [M,N] (row stride lddy), X [M,K] (row stride ldx); logical row r of dY / X lives at row
+ * (r / grp) * stride + off + r % grp when the corresponding grp != 0 (token subsets, as in afm_linear).
+ * f32 MFMA with both operands reduction-major; the M reduction is split over workgroups into `ws`
+ * (afm_linear_wgrad_workspace_bytes) and summed in a fixed order.  accumulate != 0: dW += / db +=. */
+typedef struct {
+    const float* dY; int64_t lddy;
+    const float* X; int64_t ldx;
+    float* dW; int64_t lddw;
+    float* db;
+    int32_t M, N, K;
+    int32_t dy_grp, dy_stride, dy_off;
+    int32_t x_grp, x_stride, x_off;
+    int32_t accumulate;
+    void* ws; int64_t ws_bytes;
+} afm_linear_wgrad_args;
+int64_t afm_linear_wgrad_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream);
+
+/* nn.LayerNorm backward.  x = the LayerNorm INPUT (statistics are recomputed), dy = grad of the output.
+ *   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+ *   dgamma = sum_rows dy * xhat, dbeta = sum_rows dy  (two-stage fixed-order reduction through ws)
+ * dx_drop (optional): dx with the dropout keep-mask of (drop_p, drop_seed, drop_id) applied - the gradient of the
+ * residual BRANCH when the forward was  LN(x + dropout(branch))  (encoder layer dropout1 / dropout2). */
+int64_t afm_layernorm_bwd_workspace_bytes(int64_t rows, int32_t dim);
+int afm_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dx_drop,
+                      float* dgamma, float* dbeta, int64_t rows, int32_t dim, float eps,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream);
+
+/* Training-mode attention: as afm_mha_fwd plus lse [B,H,T] (log-sum-exp of the scaled, masked logits, saved for the
+ * backward) and attention-probability dropout (F.multi_head_attention_forward dropout_p; 0 = off). */
+int afm_mha_fwd_train(const float* qkv, const uint8_t* key_mask, float* out, float* lse,
+                      int32_t B, int32_t T, int32_t H, int32_t dh,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream);
+/* Attention backward: dqkv [B*T, 3*H*dh] packed like qkv, from qkv / out / lse of the forward and dout [B*T, H*dh].
+ * Two flash-style passes on f32 MFMA (probabilities recomputed from lse, nothing [T,T]-sized is stored):
+ * dQ with one wave per 32-query block, then dK/dV with one wave per 32-key block.  ws: B*H*T floats. */
+int afm_mha_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse,
+                float* dqkv, int32_t B, int32_t T, int32_t H, int32_t dh,
+                float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream);
+
+/* d(afm_masked_mse)/d(pred): dpred[b,l,:] = dloss[b] * 2 * (pred - target) * keep[b,l] / (sum(keep[b]) * D). */
+int afm_masked_mse_bwd(const float* target, const float* pred, const uint8_t* frame_mask, const float* dloss,
+                       float* dpred, int32_t B, int32_t L, int32_t D, void* stream);
+
+/* out[r,c] = (x[r,c] + rowtab[r % period, c]) * act'(z[r,c]) * keep(r,c)/(1-p)  (rowtab, z optional; in-place allowed).
+ * The elementwise glue of the training graph: PositionalEncoding add + dropout (modules.py:43-45) and the
+ * activation / dropout backward in front of a stand-alone linear's gradient GEMMs. */
+int afm_rowop(const float* x, const float* rowtab, int32_t period, const float* z, int32_t act, float* out,
+              int64_t rows, int32_t cols, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream);
+
+/* Fused AdamW over one flat parameter (torch.optim.AdamW semantics, utils/training.py:48-53):
+ *   p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+int afm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int32_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Point-cloud operators.  Every sample holds the same number of points, so the reference's

@@ -39,10 +39,20 @@ def import_reference():
     # the reference hard-codes CUDA tensor constructors (pointtransformer.py:60, pointops.py:21-22,40-41)
     torch.cuda.IntTensor = torch.IntTensor
     torch.cuda.FloatTensor = torch.FloatTensor
-    import models.base as base              # noqa: E402  (reference's)
-    import models                           # noqa: F401  (runs the registry decorators)
-    import diffusion.gaussian_diffusion as gd
-    assert base.__file__.startswith(REFERENCE_ROOT), base.__file__
+    # the reference's `diffusion/` and `utils/` have no __init__.py (namespace packages): a regular package of the same
+    # name ANYWHERE on sys.path would win, so the product's drop-in shims are hidden while the reference is imported
+    hidden = [p for p in sys.path if os.path.isfile(os.path.join(p, "diffusion", "__init__.py"))]
+    saved = list(sys.path)
+    sys.path[:] = [p for p in sys.path if p not in hidden]
+    try:
+        import models.base as base              # noqa: E402  (reference's)
+        import models                           # noqa: F401  (runs the registry decorators)
+        import diffusion.gaussian_diffusion as gd
+        import diffusion.respace as rs
+    finally:
+        sys.path[:] = saved
+    for m in (base, gd, rs):
+        assert m.__file__.startswith(REFERENCE_ROOT), m.__file__
     return base, gd
 
 

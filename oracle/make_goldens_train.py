@@ -1,0 +1,67 @@
+"""Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
+training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
+
+Run in the build container only:   python -m oracle.make_goldens_train
+eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
+gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
+strided sample + sum / abs-sum).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.append(os.path.join(ROOT, "afford-motion_amd"))
+
+from oracle._refimport import import_reference, to_attr  # noqa: E402
+from oracle.make_goldens import GOLD, TEXTS, cmdm_cfg, diffusion_cfg, save  # noqa: E402
+
+SAMPLE = 1024
+
+
+def grad_digest(g: torch.Tensor):
+    flat = g.detach().reshape(-1)
+    if flat.numel() <= 2048:
+        sample = flat
+    else:
+        sample = flat[:: flat.numel() // SAMPLE][:SAMPLE]
+    return sample, torch.stack([flat.double().sum(), flat.double().abs().sum()])
+
+
+def main():
+    from afm import synth
+    base, _ = import_reference()
+    torch.manual_seed(0)
+    g = np.load(os.path.join(GOLD, "cmdm_forward_N1024_L16.npz"))
+    xyz, con, x_mask = torch.from_numpy(g["xyz"]), torch.from_numpy(g["contact"]), torch.from_numpy(g["x_mask"])
+    B, L, N = 2, 16, xyz.shape[1]
+    cfg = to_attr(dict(model=cmdm_cfg(num_points=N), diffusion=diffusion_cfg(1000, "")))
+    model, diff = base.create_model_and_diffusion(cfg, device="cpu")
+    synth.fill_module_(model)
+    model.eval()
+    kw = dict(c_text=TEXTS, c_pc_xyz=xyz, c_pc_contact=con, x_mask=x_mask)
+    x0 = synth.gaussian("train_x0", (B, L, 263))
+    tn = synth.gaussian("train_noise", (B, L, 263))
+    tt = torch.tensor([17, 803])
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, tt, model_kwargs=kw, noise=tn)
+    terms["loss"].mean().backward()
+    out = {"t": tt, "loss": terms["loss"].detach()}
+    n = 0
+    for name, p in model.named_parameters():
+        if name.startswith(("contact_encoder.", "text_model.")) or p.grad is None:
+            continue
+        sample, sums = grad_digest(p.grad)
+        out["g/" + name], out["s/" + name] = sample, sums
+        n += 1
+    save("cmdm_training_grads", **out)
+    print(f"{n} parameter gradients")
+
+
+if __name__ == "__main__":
+    main()

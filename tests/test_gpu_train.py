@@ -1,0 +1,345 @@
+"""`-m gpu`: the training (backward) path on the HIP kernels vs the CPU oracle (torch autograd over the functional
+restatement, oracle/train_ref.py) and vs gradients of the REAL reference (tests/golden/cmdm_training_grads.npz).
+
+Tolerances: f32 MFMA products are exact f32; differences come from summation order.  Gradients are compared after
+scaling by the reference tensor's max |value| (relative 1e-4 .. 5e-4: reductions over up to ~10^4 rows)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from afm import autograd as AG
+from afm import ffi, synth
+from afm.base import create_model_and_diffusion
+from conftest import golden
+from gpu_util import dev, load_named_weights, report
+from test_gpu_cmdm import cmdm_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(name, got, want, tol):
+    scale = max(want.detach().abs().max().item(), 1e-12)
+    return report(name + " (scaled)", got.detach().cpu() / scale, want.detach().cpu() / scale, tol)
+
+
+def g(name, shape):
+    return synth.gaussian(name, shape)
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("M,N,K", [(652, 512, 512), (10432, 1536, 512), (300, 263, 512), (300, 512, 263), (32, 512, 512), (7, 5, 3), (0, 8, 8)])
+def test_linear_wgrad(M, N, K):
+    dy, x = g("wg_dy", (max(M, 1), N))[:M].contiguous(), g("wg_x", (max(M, 1), K))[:M].contiguous()
+    dW, db = AG._wgrad(dy.to(dev()), x.to(dev()), M, N, K)
+    rel(f"dW {M}x{N}x{K}", dW, dy.double().t() @ x.double(), 2e-5)
+    rel(f"db {M}x{N}", db, dy.double().sum(0), 2e-5) if M else report("db empty", db, torch.zeros(N), 0.0)
+    dW2, _ = AG._wgrad(dy.to(dev()), x.to(dev()), M, N, K)
+    assert torch.equal(dW, dW2), "weight gradient is not deterministic"
+
+
+def test_linear_wgrad_row_maps():
+    """Token-subset rows (motion tokens of every sample) on both operands."""
+    B, T, L, N, K = 3, 50, 20, 263, 512
+    dy, x = g("wgm_dy", (B * L, N)), g("wgm_x", (B * T, K))
+    dW, db = AG._wgrad(dy.to(dev()), x.to(dev()), B * L, N, K, x_map=(L, T, T - L))
+    xs = x.view(B, T, K)[:, T - L:, :].reshape(B * L, K)
+    rel("dW with x row map", dW, dy.double().t() @ xs.double(), 2e-5)
+
+
+def test_transpose():
+    for r, c in ((512, 1536), (263, 512), (33, 7)):
+        w = g("tr", (r, c)).to(dev())
+        assert torch.equal(AG._transpose(w), w.t().contiguous())
+
+
+@pytest.mark.parametrize("rows,dim", [(10432, 512), (37, 256), (5, 1024)])
+def test_layernorm_backward(rows, dim):
+    x, dy = g("lnb_x", (rows, dim)), g("lnb_dy", (rows, dim))
+    gam, bet = 1.0 + 0.1 * g("lnb_g", (dim,)), 0.1 * g("lnb_b", (dim,))
+    xr, gr, br = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    F.layer_norm(xr, (dim,), gr, br, 1e-5).backward(dy.double())
+    dx, dxd, dg, db = AG._layernorm_bwd(x.to(dev()), gam.to(dev()), dy.to(dev()))
+    assert dxd is dx
+    rel("LN dx", dx, xr.grad, 2e-5)
+    rel("LN dgamma", dg, gr.grad, 2e-5)
+    rel("LN dbeta", db, br.grad, 2e-5)
+
+
+def _attn_ref(qkv, mask, H, keep=None):
+    """softmax(QK^T/sqrt(dh) + mask) V in float64; keep [B,H,T,T] multiplies P before P V (dropout)."""
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    q, k, v = [t.view(B, T, H, d // H).transpose(1, 2) for t in qkv.split(d, dim=-1)]
+    s = q @ k.transpose(-1, -2) / (d // H) ** 0.5
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    lse = torch.logsumexp(s, -1)
+    if keep is not None:
+        p = p * keep
+    return (p @ v).transpose(1, 2).reshape(B, T, d), lse
+
+
+def _mha_train(qkv, km, H, drop=(0.0, 0, 0)):
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    out = torch.empty(B, T, d, device=qkv.device)
+    lse = torch.empty(B, H, T, device=qkv.device)
+    ffi.check(ffi.load().afm_mha_fwd_train(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), lse.data_ptr(), B, T, H, d // H, drop[0], drop[1],
+                                           drop[2], ffi.stream_of(qkv)), "afm_mha_fwd_train")
+    return out, lse
+
+
+def _mha_bwd(qkv, km, out, dout, lse, H, drop=(0.0, 0, 0)):
+    B, T, d3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(B * H * T, device=qkv.device)
+    ffi.check(ffi.load().afm_mha_bwd(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, T, H,
+                                     d3 // 3 // H, drop[0], drop[1], drop[2], ws.data_ptr(), ws.numel() * 4, ffi.stream_of(qkv)), "afm_mha_bwd")
+    return dqkv
+
+
+@pytest.mark.parametrize("B,T,H,masked", [(2, 326, 8, True), (3, 70, 8, True), (1, 33, 2, False), (2, 400, 4, True)])
+def test_attention_backward(B, T, H, masked):
+    d = 64 * H
+    qkv = g("ab_qkv", (B, T, 3 * d))
+    dout = g("ab_do", (B, T, d))
+    mask = None
+    if masked:
+        mask = torch.zeros(B, T, dtype=torch.bool)
+        mask[0, T - 11:] = True
+        if B > 1:
+            mask[1, T // 2:] = True
+    qr = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, mask, H)
+    o_ref.backward(dout.double())
+    km = None if mask is None else mask.to(torch.uint8).to(dev())
+    out, lse = _mha_train(qkv.to(dev()), km, H)
+    report("attention out (train fwd)", out, o_ref, 2e-5)
+    report("attention lse", lse, lse_ref, 2e-5)
+    dqkv = _mha_bwd(qkv.to(dev()), km, out, dout.to(dev()), lse, H)
+    for i, n in enumerate("QKV"):
+        rel(f"attention d{n}", dqkv[..., i * d:(i + 1) * d], qr.grad[..., i * d:(i + 1) * d], 5e-5)
+    assert torch.equal(dqkv, _mha_bwd(qkv.to(dev()), km, out, dout.to(dev()), lse, H)), "attention backward is not deterministic"
+
+
+def test_attention_dropout_forward_backward_consistent():
+    """With V = one-hot rows the forward output IS the dropped probability matrix, which reveals the keep mask; the general
+    forward / backward must then equal the float64 reference evaluated with that same mask."""
+    B, T, H, p = 2, 64, 2, 0.25
+    d = 64 * H
+    drop = (p, 1234567, 40)
+    qkv = g("ad_qkv", (B, T, 3 * d))
+    probe = qkv.clone()
+    probe[..., 2 * d:] = torch.eye(64).repeat(1, H).unsqueeze(0)              # V_h = I for every head
+    pd, _ = _mha_train(probe.to(dev()), None, H, drop)
+    p0, _ = _mha_train(probe.to(dev()), None, H)
+    pd, p0 = pd.cpu().view(B, T, H, 64).transpose(1, 2), p0.cpu().view(B, T, H, 64).transpose(1, 2)     # [B,H,Tq,Tk]
+    keep = torch.where(pd > 0, torch.full_like(pd, 1 / (1 - p)), torch.zeros_like(pd))
+    report("dropped P == P * keep", pd, p0 * keep, 1e-6)
+    rate = (keep > 0).float().mean().item()
+    assert abs(rate - (1 - p)) < 0.02, rate
+    dout = g("ad_do", (B, T, d))
+    qr = qkv.double().requires_grad_(True)
+    o_ref, _ = _attn_ref(qr, None, H, keep.double())
+    o_ref.backward(dout.double())
+    out, lse = _mha_train(qkv.to(dev()), None, H, drop)
+    report("attention out with dropout", out, o_ref, 2e-5)
+    dqkv = _mha_bwd(qkv.to(dev()), None, out, dout.to(dev()), lse, H, drop)
+    rel("attention dqkv with dropout", dqkv, qr.grad, 5e-5)
+    out2, _ = _mha_train(qkv.to(dev()), None, H, (p, 1234568, 40))
+    assert not torch.equal(out, out2), "a different seed must give a different mask"
+
+
+def test_epilogue_dropout_and_rowop_share_masks():
+    """The GEMM epilogue, afm_rowop and afm_layernorm_bwd regenerate the same (seed, id, row, col) mask."""
+    M, N, K, p = 300, 512, 64, 0.1
+    drop = (p, 99, 7)
+    x, w = g("ed_x", (M, K)).to(dev()), g("ed_w", (N, K)).to(dev())
+    plain = torch.empty(M, N, device=dev())
+    AG._gemm(x, w, plain, M, N, K)
+    dropped = torch.empty(M, N, device=dev())
+    AG._gemm(x, w, dropped, M, N, K, drop=drop)
+    assert torch.equal(dropped, AG._rowop(plain, drop=drop))
+    keep = (dropped != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.01, keep
+    report("kept values scaled by 1/(1-p)", dropped, torch.where(dropped != 0, plain / (1 - p), torch.zeros_like(plain)), 1e-5)
+    dy = g("ed_dy", (M, N)).to(dev())
+    gam = torch.ones(N, device=dev())
+    dx, dxd, _, _ = AG._layernorm_bwd(plain, gam, dy, drop=drop)
+    assert torch.equal(dxd, AG._rowop(dx, drop=drop))
+
+
+def test_stand_alone_linear_and_posenc_grads():
+    B, T, L, K, N = 2, 30, 12, 64, 263
+    x = g("sl_x", (B, T, K))
+    w, b = g("sl_w", (N, K)) * 0.1, g("sl_b", (N,)) * 0.1
+    dy = g("sl_dy", (B * L, N))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    (F.silu(F.linear(xr[:, T - L:, :], wr, br)).reshape(B * L, N) * dy.double()).sum().backward()
+    xg, wg, bg = (t.to(dev()).requires_grad_(True) for t in (x, w, b))
+    y = AG.linear(xg.view(B * T, K), wg, bg, act=ffi.ACT_SILU, a_map=(L, T, T - L), rows=B * L)
+    (y * dy.to(dev())).sum().backward()
+    rel("linear dx (row-gathered)", xg.grad, xr.grad, 2e-5)
+    rel("linear dW", wg.grad, wr.grad, 2e-5)
+    rel("linear db", bg.grad, br.grad, 2e-5)
+    pe = g("sl_pe", (T, K)).to(dev())
+    xg2 = x.to(dev()).requires_grad_(True)
+    AG.posenc_dropout(xg2, pe, (0.0, 0, 0)).sum().backward()
+    assert torch.equal(xg2.grad, torch.ones_like(xg2))
+
+
+# ------------------------------------------------------------------------------------------------ encoder layer
+def test_encoder_layer_grads_vs_torch():
+    torch.manual_seed(0)
+    B, T, d, H = 2, 70, 512, 8
+    layer = torch.nn.TransformerEncoderLayer(d_model=d, nhead=H, dim_feedforward=1024, dropout=0.1, activation="gelu", batch_first=True).eval()
+    load_named_weights(layer)
+    x, dy = g("el_x", (B, T, d)), g("el_dy", (B, T, d))
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    mask[1, 50:] = True
+    ref = torch.nn.TransformerEncoderLayer(d_model=d, nhead=H, dim_feedforward=1024, dropout=0.1, activation="gelu", batch_first=True).double().eval()
+    ref.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr, src_key_padding_mask=mask)          # grad enabled -> torch takes its unfused (autograd) path
+    (yr * dy.double()).sum().backward()
+    layer = layer.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    y = AG.encoder_layer(xg, layer, mask.to(dev()), H, (0.0, 0, 0))
+    report("encoder layer forward", y, yr, 5e-5)
+    (y * dy.to(dev())).sum().backward()
+    rel("encoder layer dx", xg.grad, xr.grad, 1e-4)
+    for (n, p_), (_, pr) in zip(layer.named_parameters(), ref.named_parameters()):
+        rel(f"encoder layer d{n}", p_.grad, pr.grad, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+@pytest.fixture(scope="module")
+def cmdm_train():
+    model, diff = create_model_and_diffusion(cmdm_cfg(), device=dev())
+    load_named_weights(model)
+    model = model.to(dev())
+    model.contact_encoder.requires_grad_(False)
+    return model, diff
+
+
+def _digest(gr):
+    flat = gr.detach().reshape(-1).cpu()
+    sample = flat if flat.numel() <= 2048 else flat[:: flat.numel() // 1024][:1024]
+    return sample, flat.double().abs().sum().item()
+
+
+def test_training_losses_backward_vs_reference_gradients(cmdm_train):
+    """diffusion.training_losses(...)['loss'].mean().backward() (utils/training.py:140-152) on the HIP path vs the
+    gradients the real reference produced for the same inputs (eval mode: dropout off)."""
+    model, diff = cmdm_train
+    model.eval()
+    gf, gg = golden("cmdm_forward_N1024_L16"), golden("cmdm_training_grads")
+    x0, tn = synth.gaussian("train_x0", (2, 16, 263)).to(dev()), synth.gaussian("train_noise", (2, 16, 263)).to(dev())
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_cont_emb=gf["cont_emb"].to(dev()), x_mask=gf["x_mask"].to(dev()))
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, gg["t"].to(dev()), model_kwargs=kw, noise=tn)
+    report("training loss", terms["loss"], gg["loss"], 2e-5)
+    terms["loss"].mean().backward()
+    names = [k[2:] for k in gg if k.startswith("g/")]
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for n in names:
+        assert params[n].grad is not None, n
+        sample, abs_sum = _digest(params[n].grad)
+        scale = max(gg["g/" + n].abs().max().item(), 1e-9)
+        err = ((sample - gg["g/" + n]).abs().max() / scale).item()
+        worst = max(worst, err)
+        assert err <= 5e-4, f"{n}: scaled grad err {err:.3e}"
+        assert abs(abs_sum - gg["s/" + n][1].item()) <= 5e-4 * gg["s/" + n][1].item() + 1e-9, n
+    print(f"[parity] 72 trunk gradients vs the reference's backward: worst scaled err {worst:.3e}")
+    for n, p_ in model.named_parameters():
+        if n.startswith("contact_encoder."):
+            assert p_.grad is None
+
+
+def test_training_losses_backward_with_encoder_and_full_shapes(cmdm_train):
+    """B=4, L=196 (T=326 tokens incl. 128 contact tokens from the HIP SceneMapEncoder) vs the oracle's autograd."""
+    from oracle import diffusion_ref as df
+    from oracle import shapes as sh
+    from oracle import train_ref as tr
+    model, diff = cmdm_train
+    model.eval()
+    B, L, N = 4, 196, 1024
+    x0, tn = synth.gaussian("tf_x0", (B, L, 263)), synth.gaussian("tf_noise", (B, L, 263))
+    text = synth.text_feature(B)
+    cont = synth.gaussian("tf_cont", (B, 128, 256)) * 0.5
+    x_mask = synth.frame_mask(B, L)
+    t = torch.tensor([3, 250, 640, 999])
+    sd = sh.weights(sh.cmdm())
+    loss_ref, grads = tr.cmdm_loss_and_grads(sd, df.Schedule(1000), x0, t, tn, text, cont, x_mask)
+    kw = dict(c_text_feat=text.to(dev()), c_cont_emb=cont.to(dev()), x_mask=x_mask.to(dev()))
+    model.zero_grad()
+    terms = diff.training_losses(model, x0.to(dev()), t.to(dev()), model_kwargs=kw, noise=tn.to(dev()))
+    report("training loss (B=4, L=196)", terms["loss"], loss_ref, 5e-5)
+    terms["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for n, gr in grads.items():
+        scale = max(gr.abs().max().item(), 1e-9)
+        err = ((params[n].grad.cpu() - gr).abs().max() / scale).item()
+        worst = max(worst, err)
+        assert err <= 5e-4, f"{n}: scaled grad err {err:.3e}"
+    print(f"[parity] {len(grads)} trunk gradients at B=4, L=196 vs oracle autograd: worst scaled err {worst:.3e}")
+
+
+def test_train_mode_dropout_is_reproducible_and_trains(cmdm_train):
+    """Train mode (all dropouts on): same seed -> identical loss / grads; a few fused-AdamW steps reduce the loss."""
+    model, diff = cmdm_train
+    gf = golden("cmdm_forward_N1024_L16")
+    x0 = synth.gaussian("train_x0", (2, 16, 263)).to(dev())
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_cont_emb=gf["cont_emb"].to(dev()), x_mask=gf["x_mask"].to(dev()))
+    t = torch.tensor([17, 803], device=dev())
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model.train()
+
+    def run():
+        torch.manual_seed(5)
+        model._drop_calls, diff._loss_calls = 0, 0
+        model.zero_grad()
+        terms = diff.training_losses(model, x0, t, model_kwargs=kw)
+        terms["loss"].mean().backward()
+        return terms["loss"].detach().clone(), model.motion_layer.weight.grad.clone()
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    model.eval()
+    with torch.no_grad():
+        diff._loss_calls = 0
+        l_eval = diff.training_losses(model, x0, t, model_kwargs=kw)["loss"]
+    assert not torch.allclose(l1, l_eval), "dropout had no effect in train mode"
+    model.train()
+    opt_state, losses = {}, []
+    params = [p_ for p_ in model.parameters() if p_.requires_grad]
+    for it in range(8):
+        model.zero_grad()
+        diff._loss_calls = 0                      # same noise every iteration: the loss must go down
+        terms = diff.training_losses(model, x0, t, model_kwargs=kw)
+        terms["loss"].mean().backward()
+        losses.append(terms["loss"].mean().item())
+        AG.adamw_step(params, opt_state, lr=1e-4)
+    print("[train] losses:", [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0]
+    model.load_state_dict(state0)
+    model.eval()
+
+
+def test_adamw_matches_torch():
+    p0, gr = g("aw_p", (1000,)), g("aw_g", (1000,))
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    mine = torch.nn.Parameter(p0.clone().to(dev()))
+    st = {}
+    for i in range(3):
+        ref.grad = gr * (i + 1)
+        opt.step()
+        mine.grad = (gr * (i + 1)).to(dev())
+        AG.adamw_step([mine], st, lr=1e-3, weight_decay=0.01)
+    report("AdamW 3 steps", mine.data, ref.data, 1e-6)

@@ -128,8 +128,12 @@ def test_product_path_refuses_cpu_tensors():
         with torch.no_grad():
             model(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long), c_text_feat=torch.zeros(1, 512),
                   c_cont_emb=torch.zeros(1, 128, 256), x_mask=torch.zeros(1, 8, dtype=torch.bool))
-    with pytest.raises(NotImplementedError):       # training path is not built yet: loud, no eager fallback
+    with pytest.raises(NotImplementedError):       # SceneMapEncoder backward is not built yet: loud, no eager fallback
         model.train()(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long))
+    model.contact_encoder.requires_grad_(False)
+    with pytest.raises(ffi.AfmError):              # the training path is HIP-only as well
+        model(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long), c_text_feat=torch.zeros(1, 512),
+              c_cont_emb=torch.zeros(1, 128, 256), x_mask=torch.zeros(1, 8, dtype=torch.bool))
 
 
 def test_product_never_imports_oracle():
@@ -150,4 +154,4 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(ffi.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"missing export {name}"
-    assert ffi.load().afm_version() == 1            # pure host call, no GPU needed
+    assert ffi.load().afm_version() == 2            # pure host call, no GPU needed
