@@ -153,6 +153,35 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
     }
 }
 
+// Few columns, many partial rows: dst[c] (+)= sum_s src[s * stride + c] for c < n_total; columns >= n0 go to dst1[c - n0].
+// Block = 64 columns x 16 partial-row lanes (loads of one thread are independent and unrolled), fixed-order LDS tree.
+__global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restrict__ src, int64_t stride, int S, float* __restrict__ dst0,
+                                                           float* __restrict__ dst1, int n0, int n_total, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < n_total) {
+        int s = ty;
+        for (; s + 48 < S; s += 64) {
+            a0 += src[(int64_t)s * stride + c];
+            a1 += src[(int64_t)(s + 16) * stride + c];
+            a2 += src[(int64_t)(s + 32) * stride + c];
+            a3 += src[(int64_t)(s + 48) * stride + c];
+        }
+        for (; s < S; s += 16) a0 += src[(int64_t)s * stride + c];
+    }
+    red[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && c < n_total) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][tx];
+        float* d = c < n0 ? dst0 + c : dst1 + (c - n0);
+        *d = accumulate ? *d + v : v;
+    }
+}
+
 // partial column sums: out[chunk][n] = sum over the chunk's rows of dY[map(m)][n]; block = 64 columns x 4 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, int64_t ld, RowMap3 map, int M, int N, int rows_per_chunk,
                                                      float* __restrict__ out) {
@@ -180,7 +209,7 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     if (w.rows_per_split < RB) w.rows_per_split = RB;          // M == 0
     w.S = (M + w.rows_per_split - 1) / w.rows_per_split;
     if (w.S < 1) w.S = 1;
-    w.chunks = (M + 255) / 256; if (w.chunks > 64) w.chunks = 64; if (w.chunks < 1) w.chunks = 1;
+    w.chunks = (M + 63) / 64; if (w.chunks > 256) w.chunks = 256; if (w.chunks < 1) w.chunks = 1;
     w.rows_per_chunk = (M + w.chunks - 1) / w.chunks;
     return w;
 }
@@ -381,7 +410,7 @@ extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream)
         hipLaunchKernelGGL(colsum_kernel, dim3((a.N + 63) / 64, w.chunks), dim3(256), 0, s, a.dY, a.lddy, RowMap3{a.dy_grp, a.dy_stride, a.dy_off},
                            a.M, a.N, w.rows_per_chunk, colpart);
         AFM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, colpart, (int64_t)a.N, w.chunks, a.db, (int64_t)a.N, 1, a.N,
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3((a.N + 63) / 64), dim3(1024), 0, s, colpart, (int64_t)a.N, w.chunks, a.db, a.db, a.N, a.N,
                            a.accumulate);
         AFM_CHECK_LAUNCH();
     }
@@ -410,13 +439,15 @@ extern "C" int afm_layernorm_bwd(const float* x, const float* gamma, const float
     const int nb = ln_bwd_blocks(rows);
     if (!ws || ws_bytes < (int64_t)nb * 2 * dim * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
     float* part = (float*)ws;
+    {
     AfmProf prof(AFM_PROF_LN_BWD, 16.0 * rows * dim, s);
 #define AFM_LNB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(nb), dim3(256), 0, s, x, gamma, dy, dx, dx_drop, part, rows, dim, eps, drop_p, drop_seed, drop_id)
     if (dim <= 256) AFM_LNB(1); else if (dim <= 512) AFM_LNB(2); else AFM_LNB(4);
 #undef AFM_LNB
     AFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, part, (int64_t)2 * dim, nb, dgamma, (int64_t)dim, 1, dim, 0);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, part + dim, (int64_t)2 * dim, nb, dbeta, (int64_t)dim, 1, dim, 0);
+    }
+    AfmProf prof(AFM_PROF_TRAIN_MISC, 0.0, s);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((2 * dim + 63) / 64), dim3(1024), 0, s, part, (int64_t)2 * dim, nb, dgamma, dbeta, dim, 2 * dim, 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }
