@@ -1,0 +1,232 @@
+"""Differentiable point-cloud operators of the training path (SceneMapEncoder under model.train(),
+reference models/scene_models/pointtransformer.py:26-69,102-123): BatchNorm on batch statistics (optionally synchronised
+across ranks = nn.SyncBatchNorm of train_ddp.py), neighbour gather / grouping, group max-pool and the vector-attention
+glue, each a torch.autograd Function whose forward and backward are HIP kernels (csrc/pointnet_train.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ffi
+from .autograd import _c, _st
+
+
+def _ws(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def _sync_group():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, relu, sync):
+        lib = ffi.load()
+        xc, g, b = _c(x), _c(gamma), _c(beta)
+        res = None if residual is None else _c(residual)
+        Cn = xc.shape[-1]
+        rows = xc.numel() // Cn
+        dev = xc.device
+        mean, rstd, scale, shift = (torch.empty(Cn, device=dev, dtype=torch.float32) for _ in range(4))
+        count = rows
+        batch_stats = bn.training or bn.running_mean is None
+        if batch_stats:
+            stats = torch.empty(2 * Cn, device=dev, dtype=torch.float32)
+            ws = _ws(lib.afm_colstats_workspace_bytes(rows, Cn), dev)
+            ffi.check(lib.afm_colstats(xc.data_ptr(), rows, Cn, stats.data_ptr(), ws.data_ptr(), ws.numel(), _st(xc)), "afm_colstats")
+            if sync and _sync_group():
+                dist.all_reduce(stats)                                   # RCCL: 2*C floats per BatchNorm
+                count = rows * dist.get_world_size()
+            track = bn.training and bn.track_running_stats and bn.running_mean is not None
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            ffi.check(lib.afm_bn_finalize(stats.data_ptr(), count, g.data_ptr(), b.data_ptr(), float(bn.eps), mom,
+                                          bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                          mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), Cn, _st(xc)), "afm_bn_finalize")
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        else:                                                            # frozen BatchNorm (eval): running statistics
+            mean = bn.running_mean.detach().float().contiguous()
+            rstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
+            scale = (g * rstd).contiguous()
+            shift = (b - mean * scale).contiguous()
+        y = torch.empty_like(xc)
+        ffi.check(lib.afm_colaffine(xc.data_ptr(), scale.data_ptr(), shift.data_ptr(), ffi.ptr(res), 1 if relu else 0, y.data_ptr(), rows, Cn,
+                                    _st(xc)), "afm_colaffine")
+        ctx.save_for_backward(xc, y if relu else None, mean, rstd, g)
+        ctx.cfg = (rows, Cn, count, batch_stats, sync, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = ffi.load()
+        xc, y, mean, rstd, g = ctx.saved_tensors
+        rows, Cn, count, batch_stats, sync, has_res = ctx.cfg
+        dy = _c(dy)
+        dev = xc.device
+        stats = torch.empty(2 * Cn, device=dev, dtype=torch.float32)
+        ws = _ws(lib.afm_colstats_workspace_bytes(rows, Cn), dev)
+        ffi.check(lib.afm_bn_bwd_stats(dy.data_ptr(), xc.data_ptr(), ffi.ptr(y), mean.data_ptr(), rstd.data_ptr(), rows, Cn, stats.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _st(xc)), "afm_bn_bwd_stats")
+        dbeta, dgamma = stats[:Cn].clone(), stats[Cn:].clone()           # local sums (DDP averages parameter grads itself)
+        if not batch_stats:
+            stats = torch.zeros_like(stats)                              # statistics are constants: dx = g * gamma * rstd
+        elif sync and _sync_group():
+            dist.all_reduce(stats)
+        dx = torch.empty_like(xc)
+        dres = torch.empty_like(xc) if has_res else None
+        ffi.check(lib.afm_bn_bwd_apply(dy.data_ptr(), xc.data_ptr(), ffi.ptr(y), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), stats.data_ptr(),
+                                       count, dx.data_ptr(), ffi.ptr(dres), rows, Cn, _st(xc)), "afm_bn_bwd_apply")
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+def batch_norm(x, bn: torch.nn.BatchNorm1d, *, relu: bool = False, residual: Optional[torch.Tensor] = None, sync: bool = True):
+    """relu?(BatchNorm1d(x) + residual) over a row-major [rows, C] matrix; batch statistics when ``bn.training`` (all-reduced
+    across ranks when a process group is up and ``sync``), running statistics otherwise."""
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, residual, bn, relu, sync)
+
+
+# ------------------------------------------------------------------------------------------------ gather / group
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        xc = _c(x)
+        out = torch.empty(idx.numel(), xc.shape[1], device=xc.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_gather_rows(xc.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), xc.shape[1], _st(xc)), "afm_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(xc.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.zeros(ctx.shape, device=dy.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_scatter_add_rows(dy.data_ptr(), dy.shape[1], 0, idx.data_ptr(), dx.data_ptr(), idx.numel(), dy.shape[1], _st(dy)),
+                  "afm_scatter_add_rows")
+        return dx, None
+
+
+def gather(x, idx):
+    """x[idx] for int32 row indices (any shape, flattened) -> [idx.numel(), C]."""
+    return _GatherFn.apply(x, idx)
+
+
+class _GroupPointsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, idx, k):
+        xyz, new_xyz = _c(xyz), _c(new_xyz)
+        f = None if feat is None else _c(feat)
+        Cn = 0 if f is None else f.shape[1]
+        rows = idx.numel()
+        out = torch.empty(rows, 3 + Cn, device=xyz.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_group_points(xyz.data_ptr(), new_xyz.data_ptr(), ffi.ptr(f), idx.data_ptr(), out.data_ptr(), rows, k, Cn,
+                                              _st(xyz)), "afm_group_points")
+        ctx.save_for_backward(idx)
+        ctx.fshape = None if f is None else tuple(f.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dfeat = None
+        if ctx.fshape is not None and ctx.needs_input_grad[2]:
+            dy = _c(dy)
+            dfeat = torch.zeros(ctx.fshape, device=dy.device, dtype=torch.float32)
+            ffi.check(ffi.load().afm_scatter_add_rows(dy.data_ptr(), dy.shape[1], 3, idx.data_ptr(), dfeat.data_ptr(), idx.numel(), ctx.fshape[1],
+                                                      _st(dy)), "afm_scatter_add_rows")
+        return None, None, dfeat, None, None
+
+
+def group_points(xyz, new_xyz, feat, idx, k: int):
+    """[xyz[idx] - new_xyz | feat[idx]] -> [m*k, 3 + C]  (pointops.queryandgroup with use_xyz=True; feat may be None)."""
+    return _GroupPointsFn.apply(xyz, new_xyz, feat, idx, k)
+
+
+class _GroupMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        xc = _c(x)
+        Cn = xc.shape[-1]
+        m = xc.numel() // (k * Cn)
+        y = torch.empty(m, Cn, device=xc.device, dtype=torch.float32)
+        arg = torch.empty(m, Cn, device=xc.device, dtype=torch.int32)
+        ffi.check(ffi.load().afm_group_max(xc.data_ptr(), y.data_ptr(), arg.data_ptr(), m, k, Cn, _st(xc)), "afm_group_max")
+        ctx.save_for_backward(arg)
+        ctx.dims = (m, k, Cn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        m, k, Cn = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty(m * k, Cn, device=dy.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_group_max_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), m, k, Cn, _st(dy)), "afm_group_max_bwd")
+        return dx, None
+
+
+def group_max(x, k: int):
+    """nn.MaxPool1d(k) over the neighbour axis: [m*k, C] -> [m, C]."""
+    return _GroupMaxFn.apply(x, k)
+
+
+# ------------------------------------------------------------------------------------------------ vector attention glue
+class _PtW0Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kg, q, pr, k):
+        kg, q, pr = _c(kg), _c(q), _c(pr)
+        m, Cn = q.shape
+        out = torch.empty_like(kg)
+        ffi.check(ffi.load().afm_pt_w0(kg.data_ptr(), q.data_ptr(), pr.data_ptr(), out.data_ptr(), m, k, Cn, _st(kg)), "afm_pt_w0")
+        ctx.dims = (m, k, Cn)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        m, k, Cn = ctx.dims
+        d = _c(d)
+        dq = torch.empty(m, Cn, device=d.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_group_sum(d.data_ptr(), dq.data_ptr(), m, k, Cn, -1.0, _st(d)), "afm_group_sum")
+        return d, dq, d, None
+
+
+def pt_w0(kg, q, pr, k: int):
+    """k_g - q[:, None] + p_r over [m*k, C] (pointtransformer.py:34)."""
+    return _PtW0Fn.apply(kg, q, pr, k)
+
+
+class _PtAggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vg, pr, w2, k, share):
+        vg, pr, w2 = _c(vg), _c(pr), _c(w2)
+        Cn = vg.shape[1]
+        m = vg.shape[0] // k
+        out = torch.empty(m, Cn, device=vg.device, dtype=torch.float32)
+        sw = torch.empty_like(w2)
+        ffi.check(ffi.load().afm_pt_aggregate(vg.data_ptr(), pr.data_ptr(), w2.data_ptr(), out.data_ptr(), sw.data_ptr(), m, k, Cn, share, _st(vg)),
+                  "afm_pt_aggregate")
+        ctx.save_for_backward(vg, pr, sw)
+        ctx.dims = (m, k, Cn, share)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vg, pr, sw = ctx.saved_tensors
+        m, k, Cn, share = ctx.dims
+        dout = _c(dout)
+        da = torch.empty_like(vg)
+        dw2 = torch.empty_like(sw)
+        ffi.check(ffi.load().afm_pt_aggregate_bwd(vg.data_ptr(), pr.data_ptr(), sw.data_ptr(), dout.data_ptr(), da.data_ptr(), dw2.data_ptr(), m, k,
+                                                  Cn, share, _st(vg)), "afm_pt_aggregate_bwd")
+        return da, da, dw2, None, None
+
+
+def pt_aggregate(vg, pr, w2, k: int, share: int):
+    """sum_k (v_g + p_r) * softmax_k(w2) with the weights shared by `share` channel groups (pointtransformer.py:35-37)."""
+    return _PtAggregateFn.apply(vg, pr, w2, k, share)

@@ -230,12 +230,8 @@ class CMDM(TextEncoderMixin, nn.Module):
         `diffusion.training_losses(...)['loss'].mean().backward()` (utils/training.py:140-152) fills `.grad` of the
         transformer trunk, the adapters and the TimestepEmbedder.  Train mode applies the reference's dropouts
         (PositionalEncoding 0.1, cfg.dropout inside every encoder layer incl. attention probabilities) with
-        counter-hash masks.  The SceneMapEncoder runs frozen on running BatchNorm statistics: its backward
-        (batch-statistics BatchNorm through the fused set-abstraction kernels) is the next row."""
-        frozen = not any(p.requires_grad for p in self.contact_encoder.parameters())
-        if not frozen:
-            raise NotImplementedError("the SceneMapEncoder backward is not built yet: freeze it with "
-                                      "`model.contact_encoder.requires_grad_(False)` to train the denoiser trunk")
+        counter-hash masks; the SceneMapEncoder trains through afm.autograd_points (batch-statistics BatchNorm) unless
+        its parameters are frozen, in which case the fused inference kernels compute it."""
         ffi.require_gpu(x)
         x = ffi.f32c(x)
         B, L, _ = x.shape
@@ -261,8 +257,9 @@ class CMDM(TextEncoderMixin, nn.Module):
         text_emb = AG.linear(text_feat, self.language_adapter.weight, self.language_adapter.bias).view(B, 1, d)
         masks.append(text_mask)
         # contact tokens (cmdm.py:148-156)
-        with torch.no_grad():
-            cont = kwargs["c_cont_emb"] if "c_cont_emb" in kwargs else self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])
+        # SceneMapEncoder: differentiable passes (batch-statistics BatchNorm in train mode) when it has trainable
+        # parameters, the fused inference kernels when it is frozen
+        cont = kwargs["c_cont_emb"] if "c_cont_emb" in kwargs else self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])
         G = cont.shape[1]
         cont_mask = torch.zeros(B, G, dtype=torch.bool, device=dev)
         if "c_pc_mask" in kwargs:

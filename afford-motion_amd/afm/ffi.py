@@ -135,6 +135,21 @@ EXPORTS = {
                               C.c_void_p, i64, C.c_void_p]),
     "afm_masked_mse_bwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, i32, i32, i32, C.c_void_p]),
     "afm_rowop": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, i32, c_f32p, i64, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
+    "afm_colstats_workspace_bytes": (i64, [i64, i32]),
+    "afm_colstats": (C.c_int, [c_f32p, i64, i32, c_f32p, C.c_void_p, i64, C.c_void_p]),
+    "afm_bn_finalize": (C.c_int, [c_f32p, i64, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32,
+                                  C.c_void_p]),
+    "afm_colaffine": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p, i64, i32, C.c_void_p]),
+    "afm_bn_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, C.c_void_p, i64, C.c_void_p]),
+    "afm_bn_bwd_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, c_f32p, c_f32p, i64, i32, C.c_void_p]),
+    "afm_group_points": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, i64, i32, i32, C.c_void_p]),
+    "afm_scatter_add_rows": (C.c_int, [c_f32p, i64, i32, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),
+    "afm_group_max": (C.c_int, [c_f32p, c_f32p, C.c_void_p, i64, i32, i32, C.c_void_p]),
+    "afm_group_max_bwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i64, i32, i32, C.c_void_p]),
+    "afm_group_sum": (C.c_int, [c_f32p, c_f32p, i64, i32, i32, C.c_float, C.c_void_p]),
+    "afm_pt_w0": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, C.c_void_p]),
+    "afm_pt_aggregate": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, i32, C.c_void_p]),
+    "afm_pt_aggregate_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, i32, C.c_void_p]),
     "afm_adamw": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_void_p]),
     "afm_fps": (C.c_int, [c_f32p, i32, i32, i32, C.c_void_p, C.c_void_p]),
     "afm_knn": (C.c_int, [i32, c_f32p, c_f32p, i32, i32, i32, C.c_void_p, c_f32p, C.c_void_p]),

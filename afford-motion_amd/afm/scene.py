@@ -1,6 +1,8 @@
 """Point-cloud branch of the hot path: TransitionDown ("set abstraction"), PointTransformerLayer /
 Block and SceneMapEncoder (reference models/scene_models/pointtransformer.py:9-123,
-models/modules.py:124-167), eval mode.
+models/modules.py:124-167).  Inference (`run`, no autograd) uses the fused kernels below; with autograd enabled and
+trainable parameters the `run_train` methods compose the same functions from differentiable HIP passes
+(afm/autograd_points.py), BatchNorm on batch statistics when the module is in train mode.
 
 The nn.Modules below are parameter containers with the reference's state-dict keys; the math runs
 in the HIP point kernels (afm/pointops.py -> csrc/pointops.hip, csrc/pointnet.hip):
@@ -19,6 +21,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
+from . import autograd_points as AP
 from . import ffi, ops, pointops
 
 
@@ -58,6 +62,25 @@ class PointTransformerLayer(nn.Module):
             self.linear_w[5].weight, self.linear_w[5].bias, out_scale, out_shift, relu)
 
 
+    def run_train(self, p, x, knn_idx):
+        """Differentiable form of `run` (pointtransformer.py:26-38): every BatchNorm is its own pass."""
+        k, c, n = self.nsample, self.out_planes, x.shape[0]
+        idx = knn_idx.reshape(-1)
+        xq = AG.linear(x, self.linear_q.weight, self.linear_q.bias)
+        kg = AP.gather(AG.linear(x, self.linear_k.weight, self.linear_k.bias), idx)        # [n*k, c]
+        vg = AP.gather(AG.linear(x, self.linear_v.weight, self.linear_v.bias), idx)
+        pr = AP.group_points(p, p, None, idx, k)                                           # [n*k, 3] relative xyz
+        pr = AG.linear(pr, self.linear_p[0].weight, self.linear_p[0].bias)
+        pr = AP.batch_norm(pr, self.linear_p[1], relu=True)
+        pr = AG.linear(pr, self.linear_p[3].weight, self.linear_p[3].bias)                 # [n*k, c]
+        w = AP.pt_w0(kg, xq, pr, k)
+        w = AP.batch_norm(w, self.linear_w[0], relu=True)
+        w = AG.linear(w, self.linear_w[2].weight, self.linear_w[2].bias)
+        w = AP.batch_norm(w, self.linear_w[3], relu=True)
+        w = AG.linear(w, self.linear_w[5].weight, self.linear_w[5].bias)                   # [n*k, c/s]
+        return AP.pt_aggregate(vg, pr, w, k, self.share_planes)
+
+
 class TransitionDown(nn.Module):
     def __init__(self, in_planes, out_planes, stride=1, nsample=16):
         super().__init__()
@@ -84,6 +107,21 @@ class TransitionDown(nn.Module):
         return n_p, y
 
 
+    def run_train(self, p, x, batch: int):
+        """Differentiable form of `run` (pointtransformer.py:53-69)."""
+        if self.stride == 1:
+            return p, AP.batch_norm(AG.linear(x, self.linear.weight), self.bn, relu=True)
+        n = p.shape[0] // batch
+        m = n // self.stride
+        with torch.no_grad():
+            idx = pointops.furthest_point_sampling(p, batch, n, m)
+            n_p = pointops.gather_rows(p, idx)
+            knn_idx, _ = pointops.knn(self.nsample, p, n_p, batch, n, m)
+        g = AP.group_points(p, n_p, x, knn_idx.reshape(-1), self.nsample)                  # [m*k, 3+c]
+        y = AP.batch_norm(AG.linear(g, self.linear.weight), self.bn, relu=True)            # BN over all m*k rows
+        return n_p, AP.group_max(y, self.nsample)
+
+
 class PointTransformerBlock(nn.Module):
     expansion = 1
 
@@ -104,6 +142,13 @@ class PointTransformerBlock(nn.Module):
         y = ops.linear(x, self.linear1.weight, b1, scale=s1, act=ffi.ACT_RELU)
         y = self.transformer2.run(p, y, knn_idx, out_scale=s2, out_shift=b2, relu=True)
         return ops.linear(y, self.linear3.weight, b3, scale=s3, residual=x, act_post=ffi.ACT_RELU)   # relu(bn3(linear3) + identity)
+
+
+    def run_train(self, p, x, knn_idx):
+        """Differentiable form of `run` (pointtransformer.py:115-123)."""
+        y = AP.batch_norm(AG.linear(x, self.linear1.weight), self.bn1, relu=True)
+        y = AP.batch_norm(self.transformer2.run_train(p, y, knn_idx), self.bn2, relu=True)
+        return AP.batch_norm(AG.linear(y, self.linear3.weight), self.bn3, relu=True, residual=x)
 
 
 class SceneMapEncoder(nn.Module):
@@ -130,8 +175,27 @@ class SceneMapEncoder(nn.Module):
             layers.append(PointTransformerBlock(planes, planes, share_planes, nsample=nsample))
         return nn.Sequential(*layers)
 
+    def forward_train(self, p: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """Same function with the autograd tape attached (BatchNorm per `self.training`)."""
+        ffi.require_gpu(p, x)
+        B, N = p.shape[0], p.shape[1]
+        p0 = ffi.f32c(p).reshape(B * N, 3)
+        x0 = p0 if self.c == 3 else torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+        for lvl in range(4):
+            enc = getattr(self, f"enc{lvl + 1}")
+            p0, x0 = enc[0].run_train(p0, x0, B)
+            n = p0.shape[0] // B
+            if len(enc) > 1:
+                with torch.no_grad():
+                    knn_idx, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
+                for blk in list(enc)[1:]:
+                    x0 = blk.run_train(p0, x0, knn_idx)
+        return x0.view(B, -1, x0.shape[-1])
+
     def forward(self, p: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         ffi.require_gpu(p, x)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            return self.forward_train(p, x)
         with torch.no_grad():
             B, N = p.shape[0], p.shape[1]
             p0 = ffi.f32c(p).reshape(B * N, 3)

@@ -1,0 +1,424 @@
+// Train-mode point-cloud operators: BatchNorm on BATCH statistics breaks the single-kernel fusions of pointnet.hip
+// (every BatchNorm needs a full pass over its input before anything downstream can be computed), so the training
+// forward / backward of TransitionDown and PointTransformerLayer (pointtransformer.py:26-69) is composed from
+// bandwidth-bound passes over materialised [n, k, c] tensors - 288 GB of HBM hold them comfortably:
+//   column statistics (two-stage, fixed order), per-column affine (+ residual, ReLU), BatchNorm backward,
+//   neighbour gather / atomic scatter-add, group max (+ argmax), and the vector-attention glue
+//   (w = k_g - q + p_r;  softmax over the k neighbours;  share-planes weighted sum) with their backward passes.
+// All of them stream rows with the channel index on consecutive lanes (coalesced), one thread per element group.
+#include "common.h"
+#include "profile.h"
+#include <math.h>
+
+namespace {
+
+// dst[c] (+)= sum_s src[s * stride + c]; block = 64 columns x 16 partial-row lanes, fixed-order tree
+__global__ __launch_bounds__(1024) void reduce_cols2_kernel(const float* __restrict__ src, int64_t stride, int S, float* __restrict__ dst, int n) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < n) {
+        int s = ty;
+        for (; s + 16 < S; s += 32) { a0 += src[(int64_t)s * stride + c]; a1 += src[(int64_t)(s + 16) * stride + c]; }
+        for (; s < S; s += 16) a0 += src[(int64_t)s * stride + c];
+    }
+    red[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && c < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][tx];
+        dst[c] = v;
+    }
+}
+
+// Per-column pair sums over a chunk of rows.  MODE 0: (x, x^2).  MODE 1: (g, g * xhat) with g = dy * (y > 0 when y given),
+// xhat = (x - mean) * rstd.  Block = CW column lanes x (256 / CW) row lanes; thread keeps NC = ceil(C / CW) column pairs.
+template <int MODE, int NC>
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int C, int CW,
+                                                       int64_t rows_per_chunk, float* __restrict__ part) {
+    extern __shared__ float red[];                       // [RL][2][C]
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, RL = 256 / CW;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s0[NC], s1[NC], mu[NC], rs[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        s0[j] = 0.f; s1[j] = 0.f;
+        const int c = tx + j * CW;
+        mu[j] = (MODE == 1 && c < C) ? mean[c] : 0.f;
+        rs[j] = (MODE == 1 && c < C) ? rstd[c] : 0.f;
+    }
+    for (int64_t r = r0 + ty; r < r1; r += RL) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = tx + j * CW;
+            if (c < C) {
+                const int64_t i = r * C + c;
+                if (MODE == 0) {
+                    const float v = a[i];
+                    s0[j] += v; s1[j] += v * v;
+                } else {
+                    float g = a[i];
+                    if (y) g = y[i] > 0.0f ? g : 0.0f;
+                    s0[j] += g; s1[j] += g * ((x[i] - mu[j]) * rs[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = tx + j * CW;
+        if (c < C) { red[(ty * 2 + 0) * C + c] = s0[j]; red[(ty * 2 + 1) * C + c] = s1[j]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+        float v = 0.f;
+        for (int t = 0; t < RL; ++t) v += red[t * 2 * C + e];
+        part[(int64_t)blockIdx.x * 2 * C + e] = v;
+    }
+}
+
+struct StatPlan { int CW, NC, chunks; int64_t rows_per_chunk; };
+StatPlan stat_plan(int64_t rows, int C) {
+    StatPlan p;
+    p.CW = 4; while (p.CW < C && p.CW < 64) p.CW <<= 1;
+    p.NC = (C + p.CW - 1) / p.CW;
+    const int RL = 256 / p.CW;
+    int64_t ch = (rows + (int64_t)RL * 16 - 1) / ((int64_t)RL * 16);      // >= 16 rows per row lane
+    if (ch > 1024) ch = 1024;
+    if (ch < 1) ch = 1;
+    p.chunks = (int)ch;
+    p.rows_per_chunk = (rows + ch - 1) / ch;
+    return p;
+}
+
+template <int MODE>
+int launch_colstats(const float* a, const float* x, const float* y, const float* mean, const float* rstd, int64_t rows, int C, float* stats,
+                    void* ws, int64_t ws_bytes, hipStream_t s) {
+    if (C <= 0 || C > 512 || rows < 0) return C > 512 ? AFM_E_UNSUPPORTED : AFM_E_BADARG;
+    if (rows == 0) { hipError_t e = hipMemsetAsync(stats, 0, 2 * C * sizeof(float), s); return (int)e; }
+    const StatPlan p = stat_plan(rows, C);
+    if (!ws || ws_bytes < (int64_t)p.chunks * 2 * C * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
+    float* part = (float*)ws;
+    const size_t lds = (size_t)(256 / p.CW) * 2 * C * sizeof(float);
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, s);
+#define AFM_CS(NC) hipLaunchKernelGGL((colstats_kernel<MODE, NC>), dim3(p.chunks), dim3(256), lds, s, a, x, y, mean, rstd, rows, C, p.CW, p.rows_per_chunk, part)
+    if (p.NC == 1) AFM_CS(1); else if (p.NC == 2) AFM_CS(2); else if (p.NC <= 4) AFM_CS(4); else AFM_CS(8);
+#undef AFM_CS
+    AFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_cols2_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, part, (int64_t)2 * C, p.chunks, stats, 2 * C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = stats[c] / count;
+    float var = stats[C + c] / count - m * m;
+    var = fmaxf(var, 0.0f);
+    const float r = 1.0f / sqrtf(var + eps);
+    mean[c] = m; rstd[c] = r;
+    const float sc = gamma[c] * r;
+    scale[c] = sc; shift[c] = beta[c] - m * sc;
+    if (running_mean) {                      // nn.BatchNorm1d: running = (1 - momentum) * running + momentum * batch (unbiased variance)
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * m;
+        const float unbiased = count > 1.0f ? var * count / (count - 1.0f) : var;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// y = relu?(x * scale[c] + shift[c] + residual)
+__global__ __launch_bounds__(256) void colaffine_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ res, int relu, float* __restrict__ y, int64_t n, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        float v = x[i] * scale[c] + shift[c];
+        if (res) v += res[i];
+        y[i] = relu ? fmaxf(v, 0.0f) : v;
+    }
+}
+
+// dx = gamma * rstd * (g - sum_g / count - xhat * sum_gx / count);  dres = g  (g = dy masked by the ReLU output)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ stats, float inv_count, float* __restrict__ dx,
+                                                           float* __restrict__ dres, int64_t n, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        float g = dy[i];
+        if (y) g = y[i] > 0.0f ? g : 0.0f;
+        const float xh = (x[i] - mean[c]) * rstd[c];
+        dx[i] = gamma[c] * rstd[c] * (g - stats[c] * inv_count - xh * stats[C + c] * inv_count);
+        if (dres) dres[i] = g;
+    }
+}
+
+// out[r, 0:3] = xyz[idx[r]] - new_xyz[r / k];  out[r, 3:3+C] = feat[idx[r]]   (queryandgroup, pointops.py:79-100)
+__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz, const float* __restrict__ feat,
+                                                           const int32_t* __restrict__ idx, float* __restrict__ out, int64_t rows, int k, int C) {
+    const int W = 3 + C;
+    const int64_t n = rows * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / W;
+        const int c = (int)(i - r * W);
+        const int64_t src = idx[r];
+        out[i] = c < 3 ? xyz[src * 3 + c] - new_xyz[(r / k) * 3 + c] : feat[src * C + (c - 3)];
+    }
+}
+
+// dst[idx[r], c] += src[r * ld + off + c]   (backward of a row gather; f32 atomics, as the reference's CUDA grouping backward)
+__global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restrict__ src, int64_t ld, int off, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int64_t rows, int C) {
+    const int64_t n = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        atomicAdd(dst + (int64_t)idx[r] * C + c, src[r * ld + off + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg, int64_t m, int k, int C) {
+    const int64_t n = m * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / C;
+        const int c = (int)(i - g * C);
+        float best = x[(g * k) * C + c];
+        int bi = 0;
+        for (int j = 1; j < k; ++j) {
+            const float v = x[(g * k + j) * C + c];
+            if (v > best) { best = v; bi = j; }             // first maximum wins, like torch max_pool1d
+        }
+        y[i] = best; arg[i] = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx, int64_t m, int k, int C) {
+    const int64_t n = m * k * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        const int64_t g = r / k;
+        const int j = (int)(r - g * k);
+        dx[i] = arg[g * C + c] == j ? dy[g * C + c] : 0.0f;
+    }
+}
+
+// out[g, c] = scale * sum_j x[g, j, c]
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t m, int k, int C, float scale) {
+    const int64_t n = m * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / C;
+        const int c = (int)(i - g * C);
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) s += x[(g * k + j) * C + c];
+        out[i] = scale * s;
+    }
+}
+
+// w0[g, j, c] = kg[g, j, c] - q[g, c] + pr[g, j, c]   (pointtransformer.py:34)
+__global__ __launch_bounds__(256) void pt_w0_kernel(const float* __restrict__ kg, const float* __restrict__ q, const float* __restrict__ pr,
+                                                    float* __restrict__ out, int64_t m, int k, int C) {
+    const int64_t n = m * k * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t g = i / ((int64_t)k * C);
+        out[i] = kg[i] - q[g * C + c] + pr[i];
+    }
+}
+
+// sw = softmax over the k neighbours of w2[g, :, j];  out[g, s*Cs + j] = sum_k (vg + pr)[g, k, s*Cs + j] * sw[g, k, j]
+// (pointtransformer.py:35-37).  One thread per (g, channel c): recomputes its column's softmax (k <= 16 values).
+__global__ __launch_bounds__(256) void pt_aggregate_kernel(const float* __restrict__ vg, const float* __restrict__ pr, const float* __restrict__ w2,
+                                                           float* __restrict__ out, float* __restrict__ sw, int64_t m, int k, int C, int Cs) {
+    const int64_t n = m * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / C;
+        const int c = (int)(i - g * C), j = c % Cs;
+        float mx = -INFINITY;
+        for (int t = 0; t < k; ++t) mx = fmaxf(mx, w2[(g * k + t) * Cs + j]);
+        float den = 0.f;
+        for (int t = 0; t < k; ++t) den += __expf(w2[(g * k + t) * Cs + j] - mx);
+        const float inv = 1.0f / den;
+        float acc = 0.f;
+        for (int t = 0; t < k; ++t) {
+            const float p = __expf(w2[(g * k + t) * Cs + j] - mx) * inv;
+            acc += (vg[(g * k + t) * C + c] + pr[(g * k + t) * C + c]) * p;
+            if (c < Cs) sw[(g * k + t) * Cs + j] = p;
+        }
+        out[i] = acc;
+    }
+}
+
+// da[g,t,c] = dout[g,c] * sw[g,t,c%Cs]  (gradient of both vg and pr);
+// dsw[g,t,j] = sum_s dout[g, s*Cs+j] * a[g,t,s*Cs+j];  dw2 = sw * (dsw - sum_t sw*dsw)
+__global__ __launch_bounds__(256) void pt_aggregate_bwd_a_kernel(const float* __restrict__ dout, const float* __restrict__ sw, float* __restrict__ da,
+                                                                 int64_t m, int k, int C, int Cs) {
+    const int64_t n = m * k * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;                 // g * k + t
+        da[i] = dout[(r / k) * C + c] * sw[r * Cs + c % Cs];
+    }
+}
+__global__ __launch_bounds__(256) void pt_aggregate_bwd_w_kernel(const float* __restrict__ vg, const float* __restrict__ pr, const float* __restrict__ sw,
+                                                                 const float* __restrict__ dout, float* __restrict__ dw2, int64_t m, int k, int C, int Cs) {
+    const int64_t n = m * Cs;
+    const int S = C / Cs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / Cs;
+        const int j = (int)(i - g * Cs);
+        float dot = 0.f;
+        float dsw[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            dsw[t] = 0.f;
+            if (t < k) {
+                float d = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    const int64_t e = (g * k + t) * C + s * Cs + j;
+                    d += dout[g * C + s * Cs + j] * (vg[e] + pr[e]);
+                }
+                dsw[t] = d;
+                dot += d * sw[(g * k + t) * Cs + j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < k) dw2[(g * k + t) * Cs + j] = sw[(g * k + t) * Cs + j] * (dsw[t] - dot);
+    }
+}
+
+inline unsigned grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+}  // namespace
+
+extern "C" int64_t afm_colstats_workspace_bytes(int64_t rows, int32_t C) {
+    if (rows < 0 || C <= 0) return AFM_E_BADARG;
+    return (int64_t)stat_plan(rows, C).chunks * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int afm_colstats(const float* x, int64_t rows, int32_t C, float* stats, void* ws, int64_t ws_bytes, void* stream) {
+    if (!stats || (rows > 0 && !x)) return AFM_E_BADARG;
+    return launch_colstats<0>(x, nullptr, nullptr, nullptr, nullptr, rows, C, stats, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int afm_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift, int32_t C,
+                               void* stream) {
+    if (!stats || !gamma || !beta || !mean || !rstd || !scale || !shift || C <= 0 || count <= 0) return AFM_E_BADARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return AFM_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, (float)count, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, rstd, scale, shift, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_colaffine(const float* x, const float* scale, const float* shift, const float* residual, int32_t relu, float* y, int64_t rows,
+                             int32_t C, void* stream) {
+    if (rows == 0) return 0;
+    if (!x || !scale || !shift || !y || rows < 0 || C <= 0) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(colaffine_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, rows * C, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_bn_bwd_stats(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int64_t rows, int32_t C,
+                                float* stats, void* ws, int64_t ws_bytes, void* stream) {
+    if (!stats || !mean || !rstd || (rows > 0 && (!dy || !x))) return AFM_E_BADARG;
+    return launch_colstats<1>(dy, x, y, mean, rstd, rows, C, stats, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int afm_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, const float* gamma,
+                                const float* stats, int64_t count, float* dx, float* dres, int64_t rows, int32_t C, void* stream) {
+    if (rows == 0) return 0;
+    if (!dy || !x || !mean || !rstd || !gamma || !stats || !dx || rows < 0 || C <= 0 || count <= 0) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, x, y, mean, rstd, gamma, stats,
+                       1.0f / (float)count, dx, dres, rows * C, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_group_points(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx, float* out, int64_t rows, int32_t k,
+                                int32_t C, void* stream) {
+    if (rows == 0) return 0;
+    if (!xyz || !new_xyz || !idx || !out || rows < 0 || k <= 0 || C < 0 || (C > 0 && !feat)) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(group_points_kernel, dim3(grid_for(rows * (3 + C))), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, feat, idx, out, rows, k, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_scatter_add_rows(const float* src, int64_t ld, int32_t col_offset, const int32_t* idx, float* dst, int64_t rows, int32_t C,
+                                    void* stream) {
+    if (rows == 0) return 0;
+    if (!src || !idx || !dst || rows < 0 || C <= 0 || ld < col_offset + C) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, src, ld, col_offset, idx, dst, rows, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_group_max(const float* x, float* y, int32_t* arg, int64_t m, int32_t k, int32_t C, void* stream) {
+    if (m == 0) return 0;
+    if (!x || !y || !arg || m < 0 || k <= 0 || C <= 0) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(group_max_kernel, dim3(grid_for(m * C)), dim3(256), 0, (hipStream_t)stream, x, y, arg, m, k, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_group_max_bwd(const float* dy, const int32_t* arg, float* dx, int64_t m, int32_t k, int32_t C, void* stream) {
+    if (m == 0) return 0;
+    if (!dy || !arg || !dx || m < 0 || k <= 0 || C <= 0) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3(grid_for(m * k * C)), dim3(256), 0, (hipStream_t)stream, dy, arg, dx, m, k, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_group_sum(const float* x, float* out, int64_t m, int32_t k, int32_t C, float scale, void* stream) {
+    if (m == 0) return 0;
+    if (!x || !out || m < 0 || k <= 0 || C <= 0) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(m * C)), dim3(256), 0, (hipStream_t)stream, x, out, m, k, C, scale);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_pt_w0(const float* kg, const float* q, const float* pr, float* out, int64_t m, int32_t k, int32_t C, void* stream) {
+    if (m == 0) return 0;
+    if (!kg || !q || !pr || !out || m < 0 || k <= 0 || C <= 0) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(pt_w0_kernel, dim3(grid_for(m * k * C)), dim3(256), 0, (hipStream_t)stream, kg, q, pr, out, m, k, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_pt_aggregate(const float* vg, const float* pr, const float* w2, float* out, float* sw, int64_t m, int32_t k, int32_t C,
+                                int32_t share_planes, void* stream) {
+    if (m == 0) return 0;
+    if (!vg || !pr || !w2 || !out || !sw || m < 0 || k <= 0 || k > 16 || C <= 0 || share_planes <= 0 || C % share_planes) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(pt_aggregate_kernel, dim3(grid_for(m * C)), dim3(256), 0, (hipStream_t)stream, vg, pr, w2, out, sw, m, k, C, C / share_planes);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_pt_aggregate_bwd(const float* vg, const float* pr, const float* sw, const float* dout, float* da, float* dw2, int64_t m,
+                                    int32_t k, int32_t C, int32_t share_planes, void* stream) {
+    if (m == 0) return 0;
+    if (!vg || !pr || !sw || !dout || !da || !dw2 || m < 0 || k <= 0 || k > 16 || C <= 0 || share_planes <= 0 || C % share_planes) return AFM_E_BADARG;
+    const int Cs = C / share_planes;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(pt_aggregate_bwd_a_kernel, dim3(grid_for(m * k * C)), dim3(256), 0, (hipStream_t)stream, dout, sw, da, m, k, C, Cs);
+    hipLaunchKernelGGL(pt_aggregate_bwd_w_kernel, dim3(grid_for(m * Cs)), dim3(256), 0, (hipStream_t)stream, vg, pr, sw, dout, dw2, m, k, C, Cs);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}

@@ -191,6 +191,49 @@ int afm_masked_mse_bwd(const float* target, const float* pred, const uint8_t* fr
 int afm_rowop(const float* x, const float* rowtab, int32_t period, const float* z, int32_t act, float* out,
               int64_t rows, int32_t cols, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream);
 
+/* ---- train-mode point-cloud operators (BatchNorm on batch statistics; models/scene_models/pointtransformer.py:26-69,
+ * 102-123 under model.train()).  Batch statistics force a full pass between every BatchNorm and its consumer, so the
+ * training graph is composed from bandwidth-bound passes over materialised [n, k, c] tensors. */
+
+/* stats[0..C) = sum_r x[r,c], stats[C..2C) = sum_r x[r,c]^2 over a row-major [rows, C] matrix (C <= 512), fixed order. */
+int64_t afm_colstats_workspace_bytes(int64_t rows, int32_t C);
+int afm_colstats(const float* x, int64_t rows, int32_t C, float* stats, void* ws, int64_t ws_bytes, void* stream);
+/* nn.BatchNorm1d training-mode bookkeeping from (possibly all-reduced = SyncBatchNorm) stats over `count` rows:
+ * mean, rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and the running-statistics
+ * update running = (1-momentum)*running + momentum*batch (unbiased variance); running_* may be NULL. */
+int afm_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                    int32_t C, void* stream);
+/* y = relu?(x * scale[c] + shift[c] + residual)   (BatchNorm apply [+ identity] [+ ReLU]; residual may be NULL) */
+int afm_colaffine(const float* x, const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
+                  int64_t rows, int32_t C, void* stream);
+/* BatchNorm backward, stage 1: stats[0..C) = sum g, stats[C..2C) = sum g*xhat with g = dy * (y > 0 if y given) - these
+ * are dbeta and dgamma.  Stage 2: dx = gamma*rstd*(g - sum_g/count - xhat*sum_gx/count), dres = g (optional). */
+int afm_bn_bwd_stats(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, int64_t rows,
+                     int32_t C, float* stats, void* ws, int64_t ws_bytes, void* stream);
+int afm_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* rstd,
+                     const float* gamma, const float* stats, int64_t count, float* dx, float* dres, int64_t rows,
+                     int32_t C, void* stream);
+/* out[r, 0:3] = xyz[idx[r]] - new_xyz[r / k], out[r, 3:3+C] = feat[idx[r]]  (pointops.queryandgroup, pointops.py:79-100;
+ * C = 0: relative coordinates only). */
+int afm_group_points(const float* xyz, const float* new_xyz, const float* feat, const int32_t* idx, float* out,
+                     int64_t rows, int32_t k, int32_t C, void* stream);
+/* dst[idx[r], c] += src[r*ld + col_offset + c], c < C  (backward of a row gather; f32 atomics like the CUDA original) */
+int afm_scatter_add_rows(const float* src, int64_t ld, int32_t col_offset, const int32_t* idx, float* dst, int64_t rows,
+                         int32_t C, void* stream);
+/* nn.MaxPool1d(k) over [m, k, C] with argmax, and its backward (pointtransformer.py:66-68) */
+int afm_group_max(const float* x, float* y, int32_t* arg, int64_t m, int32_t k, int32_t C, void* stream);
+int afm_group_max_bwd(const float* dy, const int32_t* arg, float* dx, int64_t m, int32_t k, int32_t C, void* stream);
+/* out[g,c] = scale * sum_j x[g,j,c] */
+int afm_group_sum(const float* x, float* out, int64_t m, int32_t k, int32_t C, float scale, void* stream);
+/* vector-attention glue of PointTransformerLayer (pointtransformer.py:34-37):
+ * w0 = k_g - q[:,None] + p_r;  sw = softmax_k(w2);  out[g, s*Cs+j] = sum_k (v_g + p_r)[g,k,s*Cs+j] * sw[g,k,j] */
+int afm_pt_w0(const float* kg, const float* q, const float* pr, float* out, int64_t m, int32_t k, int32_t C, void* stream);
+int afm_pt_aggregate(const float* vg, const float* pr, const float* w2, float* out, float* sw, int64_t m, int32_t k,
+                     int32_t C, int32_t share_planes, void* stream);
+int afm_pt_aggregate_bwd(const float* vg, const float* pr, const float* sw, const float* dout, float* da, float* dw2,
+                         int64_t m, int32_t k, int32_t C, int32_t share_planes, void* stream);
+
 /* Fused AdamW over one flat parameter (torch.optim.AdamW semantics, utils/training.py:48-53):
  *   p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int afm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

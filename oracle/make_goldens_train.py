@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -63,5 +63,36 @@ def main():
     print(f"{n} parameter gradients")
 
 
+def scene_main():
+    """tests/golden/scene_encoder_train_N1024.npz: the reference SceneMapEncoder in train() mode (BatchNorm on batch
+    statistics) - forward output, gradients of every parameter for the loss sum(out * dy), and the updated running
+    statistics of two BatchNorm layers."""
+    from afm import synth
+    import_reference()
+    import models.modules as rmod
+    g = np.load(os.path.join(GOLD, "scene_map_encoder_N1024.npz"))
+    xyz, con = torch.from_numpy(g["xyz"]), torch.from_numpy(g["contact"])
+    sme = rmod.SceneMapEncoder(point_feat_dim=6, planes=[32, 64, 128, 256], blocks=[2, 2, 2, 2], num_points=xyz.shape[1])
+    synth.fill_module_(sme)
+    sme.train()
+    out = sme(xyz, con)
+    dy = synth.gaussian("scene_train_dy", tuple(out.shape))
+    (out * dy).sum().backward()
+    res = {"out": out.detach()}
+    n = 0
+    for name, p in sme.named_parameters():
+        sample, sums = grad_digest(p.grad)
+        res["g/" + name], res["s/" + name] = sample, sums
+        n += 1
+    for bn in ("enc1.0.bn", "enc2.1.transformer2.linear_w.0", "enc4.1.bn3"):
+        mod = dict(sme.named_modules())[bn]
+        res["rm/" + bn], res["rv/" + bn] = mod.running_mean.detach(), mod.running_var.detach()
+    save("scene_encoder_train_N1024", **res)
+    print(f"{n} scene-encoder parameter gradients")
+
+
 if __name__ == "__main__":
-    main()
+    if "--scene" in sys.argv:
+        scene_main()
+    else:
+        main()

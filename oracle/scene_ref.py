@@ -22,8 +22,41 @@ def _lin(sd: SD, pre: str, x):
     return F.linear(x, sd[pre + ".weight"], sd.get(pre + ".bias"))
 
 
+_BATCH_STATS = False      # train-mode BatchNorm (batch statistics, biased variance) instead of the running statistics
+
+
+class batch_stats:
+    """``with scene_ref.batch_stats():`` evaluates every BatchNorm below on batch statistics (model.train() semantics of
+    nn.BatchNorm1d; the running-statistics update is restated in `bn_running_update`)."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global _BATCH_STATS
+        self.prev, _BATCH_STATS = _BATCH_STATS, self.on
+
+    def __exit__(self, *a):
+        global _BATCH_STATS
+        _BATCH_STATS = self.prev
+
+
+def bn_running_update(running_mean, running_var, x2d, momentum: float = 0.1):
+    """nn.BatchNorm1d's buffer update for one train-mode forward over rows x2d [rows, C] (unbiased variance)."""
+    m, v = x2d.mean(0), x2d.var(0, unbiased=True)
+    return (1 - momentum) * running_mean + momentum * m, (1 - momentum) * running_var + momentum * v
+
+
 def _bn(sd: SD, pre: str, x, channel_dim: int = -1, eps: float = 1e-5):
-    """Eval-mode BatchNorm1d over ``channel_dim``."""
+    """BatchNorm1d over ``channel_dim``: running statistics (eval) or, inside `batch_stats()`, batch statistics."""
+    if _BATCH_STATS:
+        cd = channel_dim if channel_dim >= 0 else x.dim() + channel_dim
+        dims = [d for d in range(x.dim()) if d != cd]
+        shape = [1] * x.dim()
+        shape[cd] = -1
+        mean = x.mean(dims, keepdim=True)
+        var = x.var(dims, unbiased=False, keepdim=True)
+        return (x - mean) / torch.sqrt(var + eps) * sd[pre + ".weight"].view(shape) + sd[pre + ".bias"].view(shape)
     if channel_dim != 1 and x.dim() > 2:
         x = x.transpose(1, channel_dim if channel_dim >= 0 else x.dim() + channel_dim)
         y = F.batch_norm(x.contiguous(), sd[pre + ".running_mean"], sd[pre + ".running_var"],

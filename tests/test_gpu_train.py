@@ -343,3 +343,158 @@ def test_adamw_matches_torch():
         mine.grad = (gr * (i + 1)).to(dev())
         AG.adamw_step([mine], st, lr=1e-3, weight_decay=0.01)
     report("AdamW 3 steps", mine.data, ref.data, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ point-cloud branch (train-mode BatchNorm)
+from afm import autograd_points as AP      # noqa: E402
+from afm import scene as S                 # noqa: E402
+
+
+@pytest.mark.parametrize("rows,C,relu,res", [(20000, 32, True, False), (4097, 3, True, False), (3000, 256, False, True), (50, 512, True, True)])
+def test_batch_norm_train_forward_backward(rows, C, relu, res):
+    x, dy = g("bn_x", (rows, C)) * 1.5 + 0.3, g("bn_dy", (rows, C))
+    r = g("bn_r", (rows, C)) if res else None
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * g("bn_w", (C,))); bn.bias.copy_(0.1 * g("bn_b", (C,)))
+    ref = torch.nn.BatchNorm1d(C).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    ref.train()
+    xr = x.double().requires_grad_(True)
+    rr = None if r is None else r.double().requires_grad_(True)
+    yr = ref(xr) + (0 if rr is None else rr)
+    yr = torch.relu(yr) if relu else yr
+    (yr * dy.double()).sum().backward()
+    bn = bn.to(dev()).train()
+    xg = x.to(dev()).requires_grad_(True)
+    rg = None if r is None else r.to(dev()).requires_grad_(True)
+    y = AP.batch_norm(xg, bn, relu=relu, residual=rg)
+    report("BN train forward", y, yr, 2e-5)
+    (y * dy.to(dev())).sum().backward()
+    rel("BN dx", xg.grad, xr.grad, 5e-5)
+    rel("BN dgamma", bn.weight.grad, ref.weight.grad, 5e-5)
+    rel("BN dbeta", bn.bias.grad, ref.bias.grad, 5e-5)
+    if res:
+        rel("BN dresidual", rg.grad, rr.grad, 1e-6)
+    report("BN running_mean", bn.running_mean, ref.running_mean, 1e-5)
+    report("BN running_var", bn.running_var, ref.running_var, 1e-5)
+    assert int(bn.num_batches_tracked) == 1
+    # frozen BatchNorm (eval): running statistics, gradients still flow
+    bn.eval(); ref.eval()
+    xg.grad = None; bn.weight.grad = None; xr.grad = None; ref.weight.grad = None
+    y2 = AP.batch_norm(xg, bn, relu=relu, residual=None if rg is None else rg.detach())
+    y2r = ref(xr) + (0 if rr is None else rr.detach())
+    y2r = torch.relu(y2r) if relu else y2r
+    report("BN eval forward", y2, y2r, 2e-5)
+    (y2 * dy.to(dev())).sum().backward(); (y2r * dy.double()).sum().backward()
+    rel("BN eval dx", xg.grad, xr.grad, 5e-5)
+    rel("BN eval dgamma", bn.weight.grad, ref.weight.grad, 5e-5)
+
+
+def test_gather_group_and_max_ops():
+    n, m, k, C = 500, 120, 16, 24
+    feat, xyz = g("gg_f", (n, C)), g("gg_p", (n, 3))
+    idx = torch.randint(0, n, (m, k), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+    new_xyz = xyz[idx[:, 0].long()]
+    dy = g("gg_dy", (m * k, 3 + C))
+    fr = feat.double().requires_grad_(True)
+    gr = torch.cat([xyz.double()[idx.long().view(-1)] - new_xyz.double().repeat_interleave(k, 0), fr[idx.long().view(-1)]], 1)
+    mx_r = gr.view(m, k, 3 + C).max(1).values
+    ((gr * dy.double()).sum() + (mx_r ** 2).sum()).backward()
+    fg = feat.to(dev()).requires_grad_(True)
+    gg = AP.group_points(xyz.to(dev()), new_xyz.to(dev()), fg, idx.to(dev()).view(-1), k)
+    report("group_points", gg, gr, 1e-6)
+    mx = AP.group_max(gg, k)
+    report("group_max", mx, mx_r, 1e-6)
+    ((gg * dy.to(dev())).sum() + (mx ** 2).sum()).backward()
+    rel("group_points/max dfeat (atomic scatter-add)", fg.grad, fr.grad, 1e-5)
+    f2 = feat.to(dev()).requires_grad_(True)
+    (AP.gather(f2, idx.to(dev()).view(-1)) * dy[:, 3:].to(dev())).sum().backward()
+    f2r = feat.double().requires_grad_(True)
+    (f2r[idx.long().view(-1)] * dy[:, 3:].double()).sum().backward()
+    rel("gather backward", f2.grad, f2r.grad, 1e-5)
+
+
+def test_vector_attention_glue_ops():
+    m, k, C, share = 300, 16, 64, 8
+    kg, pr, vg = g("va_kg", (m * k, C)), g("va_pr", (m * k, C)), g("va_vg", (m * k, C))
+    q, w2 = g("va_q", (m, C)), g("va_w2", (m * k, C // share))
+    d0, d1 = g("va_d0", (m * k, C)), g("va_d1", (m, C))
+    T = lambda t: t.double().requires_grad_(True)
+    kgr, prr, vgr, qr, w2r = T(kg), T(pr), T(vg), T(q), T(w2)
+    w0r = kgr.view(m, k, C) - qr[:, None, :] + prr.view(m, k, C)
+    swr = torch.softmax(w2r.view(m, k, C // share), 1)
+    outr = ((vgr + prr).view(m, k, share, C // share) * swr[:, :, None, :]).sum(1).view(m, C)
+    ((w0r.reshape(m * k, C) * d0.double()).sum() + (outr * d1.double()).sum()).backward()
+    G = lambda t: t.to(dev()).requires_grad_(True)
+    kgg, prg, vgg, qg, w2g = G(kg), G(pr), G(vg), G(q), G(w2)
+    w0 = AP.pt_w0(kgg, qg, prg, k)
+    out = AP.pt_aggregate(vgg, prg, w2g, k, share)
+    report("pt_w0", w0, w0r.reshape(m * k, C), 1e-6)
+    report("pt_aggregate", out, outr, 1e-5)
+    ((w0 * d0.to(dev())).sum() + (out * d1.to(dev())).sum()).backward()
+    for name, a, b in (("dkg", kgg, kgr), ("dpr", prg, prr), ("dvg", vgg, vgr), ("dq", qg, qr), ("dw2", w2g, w2r)):
+        rel("vector attention " + name, a.grad, b.grad, 2e-5)
+
+
+def _zero_grad_name(name):
+    return "transformer2." in name and name.split("transformer2.")[1] in ("linear_q.bias", "linear_k.bias", "linear_v.bias", "linear_p.0.bias",
+                                                                           "linear_p.3.bias", "linear_w.2.bias", "linear_w.5.bias")
+
+
+def test_scene_encoder_train_mode_vs_reference():
+    """SceneMapEncoder under .train(): forward, every parameter gradient and the BatchNorm running statistics vs the real
+    reference (tests/golden/scene_encoder_train_N1024.npz, FPS / kNN from our own operators on both sides)."""
+    gi, gt = golden("scene_map_encoder_N1024"), golden("scene_encoder_train_N1024")
+    enc = S.SceneMapEncoder(point_feat_dim=6, planes=[32, 64, 128, 256], blocks=[2, 2, 2, 2], num_points=gi["xyz"].shape[1])
+    load_named_weights(enc)
+    enc = enc.to(dev()).train()
+    out = enc(gi["xyz"].to(dev()), gi["contact"].to(dev()))
+    report("SceneMapEncoder train-mode forward", out, gt["out"], 2e-4)
+    dy = synth.gaussian("scene_train_dy", tuple(gt["out"].shape)).to(dev())
+    (out * dy).sum().backward()
+    worst = 0.0
+    params = dict(enc.named_parameters())
+    names = [k[2:] for k in gt if k.startswith("g/")]
+    assert len(names) == 124
+    for n in names:
+        sample, _ = _digest(params[n].grad)
+        if _zero_grad_name(n):
+            assert sample.abs().max().item() < 5e-3, n
+            continue
+        scale = max(gt["g/" + n].abs().max().item(), 1e-3)
+        err = ((sample - gt["g/" + n]).abs().max() / scale).item()
+        worst = max(worst, err)
+        assert err <= 2e-3, f"{n}: scaled grad err {err:.3e}"
+    print(f"[parity] 124 scene-encoder gradients (train-mode BatchNorm) vs the reference: worst scaled err {worst:.3e}")
+    mods = dict(enc.named_modules())
+    for bn in ("enc1.0.bn", "enc2.1.transformer2.linear_w.0", "enc4.1.bn3"):
+        report(f"running_mean {bn}", mods[bn].running_mean, gt["rm/" + bn], 1e-5)
+        report(f"running_var {bn}", mods[bn].running_var, gt["rv/" + bn], 1e-4)
+
+
+def test_cmdm_trains_end_to_end_including_scene_encoder():
+    """Whole CMDM (scene encoder not frozen) in train mode: losses fall over a few AdamW steps, every parameter gets a
+    gradient - the reference's TrainLoop step (utils/training.py:138-155)."""
+    model, diff = create_model_and_diffusion(cmdm_cfg(num_points=1024), device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).train()
+    gf = golden("cmdm_forward_N1024_L16")
+    x0 = synth.gaussian("train_x0", (2, 16, 263)).to(dev())
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_pc_xyz=gf["xyz"].to(dev()), c_pc_contact=gf["contact"].to(dev()),
+              x_mask=gf["x_mask"].to(dev()))
+    t = torch.tensor([17, 803], device=dev())
+    params = [p_ for n_, p_ in model.named_parameters() if p_.requires_grad and not n_.startswith("text_model")]
+    opt = torch.optim.AdamW(params, lr=1e-4)          # the reference's own optimiser works on our parameters / gradients
+    losses = []
+    for it in range(6):
+        opt.zero_grad()
+        diff._loss_calls = 0
+        terms = diff.training_losses(model, x0, t, model_kwargs=kw)
+        terms["loss"].mean().backward()
+        losses.append(terms["loss"].mean().item())
+        opt.step()
+    assert all(p_.grad is not None for p_ in params)
+    assert all(torch.isfinite(p_.grad).all() for p_ in params)
+    print("[train] full-model losses:", [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0]

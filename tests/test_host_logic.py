@@ -128,12 +128,9 @@ def test_product_path_refuses_cpu_tensors():
         with torch.no_grad():
             model(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long), c_text_feat=torch.zeros(1, 512),
                   c_cont_emb=torch.zeros(1, 128, 256), x_mask=torch.zeros(1, 8, dtype=torch.bool))
-    with pytest.raises(NotImplementedError):       # SceneMapEncoder backward is not built yet: loud, no eager fallback
-        model.train()(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long))
-    model.contact_encoder.requires_grad_(False)
-    with pytest.raises(ffi.AfmError):              # the training path is HIP-only as well
-        model(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long), c_text_feat=torch.zeros(1, 512),
-              c_cont_emb=torch.zeros(1, 128, 256), x_mask=torch.zeros(1, 8, dtype=torch.bool))
+    with pytest.raises(ffi.AfmError):              # the training path is HIP-only as well: loud, no eager fallback
+        model.train()(torch.zeros(1, 8, 263), torch.zeros(1, dtype=torch.long), c_text_feat=torch.zeros(1, 512),
+                      c_cont_emb=torch.zeros(1, 128, 256), x_mask=torch.zeros(1, 8, dtype=torch.bool))
 
 
 def test_product_never_imports_oracle():
