@@ -23,6 +23,14 @@ def _sync_group():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _host_sync_needed(t: torch.Tensor) -> None:
+    """RCCL collectives are stream-ordered with our kernels (torch makes its communication stream wait on the current
+    stream).  The gloo backend copies CUDA tensors through the host instead; fence the device around it."""
+    import os
+    if dist.get_backend() != "nccl" or os.environ.get("AFM_DEBUG_SYNC"):
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
@@ -37,15 +45,21 @@ class _BatchNormFn(torch.autograd.Function):
         count = rows
         batch_stats = bn.training or bn.running_mean is None
         if batch_stats:
-            stats = torch.empty(2 * Cn, device=dev, dtype=torch.float32)
+            stats = torch.empty(3 * Cn, device=dev, dtype=torch.float32)
             ws = _ws(lib.afm_colstats_workspace_bytes(rows, Cn), dev)
             ffi.check(lib.afm_colstats(xc.data_ptr(), rows, Cn, stats.data_ptr(), ws.data_ptr(), ws.numel(), _st(xc)), "afm_colstats")
+            world = 1
             if sync and _sync_group():
-                dist.all_reduce(stats)                                   # RCCL: 2*C floats per BatchNorm
-                count = rows * dist.get_world_size()
+                world = dist.get_world_size()
+                gathered = torch.empty(world, 3 * Cn, device=dev, dtype=torch.float32)
+                _host_sync_needed(stats)
+                dist.all_gather_into_tensor(gathered, stats) if dist.get_backend() == "nccl" else \
+                    dist.all_gather(list(gathered.unbind(0)), stats)     # RCCL: 3*C floats per rank per BatchNorm
+                stats = gathered
+                count = rows * world
             track = bn.training and bn.track_running_stats and bn.running_mean is not None
             mom = 0.1 if bn.momentum is None else float(bn.momentum)
-            ffi.check(lib.afm_bn_finalize(stats.data_ptr(), count, g.data_ptr(), b.data_ptr(), float(bn.eps), mom,
+            ffi.check(lib.afm_bn_finalize(stats.data_ptr(), world, rows, g.data_ptr(), b.data_ptr(), float(bn.eps), mom,
                                           bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), Cn, _st(xc)), "afm_bn_finalize")
             if track and bn.num_batches_tracked is not None:
@@ -77,6 +91,7 @@ class _BatchNormFn(torch.autograd.Function):
         if not batch_stats:
             stats = torch.zeros_like(stats)                              # statistics are constants: dx = g * gamma * rstd
         elif sync and _sync_group():
+            _host_sync_needed(stats)
             dist.all_reduce(stats)
         dx = torch.empty_like(xc)
         dres = torch.empty_like(xc) if has_res else None
@@ -85,9 +100,12 @@ class _BatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None
 
 
-def batch_norm(x, bn: torch.nn.BatchNorm1d, *, relu: bool = False, residual: Optional[torch.Tensor] = None, sync: bool = True):
-    """relu?(BatchNorm1d(x) + residual) over a row-major [rows, C] matrix; batch statistics when ``bn.training`` (all-reduced
-    across ranks when a process group is up and ``sync``), running statistics otherwise."""
+def batch_norm(x, bn: torch.nn.BatchNorm1d, *, relu: bool = False, residual: Optional[torch.Tensor] = None, sync: Optional[bool] = None):
+    """relu?(BatchNorm1d(x) + residual) over a row-major [rows, C] matrix; batch statistics when ``bn.training``, running
+    statistics otherwise.  ``sync`` (default: the module is an nn.SyncBatchNorm, i.e. the model went through
+    `SyncBatchNorm.convert_sync_batchnorm` as in train_ddp.py:63) all-reduces the statistics over the process group."""
+    if sync is None:
+        sync = isinstance(bn, torch.nn.SyncBatchNorm)
     return _BatchNormFn.apply(x, bn.weight, bn.bias, residual, bn, relu, sync)
 
 

@@ -137,7 +137,7 @@ EXPORTS = {
     "afm_rowop": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, i32, c_f32p, i64, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
     "afm_colstats_workspace_bytes": (i64, [i64, i32]),
     "afm_colstats": (C.c_int, [c_f32p, i64, i32, c_f32p, C.c_void_p, i64, C.c_void_p]),
-    "afm_bn_finalize": (C.c_int, [c_f32p, i64, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32,
+    "afm_bn_finalize": (C.c_int, [c_f32p, i32, i64, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32,
                                   C.c_void_p]),
     "afm_colaffine": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p, i64, i32, C.c_void_p]),
     "afm_bn_bwd_stats": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, C.c_void_p, i64, C.c_void_p]),

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     for (int j = 0; j < NC; ++j) {
         s0[j] = 0.f; s1[j] = 0.f;
         const int c = tx + j * CW;
-        mu[j] = (MODE == 1 && c < C) ? mean[c] : 0.f;
+        // MODE 0: sums are taken about the tensor's first row (shifted-data variance: no E[x^2] - m^2 cancellation)
+        mu[j] = c < C ? (MODE == 1 ? mean[c] : a[c]) : 0.f;
         rs[j] = (MODE == 1 && c < C) ? rstd[c] : 0.f;
     }
     for (int64_t r = r0 + ty; r < r1; r += RL) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
             if (c < C) {
                 const int64_t i = r * C + c;
                 if (MODE == 0) {
-                    const float v = a[i];
+                    const float v = a[i] - mu[j];
                     s0[j] += v; s1[j] += v * v;
                 } else {
                     float g = a[i];
@@ -113,23 +114,39 @@ int launch_colstats(const float* a, const float* x, const float* y, const float*
     return 0;
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+// stats [world][3C] per rank: sum(x - K), sum((x - K)^2), K (= that rank's first row); equal row counts per rank.
+// Per-rank mean / M2 are combined with the parallel-variance formula (as torch's batch_norm_gather_stats_with_counts).
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int world, float rows, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float m = stats[c] / count;
-    float var = stats[C + c] / count - m * m;
-    var = fmaxf(var, 0.0f);
+    float msum = 0.f;
+    for (int r = 0; r < world; ++r) msum += stats[(int64_t)r * 3 * C + 2 * C + c] + stats[(int64_t)r * 3 * C + c] / rows;
+    const float m = msum / (float)world;
+    float m2 = 0.f;
+    for (int r = 0; r < world; ++r) {
+        const float s1 = stats[(int64_t)r * 3 * C + c], s2 = stats[(int64_t)r * 3 * C + C + c], k = stats[(int64_t)r * 3 * C + 2 * C + c];
+        const float mr = k + s1 / rows;
+        m2 += fmaxf(s2 - s1 * s1 / rows, 0.0f) + rows * (mr - m) * (mr - m);
+    }
+    const float count = rows * (float)world;
+    const float var = m2 / count;
     const float r = 1.0f / sqrtf(var + eps);
     mean[c] = m; rstd[c] = r;
     const float sc = gamma[c] * r;
     scale[c] = sc; shift[c] = beta[c] - m * sc;
     if (running_mean) {                      // nn.BatchNorm1d: running = (1 - momentum) * running + momentum * batch (unbiased variance)
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * m;
-        const float unbiased = count > 1.0f ? var * count / (count - 1.0f) : var;
+        const float unbiased = count > 1.0f ? m2 / (count - 1.0f) : var;
         running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
     }
+}
+
+__global__ void copy_row_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) dst[c] = src[c];
 }
 
 // y = relu?(x * scale[c] + shift[c] + residual)
@@ -303,17 +320,21 @@ extern "C" int64_t afm_colstats_workspace_bytes(int64_t rows, int32_t C) {
 }
 
 extern "C" int afm_colstats(const float* x, int64_t rows, int32_t C, float* stats, void* ws, int64_t ws_bytes, void* stream) {
-    if (!stats || (rows > 0 && !x)) return AFM_E_BADARG;
-    return launch_colstats<0>(x, nullptr, nullptr, nullptr, nullptr, rows, C, stats, ws, ws_bytes, (hipStream_t)stream);
+    if (!stats || rows <= 0 || !x) return AFM_E_BADARG;
+    const int rc = launch_colstats<0>(x, nullptr, nullptr, nullptr, nullptr, rows, C, stats, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(copy_row_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, stats + 2 * C, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
 }
 
-extern "C" int afm_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
-                               float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift, int32_t C,
-                               void* stream) {
-    if (!stats || !gamma || !beta || !mean || !rstd || !scale || !shift || C <= 0 || count <= 0) return AFM_E_BADARG;
+extern "C" int afm_bn_finalize(const float* stats, int32_t world, int64_t rows_per_rank, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                               int32_t C, void* stream) {
+    if (!stats || !gamma || !beta || !mean || !rstd || !scale || !shift || C <= 0 || rows_per_rank <= 0 || world <= 0) return AFM_E_BADARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return AFM_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, (float)count, gamma, beta, eps, momentum,
-                       running_mean, running_var, mean, rstd, scale, shift, C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, world, (float)rows_per_rank, gamma, beta, eps,
+                       momentum, running_mean, running_var, mean, rstd, scale, shift, C);
     AFM_CHECK_LAUNCH();
     return 0;
 }

@@ -196,6 +196,94 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     if (ty == 0 && c < N) out[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Skinny weight gradient (the point-cloud linears: M = n*k up to millions of rows, N or K <= 32): the output is a
+// handful of 32x32 MFMA tiles and the kernel is a pure stream over dY and X, so there is no LDS staging at all - each
+// lane loads its own MFMA operand (row m = 2s + lane/32, column lane%32: 128-byte row segments) and every wave owns a
+// contiguous row range; the bias gradient is accumulated from the same dY loads.  One partial per wave, summed in a
+// fixed order afterwards.
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X, int64_t ldx,
+                                                           int M, int N, int K, int rows_per_wave, float* __restrict__ part_w,
+                                                           float* __restrict__ part_b) {
+    const int lane = threadIdx.x & 63, r32 = lane & 31, hh = lane >> 5;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m0 = gw * rows_per_wave, m1 = min(M, m0 + rows_per_wave);
+    f32x16 acc[TN][TK];
+    float bsum[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    int ncol[TN], kcol[TK];
+    bool nok[TN], kok[TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) { nok[i] = i * 32 + r32 < N; ncol[i] = min(i * 32 + r32, N - 1); }
+#pragma unroll
+    for (int j = 0; j < TK; ++j) { kok[j] = j * 32 + r32 < K; kcol[j] = min(j * 32 + r32, K - 1); }
+    constexpr int U = (TN + TK <= 3) ? 8 : 4;             // MFMA steps per unrolled iteration (loads issued first)
+    for (int m = m0; m < m1; m += 2 * U) {
+        float a[U][TN], b[U][TK];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = m + 2 * u + hh;
+            const bool ok = row < m1;
+            const int64_t rc = min(row, m1 - 1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) { const float v = dY[rc * lddy + ncol[i]]; a[u][i] = (ok && nok[i]) ? v : 0.f; }
+#pragma unroll
+            for (int j = 0; j < TK; ++j) { const float v = X[rc * ldx + kcol[j]]; b[u][j] = (ok && kok[j]) ? v : 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                bsum[i] += a[u][i];
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = mfma32(a[u][i], b[u][j], acc[i][j]);
+            }
+        }
+    }
+    float* pw = part_w + (int64_t)gw * N * K;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int k = j * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = i * 32 + mfma_row(r, lane);
+                if (n < N && k < K) pw[(int64_t)n * K + k] = acc[i][j][r];
+            }
+        }
+        const float t = bsum[i] + __shfl_xor(bsum[i], 32);
+        if (part_b && hh == 0 && i * 32 + r32 < N) part_b[(int64_t)gw * N + i * 32 + r32] = t;
+    }
+}
+
+struct SkinnyPlan { bool ok; int tn, tk, nwaves, rows_per_wave; };
+SkinnyPlan skinny_plan(int M, int N, int K) {
+    SkinnyPlan p;
+    p.tn = (N + 31) / 32; p.tk = (K + 31) / 32;
+    p.ok = (p.tn == 1 && (p.tk == 1 || p.tk == 2 || p.tk == 4 || p.tk == 8)) || (p.tk == 1 && (p.tn == 2 || p.tn == 4 || p.tn == 8)) ||
+           (p.tn == 2 && p.tk == 2);
+    if (p.tn == 1 && p.tk == 3) { p.tk = 4; p.ok = true; }
+    if (p.tk == 1 && p.tn == 3) { p.tn = 4; p.ok = true; }
+    if ((p.tn == 1 && p.tk > 4 && p.tk < 8)) { p.tk = 8; p.ok = true; }
+    if ((p.tk == 1 && p.tn > 4 && p.tn < 8)) { p.tn = 8; p.ok = true; }
+    p.ok = p.ok && M >= 4096;                                  // small M: the tiled kernel's split is enough
+    int64_t waves = (M + 511) / 512;                           // >= 512 rows per wave
+    if (waves > 4096) waves = 4096;
+    if (waves < 4) waves = 4;
+    waves = (waves + 3) / 4 * 4;
+    p.nwaves = (int)waves;
+    p.rows_per_wave = (int)(((M + waves - 1) / waves + 15) / 16 * 16);
+    return p;
+}
+
 struct WgradPlan { int ntn, ntk, tiles, S, rows_per_split, chunks, rows_per_chunk; };
 WgradPlan wgrad_plan(int M, int N, int K) {
     WgradPlan w;
@@ -203,7 +291,7 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     int S = (768 + w.tiles - 1) / w.tiles;                    // ~3 workgroups per CU in flight
     const int maxS = (M + 4 * RB - 1) / (4 * RB);             // at least 4 stages per slice
     if (S > maxS) S = maxS;
-    if (S > 64) S = 64;
+    if (S > 1024) S = 1024;
     if (S < 1) S = 1;
     w.rows_per_split = (((M + S - 1) / S) + RB - 1) / RB * RB;
     if (w.rows_per_split < RB) w.rows_per_split = RB;          // M == 0
@@ -366,7 +454,10 @@ extern "C" int afm_transpose(const float* in, float* out, int32_t rows, int32_t 
 extern "C" int64_t afm_linear_wgrad_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     if (M < 0 || N <= 0 || K <= 0) return AFM_E_BADARG;
     const WgradPlan w = wgrad_plan(M, N, K);
-    return ((int64_t)w.S * N * K + (int64_t)w.chunks * N) * (int64_t)sizeof(float);
+    const SkinnyPlan sp = skinny_plan(M, N, K);
+    const int64_t tiled = (int64_t)w.S * N * K + (int64_t)w.chunks * N;
+    const int64_t skinny = sp.ok ? (int64_t)sp.nwaves * ((int64_t)N * K + N) : 0;
+    return (tiled > skinny ? tiled : skinny) * (int64_t)sizeof(float);
 }
 
 extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream) {
@@ -381,6 +472,27 @@ extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream)
             if (e != hipSuccess) return (int)e;
             if (a.db) { e = hipMemsetAsync(a.db, 0, (size_t)a.N * sizeof(float), s); if (e != hipSuccess) return (int)e; }
         }
+        return 0;
+    }
+    const SkinnyPlan sp = skinny_plan(a.M, a.N, a.K);
+    if (sp.ok && !a.dy_grp && !a.x_grp && a.lddw == a.K) {
+        if (!a.ws || a.ws_bytes < (int64_t)sp.nwaves * ((int64_t)a.N * a.K + a.N) * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
+        float* pw = (float*)a.ws;
+        float* pb = a.db ? pw + (int64_t)sp.nwaves * a.N * a.K : nullptr;
+        {
+            AfmProf prof(AFM_PROF_WGRAD_SKINNY, 4.0 * a.M * (a.N + a.K), s);          // work = bytes streamed
+#define AFM_SK(TN_, TK_) hipLaunchKernelGGL((wgrad_skinny_kernel<TN_, TK_>), dim3(sp.nwaves / 4), dim3(256), 0, s, a.dY, a.lddy, a.X, a.ldx, a.M, a.N, a.K, sp.rows_per_wave, pw, pb)
+            if (sp.tn == 1 && sp.tk == 1) AFM_SK(1, 1); else if (sp.tn == 1 && sp.tk == 2) AFM_SK(1, 2); else if (sp.tn == 1 && sp.tk == 4) AFM_SK(1, 4);
+            else if (sp.tn == 1 && sp.tk == 8) AFM_SK(1, 8); else if (sp.tn == 2 && sp.tk == 1) AFM_SK(2, 1); else if (sp.tn == 4 && sp.tk == 1) AFM_SK(4, 1);
+            else if (sp.tn == 8 && sp.tk == 1) AFM_SK(8, 1); else AFM_SK(2, 2);
+#undef AFM_SK
+            AFM_CHECK_LAUNCH();
+        }
+        AfmProf prof(AFM_PROF_TRAIN_MISC, 0.0, s);
+        const int nk = a.N * a.K;
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3((nk + 63) / 64), dim3(1024), 0, s, pw, (int64_t)nk, sp.nwaves, a.dW, a.dW, nk, nk, a.accumulate);
+        if (a.db) hipLaunchKernelGGL(reduce_cols_kernel, dim3((a.N + 63) / 64), dim3(1024), 0, s, pb, (int64_t)a.N, sp.nwaves, a.db, a.db, a.N, a.N, a.accumulate);
+        AFM_CHECK_LAUNCH();
         return 0;
     }
     const WgradPlan w = wgrad_plan(a.M, a.N, a.K);

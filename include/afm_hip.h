@@ -195,15 +195,19 @@ int afm_rowop(const float* x, const float* rowtab, int32_t period, const float* 
  * 102-123 under model.train()).  Batch statistics force a full pass between every BatchNorm and its consumer, so the
  * training graph is composed from bandwidth-bound passes over materialised [n, k, c] tensors. */
 
-/* stats[0..C) = sum_r x[r,c], stats[C..2C) = sum_r x[r,c]^2 over a row-major [rows, C] matrix (C <= 512), fixed order. */
+/* Column statistics of a row-major [rows, C] matrix (C <= 512, rows >= 1), fixed summation order, taken about the
+ * matrix's first row K (shifted-data variance: no E[x^2] - mean^2 cancellation):
+ *   stats[0..C) = sum_r (x[r,c] - K[c]),  stats[C..2C) = sum_r (x[r,c] - K[c])^2,  stats[2C..3C) = K. */
 int64_t afm_colstats_workspace_bytes(int64_t rows, int32_t C);
 int afm_colstats(const float* x, int64_t rows, int32_t C, float* stats, void* ws, int64_t ws_bytes, void* stream);
-/* nn.BatchNorm1d training-mode bookkeeping from (possibly all-reduced = SyncBatchNorm) stats over `count` rows:
- * mean, rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and the running-statistics
- * update running = (1-momentum)*running + momentum*batch (unbiased variance); running_* may be NULL. */
-int afm_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta, float eps, float momentum,
-                    float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
-                    int32_t C, void* stream);
+/* nn.BatchNorm1d / nn.SyncBatchNorm training-mode bookkeeping from the statistics of `world` ranks ([world][3C], as
+ * produced by afm_colstats on every rank and all-gathered; world = 1 without synchronisation), rows_per_rank rows each:
+ * per-rank means / M2 are merged with the parallel-variance formula; outputs mean, rstd = 1/sqrt(biased var + eps),
+ * scale = gamma*rstd, shift = beta - mean*scale, and the running-statistics update
+ * running = (1-momentum)*running + momentum*batch (unbiased variance); running_* may be NULL. */
+int afm_bn_finalize(const float* stats, int32_t world, int64_t rows_per_rank, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                    float* shift, int32_t C, void* stream);
 /* y = relu?(x * scale[c] + shift[c] + residual)   (BatchNorm apply [+ identity] [+ ReLU]; residual may be NULL) */
 int afm_colaffine(const float* x, const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
                   int64_t rows, int32_t C, void* stream);

@@ -29,7 +29,10 @@ def g(name, shape):
 
 
 # ------------------------------------------------------------------------------------------------ primitives
-@pytest.mark.parametrize("M,N,K", [(652, 512, 512), (10432, 1536, 512), (300, 263, 512), (300, 512, 263), (32, 512, 512), (7, 5, 3), (0, 8, 8)])
+@pytest.mark.parametrize("M,N,K", [(652, 512, 512), (10432, 1536, 512), (300, 263, 512), (300, 512, 263), (32, 512, 512), (7, 5, 3), (0, 8, 8),
+                                   # point-cloud linears: millions of grouped rows, a few channels (stream kernel, no LDS)
+                                   (300001, 32, 3), (100000, 4, 32), (70000, 3, 3), (50000, 64, 64), (40000, 256, 3), (40000, 16, 128),
+                                   (20000, 32, 256), (30000, 64, 35), (8000, 128, 67)])
 def test_linear_wgrad(M, N, K):
     dy, x = g("wg_dy", (max(M, 1), N))[:M].contiguous(), g("wg_x", (max(M, 1), K))[:M].contiguous()
     dW, db = AG._wgrad(dy.to(dev()), x.to(dev()), M, N, K)

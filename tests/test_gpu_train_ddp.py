@@ -1,0 +1,86 @@
+"""`-m gpu`: the reference's DDP recipe (train_ddp.py:63-65: SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel) over
+our modules.  Two ranks share cuda:0 (the GPU box has one GPU; RCCL refuses two ranks on one device, so the process group is
+gloo, which moves the CUDA tensors through the host) - what is tested is the math: synchronised batch statistics and
+averaged gradients must equal one process running the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(dev, blocks):
+    from afm import scene as S
+    from gpu_util import load_named_weights
+    enc = S.SceneMapEncoder(point_feat_dim=6, planes=[32, 64, 128, 256], blocks=list(blocks), num_points=1024)
+    load_named_weights(enc)
+    return enc.to(dev).train()
+
+
+def _data():
+    from afm import synth
+    xyz, con = synth.scene_cloud(4, 1024, seed=21), synth.contact_map(4, 1024, seed=21)
+    dy = synth.gaussian("ddp_dy", (4, 16, 256))
+    return xyz, con, dy
+
+
+def _rank(rank, world, port, out_path, blocks):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    enc = torch.nn.SyncBatchNorm.convert_sync_batchnorm(_make(dev, blocks))
+    ddp = torch.nn.parallel.DistributedDataParallel(enc, find_unused_parameters=True, broadcast_buffers=False)
+    xyz, con, dy = _data()
+    sl = slice(rank * 2, rank * 2 + 2)
+    out = ddp(xyz[sl].to(dev), con[sl].to(dev))
+    ((out * dy[sl].to(dev)).sum() / 2).backward()                # per-rank mean over its 2 samples; DDP averages the ranks
+    if rank == 0:
+        torch.save({"out": out.detach().cpu(), "grads": {n: p.grad.cpu() for n, p in enc.named_parameters()},
+                    "rm": enc.enc1[0].bn.running_mean.cpu(), "rv": enc.enc1[0].bn.running_var.cpu()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("blocks,tight_tol,loose_tol", [((2, 2, 2, 1), 1e-4, 1e-4), ((2, 2, 2, 2), 5e-3, 2e-2)])
+def test_syncbn_ddp_two_ranks_equal_one_process(tmp_path, blocks, tight_tol, loose_tol):
+    from test_gpu_train import _zero_grad_name
+    path = str(tmp_path / "rank0.pt")
+    mp.spawn(_rank, args=(2, _free_port(), path, blocks), nprocs=2, join=True)
+    got = torch.load(path)
+    dev = torch.device("cuda:0")
+    enc = _make(dev, blocks)
+    xyz, con, dy = _data()
+    out = enc(xyz.to(dev), con.to(dev))
+    ((out * dy.to(dev)).sum() / 4).backward()
+    err = (out[:2].detach().cpu() - got["out"]).abs().max().item()
+    print(f"[parity] SyncBatchNorm forward, 2 ranks vs 1 process: max|diff|={err:.3e}")
+    assert err <= 1e-4
+    # Criterion: relative L2 error per parameter tensor.  Two evaluations of the same network that differ only in summation
+    # order (here: per-rank partial statistics) can flip a ReLU whose pre-activation is within rounding of 0.  With the
+    # reference's block layout (2,2,2,2) and this input exactly one element of the last level (64 rows) flips: the few
+    # gradients it feeds move by ~1e-2 and everything upstream by ~1e-3, so that case gets a loose bound; the (2,2,2,1) layout
+    # has no flip and must agree to 1e-4 - the synchronised statistics and gradient averaging themselves are exact.
+    errs = []
+    for n, p in enc.named_parameters():
+        if _zero_grad_name(n):
+            continue
+        ref = p.grad.cpu().double()
+        errs.append(((got["grads"][n].double() - ref).norm().item() / max(ref.norm().item(), 1e-9), n))
+    errs.sort(reverse=True)
+    median = errs[len(errs) // 2][0]
+    print(f"[parity] blocks={blocks}: DDP-averaged gradients vs single-process full batch over {len(errs)} tensors: rel-L2 median {median:.2e}, "
+          f"largest {[(round(e, 6), n) for e, n in errs[:2]]}")
+    assert median <= tight_tol and errs[0][0] <= loose_tol, errs[:5]
+    assert (enc.enc1[0].bn.running_mean.cpu() - got["rm"]).abs().max().item() <= 1e-5
+    assert (enc.enc1[0].bn.running_var.cpu() - got["rv"]).abs().max().item() <= 1e-4

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=196)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--scene", action="store_true", help="train the SceneMapEncoder too (N=8192 points per sample, batch-statistics BatchNorm)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B, L = a.batch, a.frames
@@ -61,11 +62,15 @@ def main():
     model, diff = create_model_and_diffusion(cfg, device=dev)
     synth.fill_module_(model)
     model = model.to(dev).train()
-    model.contact_encoder.requires_grad_(False)
+    if not a.scene:
+        model.contact_encoder.requires_grad_(False)
     params = [p for p in model.parameters() if p.requires_grad]
     x0 = synth.gaussian("bt_x0", (B, L, 263)).to(dev)
-    kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_cont_emb=(synth.gaussian("bt_cont", (B, 128, 256)) * 0.5).to(dev),
-              x_mask=synth.frame_mask(B, L).to(dev))
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev), x_mask=synth.frame_mask(B, L).to(dev))
+    if a.scene:
+        kw.update(c_pc_xyz=synth.scene_cloud(B, 8192).to(dev), c_pc_contact=synth.contact_map(B, 8192).to(dev))
+    else:
+        kw.update(c_cont_emb=(synth.gaussian("bt_cont", (B, 128, 256)) * 0.5).to(dev))
     state = {}
     gen = torch.Generator(device="cpu").manual_seed(0)
 
@@ -97,13 +102,14 @@ def main():
     gemm = 2.0 * M * d * (3 * d + d + 2 * ff) * 5 + 2.0 * B * L * 263 * d * 2
     attn = 4.0 * B * 8 * T * T * 64 * 5
     flops = 3 * gemm + attn * (1 + 7 / 2)          # fwd + dX + dW GEMMs; attention fwd (2 products) + bwd (7 products)
-    out = {"config": f"CMDM trunk training step, B={B}, L={L}, T={T} tokens, f32, train mode (dropout on), 1 MI355X",
+    what = "CMDM full-model (trunk + SceneMapEncoder over N=8192 points)" if a.scene else "CMDM trunk"
+    out = {"config": f"{what} training step, B={B}, L={L}, T={T} tokens, f32, train mode (dropout on), 1 MI355X",
            "metric": "optimisation steps/sec", "value": round(1 / dt, 3), "ms_per_step": round(1e3 * dt, 3), "samples_per_sec": round(B / dt, 1),
            "final_loss": round(loss.item(), 4), "executed_tflops": round(flops / dt / 1e12, 1),
            "trainable_params": sum(p.numel() for p in params),
            "kernels_ms_per_step": {k: round(v["total_ms"] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
            "kernels_tflops": {k: round(v["total_work"] / (v["total_ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["total_work"] > 0 and v["total_ms"] > 0}}
-    if a.cpu_steps > 0:
+    if a.cpu_steps > 0 and not a.scene:
         cdt, nt = cpu_baseline(B, L, a.cpu_steps)
         out["cpu_baseline"] = {"value": round(1 / cdt, 4), "unit": "steps/s", "cores": nt, "kind": "port",
                                "sample": f"{a.cpu_steps} forward+backward step(s) of the oracle restatement (torch autograd, f32), same B/L"}
