@@ -291,19 +291,26 @@ def masked_mse(target, pred, frame_mask):
 
 # ------------------------------------------------------------------------------------------------ optimiser
 def adamw_step(params, state: dict, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0) -> None:
-    """torch.optim.AdamW semantics (utils/training.py:48-53) as one fused kernel per parameter tensor; ``state`` maps
-    parameter -> (step, exp_avg, exp_avg_sq) and is created on first use."""
+    """torch.optim.AdamW semantics (utils/training.py:48-53) for every parameter with a gradient in ONE kernel launch
+    (afm_adamw_multi); ``state`` holds the step count and the per-parameter moments and is created on first use."""
     lib = ffi.load()
-    for p in params:
-        if p.grad is None:
-            continue
-        ffi.require_gpu(p)
+    live = [p for p in params if p.grad is not None]
+    if not live:
+        return
+    ffi.require_gpu(*live)
+    state["step"] = state.get("step", 0) + 1
+    rows = []
+    keep = []
+    for p in live:
+        assert p.is_contiguous() and p.dtype == torch.float32
         st = state.get(p)
         if st is None:
-            st = [0, torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format)]
+            st = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
             state[p] = st
-        st[0] += 1
         g = ffi.f32c(p.grad)
-        assert p.is_contiguous() and p.dtype == torch.float32
-        ffi.check(lib.afm_adamw(p.data_ptr(), g.data_ptr(), st[1].data_ptr(), st[2].data_ptr(), p.numel(), lr, betas[0], betas[1], eps,
-                                weight_decay, st[0], _st(p)), "afm_adamw")
+        keep.append(g)
+        rows.append((p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()))
+    table = torch.tensor(rows, dtype=torch.int64).to(live[0].device, non_blocking=True)       # 5 x int64 per tensor = afm_adamw_tensor
+    ffi.check(lib.afm_adamw_multi(table.data_ptr(), len(rows), max(r[4] for r in rows), lr, betas[0], betas[1], eps, weight_decay,
+                                  state["step"], _st(live[0])), "afm_adamw_multi")
+    state["_keep"] = (table, keep)          # alive until the next step's launch is enqueued behind this one

@@ -95,26 +95,30 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int
     }
 }
 
-// per-sample masked MSE: sum((a-b)^2 * keep) / (sum(keep) * D), one workgroup per sample
-__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         const uint8_t* __restrict__ mask, float* __restrict__ out, int L, int D) {
-    __shared__ float red[2][4];
+// per-sample masked MSE: sum((a-b)^2 * keep) / (sum(keep) * D), one 1024-thread workgroup per sample: a thread walks
+// whole frames (row l, then its D contiguous values are spread over the 16 lanes of its group -> coalesced, no division
+// per element), fixed-order tree at the end
+__global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const uint8_t* __restrict__ mask, float* __restrict__ out, int L, int D) {
+    __shared__ float red[2][16];
     const int s = blockIdx.x;
-    const int64_t base = (int64_t)s * L * D;
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;       // 64 groups of 16 lanes, one frame per group at a time
     float acc = 0.f, cnt = 0.f;
-    for (int64_t i = threadIdx.x; i < (int64_t)L * D; i += blockDim.x) {
-        const int l = (int)(i / D);
-        const bool keep = !(mask && mask[(int64_t)s * L + l]);
-        const float d = a[base + i] - b[base + i];
-        if (keep) { acc += d * d; cnt += 1.0f; }
+    for (int l = grp; l < L; l += 64) {
+        if (mask && mask[(int64_t)s * L + l]) continue;
+        const float* ap = a + ((int64_t)s * L + l) * D;
+        const float* bp = b + ((int64_t)s * L + l) * D;
+        for (int c = sub; c < D; c += 16) { const float d = ap[c] - bp[c]; acc += d * d; }
+        if (sub == 0) cnt += (float)D;
     }
     acc = wave_sum(acc); cnt = wave_sum(cnt);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc; red[1][threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float sa = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const float sc = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        out[s] = sa / sc;            // sc == sum(keep) * D because every kept frame contributes D elements
+        float sa = 0.f, sc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sa += red[0][i]; sc += red[1][i]; }
+        out[s] = sa / sc;            // sc == sum(keep) * D
     }
 }
 
@@ -124,7 +128,7 @@ extern "C" int afm_masked_mse(const float* target, const float* pred, const uint
                               int32_t L, int32_t D, void* stream) {
     if (!target || !pred || !out || B < 0 || L <= 0 || D <= 0) return AFM_E_BADARG;
     if (B == 0) return 0;
-    hipLaunchKernelGGL(masked_mse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, target, pred, frame_mask, out, L, D);
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, target, pred, frame_mask, out, L, D);
     AFM_CHECK_LAUNCH();
     return 0;
 }

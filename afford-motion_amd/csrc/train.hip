@@ -441,7 +441,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// one launch for every parameter tensor: blockIdx.y = tensor, blockIdx.x = 16K-element chunk of it
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const afm_adamw_tensor* __restrict__ tab, float lr, float b1, float b2, float eps, float wd,
+                                                          float bc1, float bc2_sqrt) {
+    const afm_adamw_tensor t = tab[blockIdx.y];
+    const int64_t lo = (int64_t)blockIdx.x * 16384, hi = min(t.n, lo + 16384);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float gi = t.g[i];
+        float pi = t.p[i] * (1.0f - lr * wd);
+        const float mi = b1 * t.m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * t.v[i] + (1.0f - b2) * gi * gi;
+        t.m[i] = mi; t.v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        t.p[i] = pi;
+    }
+}
+
 }  // namespace
+
+extern "C" int afm_adamw_multi(const afm_adamw_tensor* d_table, int32_t n_tensors, int64_t max_n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int32_t step, void* stream) {
+    if (n_tensors == 0) return 0;
+    if (!d_table || n_tensors < 0 || n_tensors > 65535 || max_n <= 0 || step < 1) return AFM_E_BADARG;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)((max_n + 16383) / 16384), n_tensors), dim3(256), 0, (hipStream_t)stream, d_table, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int afm_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream) {
     if (rows == 0 || cols == 0) return 0;

@@ -242,6 +242,11 @@ int afm_pt_aggregate_bwd(const float* vg, const float* pr, const float* sw, cons
  *   p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int afm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int32_t step, void* stream);
+/* The same update for every parameter tensor of the model in ONE launch: d_table is a DEVICE array of n_tensors
+ * descriptors (all tensors at the same step count), max_n the largest element count. */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } afm_adamw_tensor;
+int afm_adamw_multi(const afm_adamw_tensor* d_table, int32_t n_tensors, int64_t max_n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Point-cloud operators.  Every sample holds the same number of points, so the reference's
