@@ -128,23 +128,25 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------ stand-alone linear
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, a_map, rows):
+    def forward(ctx, x, weight, bias, act, a_map, rows, residual):
         xc, w = _c(x), _c(weight)
         b = None if bias is None else _c(bias)
         K, N = w.shape[1], w.shape[0]
         M = rows if rows is not None else xc.numel() // K
         out = torch.empty(M, N, device=xc.device, dtype=torch.float32)
         z = torch.empty_like(out) if act else None
-        _gemm(xc.view(-1, K), w, out, M, N, K, bias=b, act=act, preact=z, a_map=a_map)
+        res = None if residual is None else _c(residual).view(M, N)
+        _gemm(xc.view(-1, K), w, out, M, N, K, bias=b, act=act, preact=z, a_map=a_map, residual=res)
         ctx.save_for_backward(xc, w, z)
-        ctx.cfg = (act, a_map, M, N, K, tuple(x.shape), bias is not None)
+        ctx.cfg = (act, a_map, M, N, K, tuple(x.shape), bias is not None, None if residual is None else tuple(residual.shape))
         return out if rows is not None or a_map else out.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         xc, w, z = ctx.saved_tensors
-        act, a_map, M, N, K, xshape, has_bias = ctx.cfg
+        act, a_map, M, N, K, xshape, has_bias, res_shape = ctx.cfg
         dy = _c(dy).view(M, N)
+        dres = dy.view(res_shape) if res_shape is not None and ctx.needs_input_grad[6] else None     # identity path
         if act:
             dy = _rowop(dy, z=z, act=act)
         dx = dw = db = None
@@ -157,13 +159,14 @@ class _LinearFn(torch.autograd.Function):
                 dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             _gemm(dy, _transpose(w), dx, M, K, N, c_map=a_map)
             dx = dx.view(xshape)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, dres
 
 
-def linear(x, weight, bias=None, *, act: int = ffi.ACT_NONE, a_map: Optional[RowMap] = None, rows: Optional[int] = None):
-    """act(x @ weight.T + bias) with a HIP backward.  ``a_map`` + ``rows`` gather a strided subset of x's rows
+def linear(x, weight, bias=None, *, act: int = ffi.ACT_NONE, a_map: Optional[RowMap] = None, rows: Optional[int] = None,
+           residual: Optional[torch.Tensor] = None):
+    """act(x @ weight.T + bias) + residual with a HIP backward.  ``a_map`` + ``rows`` gather a strided subset of x's rows
     (the motion tokens of every sample, cmdm.py:169)."""
-    return _LinearFn.apply(x, weight, bias, act, a_map, rows)
+    return _LinearFn.apply(x, weight, bias, act, a_map, rows, residual)
 
 
 # ------------------------------------------------------------------------------------------------ PositionalEncoding
@@ -257,6 +260,129 @@ def encoder_layer(x, layer: torch.nn.TransformerEncoderLayer, key_mask, heads: i
                                  layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
                                  layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
                                  layer.norm2.bias)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / self-attention / Perceiver attention
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        xc, g, b = _c(x), _c(weight), _c(bias)
+        ctx.save_for_backward(xc, g)
+        ctx.eps = eps
+        return _layernorm(xc, g, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, g = ctx.saved_tensors
+        dx, _, dg, db = _layernorm_bwd(xc, g, _c(dy), eps=ctx.eps)
+        return dx, dg, db, None
+
+
+def layer_norm(x, ln: torch.nn.LayerNorm):
+    """nn.LayerNorm over the last dimension with the HIP backward."""
+    return _LayerNormFn.apply(x, ln.weight, ln.bias, float(ln.eps))
+
+
+class _SelfAttentionFn(torch.autograd.Function):
+    """Packed qkv [B, T, 3*C] -> softmax(QK^T/sqrt(dh)) V [B, T, C] (dh = 64), attention dropout by counter hash."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, drop):
+        lib = ffi.load()
+        q = _c(qkv)
+        B, T, c3 = q.shape
+        Cn = c3 // 3
+        out = torch.empty(B, T, Cn, device=q.device, dtype=torch.float32)
+        lse = torch.empty(B * heads * T, device=q.device, dtype=torch.float32)
+        ffi.check(lib.afm_mha_fwd_train(q.data_ptr(), None, out.data_ptr(), lse.data_ptr(), B, T, heads, Cn // heads, drop[0], drop[1], drop[2],
+                                        _st(q)), "afm_mha_fwd_train")
+        ctx.save_for_backward(q, out, lse)
+        ctx.cfg = (B, T, heads, Cn, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = ffi.load()
+        q, out, lse = ctx.saved_tensors
+        B, T, heads, Cn, drop = ctx.cfg
+        dout = _c(dout)
+        dqkv = torch.empty_like(q)
+        ws = torch.empty(B * heads * T, device=q.device, dtype=torch.float32)
+        ffi.check(lib.afm_mha_bwd(q.data_ptr(), None, out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, T, heads, Cn // heads,
+                                  drop[0], drop[1], drop[2], ws.data_ptr(), ws.numel() * 4, _st(q)), "afm_mha_bwd")
+        return dqkv, None, None
+
+
+def self_attention(qkv, heads: int, drop=(0.0, 0, 0)):
+    return _SelfAttentionFn.apply(qkv, heads, drop)
+
+
+class _FewQueryAttentionFn(torch.autograd.Function):
+    """Q [B, 2, C] over K, V [B, N, C] (ContactPerceiver encoder cross-attention, modules.py:301-381)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, drop):
+        lib = ffi.load()
+        q, k, v = _c(q), _c(k), _c(v)
+        B, N, Cn = k.shape
+        P = torch.empty(B, heads * 2, N, device=q.device, dtype=torch.float32)
+        O = torch.empty(B, 2, Cn, device=q.device, dtype=torch.float32)
+        ws = torch.empty(max(int(lib.afm_xq_workspace_bytes(B, N, Cn)), 16), dtype=torch.uint8, device=q.device)
+        ffi.check(lib.afm_xq_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), P.data_ptr(), O.data_ptr(), B, N, heads, Cn, drop[0], drop[1],
+                                           drop[2], ws.data_ptr(), ws.numel(), _st(q)), "afm_xq_attention_fwd")
+        ctx.save_for_backward(q, k, v, P)
+        ctx.cfg = (B, N, heads, Cn, drop)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        lib = ffi.load()
+        q, k, v, P = ctx.saved_tensors
+        B, N, heads, Cn, drop = ctx.cfg
+        dO = _c(dO)
+        dS = torch.empty_like(P)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty(max(int(lib.afm_xq_workspace_bytes(B, N, Cn)), 16), dtype=torch.uint8, device=q.device)
+        ffi.check(lib.afm_xq_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), P.data_ptr(), dO.data_ptr(), dS.data_ptr(), dq.data_ptr(),
+                                           dk.data_ptr(), dv.data_ptr(), B, N, heads, Cn, drop[0], drop[1], drop[2], ws.data_ptr(), ws.numel(),
+                                           _st(q)), "afm_xq_attention_bwd")
+        return dq, dk, dv, None, None
+
+
+def few_query_attention(q, k, v, heads: int, drop=(0.0, 0, 0)):
+    return _FewQueryAttentionFn.apply(q, k, v, heads, drop)
+
+
+class _FewKeyAttentionFn(torch.autograd.Function):
+    """Q [B, N, C] over K, V [B, 2, C] (ContactPerceiver decoder cross-attention)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, drop):
+        lib = ffi.load()
+        q, k, v = _c(q), _c(k), _c(v)
+        B, N, Cn = q.shape
+        O = torch.empty_like(q)
+        ffi.check(lib.afm_xk_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O.data_ptr(), B, N, heads, Cn, drop[0], drop[1], drop[2],
+                                           _st(q)), "afm_xk_attention_fwd")
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (B, N, heads, Cn, drop)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        lib = ffi.load()
+        q, k, v = ctx.saved_tensors
+        B, N, heads, Cn, drop = ctx.cfg
+        dO = _c(dO)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty(max(int(lib.afm_xk_workspace_bytes(B, N, Cn)), 16), dtype=torch.uint8, device=q.device)
+        ffi.check(lib.afm_xk_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), dO.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, N,
+                                           heads, Cn, drop[0], drop[1], drop[2], ws.data_ptr(), ws.numel(), _st(q)), "afm_xk_attention_bwd")
+        return dq, dk, dv, None, None
+
+
+def few_key_attention(q, k, v, heads: int, drop=(0.0, 0, 0)):
+    return _FewKeyAttentionFn.apply(q, k, v, heads, drop)
 
 
 # ------------------------------------------------------------------------------------------------ loss

@@ -14,6 +14,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ffi
 from .base import Model
 from .cmdm import TimestepEmbedder, _param_version
@@ -220,8 +221,8 @@ class CDM(TextEncoderMixin, nn.Module):
 
     def forward(self, x, timesteps, **kwargs):
         """x [B, N, contact_dim], timesteps [B] -> predicted x_0 (same shape)."""
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("CDM backward is a later row (SURVEY.md section 8f-3); call under torch.no_grad() / eval()")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            return self.forward_train(x, timesteps, **kwargs)
         ffi.require_gpu(x)
         with torch.no_grad():
             lib = ffi.load()
@@ -243,3 +244,64 @@ class CDM(TextEncoderMixin, nn.Module):
                                           tcu.data_ptr(), out.data_ptr(), None, B, N, ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
                       "afm_cdm_forward")
         return out
+
+    # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
+    def _mha_train(self, att: _MHA, xq, xkv, heads: int, drop, kind: str, residual):
+        """MultiHeadAttention.forward (modules.py:301-381) on differentiable HIP ops; kind selects the attention kernel."""
+        q = AG.linear(xq, att.q_proj.weight, att.q_proj.bias)
+        k = AG.linear(xkv, att.k_proj.weight, att.k_proj.bias)
+        v = AG.linear(xkv, att.v_proj.weight, att.v_proj.bias)
+        if kind == "few_query":
+            o = AG.few_query_attention(q, k, v, heads, drop)
+        elif kind == "few_key":
+            o = AG.few_key_attention(q, k, v, heads, drop)
+        else:
+            o = AG.self_attention(torch.cat([q, k, v], dim=-1), heads, drop)
+        return AG.linear(o, att.o_proj.weight, att.o_proj.bias, residual=residual)           # Residual wrapper (modules.py:222-231)
+
+    @staticmethod
+    def _mlp_train(mlp: nn.Sequential, x):
+        """x + MLP(x) (modules.py:651-661 inside Residual)."""
+        h = AG.linear(AG.layer_norm(x, mlp[0]), mlp[1].weight, mlp[1].bias, act=ffi.ACT_GELU)
+        return AG.linear(h, mlp[3].weight, mlp[3].bias, residual=x)
+
+    def forward_train(self, x, timesteps, **kwargs):
+        """CDM.forward + ContactPerceiver.forward (cdm.py:474-513,155-188) as written, composed from differentiable HIP ops so
+        that `training_losses(...)['loss'].mean().backward()` fills `.grad` of every trainable parameter.  Train mode applies the
+        attention-probability dropout of the three attention types (arch_perceiver.*_dropout); residual dropout must be 0
+        (as in every reference config)."""
+        ffi.require_gpu(x)
+        a = self.arch_cfg
+        if float(a.encoder_residual_dropout) != 0.0 or float(a.decoder_residual_dropout) != 0.0:
+            raise NotImplementedError("residual dropout != 0 is not used by any reference config")
+        x = ffi.f32c(x)
+        B, N, _ = x.shape
+        cm, dev = self.contact_model, x.device
+        p_enc = float(a.encoder_dropout) if self.training else 0.0
+        p_dec = float(a.decoder_dropout) if self.training else 0.0
+        self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls) & (2**64 - 1)
+        te = self.timestep_embedder
+        t_idx = timesteps.to(device=dev, dtype=torch.int64)
+        time_emb = AG.linear(AG.linear(te.pe[t_idx, 0, :], te.time_embed[0].weight, te.time_embed[0].bias, act=ffi.ACT_SILU),
+                             te.time_embed[2].weight, te.time_embed[2].bias)                                # [B, te]
+        text = ffi.f32c(self.encode_text(kwargs).to(dev))
+        feat = self._features(x, kwargs)                                                                     # [B, N, feat]
+        enc_kv = AG.linear(feat, cm.encoder_adapter.weight, cm.encoder_adapter.bias)                         # [B, N, dkv]
+        enc_q = torch.cat([AG.linear(text, cm.language_adapter.weight, cm.language_adapter.bias).view(B, 1, cm.dq),
+                           AG.linear(time_emb, cm.time_embedding_adapter.weight, cm.time_embedding_adapter.bias).view(B, 1, cm.dq)], dim=1)
+        ca = cm.encoder_cross_attn[0].module
+        h = self._mha_train(ca.attention, AG.layer_norm(enc_q, ca.q_norm), AG.layer_norm(enc_kv, ca.kv_norm), cm.enc_heads, (p_enc, seed, 1),
+                            "few_query", enc_q)
+        enc_q = self._mlp_train(cm.encoder_cross_attn[1].module, h)
+        for i, layer in enumerate(cm.encoder_self_attn):
+            sa = layer[0].module
+            xn = AG.layer_norm(enc_q, sa.norm)
+            h = self._mha_train(sa.attention, xn, xn, cm.enc_heads, (p_enc, seed, 2 + i), "self", enc_q)
+            enc_q = self._mlp_train(layer[1].module, h)
+        dec_q = AG.linear(enc_kv, cm.decoder_adapter.weight, cm.decoder_adapter.bias)                        # [B, N, dkv]
+        da = cm.decoder_cross_attn[0].module
+        h = self._mha_train(da.attention, AG.layer_norm(dec_q, da.q_norm), AG.layer_norm(enc_q, da.kv_norm), cm.dec_heads, (p_dec, seed, 8),
+                            "few_key", dec_q)
+        dec_q = self._mlp_train(cm.decoder_cross_attn[1].module, h)
+        return AG.linear(dec_q, self.contact_layer.weight, self.contact_layer.bias)

@@ -150,6 +150,15 @@ EXPORTS = {
     "afm_pt_w0": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, C.c_void_p]),
     "afm_pt_aggregate": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, i32, C.c_void_p]),
     "afm_pt_aggregate_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, i32, C.c_void_p]),
+    "afm_xq_workspace_bytes": (i64, [i32, i32, i32]),
+    "afm_xq_attention_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32, C.c_void_p, i64,
+                                       C.c_void_p]),
+    "afm_xq_attention_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64,
+                                       C.c_uint32, C.c_void_p, i64, C.c_void_p]),
+    "afm_xk_workspace_bytes": (i64, [i32, i32, i32]),
+    "afm_xk_attention_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
+    "afm_xk_attention_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32,
+                                       C.c_void_p, i64, C.c_void_p]),
     "afm_adamw_multi": (C.c_int, [C.c_void_p, i32, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_void_p]),
     "afm_adamw": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_void_p]),
     "afm_fps": (C.c_int, [c_f32p, i32, i32, i32, C.c_void_p, C.c_void_p]),

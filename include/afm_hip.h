@@ -238,6 +238,25 @@ int afm_pt_aggregate(const float* vg, const float* pr, const float* w2, float* o
 int afm_pt_aggregate_bwd(const float* vg, const float* pr, const float* sw, const float* dout, float* da, float* dw2,
                          int64_t m, int32_t k, int32_t C, int32_t share_planes, void* stream);
 
+/* ---- training-path attention of the CDM ContactPerceiver (models/cdm.py:155-188 under model.train()).
+ * Few-query cross-attention (encoder, 2 latent queries over N point keys): Q [B,2,C], K/V [B,N,C], H heads;
+ * P [B, H*2, N] (row h*2+q) receives the softmax probabilities (saved for the backward), O [B,2,C];
+ * attention-probability dropout by the (seed, id, row of P, n) counter hash.  C in {256, 512}. */
+int64_t afm_xq_workspace_bytes(int32_t B, int32_t N, int32_t C);
+int afm_xq_attention_fwd(const float* Q, const float* K, const float* V, float* P, float* O, int32_t B, int32_t N, int32_t H,
+                         int32_t C, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream);
+int afm_xq_attention_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, float* dS,
+                         float* dQ, float* dK, float* dV, int32_t B, int32_t N, int32_t H, int32_t C, float drop_p,
+                         uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream);
+/* Few-key cross-attention (decoder, N point queries over 2 latent keys): Q/O [B,N,C], K/V [B,2,C]; probabilities are
+ * recomputed in the backward; dK/dV are fixed-order sums of per-workgroup partials (ws). */
+int64_t afm_xk_workspace_bytes(int32_t B, int32_t N, int32_t C);
+int afm_xk_attention_fwd(const float* Q, const float* K, const float* V, float* O, int32_t B, int32_t N, int32_t H, int32_t C,
+                         float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream);
+int afm_xk_attention_bwd(const float* Q, const float* K, const float* V, const float* dO, float* dQ, float* dK, float* dV,
+                         int32_t B, int32_t N, int32_t H, int32_t C, float drop_p, uint64_t drop_seed, uint32_t drop_id,
+                         void* ws, int64_t ws_bytes, void* stream);
+
 /* Fused AdamW over one flat parameter (torch.optim.AdamW semantics, utils/training.py:48-53):
  *   p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int afm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -91,8 +91,40 @@ def scene_main():
     print(f"{n} scene-encoder parameter gradients")
 
 
+def cdm_main():
+    """tests/golden/cdm_training_grads.npz: the reference CDM (Perceiver, N=256) training_losses + backward, eval mode."""
+    from afm import synth
+    from oracle.make_goldens import cdm_cfg
+    base, _ = import_reference()
+    torch.manual_seed(0)
+    B, Nc = 2, 256
+    ccfg = to_attr(dict(model=cdm_cfg(num_points=Nc), diffusion=diffusion_cfg(500, "")))
+    cdm, cdiff = base.create_model_and_diffusion(ccfg, device="cpu")
+    synth.fill_module_(cdm)
+    cdm.eval()
+    cxyz = synth.scene_cloud(B, Nc, seed=14)
+    x0 = synth.gaussian("cdm_train_x0", (B, Nc, 6))
+    tn = synth.gaussian("cdm_train_noise", (B, Nc, 6))
+    tt = torch.tensor([33, 470])
+    cdm.zero_grad()
+    terms = cdiff.training_losses(cdm, x0, tt, model_kwargs=dict(c_text=TEXTS, c_pc_xyz=cxyz), noise=tn)
+    terms["loss"].mean().backward()
+    out = {"t": tt, "loss": terms["loss"].detach()}
+    n = 0
+    for name, p in cdm.named_parameters():
+        if name.startswith("text_model.") or p.grad is None:
+            continue
+        sample, sums = grad_digest(p.grad)
+        out["g/" + name], out["s/" + name] = sample, sums
+        n += 1
+    save("cdm_training_grads", **out)
+    print(f"{n} CDM parameter gradients")
+
+
 if __name__ == "__main__":
-    if "--scene" in sys.argv:
+    if "--cdm" in sys.argv:
+        cdm_main()
+    elif "--scene" in sys.argv:
         scene_main()
     else:
         main()

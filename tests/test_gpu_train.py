@@ -501,3 +501,161 @@ def test_cmdm_trains_end_to_end_including_scene_encoder():
     assert all(torch.isfinite(p_.grad).all() for p_ in params)
     print("[train] full-model losses:", [round(v, 4) for v in losses])
     assert losses[-1] < losses[0]
+
+
+# ------------------------------------------------------------------------------------------------ CDM (Perceiver) training
+def _xattn_ref(q, k, v, H, keep=None):
+    B, Tq, C = q.shape
+    sp = lambda z: z.view(z.shape[0], z.shape[1], H, C // H).transpose(1, 2)
+    qh, kh, vh = sp(q), sp(k), sp(v)
+    a = torch.softmax(qh @ kh.transpose(-1, -2) / (C // H) ** 0.5, -1)
+    if keep is not None:
+        a = a * keep
+    return (a @ vh).transpose(1, 2).reshape(B, Tq, C), a
+
+
+@pytest.mark.parametrize("B,N,H,C", [(2, 8192, 8, 512), (3, 300, 8, 512), (2, 1000, 8, 256)])
+def test_few_query_attention_fwd_bwd(B, N, H, C):
+    q, k, v, dO = g("fq_q", (B, 2, C)), g("fq_k", (B, N, C)) * 0.5, g("fq_v", (B, N, C)), g("fq_do", (B, 2, C))
+    T = lambda t: t.double().requires_grad_(True)
+    qr, kr, vr = T(q), T(k), T(v)
+    o_ref, _ = _xattn_ref(qr, kr, vr, H)
+    (o_ref * dO.double()).sum().backward()
+    G = lambda t: t.to(dev()).requires_grad_(True)
+    qg, kg, vg = G(q), G(k), G(v)
+    o = AG.few_query_attention(qg, kg, vg, H)
+    report("few-query attention out", o, o_ref, 2e-5)
+    (o * dO.to(dev())).sum().backward()
+    rel("few-query dQ", qg.grad, qr.grad, 5e-5)
+    rel("few-query dK", kg.grad, kr.grad, 5e-5)
+    rel("few-query dV", vg.grad, vr.grad, 5e-5)
+
+
+@pytest.mark.parametrize("B,N,H,C", [(2, 8192, 8, 256), (3, 301, 8, 256), (2, 500, 8, 512)])
+def test_few_key_attention_fwd_bwd(B, N, H, C):
+    q, k, v, dO = g("fk_q", (B, N, C)), g("fk_k", (B, 2, C)), g("fk_v", (B, 2, C)), g("fk_do", (B, N, C))
+    T = lambda t: t.double().requires_grad_(True)
+    qr, kr, vr = T(q), T(k), T(v)
+    o_ref, _ = _xattn_ref(qr, kr, vr, H)
+    (o_ref * dO.double()).sum().backward()
+    G = lambda t: t.to(dev()).requires_grad_(True)
+    qg, kg, vg = G(q), G(k), G(v)
+    o = AG.few_key_attention(qg, kg, vg, H)
+    report("few-key attention out", o, o_ref, 2e-5)
+    (o * dO.to(dev())).sum().backward()
+    rel("few-key dQ", qg.grad, qr.grad, 5e-5)
+    rel("few-key dK", kg.grad, kr.grad, 5e-5)
+    rel("few-key dV", vg.grad, vr.grad, 5e-5)
+
+
+def test_perceiver_attention_dropout_consistent():
+    """Same trick as for the encoder layers: a one-hot V exposes the dropped probabilities, i.e. the keep mask; forward and
+    backward with that mask must equal float64."""
+    B, H, p = 2, 8, 0.3
+    # few-query: N = 64 keys, C = 512 (dh = 64): V_h = identity over the keys
+    N, C = 64, 512
+    drop = (p, 4242, 3)
+    q, k, dO = g("pd_q", (B, 2, C)), g("pd_k", (B, N, C)) * 0.5, g("pd_do", (B, 2, C))
+    eye = torch.eye(64).repeat(1, H).unsqueeze(0).expand(B, N, C).contiguous()
+    pd = AG.few_query_attention(q.to(dev()), k.to(dev()), eye.to(dev()), H, drop).cpu().view(B, 2, H, 64).transpose(1, 2)     # [B,H,2,N]
+    p0 = AG.few_query_attention(q.to(dev()), k.to(dev()), eye.to(dev()), H).cpu().view(B, 2, H, 64).transpose(1, 2)
+    keep = torch.where(pd > 0, torch.full_like(pd, 1 / (1 - p)), torch.zeros_like(pd))
+    report("few-query dropped P == P * keep", pd, p0 * keep, 1e-6)
+    v = g("pd_v", (B, N, C))
+    T = lambda t: t.double().requires_grad_(True)
+    qr, kr, vr = T(q), T(k), T(v)
+    o_ref, _ = _xattn_ref(qr, kr, vr, H, keep.double())
+    (o_ref * dO.double()).sum().backward()
+    G = lambda t: t.to(dev()).requires_grad_(True)
+    qg, kg, vg = G(q), G(k), G(v)
+    o = AG.few_query_attention(qg, kg, vg, H, drop)
+    report("few-query out with dropout", o, o_ref, 2e-5)
+    (o * dO.to(dev())).sum().backward()
+    for n_, a_, b_ in (("dQ", qg, qr), ("dK", kg, kr), ("dV", vg, vr)):
+        rel("few-query dropout " + n_, a_.grad, b_.grad, 5e-5)
+    # few-key: 2 keys, C = 256 (dh = 32): V rows = two one-hot vectors per head expose both probabilities
+    N, C = 500, 256
+    q, k, dO = g("pk_q", (B, N, C)), g("pk_k", (B, 2, C)), g("pk_do", (B, N, C))
+    onehot = torch.zeros(B, 2, C)
+    for h in range(H):
+        onehot[:, 0, h * 32] = 1.0; onehot[:, 1, h * 32 + 1] = 1.0
+    pd = AG.few_key_attention(q.to(dev()), k.to(dev()), onehot.to(dev()), H, drop).cpu().view(B, N, H, 32)[..., :2].permute(0, 2, 1, 3)   # [B,H,N,2]
+    p0 = AG.few_key_attention(q.to(dev()), k.to(dev()), onehot.to(dev()), H).cpu().view(B, N, H, 32)[..., :2].permute(0, 2, 1, 3)
+    keep = torch.where(pd > 0, torch.full_like(pd, 1 / (1 - p)), torch.zeros_like(pd))
+    report("few-key dropped P == P * keep", pd, p0 * keep, 1e-6)
+    assert abs((keep > 0).float().mean().item() - (1 - p)) < 0.03
+    v = g("pk_v", (B, 2, C))
+    qr, kr, vr = T(q), T(k), T(v)
+    o_ref, _ = _xattn_ref(qr, kr, vr, H, keep.double())
+    (o_ref * dO.double()).sum().backward()
+    qg, kg, vg = G(q), G(k), G(v)
+    o = AG.few_key_attention(qg, kg, vg, H, drop)
+    report("few-key out with dropout", o, o_ref, 2e-5)
+    (o * dO.to(dev())).sum().backward()
+    for n_, a_, b_ in (("dQ", qg, qr), ("dK", kg, kr), ("dV", vg, vr)):
+        rel("few-key dropout " + n_, a_.grad, b_.grad, 5e-5)
+
+
+def _cdm_model():
+    from afm.config import load_config
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.scene_model.use_scene_model=False",
+                                                           "model.input_feats=6", "model.text_model.max_length=20", "diffusion.steps=500"])
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    return model.to(dev()), diff
+
+
+def test_cdm_training_losses_backward_vs_reference_gradients():
+    """CDM (Perceiver): training_losses(...)['loss'].mean().backward() on the HIP path vs the real reference's gradients."""
+    model, diff = _cdm_model()
+    model.eval()
+    gf, gg = golden("cdm_forward_N256"), golden("cdm_training_grads")
+    x0, tn = synth.gaussian("cdm_train_x0", (2, 256, 6)).to(dev()), synth.gaussian("cdm_train_noise", (2, 256, 6)).to(dev())
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_pc_xyz=gf["xyz"].to(dev()))
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, gg["t"].to(dev()), model_kwargs=kw, noise=tn)
+    report("CDM training loss", terms["loss"], gg["loss"], 2e-5)
+    terms["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    names = [k[2:] for k in gg if k.startswith("g/")]
+    assert len(names) == 82
+    worst = 0.0
+    for n in names:
+        sample, _ = _digest(params[n].grad)
+        scale = max(gg["g/" + n].abs().max().item(), 1e-4)
+        err = ((sample - gg["g/" + n]).abs().max() / scale).item()
+        worst = max(worst, err)
+        assert err <= 1e-3, f"{n}: scaled grad err {err:.3e}"
+    print(f"[parity] 82 CDM gradients vs the reference's backward: worst scaled err {worst:.3e}")
+
+
+def test_cdm_train_mode_full_size_and_learning():
+    """N = 8192 points, train mode (attention dropout on): reproducible with a fixed seed, loss falls under fused AdamW."""
+    model, diff = _cdm_model()
+    model.train()
+    B, N = 4, 8192
+    x0 = synth.gaussian("cdm_tf_x0", (B, N, 6)).to(dev())
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_pc_xyz=synth.scene_cloud(B, N).to(dev()))
+    t = torch.tensor([5, 120, 333, 499], device=dev())
+
+    def run():
+        torch.manual_seed(9)
+        model._drop_calls, diff._loss_calls = 0, 0
+        model.zero_grad()
+        terms = diff.training_losses(model, x0, t, model_kwargs=kw)
+        terms["loss"].mean().backward()
+        return terms["loss"].detach().clone(), model.contact_layer.weight.grad.clone()
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    params = [p_ for n_, p_ in model.named_parameters() if p_.requires_grad and not n_.startswith("text_model")]
+    st, losses = {}, []
+    for it in range(8):
+        model.zero_grad()
+        diff._loss_calls = 0
+        terms = diff.training_losses(model, x0, t, model_kwargs=kw)
+        terms["loss"].mean().backward()
+        losses.append(terms["loss"].mean().item())
+        AG.adamw_step(params, st, lr=1e-4)
+    print("[train] CDM losses:", [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0]
