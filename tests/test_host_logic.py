@@ -152,3 +152,27 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"missing export {name}"
     assert ffi.load().afm_version() == 2            # pure host call, no GPU needed
+
+
+def test_evaluator_file_formats_round_trip(tmp_path):
+    """ADM -> file -> AMDM hand-off (utils/evaluate.py:41-82, datasets/humanml3d.py:763-774) and the motion pickle; the glue
+    values are pinned by the reference-generated golden."""
+    from afm import io as aio
+    g = golden("adm_to_amdm_glue")
+    raw, mean, std, sigma = g["sample"], float(g["mean"]), float(g["std"]), float(g["sigma"])
+    path = aio.save_pred_contact(str(tmp_path), "000021", 3, raw[0], mean=mean, std=std, sigma=sigma)
+    assert path.endswith("H3D/pred_contact/000021-3.npy")
+    stored = np.load(path)
+    assert stored.shape == (1, 64, 6) and stored.dtype == np.float32
+    np.testing.assert_allclose(stored[0], g["dist"].numpy()[0], rtol=1e-6, atol=1e-7)
+    cond = aio.load_pred_contact(str(tmp_path), "M_000021", 3, sigma=sigma)          # dataset strips the mirror prefix
+    np.testing.assert_allclose(cond[0], g["cond"].numpy()[0], rtol=1e-5, atol=1e-7)
+    aio.save_pred_contact(str(tmp_path), "000022", 0, raw, mean=mean, std=std, sigma=sigma)   # k samples stay (k, N, J)
+    assert np.load(os.path.join(tmp_path, "H3D/pred_contact/000022-0.npy")).shape == (2, 64, 6)
+    motion = torch.randn(16, 263)
+    x_mask = torch.zeros(16, dtype=torch.bool); x_mask[12:] = True
+    p = aio.save_motion_sample(str(tmp_path), "000021", 3, text="a person walks", tokens=["a/DET"], motion=motion, x_mask=x_mask,
+                               mean=torch.ones(263), std=torch.full((263,), 2.0))
+    rec = aio.load_motion_sample(p)
+    assert set(rec) == {"name", "text", "tokens", "motion", "m_len"} and rec["m_len"] == 12
+    np.testing.assert_allclose(rec["motion"], motion.numpy() * 2.0 + 1.0, rtol=1e-6)
