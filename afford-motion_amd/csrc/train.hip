@@ -275,8 +275,10 @@ SkinnyPlan skinny_plan(int M, int N, int K) {
     if ((p.tn == 1 && p.tk > 4 && p.tk < 8)) { p.tk = 8; p.ok = true; }
     if ((p.tk == 1 && p.tn > 4 && p.tn < 8)) { p.tn = 8; p.ok = true; }
     p.ok = p.ok && M >= 4096;                                  // small M: the tiled kernel's split is enough
-    int64_t waves = (M + 511) / 512;                           // >= 512 rows per wave
-    if (waves > 4096) waves = 4096;
+    int64_t waves = (M + 127) / 128;                           // >= 128 rows per wave; many short waves keep more loads in flight
+    if (waves > 16384) waves = 16384;
+    const int64_t cap = (64ll << 20) / ((int64_t)N * K * 4);   // partials stay under 64 MB
+    if (waves > cap) waves = cap;
     if (waves < 4) waves = 4;
     waves = (waves + 3) / 4 * 4;
     p.nwaves = (int)waves;
