@@ -75,6 +75,9 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", sinusoid_table(max_len, time_emb_dim))
 
 
+COND_SWITCHES = ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase")
+
+
 def _param_version(module: nn.Module) -> int:
     return sum(p._version for p in module.parameters()) + sum(b._version for b in module.buffers())
 
@@ -178,9 +181,6 @@ class CMDM(TextEncoderMixin, nn.Module):
     def condition_tokens(self, **kwargs) -> torch.Tensor:
         """[B, 1 + G, d]: language_adapter(text) and contact_adapter(SceneMapEncoder(xyz, contact)),
         positional encoding of sequence positions 1 .. 1+G already added (cmdm.py:134-156,161-162)."""
-        for k in ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase"):
-            if k in kwargs:
-                raise NotImplementedError(f"{k}: training-time condition dropout is not on the sampling path")
         tensors = [kwargs.get(k) for k in ("c_pc_xyz", "c_pc_contact", "c_text_feat", "c_cont_emb")]
         key = (tuple((t.data_ptr(), t._version, tuple(t.shape)) if isinstance(t, torch.Tensor) else None for t in tensors),
                tuple(kwargs["c_text"]) if "c_text" in kwargs and "c_text_feat" not in kwargs else None, _param_version(self))
@@ -206,6 +206,11 @@ class CMDM(TextEncoderMixin, nn.Module):
         c_pc_xyz, c_pc_contact, info_* ignored) -> predicted x_0, same shape as x."""
         if torch.is_grad_enabled() and (self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self.forward_train(x, timesteps, **kwargs)
+        if any(k in kwargs for k in COND_SWITCHES):
+            # training-time condition switches (datasets/transforms.py:50-106) change the key mask / the embeddings per
+            # sample: evaluate through the per-operator composition, which implements them (no autograd, no dropout in eval)
+            with torch.no_grad():
+                return self.forward_train(x, timesteps, **kwargs)
         ffi.require_gpu(x)
         with torch.no_grad():
             lib = ffi.load()
@@ -285,6 +290,9 @@ class CMDM(TextEncoderMixin, nn.Module):
     # ------------------------------------------------------------------ native sampling loop
     def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0):
         """Whole p_sample_loop on the device: x holds x_T on entry, returns the final sample."""
+        if any(k in model_kwargs for k in COND_SWITCHES):
+            raise NotImplementedError("condition switches (c_*_mask / c_*_erase) are training-time augmentations; sample step by step "
+                                      "(`progress=True`) if you really need them")
         lib = ffi.load()
         ffi.require_gpu(x)
         with torch.no_grad():

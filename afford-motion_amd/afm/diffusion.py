@@ -199,8 +199,9 @@ class GaussianDiffusion:
         (seed, sample_index0 + b, step).  Denoisers exposing ``afm_native_loop`` (our CMDM / CDM)
         run the whole loop natively without host synchronisation."""
         native = getattr(model, "afm_native_loop", None)
+        switches = any(k in (model_kwargs or {}) for k in ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase"))
         if native is not None and not clip_denoised and denoised_fn is None and cond_fn is None and not progress \
-                and not self.rescale_timesteps:
+                and not self.rescale_timesteps and not switches:
             if device is None:
                 device = next(model.parameters()).device
             seed = int(torch.initial_seed()) if seed is None else seed

@@ -65,7 +65,7 @@ def encoder_layer(sd: SD, pre: str, x: torch.Tensor, key_padding_mask: Optional[
 def cmdm_forward(sd: SD, x, t, text_feat, c_pc_xyz=None, c_pc_contact=None, x_mask=None, *,
                  time_emb_dim: int = 512, nhead: int = 8, num_layers: int = 5,
                  blocks=(2, 2, 2, 2), mask_motion: bool = True, cont_emb: Optional[torch.Tensor] = None,
-                 return_tokens: bool = False):
+                 return_tokens: bool = False, c_text_mask=None, c_text_erase=None, c_pc_mask=None, c_pc_erase=None):
     """CMDM.forward, `trans_enc` branch (cmdm.py:118-170,195).
 
     ``cont_emb`` (the SceneMapEncoder output, [B, G, planes[-1]]) may be passed in to
@@ -75,9 +75,14 @@ def cmdm_forward(sd: SD, x, t, text_feat, c_pc_xyz=None, c_pc_contact=None, x_ma
     B, L, _ = x.shape
     d = sd["motion_adapter.weight"].shape[0]
     time_emb = timestep_embed(sd, "timestep_embedder", t, time_emb_dim)           # [B,1,d]
-    text_emb = _lin(sd, "language_adapter", text_feat.unsqueeze(1).float())        # [B,1,d]
+    text = text_feat.unsqueeze(1).float()
+    if c_text_erase is not None:                                                   # cmdm.py:144-145
+        text = text * (1.0 - c_text_erase.unsqueeze(-1).float())
+    text_emb = _lin(sd, "language_adapter", text)                                  # [B,1,d]
     if cont_emb is None:
         cont_emb = scene_ref.scene_map_encoder(sd, "contact_encoder", c_pc_xyz, c_pc_contact, blocks=blocks)
+    if c_pc_erase is not None:                                                     # cmdm.py:154-155
+        cont_emb = cont_emb * (1.0 - c_pc_erase.unsqueeze(-1).float())
     cont = _lin(sd, "contact_adapter", cont_emb)                                   # [B,G,d]
     G = cont.shape[1]
     seq = torch.cat([time_emb, text_emb, cont, _lin(sd, "motion_adapter", x)], dim=1)
@@ -87,7 +92,9 @@ def cmdm_forward(sd: SD, x, t, text_feat, c_pc_xyz=None, c_pc_contact=None, x_ma
     if mask_motion:
         if x_mask is None:
             x_mask = torch.zeros(B, L, dtype=torch.bool)
-        mask = torch.cat([torch.zeros(B, 2 + G, dtype=torch.bool), x_mask], dim=1)
+        tm = torch.zeros(B, 1, dtype=torch.bool) if c_text_mask is None else c_text_mask.bool().reshape(B, 1)      # cmdm.py:142-143
+        cm = torch.zeros(B, G, dtype=torch.bool) if c_pc_mask is None else c_pc_mask.bool().reshape(B, 1).repeat(1, G)   # :152-153
+        mask = torch.cat([torch.zeros(B, 1, dtype=torch.bool), tm, cm, x_mask], dim=1)
     for i in range(num_layers):
         seq = encoder_layer(sd, f"self_attn_layer.layers.{i}", seq, mask, nhead)
     out = _lin(sd, "motion_layer", seq[:, 2 + G:, :])

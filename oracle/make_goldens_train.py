@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -121,8 +121,32 @@ def cdm_main():
     print(f"{n} CDM parameter gradients")
 
 
+def masks_main():
+    """tests/golden/cmdm_forward_cond_masks.npz: CMDM.forward with the training-time condition switches of
+    datasets/transforms.py (c_text_mask / c_text_erase / c_pc_mask / c_pc_erase), eval mode."""
+    from afm import synth
+    base, _ = import_reference()
+    g = np.load(os.path.join(GOLD, "cmdm_forward_N1024_L16.npz"))
+    xyz, con, x_mask = torch.from_numpy(g["xyz"]), torch.from_numpy(g["contact"]), torch.from_numpy(g["x_mask"])
+    cfg = to_attr(dict(model=cmdm_cfg(num_points=xyz.shape[1]), diffusion=diffusion_cfg(1000, "")))
+    model = base.create_model(cfg, device="cpu")
+    synth.fill_module_(model)
+    model.eval()
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
+    kw = dict(c_text=TEXTS, c_pc_xyz=xyz, c_pc_contact=con, x_mask=x_mask)
+    sw = dict(c_text_mask=torch.tensor([[True], [False]]), c_text_erase=torch.tensor([[False], [True]]),
+              c_pc_mask=torch.tensor([[False], [True]]), c_pc_erase=torch.tensor([[True], [False]]))
+    with torch.no_grad():
+        out_all = model(x, t, **kw, **sw)
+        out_tm = model(x, t, **kw, c_text_mask=sw["c_text_mask"])
+        out_pe = model(x, t, **kw, c_pc_erase=sw["c_pc_erase"])
+    save("cmdm_forward_cond_masks", out_all=out_all, out_text_mask=out_tm, out_pc_erase=out_pe, **{k: v for k, v in sw.items()})
+
+
 if __name__ == "__main__":
-    if "--cdm" in sys.argv:
+    if "--masks" in sys.argv:
+        masks_main()
+    elif "--cdm" in sys.argv:
         cdm_main()
     elif "--scene" in sys.argv:
         scene_main()

@@ -189,3 +189,17 @@ def test_full_size_properties():
     out2 = model(x2, t, **kw)
     valid = ~mask
     assert torch.equal(out2[valid], out[valid])                                        # masked keys carry exactly zero weight
+
+
+def test_forward_with_condition_switches_vs_reference_golden(cmdm):
+    """c_text_mask / c_text_erase / c_pc_mask / c_pc_erase (training-time augmentations, cmdm.py:142-155) in eval mode."""
+    model, diff = cmdm
+    g, gm = golden("cmdm_forward_N1024_L16"), golden("cmdm_forward_cond_masks")
+    sw = {k: gm[k].to(dev()) for k in ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase")}
+    x, t = g["x"].to(dev()), g["t"].to(dev())
+    report("CMDM forward, all four switches", model(x, t, **_kw(g), **sw), gm["out_all"], 2e-4)
+    report("CMDM forward, c_text_mask", model(x, t, **_kw(g), c_text_mask=sw["c_text_mask"]), gm["out_text_mask"], 2e-4)
+    report("CMDM forward, c_pc_erase", model(x, t, **_kw(g), c_pc_erase=sw["c_pc_erase"]), gm["out_pc_erase"], 2e-4)
+    # the per-operator composition equals the fused forward when no switch is set
+    with torch.no_grad():
+        report("composed forward == fused forward", model.forward_train(x, t, **_kw(g)), model(x, t, **_kw(g)), 2e-5)
