@@ -385,6 +385,28 @@ def few_key_attention(q, k, v, heads: int, drop=(0.0, 0, 0)):
     return _FewKeyAttentionFn.apply(q, k, v, heads, drop)
 
 
+class _SegmentMeanFn(torch.autograd.Function):
+    """x [B, N, C] -> mean over the N points of every sample [B, C] (PointSceneMLP scene feature, cdm.py:35)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = _c(x)
+        B, N, Cn = xc.shape
+        out = torch.empty(B, Cn, device=xc.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_segment_mean(xc.data_ptr(), out.data_ptr(), B, N, Cn, _st(xc)), "afm_segment_mean")
+        ctx.dims = (B, N, Cn)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, Cn = ctx.dims
+        return (_c(dy) / N).view(B, 1, Cn).expand(B, N, Cn)
+
+
+def segment_mean(x):
+    return _SegmentMeanFn.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ loss
 class _MaskedMseFn(torch.autograd.Function):
     @staticmethod

@@ -59,6 +59,51 @@ def _mlp(ch: int, widening: int) -> nn.Sequential:
     return nn.Sequential(nn.LayerNorm(ch), nn.Linear(ch, widening * ch), nn.GELU(), nn.Linear(widening * ch, ch))
 
 
+class PointSceneMLP(nn.Module):
+    """Parameter container with the reference's names (cdm.py:13-39): per-point MLP, then a second MLP over
+    [point feature | mean feature of the sample]."""
+
+    def __init__(self, in_dim: int, out_dim: int, widening_factor: int = 1, bias: bool = True) -> None:
+        super().__init__()
+        self.mlp_pre = nn.Sequential(nn.LayerNorm(in_dim), nn.Linear(in_dim, widening_factor * in_dim, bias=bias), nn.GELU(),
+                                     nn.Linear(widening_factor * in_dim, out_dim, bias=bias))
+        self.mlp_post = nn.Sequential(nn.LayerNorm(2 * out_dim), nn.Linear(2 * out_dim, 2 * out_dim, bias=bias), nn.GELU(),
+                                      nn.Linear(2 * out_dim, out_dim, bias=bias))
+
+    @staticmethod
+    def _mlp(seq: nn.Sequential, x):
+        h = AG.linear(AG.layer_norm(x, seq[0]), seq[1].weight, seq[1].bias, act=ffi.ACT_GELU)
+        return AG.linear(h, seq[3].weight, seq[3].bias)
+
+    def run(self, x):
+        """x [B, N, in] -> [B, N, out] on the (differentiable) HIP operators."""
+        pf = self._mlp(self.mlp_pre, x)
+        B, N, Cn = pf.shape
+        scene = AG.segment_mean(pf).view(B, 1, Cn).expand(B, N, Cn)
+        return self._mlp(self.mlp_post, torch.cat([pf, scene], dim=-1))
+
+
+class ContactMLP(nn.Module):
+    """`arch: 'MLP'` - the default of configs/model/cdm.yaml (cdm.py:41-85)."""
+
+    def __init__(self, arch_cfg, contact_dim: int, point_feat_dim: int, text_feat_dim: int, time_emb_dim: int) -> None:
+        super().__init__()
+        layers, idim = [], contact_dim + point_feat_dim + text_feat_dim + time_emb_dim
+        for odim in arch_cfg.point_mlp_dims:
+            layers.append(PointSceneMLP(idim, odim, widening_factor=arch_cfg.point_mlp_widening_factor, bias=arch_cfg.point_mlp_bias))
+            idim = odim
+        self.point_mlp = nn.Sequential(*layers)
+
+    def run(self, x, point_feat, language_feat, time_embedding):
+        """x [B,N,J], point_feat [B,N,F] or None, language_feat [B,1,Ft], time_embedding [B,1,Te] -> [B,N,last_dim]."""
+        B, N, _ = x.shape
+        parts = [x] + ([point_feat] if point_feat is not None else []) + [language_feat.expand(B, N, -1), time_embedding.expand(B, N, -1)]
+        h = torch.cat(parts, dim=-1)
+        for layer in self.point_mlp:
+            h = layer.run(h)
+        return h
+
+
 class ContactPerceiver(nn.Module):
     """Parameter container with the reference's names (cdm.py:88-153)."""
 
@@ -118,11 +163,15 @@ class CDM(TextEncoderMixin, nn.Module):
             self.point_feat_dim = sm.point_feat_dim
             self._scene_cache = None
         self.arch = cfg.arch
-        if self.arch != "Perceiver":
-            raise NotImplementedError(f"arch={self.arch!r}: only 'Perceiver' is selected by the reference's scripts")
-        self.arch_cfg = cfg.arch_perceiver
-        self.contact_model = ContactPerceiver(self.arch_cfg, contact_dim=self.contact_dim, point_feat_dim=self.point_feat_dim,
-                                              text_feat_dim=self.text_feat_dim, time_emb_dim=self.time_emb_dim)
+        if self.arch == "Perceiver":
+            self.arch_cfg, contact_model = cfg.arch_perceiver, ContactPerceiver
+        elif self.arch == "MLP":
+            self.arch_cfg, contact_model = cfg.arch_mlp, ContactMLP
+        else:
+            raise NotImplementedError(f"arch={self.arch!r}: 'Perceiver' (every script) and 'MLP' (the config default) are built; "
+                                      "'PointTrans' / 'PointTransV2' are not (SURVEY.md section 8f-4)")
+        self.contact_model = contact_model(self.arch_cfg, contact_dim=self.contact_dim, point_feat_dim=self.point_feat_dim,
+                                           text_feat_dim=self.text_feat_dim, time_emb_dim=self.time_emb_dim)
         self.contact_layer = nn.Linear(self.arch_cfg.last_dim, self.contact_dim, bias=True)
         self._pack = None
         self._text_cache = None
@@ -221,6 +270,8 @@ class CDM(TextEncoderMixin, nn.Module):
 
     def forward(self, x, timesteps, **kwargs):
         """x [B, N, contact_dim], timesteps [B] -> predicted x_0 (same shape)."""
+        if self.arch == "MLP":
+            return self.forward_mlp(x, timesteps, **kwargs)
         if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
             return self.forward_train(x, timesteps, **kwargs)
         ffi.require_gpu(x)
@@ -244,6 +295,37 @@ class CDM(TextEncoderMixin, nn.Module):
                                           tcu.data_ptr(), out.data_ptr(), None, B, N, ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
                       "afm_cdm_forward")
         return out
+
+    # ------------------------------------------------------------------ 'MLP' arch (per-operator composition, inference and training)
+    def _point_features(self, x, kwargs):
+        """pc_emb of CDM.forward (cdm.py:495-508): frozen scene backbone output, given per-point features, or None."""
+        if hasattr(self, "scene_model"):
+            xyz, col = kwargs["c_pc_xyz"], kwargs.get("c_pc_feat")
+            key = (xyz.data_ptr(), xyz._version, None if col is None else (col.data_ptr(), col._version), tuple(xyz.shape))
+            if self._scene_cache is None or self._scene_cache[0] != key:
+                self._scene_cache = (key, self.scene_model((xyz.to(x), None if col is None else col.to(x))))
+            return self._scene_cache[1]
+        if self.point_feat_dim > 0:
+            pf = kwargs["c_pc_feat"]
+            if self.point_feat_dim == 1 and pf.shape[-1] != 1:
+                raise NotImplementedError("openscene text-similarity feature (cdm.py:500-503)")
+            return pf.to(x)
+        return None
+
+    def forward_mlp(self, x, timesteps, **kwargs):
+        """CDM.forward with ContactMLP (cdm.py:41-85,474-513): every op is a (differentiable) HIP operator; runs under
+        torch.no_grad() for sampling and with the tape for training."""
+        ffi.require_gpu(x)
+        x = ffi.f32c(x)
+        B, N, _ = x.shape
+        dev = x.device
+        te = self.timestep_embedder
+        t_idx = timesteps.to(device=dev, dtype=torch.int64)
+        time_emb = AG.linear(AG.linear(te.pe[t_idx, 0, :], te.time_embed[0].weight, te.time_embed[0].bias, act=ffi.ACT_SILU),
+                             te.time_embed[2].weight, te.time_embed[2].bias).view(B, 1, -1)
+        text = ffi.f32c(self.encode_text(kwargs).to(dev)).view(B, 1, -1)
+        h = self.contact_model.run(x, self._point_features(x, kwargs), text, time_emb)
+        return AG.linear(h, self.contact_layer.weight, self.contact_layer.bias)
 
     # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
     def _mha_train(self, att: _MHA, xq, xkv, heads: int, drop, kind: str, residual):

@@ -51,6 +51,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// any dim (not a multiple of 4, e.g. the 646-wide input LayerNorm of the CDM 'MLP' arch, cdm.py:18-23): wave per row,
+// lane-strided scalar accesses, three passes over the (L1/L2-resident) row
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y, int64_t rows, int dim,
+                                                                float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xp = x + row * dim;
+    float sum = 0.f;
+    for (int c = lane; c < dim; c += 64) sum += xp[c];
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float d = xp[c] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+    float* yp = y + row * dim;
+    for (int c = lane; c < dim; c += 64) yp[c] = (xp[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
 // x_next = (c1*x0 + c2*x_t) + sigma*noise with every product and sum individually rounded
 // (bit-identical to the reference's float32 torch expression).
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x0, const float* __restrict__ xt,
@@ -143,10 +162,16 @@ extern "C" int afm_layernorm(const float* x, const float* gamma, const float* be
 
 extern "C" int afm_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
                                   float eps, int32_t grp, int32_t stride, int32_t off, void* stream) {
-    if (dim <= 0 || (dim & 3)) return AFM_E_BADARG;
+    if (dim <= 0) return AFM_E_BADARG;
     if (rows == 0) return 0;                                  // empty batch (pointers may be null)
     if (!x || !gamma || !beta || !y || rows < 0) return AFM_E_BADARG;
-    if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) return AFM_E_BADARG;
+    if ((dim & 3) || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15)) {
+        if (grp) return AFM_E_UNSUPPORTED;                     // the row-subset form is only used with d_model (multiple of 4)
+        AfmProf prof(AFM_PROF_LN, 8.0 * rows * dim, (hipStream_t)stream);
+        hipLaunchKernelGGL(layernorm_generic_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, dim, eps);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256), grid((unsigned)((rows + 3) / 4));

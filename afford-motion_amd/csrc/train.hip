@@ -384,6 +384,52 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// any dim <= 1024 (not a multiple of 4): lane-strided scalar accesses, per-lane dgamma / dbeta for columns lane + 64 j
+__global__ __launch_bounds__(256) void layernorm_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part,
+                                                                    int64_t rows, int dim, float eps) {
+    constexpr int MAXJ = 16;
+    __shared__ float red[4][2][64 * MAXJ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[MAXJ], db[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+    const float inv_dim = 1.0f / (float)dim;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xp = x + row * dim;
+        const float* gp = dy + row * dim;
+        float sum = 0.f;
+        for (int c = lane; c < dim; c += 64) sum += xp[c];
+        const float mean = wave_sum(sum) * inv_dim;
+        float sq = 0.f;
+        for (int c = lane; c < dim; c += 64) { const float d = xp[c] - mean; sq += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_dim + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < dim) {
+                const float xh = (xp[c] - mean) * rstd, g = gp[c];
+                dg[j] += g * xh; db[j] += g;
+                const float gg = g * gamma[c];
+                s1 += gg; s2 += gg * xh;
+            }
+        }
+        s1 = wave_sum(s1) * inv_dim; s2 = wave_sum(s2) * inv_dim;
+        for (int c = lane; c < dim; c += 64) {
+            const float xh = (xp[c] - mean) * rstd;
+            dx[row * dim + c] = rstd * (gp[c] * gamma[c] - s1 - xh * s2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { red[wave][0][lane + 64 * j] = dg[j]; red[wave][1][lane + 64 * j] = db[j]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * dim; e += 256) {
+        const int which = e / dim, c = e % dim;
+        part[(int64_t)blockIdx.x * 2 * dim + e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
 int ln_bwd_blocks(int64_t rows) {
     int64_t b = (rows + 15) / 16;               // >= 4 rows per wave
     if (b > 512) b = 512;
@@ -566,7 +612,7 @@ extern "C" int64_t afm_layernorm_bwd_workspace_bytes(int64_t rows, int32_t dim) 
 extern "C" int afm_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dx_drop, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t dim, float eps, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws,
                                  int64_t ws_bytes, void* stream) {
-    if (dim <= 0 || (dim & 3) || dim > 1024) return dim > 1024 ? AFM_E_UNSUPPORTED : AFM_E_BADARG;
+    if (dim <= 0 || dim > 1024) return dim > 1024 ? AFM_E_UNSUPPORTED : AFM_E_BADARG;
     if (!dgamma || !dbeta || rows < 0) return AFM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (rows == 0) {
@@ -575,12 +621,17 @@ extern "C" int afm_layernorm_bwd(const float* x, const float* gamma, const float
         return (int)e;
     }
     if (!x || !gamma || !dy || !dx) return AFM_E_BADARG;
-    if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)dx_drop) | ((uintptr_t)gamma)) & 15) return AFM_E_BADARG;
     if (drop_p < 0.0f || drop_p >= 1.0f) return AFM_E_BADARG;
     const int nb = ln_bwd_blocks(rows);
     if (!ws || ws_bytes < (int64_t)nb * 2 * dim * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
     float* part = (float*)ws;
-    {
+    const bool generic = (dim & 3) || ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)dx_drop) | ((uintptr_t)gamma)) & 15);
+    if (generic) {
+        if (dx_drop && drop_p > 0.0f) return AFM_E_UNSUPPORTED;
+        AfmProf prof(AFM_PROF_LN_BWD, 16.0 * rows * dim, s);
+        hipLaunchKernelGGL(layernorm_bwd_generic_kernel, dim3(nb), dim3(256), 0, s, x, gamma, dy, dx, part, rows, dim, eps);
+        AFM_CHECK_LAUNCH();
+    } else {
     AfmProf prof(AFM_PROF_LN_BWD, 16.0 * rows * dim, s);
 #define AFM_LNB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(nb), dim3(256), 0, s, x, gamma, dy, dx, dx_drop, part, rows, dim, eps, drop_p, drop_seed, drop_id)
     if (dim <= 256) AFM_LNB(1); else if (dim <= 512) AFM_LNB(2); else AFM_LNB(4);

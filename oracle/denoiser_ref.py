@@ -157,3 +157,22 @@ def cdm_forward(sd: SD, x, t, text_feat, c_pc_xyz, pc_emb=None, *, time_emb_dim:
     dec_q = _lin(sd, cm + ".decoder_adapter", enc_kv)                              # [B,N,256]
     dec_q = cross_attention_layer(sd, cm + ".decoder_cross_attn", dec_q, enc_q, dec_heads)
     return _lin(sd, "contact_layer", dec_q)
+
+
+def cdm_mlp_forward(sd: SD, x, t, text_feat, pc_emb=None, *, time_emb_dim: int = 128, n_layers: int = 2):
+    """CDM.forward with ContactMLP (cdm.py:13-85,474-513): per-point MLP over [x | point feature | text | time], each
+    PointSceneMLP concatenating the sample's mean feature before its second MLP."""
+    B, N, _ = x.shape
+    time_emb = timestep_embed(sd, "timestep_embedder", t, time_emb_dim)           # [B,1,te]
+    text = text_feat.unsqueeze(1).float()
+    parts = [x] + ([pc_emb] if pc_emb is not None else []) + [text.repeat(1, N, 1), time_emb.repeat(1, N, 1)]
+    h = torch.cat(parts, dim=-1)
+
+    def mlp(pre, z):
+        return _lin(sd, pre + ".3", F.gelu(_lin(sd, pre + ".1", _ln(sd, pre + ".0", z))))
+    for i in range(n_layers):
+        pre = f"contact_model.point_mlp.{i}"
+        pf = mlp(pre + ".mlp_pre", h)
+        scene = pf.mean(dim=1, keepdim=True).repeat(1, N, 1)
+        h = mlp(pre + ".mlp_post", torch.cat([pf, scene], dim=-1))
+    return _lin(sd, "contact_layer", h)

@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -143,8 +143,46 @@ def masks_main():
     save("cmdm_forward_cond_masks", out_all=out_all, out_text_mask=out_tm, out_pc_erase=out_pe, **{k: v for k, v in sw.items()})
 
 
+def mlp_main():
+    """tests/golden/cdm_mlp_N256.npz: the reference CDM with `arch: 'MLP'` (the config default) - forward output and the
+    gradients of training_losses + backward (eval mode), N = 256 points, 32-d per-point features supplied."""
+    from afm import synth
+    from oracle.make_goldens import cdm_cfg
+    base, _ = import_reference()
+    B, Nc = 2, 256
+    mc = cdm_cfg(num_points=Nc)
+    mc.update(arch="MLP", arch_mlp=dict(last_dim=512, point_mlp_dims=[512, 512], point_mlp_widening_factor=1, point_mlp_bias=True))
+    # the reference's ContactMLP only runs WITH per-point features (cdm.py:80 uses `num_points` that is unbound otherwise)
+    mc["scene_model"].update(use_scene_model=True, use_openscene=True, point_feat_dim=32)
+    cdm, cdiff = base.create_model_and_diffusion(to_attr(dict(model=mc, diffusion=diffusion_cfg(500, ""))), device="cpu")
+    synth.fill_module_(cdm)
+    cdm.eval()
+    cxyz = synth.scene_cloud(B, Nc, seed=14)
+    cx = synth.gaussian("cdm_x", (B, Nc, 6))
+    tc = torch.tensor([499, 7])
+    kw = dict(c_text=TEXTS, c_pc_xyz=cxyz, c_pc_feat=synth.gaussian("cdm_pc_feat", (B, Nc, 32)))
+    with torch.no_grad():
+        out = cdm(cx, tc, **kw)
+    x0, tn = synth.gaussian("cdm_train_x0", (B, Nc, 6)), synth.gaussian("cdm_train_noise", (B, Nc, 6))
+    tt = torch.tensor([33, 470])
+    cdm.zero_grad()
+    terms = cdiff.training_losses(cdm, x0, tt, model_kwargs=kw, noise=tn)
+    terms["loss"].mean().backward()
+    res = {"t": tc, "out": out, "t_train": tt, "loss": terms["loss"].detach()}
+    for name, p in cdm.named_parameters():
+        if name.startswith("text_model.") or p.grad is None:
+            continue
+        res["g/" + name], res["s/" + name] = grad_digest(p.grad)
+    save("cdm_mlp_N256", **res)
+    keys = sorted(k for k in cdm.state_dict().keys() if "text_model" not in k)
+    with open(os.path.join(GOLD, "cdm_mlp_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(f"{k} {tuple(cdm.state_dict()[k].shape)}" for k in keys) + "\n")
+
+
 if __name__ == "__main__":
-    if "--masks" in sys.argv:
+    if "--mlp" in sys.argv:
+        mlp_main()
+    elif "--masks" in sys.argv:
         masks_main()
     elif "--cdm" in sys.argv:
         cdm_main()

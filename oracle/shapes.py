@@ -136,6 +136,20 @@ def cdm(contact_dim=6, point_feat_dim=0, te=128, text_dim=512, cq=512, ckv=256, 
     return s
 
 
+def cdm_mlp(contact_dim=6, point_feat_dim=0, te=128, text_dim=512, dims=(512, 512), last_dim=512) -> Shapes:
+    """CDM with `arch: 'MLP'` (cdm.py:13-85): PointSceneMLP stacks, widening 1, bias on."""
+    s = timestep_embedder("timestep_embedder", te, te)
+    idim = contact_dim + point_feat_dim + text_dim + te
+    for i, odim in enumerate(dims):
+        pre = f"contact_model.point_mlp.{i}"
+        s.update(_ln(pre + ".mlp_pre.0", idim)); s.update(_lin(pre + ".mlp_pre.1", idim, idim)); s.update(_lin(pre + ".mlp_pre.3", idim, odim))
+        s.update(_ln(pre + ".mlp_post.0", 2 * odim)); s.update(_lin(pre + ".mlp_post.1", 2 * odim, 2 * odim))
+        s.update(_lin(pre + ".mlp_post.3", 2 * odim, odim))
+        idim = odim
+    s.update(_lin("contact_layer", last_dim, contact_dim))
+    return s
+
+
 def weights(shapes: Shapes, seed=None):
     """Materialise name-keyed weights for a shape table."""
     import sys, os

@@ -659,3 +659,49 @@ def test_cdm_train_mode_full_size_and_learning():
         AG.adamw_step(params, st, lr=1e-4)
     print("[train] CDM losses:", [round(v, 4) for v in losses])
     assert losses[-1] < losses[0]
+
+
+# ------------------------------------------------------------------------------------------------ CDM 'MLP' arch (config default)
+@pytest.mark.parametrize("rows,dim", [(513, 646), (100, 38), (7, 1022)])
+def test_layernorm_any_width_forward_backward(rows, dim):
+    from afm import ops
+    x, dy = g("lg_x", (rows, dim)), g("lg_dy", (rows, dim))
+    gam, bet = 1.0 + 0.1 * g("lg_g", (dim,)), 0.1 * g("lg_b", (dim,))
+    xr, gr, br = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (dim,), gr, br, 1e-5)
+    yr.backward(dy.double())
+    report("LN (any width) forward", ops.layernorm(x.to(dev()), gam.to(dev()), bet.to(dev())), yr, 2e-5)
+    dx, _, dg, db = AG._layernorm_bwd(x.to(dev()), gam.to(dev()), dy.to(dev()))
+    rel("LN (any width) dx", dx, xr.grad, 2e-5)
+    rel("LN (any width) dgamma", dg, gr.grad, 2e-5)
+    rel("LN (any width) dbeta", db, br.grad, 2e-5)
+
+
+def test_cdm_mlp_arch_forward_and_gradients_vs_reference():
+    from afm.config import load_config
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "task.dataset.use_openscene=True", "diffusion.steps=500",
+                                                           "model.text_model.max_length=20"])
+    assert cfg.model.arch == "MLP"
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    gf, gm = golden("cdm_forward_N256"), golden("cdm_mlp_N256")
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_pc_xyz=gf["xyz"].to(dev()), c_pc_feat=synth.gaussian("cdm_pc_feat", (2, 256, 32)).to(dev()))
+    with torch.no_grad():
+        out = model(gf["x"].to(dev()), gm["t"].to(dev()), **kw)
+    report("CDM 'MLP' arch forward vs reference", out, gm["out"], 2e-4)
+    x0, tn = synth.gaussian("cdm_train_x0", (2, 256, 6)).to(dev()), synth.gaussian("cdm_train_noise", (2, 256, 6)).to(dev())
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, gm["t_train"].to(dev()), model_kwargs=kw, noise=tn)
+    report("CDM 'MLP' training loss", terms["loss"], gm["loss"], 5e-5)
+    terms["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    names = [k[2:] for k in gm if k.startswith("g/")]
+    for n in names:
+        sample, _ = _digest(params[n].grad)
+        scale = max(gm["g/" + n].abs().max().item(), 1e-4)
+        err = ((sample - gm["g/" + n]).abs().max() / scale).item()
+        worst = max(worst, err)
+        assert err <= 1e-3, f"{n}: {err:.3e}"
+    print(f"[parity] {len(names)} gradients of the CDM 'MLP' arch vs the reference's backward: worst scaled err {worst:.3e}")

@@ -116,7 +116,15 @@ def test_cdm_state_dict_keys_match_reference():
         k, shp = line.strip().split(" ", 1)
         want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
     assert have == want                                                      # frozen scene backbone: reference key names
-    for bad in (["model.arch=MLP"],):
+    mlp = base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "task.dataset.use_openscene=True"]),
+                            device="cpu")                                    # yaml default arch: 'MLP' (configs/model/cdm.yaml)
+    have = {k: tuple(v.shape) for k, v in mlp.state_dict().items()}
+    want = {}
+    for line in open(os.path.join(GOLDEN, "cdm_mlp_state_dict_keys.txt")):
+        k, shp = line.strip().split(" ", 1)
+        want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
+    assert have == want
+    for bad in (["model.arch=PointTrans"],):
         with pytest.raises(NotImplementedError):                             # unbuilt variants fail loudly
             base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver"] + bad),
                               device="cpu")
