@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import autograd as AG
-from . import ffi
+from . import ffi, ops
 from .base import Model
 from .cmdm import TimestepEmbedder, _param_version
 from .text import TextEncoderMixin, lang_feat_dim_type
@@ -104,6 +104,97 @@ class ContactMLP(nn.Module):
         return h
 
 
+class ContactPointTrans(nn.Module):
+    """`arch: 'PointTrans'` / `'PointTransV2'` (cdm.py:190-410): a 4-level Point Transformer U-Net over the noisy contact map
+    itself (planes 64..512), the text / time context injected through small MLPs at the bottleneck (V1) or at levels 4, 3, 2
+    plus one ReLU transformer-encoder layer over the N/64 bottleneck tokens (V2).  Inference only; built from the fused point
+    kernels of afm.scene (eval-mode BatchNorm)."""
+
+    def __init__(self, arch_cfg, contact_dim: int, point_feat_dim: int, text_feat_dim: int, time_emb_dim: int, v2: bool = False) -> None:
+        super().__init__()
+        from .scene import PointTransformerBlock, TransitionDown, TransitionUp
+        self.v2 = v2
+        self.num_points = arch_cfg.num_points
+        self.c = contact_dim + point_feat_dim + 3
+        blocks, planes, share = list(arch_cfg.blocks), [64, 128, 256, 512], 8
+        self.strides, self.nsamples = [1, 4, 4, 4], [8, 16, 16, 16]
+        self.in_planes = self.c
+        for i in range(4):
+            layers = [TransitionDown(self.in_planes, planes[i], self.strides[i], self.nsamples[i])]
+            self.in_planes = planes[i]
+            layers += [PointTransformerBlock(planes[i], planes[i], share, nsample=self.nsamples[i]) for _ in range(1, blocks[i])]
+            setattr(self, f"enc{i + 1}", nn.Sequential(*layers))
+        for i in (3, 2, 1, 0):
+            layers = [TransitionUp(self.in_planes, None if i == 3 else planes[i])]
+            self.in_planes = planes[i]
+            layers.append(PointTransformerBlock(planes[i], planes[i], share, nsample=self.nsamples[i]))
+            setattr(self, f"dec{i + 1}", nn.Sequential(*layers))
+        ctx_dim = text_feat_dim + time_emb_dim
+
+        def ctx(c):
+            return nn.Sequential(nn.Linear(c + ctx_dim, c), nn.BatchNorm1d(c), nn.ReLU(inplace=True), nn.Linear(c, c))
+        if v2:
+            self.ctx4, self.ctx3, self.ctx2 = ctx(planes[3]), ctx(planes[2]), ctx(planes[1])
+            self.self_attn_layers = nn.TransformerEncoder(
+                nn.TransformerEncoderLayer(d_model=planes[-1], nhead=8, dim_feedforward=1024, dropout=0.1, activation="relu", batch_first=True),
+                num_layers=1, enable_nested_tensor=False)
+        else:
+            self.ctx = ctx(planes[3])
+
+    @staticmethod
+    def _ctx(seq: nn.Sequential, x, context, batch: int):
+        """Linear -> BN(eval) -> ReLU -> Linear over [x | context of the sample] (cdm.py:236-243)."""
+        from .scene import _bn_fold
+        n = x.shape[0] // batch
+        cat = torch.cat((x, context.repeat_interleave(n, dim=0)), 1)
+        s, b = _bn_fold(seq[1])
+        h = ops.linear(cat, seq[0].weight, seq[0].bias * s + b, scale=s, act=ffi.ACT_RELU)
+        return ops.linear(h, seq[3].weight, seq[3].bias)
+
+    def _encoder_layer_relu(self, x):
+        """nn.TransformerEncoderLayer(post-LN, ReLU) over [B, G, 512] (V2 bottleneck, cdm.py:317-327)."""
+        l = self.self_attn_layers.layers[0]
+        B, G, d = x.shape
+        flat = x.reshape(B * G, d)
+        a = ops.mha(ops.linear(flat, l.self_attn.in_proj_weight, l.self_attn.in_proj_bias).view(B, G, 3 * d), None, l.self_attn.num_heads)
+        y = ops.layernorm(ops.linear(a.view(B * G, d), l.self_attn.out_proj.weight, l.self_attn.out_proj.bias, residual=flat), l.norm1.weight,
+                          l.norm1.bias, l.norm1.eps)
+        h = ops.linear(y, l.linear1.weight, l.linear1.bias, act=ffi.ACT_RELU)
+        return ops.layernorm(ops.linear(h, l.linear2.weight, l.linear2.bias, residual=y), l.norm2.weight, l.norm2.bias, l.norm2.eps).view(B, G, d)
+
+    def run(self, x, point_feat, language_feat, time_embedding, xyz):
+        """x [B,N,J], point_feat [B,N,F] | None, language_feat [B,Ft], time_embedding [B,Te], xyz [B,N,3] -> [B,N,64]."""
+        from . import pointops
+        B, N, _ = x.shape
+        if point_feat is not None:
+            x = torch.cat([x, point_feat], dim=-1)
+        context = torch.cat([language_feat, time_embedding], dim=-1)                       # [B, Ft + Te]
+        p0 = ffi.f32c(xyz).reshape(B * N, 3)
+        x0 = torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+        ps, xs, knns = [], [], []
+        for lvl in range(4):
+            enc = getattr(self, f"enc{lvl + 1}")
+            p0, x0 = enc[0].run(p0, x0, B)
+            n = p0.shape[0] // B
+            ki, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
+            for blk in list(enc)[1:]:
+                x0 = blk.run(p0, x0, ki)
+            ps.append(p0); xs.append(x0); knns.append(ki)
+        if self.v2:
+            x4 = self._encoder_layer_relu(xs[3].view(B, -1, xs[3].shape[-1])).reshape(xs[3].shape)
+            x4 = self._ctx(self.ctx4, x4, context, B)
+        else:
+            x4 = self._ctx(self.ctx, xs[3], context, B)
+        y = self.dec4[1].run(ps[3], self.dec4[0].run_head(x4, B), knns[3])
+        for lvl in (2, 1, 0):
+            dec = getattr(self, f"dec{lvl + 1}")
+            xl = xs[lvl]
+            if self.v2 and lvl in (2, 1):
+                xl = self._ctx(self.ctx3 if lvl == 2 else self.ctx2, xl, context, B)
+            y = dec[1].run(ps[lvl], dec[0].run_fuse(ps[lvl], xl, ps[lvl + 1], y, B), knns[lvl])
+        return y.view(B, N, -1)
+
+
 class ContactPerceiver(nn.Module):
     """Parameter container with the reference's names (cdm.py:88-153)."""
 
@@ -167,9 +258,11 @@ class CDM(TextEncoderMixin, nn.Module):
             self.arch_cfg, contact_model = cfg.arch_perceiver, ContactPerceiver
         elif self.arch == "MLP":
             self.arch_cfg, contact_model = cfg.arch_mlp, ContactMLP
+        elif self.arch in ("PointTrans", "PointTransV2"):
+            import functools
+            self.arch_cfg, contact_model = cfg.arch_pointtrans, functools.partial(ContactPointTrans, v2=self.arch == "PointTransV2")
         else:
-            raise NotImplementedError(f"arch={self.arch!r}: 'Perceiver' (every script) and 'MLP' (the config default) are built; "
-                                      "'PointTrans' / 'PointTransV2' are not (SURVEY.md section 8f-4)")
+            raise NotImplementedError(f"arch={self.arch!r}: one of 'MLP', 'Perceiver', 'PointTrans', 'PointTransV2' (cdm.py:449-462)")
         self.contact_model = contact_model(self.arch_cfg, contact_dim=self.contact_dim, point_feat_dim=self.point_feat_dim,
                                            text_feat_dim=self.text_feat_dim, time_emb_dim=self.time_emb_dim)
         self.contact_layer = nn.Linear(self.arch_cfg.last_dim, self.contact_dim, bias=True)
@@ -272,6 +365,8 @@ class CDM(TextEncoderMixin, nn.Module):
         """x [B, N, contact_dim], timesteps [B] -> predicted x_0 (same shape)."""
         if self.arch == "MLP":
             return self.forward_mlp(x, timesteps, **kwargs)
+        if self.arch in ("PointTrans", "PointTransV2"):
+            return self.forward_pointtrans(x, timesteps, **kwargs)
         if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
             return self.forward_train(x, timesteps, **kwargs)
         ffi.require_gpu(x)
@@ -326,6 +421,20 @@ class CDM(TextEncoderMixin, nn.Module):
         text = ffi.f32c(self.encode_text(kwargs).to(dev)).view(B, 1, -1)
         h = self.contact_model.run(x, self._point_features(x, kwargs), text, time_emb)
         return AG.linear(h, self.contact_layer.weight, self.contact_layer.bias)
+
+    def forward_pointtrans(self, x, timesteps, **kwargs):
+        """CDM.forward with ContactPointTrans / V2 (cdm.py:190-410,474-513); inference only."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the PointTrans archs are built for sampling only; call under torch.no_grad()")
+        ffi.require_gpu(x)
+        with torch.no_grad():
+            x = ffi.f32c(x)
+            dev = x.device
+            t_idx = timesteps.to(device=dev, dtype=torch.int64)
+            time_emb = self.timestep_embedder.table()[t_idx]                                   # [B, te]
+            text = ffi.f32c(self.encode_text(kwargs).to(dev))
+            h = self.contact_model.run(x, self._point_features(x, kwargs), text, time_emb, kwargs["c_pc_xyz"].to(x))
+            return ops.linear(h, self.contact_layer.weight, self.contact_layer.bias)
 
     # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
     def _mha_train(self, att: _MHA, xq, xkv, heads: int, drop, kind: str, residual):

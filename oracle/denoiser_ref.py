@@ -176,3 +176,59 @@ def cdm_mlp_forward(sd: SD, x, t, text_feat, pc_emb=None, *, time_emb_dim: int =
         scene = pf.mean(dim=1, keepdim=True).repeat(1, N, 1)
         h = mlp(pre + ".mlp_post", torch.cat([pf, scene], dim=-1))
     return _lin(sd, "contact_layer", h)
+
+
+def _ctx_mlp(sd, pre, x, context, batch):
+    """cdm.py:236-243: Linear -> BN (eval) -> ReLU -> Linear over [x | context of the sample]; x [(b n), c]."""
+    n = x.shape[0] // batch
+    h = torch.cat((x, context.repeat_interleave(n, dim=0)), 1)
+    h = F.relu(scene_ref._bn(sd, pre + ".1", _lin(sd, pre + ".0", h)))
+    return _lin(sd, pre + ".3", h)
+
+
+def encoder_layer_relu(sd: SD, pre: str, x: torch.Tensor, nhead: int):
+    """nn.TransformerEncoderLayer(batch_first, post-LN, ReLU) without mask (ContactPointTransV2 bottleneck)."""
+    B, T, d = x.shape
+    qkv = F.linear(x, sd[pre + ".self_attn.in_proj_weight"], sd[pre + ".self_attn.in_proj_bias"])
+    q, k, v = [z.view(B, T, nhead, d // nhead).transpose(1, 2) for z in qkv.split(d, dim=-1)]
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d // nhead), dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, T, d)
+    x = _ln(sd, pre + ".norm1", x + _lin(sd, pre + ".self_attn.out_proj", a))
+    return _ln(sd, pre + ".norm2", x + _lin(sd, pre + ".linear2", F.relu(_lin(sd, pre + ".linear1", x))))
+
+
+def cdm_pointtrans_forward(sd: SD, x, t, text_feat, c_pc_xyz, pc_emb=None, *, v2: bool = False, time_emb_dim: int = 128,
+                           blocks=(2, 2, 2, 2)):
+    """CDM.forward with ContactPointTrans / ContactPointTransV2 (cdm.py:190-410, 474-513), eval mode."""
+    sr = scene_ref
+    cm = "contact_model"
+    B, N, _ = x.shape
+    time_emb = timestep_embed(sd, "timestep_embedder", t, time_emb_dim)[:, 0, :]
+    context = torch.cat([text_feat.float(), time_emb], dim=-1)
+    feat = x if pc_emb is None else torch.cat([x, pc_emb], dim=-1)
+    stride, nsample = (1, 4, 4, 4), (8, 16, 16, 16)
+    o = torch.arange(1, B + 1, dtype=torch.int32) * N
+    p0 = c_pc_xyz.reshape(B * N, 3).contiguous()
+    x0 = torch.cat((p0, feat.reshape(B * N, -1)), 1)
+    ps, xs, os_, knn = [], [], [], []
+    for lvl in range(4):
+        e = f"{cm}.enc{lvl + 1}"
+        p0, x0, o, _ = sr.transition_down(sd, e + ".0", p0, x0, o, stride[lvl], nsample[lvl])
+        ki, _ = sr.po.knn_query(nsample[lvl], p0, p0, o, o)
+        for j in range(1, blocks[lvl]):
+            x0 = sr.point_transformer_block(sd, f"{e}.{j}", p0, x0, o, nsample[lvl], 8, ki)
+        ps.append(p0); xs.append(x0); os_.append(o); knn.append(ki)
+    if v2:
+        x4 = encoder_layer_relu(sd, cm + ".self_attn_layers.layers.0", xs[3].view(B, -1, xs[3].shape[-1]), 8).reshape(xs[3].shape)
+        x4 = _ctx_mlp(sd, cm + ".ctx4", x4, context, B)
+    else:
+        x4 = _ctx_mlp(sd, cm + ".ctx", xs[3], context, B)
+    y = sr.transition_up(sd, cm + ".dec4.0", ps[3], x4, os_[3])
+    y = sr.point_transformer_block(sd, cm + ".dec4.1", ps[3], y, os_[3], nsample[3], 8, knn[3])
+    for lvl in (2, 1, 0):
+        xl = xs[lvl]
+        if v2 and lvl in (2, 1):
+            xl = _ctx_mlp(sd, f"{cm}.ctx{lvl + 1}", xl, context, B)
+        y = sr.transition_up(sd, f"{cm}.dec{lvl + 1}.0", ps[lvl], xl, os_[lvl], ps[lvl + 1], y, os_[lvl + 1])
+        y = sr.point_transformer_block(sd, f"{cm}.dec{lvl + 1}.1", ps[lvl], y, os_[lvl], nsample[lvl], 8, knn[lvl])
+    return _lin(sd, "contact_layer", y.view(B, N, -1))

@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -179,8 +179,34 @@ def mlp_main():
         f.write("\n".join(f"{k} {tuple(cdm.state_dict()[k].shape)}" for k in keys) + "\n")
 
 
+def pointtrans_main():
+    """tests/golden/cdm_pointtrans{,v2}_N1024.npz: forward of the reference CDM with `arch: 'PointTrans'` / `'PointTransV2'`."""
+    from afm import synth
+    from oracle.make_goldens import cdm_cfg
+    base, _ = import_reference()
+    B, Nc = 2, 1024
+    cxyz = synth.scene_cloud(B, Nc, seed=16)
+    cx = synth.gaussian("cdm_pt_x", (B, Nc, 6))
+    tc = torch.tensor([499, 7])
+    for arch, tag in (("PointTrans", "cdm_pointtrans_N1024"), ("PointTransV2", "cdm_pointtransv2_N1024")):
+        mc = cdm_cfg(num_points=Nc)
+        mc.update(arch=arch, arch_pointtrans=dict(last_dim=64, num_points=Nc, blocks=[2, 2, 2, 2]))
+        cdm = base.create_model(to_attr(dict(model=mc)), device="cpu")
+        synth.fill_module_(cdm)
+        cdm.eval()
+        with torch.no_grad():
+            out = cdm(cx, tc, c_text=TEXTS, c_pc_xyz=cxyz)
+        sel = torch.arange(0, Nc, 4)
+        save(tag, t=tc, rows=sel, out_rows=out[:, sel], out_sum=out.double().sum(), out_abs_sum=out.double().abs().sum())
+        keys = sorted(k for k in cdm.state_dict().keys() if "text_model" not in k)
+        with open(os.path.join(GOLD, tag.replace("_N1024", "") + "_state_dict_keys.txt"), "w") as f:
+            f.write("\n".join(f"{k} {tuple(cdm.state_dict()[k].shape)}" for k in keys) + "\n")
+
+
 if __name__ == "__main__":
-    if "--mlp" in sys.argv:
+    if "--pointtrans" in sys.argv:
+        pointtrans_main()
+    elif "--mlp" in sys.argv:
         mlp_main()
     elif "--masks" in sys.argv:
         masks_main()

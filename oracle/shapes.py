@@ -150,6 +150,35 @@ def cdm_mlp(contact_dim=6, point_feat_dim=0, te=128, text_dim=512, dims=(512, 51
     return s
 
 
+def cdm_pointtrans(contact_dim=6, point_feat_dim=0, te=128, text_dim=512, blocks=(2, 2, 2, 2), v2=False, last_dim=64) -> Shapes:
+    """CDM with `arch: 'PointTrans'` / `'PointTransV2'` (cdm.py:190-410)."""
+    cm = "contact_model"
+    planes, stride = (64, 128, 256, 512), (1, 4, 4, 4)
+    s = timestep_embedder("timestep_embedder", te, te)
+    cin = contact_dim + point_feat_dim + 3
+    for l in range(4):
+        e = f"{cm}.enc{l + 1}"
+        s.update(transition_down(f"{e}.0", cin, planes[l], stride[l]))
+        cin = planes[l]
+        for j in range(1, blocks[l]):
+            s.update(pt_block(f"{e}.{j}", cin))
+    for l in (3, 2, 1, 0):
+        d = f"{cm}.dec{l + 1}"
+        s.update(transition_up(f"{d}.0", cin, None if l == 3 else planes[l]))
+        cin = planes[l]
+        s.update(pt_block(f"{d}.1", cin))
+
+    def ctx(pre, c):
+        return {**_lin(pre + ".0", c + text_dim + te, c), **_bn(pre + ".1", c), **_lin(pre + ".3", c, c)}
+    if v2:
+        s.update(ctx(cm + ".ctx4", planes[3])); s.update(ctx(cm + ".ctx3", planes[2])); s.update(ctx(cm + ".ctx2", planes[1]))
+        s.update(encoder_layer(cm + ".self_attn_layers.layers.0", planes[3], 1024))
+    else:
+        s.update(ctx(cm + ".ctx", planes[3]))
+    s.update(_lin("contact_layer", last_dim, contact_dim))
+    return s
+
+
 def weights(shapes: Shapes, seed=None):
     """Materialise name-keyed weights for a shape table."""
     import sys, os

@@ -100,3 +100,22 @@ def test_two_stage_adm_to_amdm_pipeline_vs_oracle():
     report("two-stage: ADM contact", out["contact"], c_ref, 1e-4)
     report("two-stage: glue", out["cond"], cond_ref, 1e-4)
     report("two-stage: AMDM motion", out["motion"], m_ref, 1e-3)
+
+
+@pytest.mark.parametrize("arch,tag", [("PointTrans", "cdm_pointtrans_N1024"), ("PointTransV2", "cdm_pointtransv2_N1024")])
+def test_pointtrans_archs_forward_vs_reference_golden(arch, tag):
+    """`model.arch=PointTrans` / `PointTransV2` (cdm.py:190-410): a Point Transformer U-Net over the contact map per step."""
+    from afm.config import load_config
+    from afm.base import create_model
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.scene_model.use_scene_model=False", f"model.arch={arch}",
+                                                           "task.dataset.num_points=1024", "model.text_model.max_length=20"])
+    model = create_model(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    gp, g = golden(tag), golden("cdm_forward_N256")
+    x, xyz = synth.gaussian("cdm_pt_x", (2, 1024, 6)).to(dev()), synth.scene_cloud(2, 1024, seed=16).to(dev())
+    with torch.no_grad():
+        out = model(x, gp["t"].to(dev()), c_text_feat=g["text_feat"].to(dev()), c_pc_xyz=xyz)
+    report(f"CDM {arch} forward vs reference", out[:, gp["rows"].to(dev())], gp["out_rows"], 5e-4)
+    s = out.double().abs().sum().item()
+    assert abs(s - gp["out_abs_sum"].item()) <= 1e-4 * gp["out_abs_sum"].item()

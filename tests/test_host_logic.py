@@ -124,10 +124,17 @@ def test_cdm_state_dict_keys_match_reference():
         k, shp = line.strip().split(" ", 1)
         want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
     assert have == want
-    for bad in (["model.arch=PointTrans"],):
-        with pytest.raises(NotImplementedError):                             # unbuilt variants fail loudly
-            base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver"] + bad),
-                              device="cpu")
+    for arch, listing in (("PointTrans", "cdm_pointtrans_state_dict_keys.txt"), ("PointTransV2", "cdm_pointtransv2_state_dict_keys.txt")):
+        m = base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.scene_model.use_scene_model=False",
+                                                                               f"model.arch={arch}", "task.dataset.num_points=1024"]), device="cpu")
+        have = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        want = {}
+        for line in open(os.path.join(GOLDEN, listing)):
+            k, shp = line.strip().split(" ", 1)
+            want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
+        assert have == want, (arch, set(have) ^ set(want))
+    with pytest.raises(NotImplementedError):                                 # unknown variants fail loudly
+        base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Nope"]), device="cpu")
 
 
 def test_product_path_refuses_cpu_tensors():
