@@ -24,7 +24,7 @@ import torch.nn as nn
 from . import autograd as AG
 from . import ffi, ops
 from .base import Model
-from .scene import SceneMapEncoder
+from .scene import SceneMapEncoder, SceneMapEncoderDecoder
 from .text import TextEncoderMixin, lang_feat_dim_type
 
 
@@ -94,19 +94,19 @@ class CMDM(TextEncoderMixin, nn.Module):
         self.latent_dim = cfg.latent_dim
         self.mask_motion = cfg.mask_motion
         self.arch = cfg.arch
-        if self.arch != "trans_enc":
-            raise NotImplementedError(f"arch={self.arch!r}: only 'trans_enc' is used by the reference's scripts "
-                                      "(trans_dec is out of the hot-path scope, SURVEY.md section 8f-4)")
+        if self.arch not in ("trans_enc", "trans_dec"):
+            raise NotImplementedError(f"arch={self.arch!r}: 'trans_enc' or 'trans_dec' (cmdm.py:65-113)")
         self.time_emb_dim = cfg.time_emb_dim
         self.timestep_embedder = TimestepEmbedder(self.latent_dim, self.time_emb_dim, max_len=1000)
 
         self.contact_type = cfg.contact_model.contact_type
         self.contact_dim = compute_repr_dimesion(self.contact_type)
         self.planes = list(cfg.contact_model.planes)
-        self.contact_adapter = nn.Linear(self.planes[-1], self.latent_dim, bias=True)
-        self.contact_encoder = SceneMapEncoder(point_feat_dim=self.contact_dim, planes=self.planes,
-                                               blocks=list(cfg.contact_model.blocks),
-                                               num_points=cfg.contact_model.num_points)
+        if self.arch == "trans_enc":
+            self.contact_adapter = nn.Linear(self.planes[-1], self.latent_dim, bias=True)
+        scene_module = SceneMapEncoder if self.arch == "trans_enc" else SceneMapEncoderDecoder
+        self.contact_encoder = scene_module(point_feat_dim=self.contact_dim, planes=self.planes, blocks=list(cfg.contact_model.blocks),
+                                            num_points=cfg.contact_model.num_points)
 
         self.text_model_name = cfg.text_model.version
         self.text_max_length = cfg.text_model.max_length
@@ -118,13 +118,25 @@ class CMDM(TextEncoderMixin, nn.Module):
         self.positional_encoder = PositionalEncoding(self.latent_dim, dropout=0.1, max_len=5000)
         self.num_layers = list(cfg.num_layers)
         self.num_heads = cfg.num_heads
-        # parameter container with torch's own key names (in_proj_weight, out_proj, linear1/2, norm1/2)
-        self.self_attn_layer = nn.TransformerEncoder(
-            nn.TransformerEncoderLayer(d_model=self.latent_dim, nhead=cfg.num_heads, dim_feedforward=cfg.dim_feedforward,
-                                       dropout=cfg.dropout, activation="gelu", batch_first=True),
-            enable_nested_tensor=False, num_layers=sum(self.num_layers))
+        # parameter containers with torch's own key names (in_proj_weight, out_proj, linear1/2, norm1/2/3)
+        enc_layer = lambda: nn.TransformerEncoderLayer(d_model=self.latent_dim, nhead=cfg.num_heads, dim_feedforward=cfg.dim_feedforward,
+                                                       dropout=cfg.dropout, activation="gelu", batch_first=True)
+        if self.arch == "trans_enc":
+            self.self_attn_layer = nn.TransformerEncoder(enc_layer(), enable_nested_tensor=False, num_layers=sum(self.num_layers))
+        else:                                               # trans_dec (cmdm.py:78-113): self-attention stacks interleaved with cross-attention
+            self.self_attn_layers, self.kv_mappling_layers, self.cross_attn_layers = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+            for i, n in enumerate(self.num_layers):
+                self.self_attn_layers.append(nn.TransformerEncoder(enc_layer(), num_layers=n, enable_nested_tensor=False))
+                if i != len(self.num_layers) - 1:
+                    self.kv_mappling_layers.append(nn.Sequential(nn.Linear(self.planes[-1 - i], self.latent_dim, bias=True),
+                                                                 nn.LayerNorm(self.latent_dim)))
+                    self.cross_attn_layers.append(nn.TransformerDecoderLayer(d_model=self.latent_dim, nhead=cfg.num_heads,
+                                                                             dim_feedforward=cfg.dim_feedforward, dropout=cfg.dropout,
+                                                                             activation="gelu", batch_first=True))
         self.motion_layer = nn.Linear(self.latent_dim, self.motion_dim, bias=True)
 
+        if self.arch == "trans_dec":
+            self.afm_native_loop = None      # the fused native sampling loop covers trans_enc; trans_dec samples step by step
         self.dropout_p = float(cfg.dropout)
         self._drop_calls = 0       # forward passes with dropout so far: every pass draws fresh masks
         self.hoist_conditions = True
@@ -204,6 +216,8 @@ class CMDM(TextEncoderMixin, nn.Module):
     def forward(self, x, timesteps, **kwargs):
         """x [B, L, motion_dim], timesteps [B] int64, kwargs = batch dict (x_mask, c_text | c_text_feat,
         c_pc_xyz, c_pc_contact, info_* ignored) -> predicted x_0, same shape as x."""
+        if self.arch == "trans_dec":
+            return self.forward_trans_dec(x, timesteps, **kwargs)
         if torch.is_grad_enabled() and (self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self.forward_train(x, timesteps, **kwargs)
         if any(k in kwargs for k in COND_SWITCHES):
@@ -228,6 +242,91 @@ class CMDM(TextEncoderMixin, nn.Module):
                                            out.data_ptr(), None, B, L, ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
                       "afm_cmdm_forward")
         return out
+
+    # ------------------------------------------------------------------ trans_dec variant (per-operator composition, inference)
+    def _enc_layer(self, x, layer, key_mask):
+        """Post-LN nn.TransformerEncoderLayer (GELU) on [B, T, d]."""
+        B, T, d = x.shape
+        flat = x.reshape(B * T, d)
+        a = ops.mha(ops.linear(flat, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias).view(B, T, 3 * d), key_mask, self.num_heads)
+        y = ops.layernorm(ops.linear(a.view(B * T, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, residual=flat),
+                          layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+        h = ops.linear(y, layer.linear1.weight, layer.linear1.bias, act=ffi.ACT_GELU)
+        return ops.layernorm(ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=y), layer.norm2.weight, layer.norm2.bias,
+                             layer.norm2.eps).view(B, T, d)
+
+    def _dec_layer(self, x, layer, key_mask, kv, mem_mask):
+        """Post-LN nn.TransformerDecoderLayer (GELU): self-attention, cross-attention over the memory (kv = its packed K | V
+        projections, step-invariant), feed-forward."""
+        B, T, d = x.shape
+        flat = x.reshape(B * T, d)
+        a = ops.mha(ops.linear(flat, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias).view(B, T, 3 * d), key_mask, self.num_heads)
+        y = ops.layernorm(ops.linear(a.view(B * T, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, residual=flat),
+                          layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+        ca = layer.multihead_attn
+        q = ops.linear(y, ca.in_proj_weight[:d], ca.in_proj_bias[:d]).view(B, T, d)
+        c = ops.mha_cross(q, kv, mem_mask, self.num_heads)
+        y = ops.layernorm(ops.linear(c.view(B * T, d), ca.out_proj.weight, ca.out_proj.bias, residual=y), layer.norm2.weight, layer.norm2.bias,
+                          layer.norm2.eps)
+        h = ops.linear(y, layer.linear1.weight, layer.linear1.bias, act=ffi.ACT_GELU)
+        return ops.layernorm(ops.linear(h, layer.linear2.weight, layer.linear2.bias, residual=y), layer.norm3.weight, layer.norm3.bias,
+                             layer.norm3.eps).view(B, T, d)
+
+    def _trans_dec_memories(self, kwargs):
+        """Step-invariant part of trans_dec: SceneMapEncoderDecoder features -> kv_mappling (Linear + LayerNorm) -> the packed
+        K | V projections of every cross-attention layer; cached per scene batch like the trans_enc condition tokens."""
+        tensors = [kwargs.get(k) for k in ("c_pc_xyz", "c_pc_contact", "c_pc_erase")]
+        key = (tuple((t.data_ptr(), t._version, tuple(t.shape)) if isinstance(t, torch.Tensor) else None for t in tensors), _param_version(self))
+        if self.hoist_conditions and self._cond_cache is not None and self._cond_cache[0] == key:
+            return self._cond_cache[1]
+        feats = self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])                     # [x4, x3, x2, x1]
+        d, out = self.latent_dim, []
+        for i, layer in enumerate(self.cross_attn_layers):
+            mem = feats[i]
+            if "c_pc_erase" in kwargs:
+                mem = mem * (1.0 - kwargs["c_pc_erase"].to(mem.device).float().reshape(-1, 1, 1))
+            B, n, c = mem.shape
+            km = self.kv_mappling_layers[i]
+            m = ops.layernorm(ops.linear(mem.reshape(B * n, c), km[0].weight, km[0].bias), km[1].weight, km[1].bias, km[1].eps)
+            ca = layer.multihead_attn
+            out.append(ops.linear(m, ca.in_proj_weight[d:], ca.in_proj_bias[d:]).view(B, n, 2 * d))
+        self._cond_cache = (key, out) if self.hoist_conditions else None
+        return out
+
+    def forward_trans_dec(self, x, timesteps, **kwargs):
+        """CMDM.forward, `trans_dec` branch (cmdm.py:171-191): tokens [time | text | motion]; five self-attention stacks
+        interleaved with four decoder layers whose memories are the multi-scale scene features (N/64 ... N points)."""
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("trans_dec is built for sampling only; call under torch.no_grad() / model.eval()")
+        ffi.require_gpu(x)
+        with torch.no_grad():
+            x = ffi.f32c(x)
+            B, L, _ = x.shape
+            d, dev, T = self.latent_dim, x.device, 2 + L
+            kvs = self._trans_dec_memories(kwargs)
+            pe = self.positional_encoder.pe[:, 0, :]
+            tok = torch.empty(B, T, d, device=dev, dtype=torch.float32)
+            flat = tok.view(B * T, d)
+            t_idx = timesteps.to(device=dev, dtype=torch.int64)
+            tok[:, 0, :] = self.timestep_embedder.table()[t_idx] + pe[0]
+            text = self.encode_text(kwargs)
+            if "c_text_erase" in kwargs:
+                text = text * (1.0 - kwargs["c_text_erase"].to(dev).float().reshape(B, 1))
+            ops.linear(text, self.language_adapter.weight, self.language_adapter.bias, rowtab=pe[1:2], out=flat, c_map=(1, T, 1))
+            ops.linear(x.view(B * L, -1), self.motion_adapter.weight, self.motion_adapter.bias, rowtab=pe[2:2 + L], out=flat, c_map=(L, T, 2))
+            key_mask = None
+            if self.mask_motion:
+                tm = kwargs["c_text_mask"].to(dev).bool().reshape(B, 1) if "c_text_mask" in kwargs else torch.zeros(B, 1, dtype=torch.bool, device=dev)
+                key_mask = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=dev), tm, kwargs["x_mask"].to(dev).bool().reshape(B, L)], dim=1)
+            for i, stack in enumerate(self.self_attn_layers):
+                for layer in stack.layers:
+                    tok = self._enc_layer(tok, layer, key_mask)
+                if i != len(self.self_attn_layers) - 1:
+                    mem_mask = None
+                    if "c_pc_mask" in kwargs:
+                        mem_mask = kwargs["c_pc_mask"].to(dev).bool().reshape(B, 1).repeat(1, kvs[i].shape[1])
+                    tok = self._dec_layer(tok, self.cross_attn_layers[i], key_mask, kvs[i], mem_mask)
+            return ops.linear(tok.view(B * T, d), self.motion_layer.weight, self.motion_layer.bias, a_map=(L, T, 2), rows=B * L).view(B, L, self.motion_dim)
 
     # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
     def forward_train(self, x, timesteps, **kwargs):

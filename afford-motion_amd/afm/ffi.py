@@ -119,6 +119,7 @@ EXPORTS = {
     "afm_version": (C.c_int, []),
     "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
+    "afm_mha_cross_fwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, C.c_void_p]),
     "afm_layernorm_rows": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, i32, i32, i32, C.c_void_p]),
     "afm_ddpm_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),

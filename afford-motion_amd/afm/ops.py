@@ -79,6 +79,24 @@ def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torc
     return out
 
 
+def mha_cross(q: torch.Tensor, kv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
+    """q [B, Tq, d], kv [B, Tk, 2*d] (packed k | v), key_mask [B, Tk] (True = ignore) -> [B, Tq, d]."""
+    lib = ffi.load()
+    ffi.require_gpu(q, kv)
+    q, kv = ffi.f32c(q), ffi.f32c(kv)
+    B, Tq, d = q.shape
+    Tk = kv.shape[1]
+    assert kv.shape[2] == 2 * d
+    out = torch.empty(B, Tq, d, device=q.device, dtype=torch.float32)
+    km = None
+    if key_mask is not None:
+        km = key_mask.to(torch.uint8).contiguous()
+        assert km.shape == (B, Tk)
+    ffi.check(lib.afm_mha_cross_fwd(q.data_ptr(), kv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, Tq, Tk, heads, d // heads, ffi.stream_of(q)),
+              "afm_mha_cross_fwd")
+    return out
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = ffi.load()

@@ -243,6 +243,59 @@ class TransitionUp(nn.Module):
         return pointops.interpolate(p2, p1, b, batch, n2, n1, base=a)
 
 
+class SceneMapEncoderDecoder(nn.Module):
+    """Multi-scale contact encoder of the CMDM `trans_dec` variant (reference models/modules.py:55-122): the SceneMapEncoder
+    levels followed by an FPN-style decoder; returns the four level features [x4, x3, x2, x1] as [B, n_l, planes_l]
+    (n_l = N/64, N/16, N/4, N), which become the memories of the cross-attention layers."""
+
+    def __init__(self, point_feat_dim: int, planes: List, blocks: List, num_points: int = 8192) -> None:
+        super().__init__()
+        self.num_points = num_points
+        self.c = point_feat_dim + 3
+        self.in_planes, share = self.c, 8
+        self.strides, self.nsamples = [1, 4, 4, 4], [8, 16, 16, 16]
+        for i in range(4):
+            layers = [TransitionDown(self.in_planes, planes[i], self.strides[i], self.nsamples[i])]
+            self.in_planes = planes[i]
+            layers += [PointTransformerBlock(planes[i], planes[i], share, nsample=self.nsamples[i]) for _ in range(1, blocks[i])]
+            setattr(self, f"enc{i + 1}", nn.Sequential(*layers))
+        for i in (3, 2, 1, 0):
+            layers = [TransitionUp(self.in_planes, None if i == 3 else planes[i])]
+            self.in_planes = planes[i]
+            layers.append(PointTransformerBlock(planes[i], planes[i], share, nsample=self.nsamples[i]))
+            setattr(self, f"dec{i + 1}", nn.Sequential(*layers))
+
+    @property
+    def num_groups(self):
+        return self.num_points // 64
+
+    def forward(self, p: torch.Tensor, x: torch.Tensor):
+        ffi.require_gpu(p, x)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            raise NotImplementedError("SceneMapEncoderDecoder is built for sampling only; call under torch.no_grad()")
+        with torch.no_grad():
+            B, N = p.shape[0], p.shape[1]
+            p0 = ffi.f32c(p).reshape(B * N, 3)
+            x0 = p0 if self.c == 3 else torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+            ps, xs, knns = [], [], []
+            for lvl in range(4):
+                enc = getattr(self, f"enc{lvl + 1}")
+                p0, x0 = enc[0].run(p0, x0, B)
+                n = p0.shape[0] // B
+                ki, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
+                for blk in list(enc)[1:]:
+                    x0 = blk.run(p0, x0, ki)
+                ps.append(p0); xs.append(x0); knns.append(ki)
+            outs = [None] * 4
+            y = self.dec4[1].run(ps[3], self.dec4[0].run_head(xs[3], B), knns[3])
+            outs[3] = y
+            for lvl in (2, 1, 0):
+                dec = getattr(self, f"dec{lvl + 1}")
+                y = dec[1].run(ps[lvl], dec[0].run_fuse(ps[lvl], xs[lvl], ps[lvl + 1], y, B), knns[lvl])
+                outs[lvl] = y
+            return [outs[l].view(B, -1, outs[l].shape[-1]) for l in (3, 2, 1, 0)]
+
+
 class PointTransformerSeg(nn.Module):
     """Frozen scene backbone of the HUMANISE / novel ADM (reference pointtransformer.py:126-213,
     `pointtransformer_seg_repro`: blocks [2,3,4,6,3]): (xyz [B,N,3], colour [B,N,c-3]) -> per-point features [B,N,32].

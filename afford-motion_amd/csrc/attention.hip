@@ -26,9 +26,12 @@ constexpr int MAX_WAVES = 12;      // 3 waves per SIMD -> 168 VGPRs each, no spi
 // TRAIN: also writes lse[b,h,q] = log-sum-exp of the scaled, masked logits (saved for afm_mha_bwd) and applies
 // attention-probability dropout to the P used in P V (the softmax normaliser uses the undropped P, as in torch).
 template <int NST, bool TRAIN>
-__global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
-                                                       float* __restrict__ out, int T, int H, float scale,
+__global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
+                                                       const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
+                                                       float* __restrict__ out, int Tq, int T, int H, float scale,
                                                        float* __restrict__ lse, float drop_p, uint64_t drop_seed, uint32_t drop_id) {
+    // Tq queries (rows of qp_, stride ldq) attend over T keys / values (rows of kp_ / vp_, stride ldkv): self-attention passes the
+    // packed in_proj output three times (q | k | v, ld = 3D, Tq == T), cross-attention a [B,Tq,D] query and a packed [B,T,2D] memory.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                               // [2][KB][LDKK]
     float* Vs = smem + 2 * KB * LDKK;               // [2][KB][DH]
@@ -38,9 +41,11 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
-    const int D = H * DH, ld = 3 * D;
-    const int nkb = (T + KB - 1) / KB, nqb = nkb;
-    const float* base = qkv + (int64_t)b * T * ld + h * DH;
+    const int D = H * DH;
+    const int nkb = (T + KB - 1) / KB, nqb = (Tq + 31) / 32;
+    const float* qbase = qp_ + (int64_t)b * Tq * ldq + h * DH;
+    const float* kbase = kp_ + (int64_t)b * T * ldkv + h * DH;
+    const float* vbase = vp_ + (int64_t)b * T * ldkv + h * DH;
     const float NEG_INF = -INFINITY;
 
     for (int i = tid; i < nkb; i += blockDim.x) blk_valid[i] = 0;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
             if (e < 1024) {
                 const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
                 const int key = kb * KB + row;
-                if (key < T) v = *reinterpret_cast<const float4*>(base + (int64_t)key * ld + (1 + isv) * D + c4 * 4);
+                if (key < T) v = *reinterpret_cast<const float4*>((isv ? vbase : kbase) + (int64_t)key * ldkv + c4 * 4);
             }
             stage[i] = v;
         }
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
         // Q fragment: query row (clamped), head dims 32*hh .. 32*hh+31, pre-scaled
         float q[32];
         {
-            const int qrow = min(qb * 32 + r32, T - 1);
-            const float* qp = base + (int64_t)(active ? qrow : 0) * ld + hh * 32;
+            const int qrow = min(qb * 32 + r32, Tq - 1);
+            const float* qp = qbase + (int64_t)(active ? qrow : 0) * ldq + hh * 32;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float4 v = *reinterpret_cast<const float4*>(qp + i * 4);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
                 // ---- O^T += V^T P^T : step r multiplies key (r&3) + 8*(r>>2) + 4*hh
                 if (TRAIN && drop_p > 0.0f) {
                     const DropKey dk(drop_p, drop_seed, drop_id);
-                    const uint32_t row_ix = blockIdx.x * T + min(qb * 32 + r32, T - 1), col0 = kb * KB + 4 * hh;
+                    const uint32_t row_ix = blockIdx.x * Tq + min(qb * 32 + r32, Tq - 1), col0 = kb * KB + 4 * hh;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] *= dk(row_ix, col0 + (r & 3) + 8 * (r >> 2));
                 }
@@ -164,10 +169,10 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
 
         if (active) {
             const int qrow = qb * 32 + r32;
-            if (qrow < T) {
-                if (TRAIN && hh == 0) lse[(int64_t)blockIdx.x * T + qrow] = m_run + __logf(l_run);
+            if (qrow < Tq) {
+                if (TRAIN && hh == 0) lse[(int64_t)blockIdx.x * Tq + qrow] = m_run + __logf(l_run);
                 const float inv = 1.0f / l_run;
-                float* op = out + ((int64_t)b * T + qrow) * D + h * DH + 4 * hh;
+                float* op = out + ((int64_t)b * Tq + qrow) * D + h * DH + 4 * hh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     *reinterpret_cast<float4*>(op + 8 * g) =
@@ -180,21 +185,33 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
     }
 }
 
-int mha_fwd_launch(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t T, int32_t H, int32_t dh,
-                          float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, void* stream) {
+int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, float* lse, int32_t B,
+                   int32_t Tq, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, void* stream) {
     if (dh != DH) return AFM_E_UNSUPPORTED;
     if (B == 0) return 0;                                     // empty batch (pointers may be null)
-    if (!qkv || !out || B < 0 || T <= 0 || H <= 0) return AFM_E_BADARG;
-    if ((((uintptr_t)qkv) & 15) || (((uintptr_t)out) & 15)) return AFM_E_BADARG;
+    if (!q || !k || !v || !out || B < 0 || T <= 0 || Tq <= 0 || H <= 0) return AFM_E_BADARG;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return AFM_E_BADARG;
     if (train && (!lse || drop_p < 0.0f || drop_p >= 1.0f)) return AFM_E_BADARG;
-    const int nqb = (T + 31) / 32;
+    const int nqb = (Tq + 31) / 32, nkb = (T + 31) / 32;
     int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
-    const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nqb * KB) * sizeof(float) + (size_t)nqb * sizeof(int);
-    if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nkb * KB) * sizeof(float) + (size_t)nkb * sizeof(int);
+    if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~30000 keys
+    if (lds > 64 * 1024) {                                     // long memories (cross-attention over N = 8192 points): opt in once
+        static bool attr_set = false;
+        if (!attr_set) {
+            const void* fns[4] = {(const void*)mha_fwd_kernel<2, false>, (const void*)mha_fwd_kernel<4, false>, (const void*)mha_fwd_kernel<2, true>,
+                                  (const void*)mha_fwd_kernel<4, true>};
+            for (int i = 0; i < 4; ++i) {
+                hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+            }
+            attr_set = true;
+        }
+    }
     const float scale = 1.0f / sqrtf((float)dh);
     hipStream_t s = (hipStream_t)stream;
-    AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)T * T * dh, s);
-#define AFM_MHA(NST, TR) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR>), dim3(B * H), dim3(nw * 64), lds, s, qkv, key_mask, out, T, H, scale, lse, drop_p, drop_seed, drop_id)
+    AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
+#define AFM_MHA(NST, TR) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR>), dim3(B * H), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id)
     if (train) { if (nw >= 8) AFM_MHA(2, true); else AFM_MHA(4, true); }
     else { if (nw >= 8) AFM_MHA(2, false); else AFM_MHA(4, false); }
 #undef AFM_MHA
@@ -206,10 +223,20 @@ int mha_fwd_launch(const float* qkv, const uint8_t* key_mask, float* out, float*
 
 extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
                            int32_t dh, void* stream) {
-    return mha_fwd_launch(qkv, key_mask, out, nullptr, B, T, H, dh, 0.0f, 0, 0, false, stream);
+    const int D = H * dh;
+    return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, nullptr, B, T, T, H, dh, 0.0f, 0, 0, false,
+                          stream);
 }
 
 extern "C" int afm_mha_fwd_train(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t T, int32_t H,
                                  int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream) {
-    return mha_fwd_launch(qkv, key_mask, out, lse, B, T, H, dh, drop_p, drop_seed, drop_id, true, stream);
+    const int D = H * dh;
+    return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, lse, B, T, T, H, dh, drop_p, drop_seed,
+                          drop_id, true, stream);
+}
+
+extern "C" int afm_mha_cross_fwd(const float* q, const float* kv, const uint8_t* key_mask, float* out, int32_t B, int32_t Tq, int32_t Tk, int32_t H,
+                                 int32_t dh, void* stream) {
+    const int D = H * dh;
+    return mha_fwd_launch(q, D, kv, kv ? kv + D : nullptr, 2 * D, key_mask, out, nullptr, B, Tq, Tk, H, dh, 0.0f, 0, 0, false, stream);
 }

@@ -97,6 +97,11 @@ int afm_linear(const afm_linear_args* args, void* stream);
 int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out,
                 int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
 
+/* Cross-attention core of nn.TransformerDecoderLayer (CMDM `trans_dec`, cmdm.py:78-113,171-191): Tq queries q [B*Tq, H*dh] over a
+ * packed memory kv [B*Tk, 2*H*dh] (k | v), key_mask [B,Tk] or NULL.  Same kernel as afm_mha_fwd (dh = 64). */
+int afm_mha_cross_fwd(const float* q, const float* kv, const uint8_t* key_mask, float* out,
+                      int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, void* stream);
+
 /* afm_layernorm: y = LN(x) * gamma + beta over the last dim (eps 1e-5).  Replaces nn.LayerNorm
  * (norm1 / norm2 of the encoder layer, modules.py:399-400,459,653).  In-place allowed. */
 int afm_layernorm(const float* x, const float* gamma, const float* beta, float* y,

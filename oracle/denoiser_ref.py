@@ -232,3 +232,48 @@ def cdm_pointtrans_forward(sd: SD, x, t, text_feat, c_pc_xyz, pc_emb=None, *, v2
         y = sr.transition_up(sd, f"{cm}.dec{lvl + 1}.0", ps[lvl], xl, os_[lvl], ps[lvl + 1], y, os_[lvl + 1])
         y = sr.point_transformer_block(sd, f"{cm}.dec{lvl + 1}.1", ps[lvl], y, os_[lvl], nsample[lvl], 8, knn[lvl])
     return _lin(sd, "contact_layer", y.view(B, N, -1))
+
+
+def _attn(q, k, v, nhead, key_mask=None):
+    B, Tq, d = q.shape
+    sp = lambda z: z.view(B, z.shape[1], nhead, d // nhead).transpose(1, 2)
+    s = sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(d // nhead)
+    if key_mask is not None:
+        s = s.masked_fill(key_mask[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, dim=-1) @ sp(v)).transpose(1, 2).reshape(B, Tq, d)
+
+
+def decoder_layer(sd: SD, pre: str, x, mem, tgt_mask, mem_mask, nhead: int):
+    """nn.TransformerDecoderLayer(batch_first, post-LN, exact-erf GELU): self-attention, cross-attention over `mem`, FFN."""
+    d = x.shape[-1]
+    qkv = F.linear(x, sd[pre + ".self_attn.in_proj_weight"], sd[pre + ".self_attn.in_proj_bias"])
+    q, k, v = qkv.split(d, dim=-1)
+    x = _ln(sd, pre + ".norm1", x + _lin(sd, pre + ".self_attn.out_proj", _attn(q, k, v, nhead, tgt_mask)))
+    W, bq = sd[pre + ".multihead_attn.in_proj_weight"], sd[pre + ".multihead_attn.in_proj_bias"]
+    q = F.linear(x, W[:d], bq[:d])
+    k, v = F.linear(mem, W[d:2 * d], bq[d:2 * d]), F.linear(mem, W[2 * d:], bq[2 * d:])
+    x = _ln(sd, pre + ".norm2", x + _lin(sd, pre + ".multihead_attn.out_proj", _attn(q, k, v, nhead, mem_mask)))
+    return _ln(sd, pre + ".norm3", x + _lin(sd, pre + ".linear2", F.gelu(_lin(sd, pre + ".linear1", x))))
+
+
+def cmdm_trans_dec_forward(sd: SD, x, t, text_feat, c_pc_xyz, c_pc_contact, x_mask=None, *, time_emb_dim: int = 512, nhead: int = 8,
+                           num_layers=(1, 1, 1, 1, 1), blocks=(2, 2, 2, 2)):
+    """CMDM.forward, `trans_dec` branch (cmdm.py:118-133,171-195)."""
+    B, L, _ = x.shape
+    d = sd["motion_adapter.weight"].shape[0]
+    time_emb = timestep_embed(sd, "timestep_embedder", t, time_emb_dim)
+    text_emb = _lin(sd, "language_adapter", text_feat.unsqueeze(1).float())
+    cont = scene_ref.scene_map_encoder_decoder(sd, "contact_encoder", c_pc_xyz, c_pc_contact, blocks=blocks)
+    seq = torch.cat([time_emb, text_emb, _lin(sd, "motion_adapter", x)], dim=1)
+    T = seq.shape[1]
+    seq = seq + sinusoid_table(5000, d)[:T].unsqueeze(0)
+    if x_mask is None:
+        x_mask = torch.zeros(B, L, dtype=torch.bool)
+    mask = torch.cat([torch.zeros(B, 2, dtype=torch.bool), x_mask], dim=1)
+    for i, n in enumerate(num_layers):
+        for j in range(n):
+            seq = encoder_layer(sd, f"self_attn_layers.{i}.layers.{j}", seq, mask, nhead)
+        if i != len(num_layers) - 1:
+            mem = _ln(sd, f"kv_mappling_layers.{i}.1", _lin(sd, f"kv_mappling_layers.{i}.0", cont[i]))
+            seq = decoder_layer(sd, f"cross_attn_layers.{i}", seq, mem, mask, None, nhead)
+    return _lin(sd, "motion_layer", seq[:, 2:, :])

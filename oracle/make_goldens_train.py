@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans | --trans_dec]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -203,8 +203,29 @@ def pointtrans_main():
             f.write("\n".join(f"{k} {tuple(cdm.state_dict()[k].shape)}" for k in keys) + "\n")
 
 
+def trans_dec_main():
+    """tests/golden/cmdm_trans_dec_N1024_L16.npz: CMDM.forward of the reference with `arch: 'trans_dec'`."""
+    from afm import synth
+    base, _ = import_reference()
+    g = np.load(os.path.join(GOLD, "cmdm_forward_N1024_L16.npz"))
+    xyz, con, x_mask = torch.from_numpy(g["xyz"]), torch.from_numpy(g["contact"]), torch.from_numpy(g["x_mask"])
+    mc = cmdm_cfg(num_points=xyz.shape[1])
+    mc["arch"] = "trans_dec"
+    model = base.create_model(to_attr(dict(model=mc)), device="cpu")
+    synth.fill_module_(model)
+    model.eval()
+    with torch.no_grad():
+        out = model(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), c_text=TEXTS, c_pc_xyz=xyz, c_pc_contact=con, x_mask=x_mask)
+    save("cmdm_trans_dec_N1024_L16", out=out)
+    keys = sorted(k for k in model.state_dict().keys() if "text_model" not in k)
+    with open(os.path.join(GOLD, "cmdm_trans_dec_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(f"{k} {tuple(model.state_dict()[k].shape)}" for k in keys) + "\n")
+
+
 if __name__ == "__main__":
-    if "--pointtrans" in sys.argv:
+    if "--trans_dec" in sys.argv:
+        trans_dec_main()
+    elif "--pointtrans" in sys.argv:
         pointtrans_main()
     elif "--mlp" in sys.argv:
         mlp_main()

@@ -203,3 +203,31 @@ def point_transformer_seg(sd: SD, pre: str, p: torch.Tensor, x: torch.Tensor, bl
         y = transition_up(sd, d + ".0", ps[lvl], xs[lvl], os_[lvl], ps[lvl + 1], y, os_[lvl + 1])
         y = point_transformer_block(sd, d + ".1", ps[lvl], y, os_[lvl], nsample[lvl], 8, knn[lvl])
     return y.view(B, N, -1)
+
+
+def scene_map_encoder_decoder(sd: SD, pre: str, p: torch.Tensor, x: torch.Tensor, blocks=(2, 2, 2, 2), stride=(1, 4, 4, 4),
+                              nsample=(8, 16, 16, 16)):
+    """modules.py:55-122: SceneMapEncoder levels + FPN decoder; returns [x4, x3, x2, x1] as [B, n_l, c_l]."""
+    B, N = p.shape[:2]
+    P = lambda n: f"{pre}.{n}" if pre else n
+    o = torch.arange(1, B + 1, dtype=torch.int32) * N
+    p0 = p.reshape(B * N, 3).contiguous()
+    x0 = torch.cat((p0, x.reshape(B * N, -1)), 1)
+    ps, xs, os_, knn = [], [], [], []
+    for lvl in range(4):
+        e = P(f"enc{lvl + 1}")
+        p0, x0, o, _ = transition_down(sd, e + ".0", p0, x0, o, stride[lvl], nsample[lvl])
+        ki, _ = po.knn_query(nsample[lvl], p0, p0, o, o)
+        for j in range(1, blocks[lvl]):
+            x0 = point_transformer_block(sd, f"{e}.{j}", p0, x0, o, nsample[lvl], 8, ki)
+        ps.append(p0); xs.append(x0); os_.append(o); knn.append(ki)
+    outs = [None] * 4
+    y = transition_up(sd, P("dec4.0"), ps[3], xs[3], os_[3])
+    y = point_transformer_block(sd, P("dec4.1"), ps[3], y, os_[3], nsample[3], 8, knn[3])
+    outs[3] = y
+    for lvl in (2, 1, 0):
+        d = P(f"dec{lvl + 1}")
+        y = transition_up(sd, d + ".0", ps[lvl], xs[lvl], os_[lvl], ps[lvl + 1], y, os_[lvl + 1])
+        y = point_transformer_block(sd, d + ".1", ps[lvl], y, os_[lvl], nsample[lvl], 8, knn[lvl])
+        outs[lvl] = y
+    return [outs[l].view(B, -1, outs[l].shape[-1]) for l in (3, 2, 1, 0)]

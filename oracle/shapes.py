@@ -108,6 +108,37 @@ def cmdm(input_feats=263, d=512, te=512, ff=1024, layers=5, text_dim=512, contac
     return s
 
 
+def scene_map_encoder_decoder(pre, cin=9, planes=(32, 64, 128, 256), blocks=(2, 2, 2, 2)) -> Shapes:
+    s = scene_map_encoder(pre, cin, planes, blocks)
+    c = planes[3]
+    for l in (3, 2, 1, 0):
+        d = _p(pre, f"dec{l + 1}")
+        s.update(transition_up(f"{d}.0", c, None if l == 3 else planes[l]))
+        c = planes[l]
+        s.update(pt_block(f"{d}.1", c))
+    return s
+
+
+def decoder_layer(pre, d=512, ff=1024) -> Shapes:
+    return {**encoder_layer(pre, d, ff), _p(pre, "multihead_attn.in_proj_weight"): (3 * d, d), _p(pre, "multihead_attn.in_proj_bias"): (3 * d,),
+            **_lin(_p(pre, "multihead_attn.out_proj"), d, d), **_ln(_p(pre, "norm3"), d)}
+
+
+def cmdm_trans_dec(input_feats=263, d=512, te=512, ff=1024, num_layers=(1, 1, 1, 1, 1), text_dim=512, contact_dim=6,
+                   planes=(32, 64, 128, 256), blocks=(2, 2, 2, 2)) -> Shapes:
+    s = timestep_embedder("timestep_embedder", d, te)
+    s.update(scene_map_encoder_decoder("contact_encoder", contact_dim + 3, planes, blocks))
+    s.update(_lin("language_adapter", text_dim, d)); s.update(_lin("motion_adapter", input_feats, d))
+    for i, n in enumerate(num_layers):
+        for j in range(n):
+            s.update(encoder_layer(f"self_attn_layers.{i}.layers.{j}", d, ff))
+        if i != len(num_layers) - 1:
+            s.update(_lin(f"kv_mappling_layers.{i}.0", planes[-1 - i], d)); s.update(_ln(f"kv_mappling_layers.{i}.1", d))
+            s.update(decoder_layer(f"cross_attn_layers.{i}", d, ff))
+    s.update(_lin("motion_layer", d, input_feats))
+    return s
+
+
 def _mha(pre, cq, ckv, cqk) -> Shapes:
     return {**_lin(pre + ".q_proj", cq, cqk), **_lin(pre + ".k_proj", ckv, cqk),
             **_lin(pre + ".v_proj", ckv, cqk), **_lin(pre + ".o_proj", cqk, cq)}

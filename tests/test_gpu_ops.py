@@ -163,8 +163,8 @@ def test_empty_and_degenerate_inputs():
     assert ops.layernorm(torch.zeros(0, 512, device=d), torch.ones(512, device=d), torch.zeros(512, device=d)).shape == (0, 512)
     with pytest.raises(ffi.AfmError):                      # head dim other than 64 is unsupported, loudly
         ops.mha(torch.zeros(1, 8, 3 * 256, device=d), None, 8)
-    with pytest.raises(ffi.AfmError):                      # LayerNorm dim must be a multiple of 4
-        ops.layernorm(torch.zeros(2, 6, device=d), torch.ones(6, device=d), torch.zeros(6, device=d))
+    ln6 = ops.layernorm(synth.gaussian("deg_ln", (2, 6)).to(d), torch.ones(6, device=d), torch.zeros(6, device=d))   # any width is supported
+    report("LayerNorm dim 6", ln6, torch.nn.functional.layer_norm(synth.gaussian("deg_ln", (2, 6)), (6,)), 1e-5)
     with pytest.raises(ffi.AfmError):                      # CPU tensors never reach a kernel
         ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
     # a single token / single key attention is the identity on V

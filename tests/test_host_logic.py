@@ -97,6 +97,17 @@ def test_cmdm_state_dict_keys_match_reference():
     assert sum(p.numel() for p in model.parameters()) == 12204111
 
 
+def test_cmdm_trans_dec_state_dict_keys_match_reference():
+    model = base.create_model(load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263",
+                                                                                       "model.arch=trans_dec"]), device="cpu")
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    want = {}
+    for line in open(os.path.join(GOLDEN, "cmdm_trans_dec_state_dict_keys.txt")):
+        k, shp = line.strip().split(" ", 1)
+        want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
+    assert have == want, set(have) ^ set(want)
+
+
 def test_cdm_state_dict_keys_match_reference():
     cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.scene_model.use_scene_model=False",
                                                            "model.input_feats=6"])
