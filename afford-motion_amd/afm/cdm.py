@@ -269,6 +269,10 @@ class CDM(TextEncoderMixin, nn.Module):
         self._pack = None
         self._text_cache = None
         self._ws = {}
+        import os
+        self.overlap_streams = os.environ.get("AFM_CDM_OVERLAP", "1") != "0"
+        self.sub_batches = int(os.environ.get("AFM_CDM_SUBBATCH", "1"))     # >1 costs more host time per step than it hides (measured)
+        self._streams = []
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
@@ -378,17 +382,40 @@ class CDM(TextEncoderMixin, nn.Module):
             feat = self._features(x, kwargs)
             tq0, tu, tcu = self._text_latent(w, kwargs, x.device)
             t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
-            key = (B, N, str(x.device))
-            if key not in self._ws:
-                nbytes = lib.afm_cdm_workspace_bytes(C.byref(w), B, N)
-                if nbytes < 0:
-                    ffi.check(int(nbytes), "afm_cdm_workspace_bytes")
-                self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=x.device)}
-            ws = self._ws[key]
             out = torch.empty_like(x)
-            ffi.check(lib.afm_cdm_forward(C.byref(w), feat.data_ptr(), x.data_ptr(), t.data_ptr(), tq0.data_ptr(), tu.data_ptr(),
-                                          tcu.data_ptr(), out.data_ptr(), None, B, N, ws.data_ptr(), ws.numel(), ffi.stream_of(x)),
-                      "afm_cdm_forward")
+            # Two levels of concurrency hide the per-sample latent chain (one workgroup per sample, ~0.5 ms serial): inside a
+            # call the decoder-adapter GEMM runs on a side stream underneath it (AFM_CDM_OVERLAP=0 disables), and the batch is
+            # can be split into sub-batches on their own streams (AFM_CDM_SUBBATCH=n; off by default: driven from Python it costs
+            # more host time per step than it hides).  Results are identical: samples are independent.
+            nsub = max(1, min(self.sub_batches, B))
+            bounds = [(B * i // nsub, B * (i + 1) // nsub) for i in range(nsub)]
+            cur = torch.cuda.current_stream(x.device)
+            while len(self._streams) < 2 * nsub:
+                self._streams.append(torch.cuda.Stream(device=x.device))
+            fork = None
+            if nsub > 1:
+                fork = torch.cuda.Event()
+                fork.record(cur)
+            for i, (lo, hi) in enumerate(bounds):
+                n = hi - lo
+                key = (n, N, i, str(x.device))
+                if key not in self._ws:
+                    nbytes = lib.afm_cdm_workspace_bytes(C.byref(w), n, N)
+                    if nbytes < 0:
+                        ffi.check(int(nbytes), "afm_cdm_workspace_bytes")
+                    self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                ws = self._ws[key]
+                main = cur if nsub == 1 else self._streams[2 * i]
+                if fork is not None:
+                    main.wait_event(fork)
+                side = self._streams[2 * i + 1].cuda_stream if self.overlap_streams else None
+                ffi.check(lib.afm_cdm_forward_overlap(C.byref(w), feat[lo:hi].data_ptr(), x[lo:hi].data_ptr(), t[lo:hi].data_ptr(),
+                                                      tq0[lo:hi].data_ptr(), tu[lo:hi].data_ptr(), tcu[lo:hi].data_ptr(), out[lo:hi].data_ptr(), None,
+                                                      n, N, ws.data_ptr(), ws.numel(), side, main.cuda_stream), "afm_cdm_forward_overlap")
+                if fork is not None:
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    cur.wait_event(done)
         return out
 
     # ------------------------------------------------------------------ 'MLP' arch (per-operator composition, inference and training)

@@ -416,10 +416,10 @@ extern "C" int afm_cdm_latent_tokens(const afm_cdm_weights* wp, int32_t which, c
     return 0;
 }
 
-extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
-                               const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
-                               const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
-                               void* stream) {
+static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
+                            const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
+                            const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
+                            void* side_stream, void* stream) {
     AFM_TRY(validate(wp, B, N));
     if (!feat || !t || !text_q0 || !text_u || !text_cu || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
     if (!wp->time_q0 || !wp->time_u || !wp->time_cu) return AFM_E_BADARG;
@@ -435,20 +435,47 @@ extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, con
     a.A = feat; a.lda = w.feat_dim; a.W = w.encoder_adapter.w; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = w.feat_dim; a.bias = w.encoder_adapter.b;
     AFM_TRY(afm_linear(&a, s));
+    // The decoder adapter GEMM (34 GFLOP at B = 32) only needs enc_kv, while the latent chain (enc_reduce -> latent_post: one
+    // workgroup per SAMPLE, a serial 0.5 ms dependency chain that leaves the chip idle) only produces the 2 latent tokens:
+    // with a side stream the GEMM runs under the latent chain and the two join in front of dec_attend.
+    hipStream_t side = (hipStream_t)side_stream;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
         hipLaunchKernelGGL(enc_reduce_kernel<16>, dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
                            w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc);
         AFM_CHECK_LAUNCH();
+    }
+    if (side) {           // fork AFTER enc_reduce (a full-chip kernel): the GEMM shares the chip with latent_post only
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        (void)hipEventRecord(ev_fork, s);
+    }
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
         const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
         AFM_CHECK_LAUNCH();
     }
-    a = {};
-    a.A = ws.enc_kv; a.lda = dkv; a.W = w.decoder_adapter.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
-    a.M = M; a.N = dkv; a.K = dkv; a.bias = w.decoder_adapter.b;
-    AFM_TRY(afm_linear(&a, s));
+    if (side) {           // enqueued after latent_post so that its 32 workgroups get their CUs first
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        afm_linear_args d = {};
+        d.A = ws.enc_kv; d.lda = dkv; d.W = w.decoder_adapter.w; d.ldw = dkv; d.C = ws.bufB; d.ldc = dkv;
+        d.M = M; d.N = dkv; d.K = dkv; d.bias = w.decoder_adapter.b;
+        const int rc = afm_linear(&d, side);
+        (void)hipEventRecord(ev_join, side);
+        if (rc) { (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); return rc; }
+    }
+    if (side) {
+        (void)hipStreamWaitEvent(s, ev_join, 0);
+        (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join);
+    } else {
+        a = {};
+        a.A = ws.enc_kv; a.lda = dkv; a.W = w.decoder_adapter.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
+        a.M = M; a.N = dkv; a.K = dkv; a.bias = w.decoder_adapter.b;
+        AFM_TRY(afm_linear(&a, s));
+    }
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
         int chunks = (N + 255) / 256;
@@ -474,4 +501,18 @@ extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, con
     }
     AFM_TRY(afm_linear(&a, s));
     return 0;
+}
+
+extern "C" int afm_cdm_forward(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
+                               const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
+                               const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+    return cdm_forward_impl(wp, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int afm_cdm_forward_overlap(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
+                                       const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
+                                       const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
+                                       void* side_stream, void* stream) {
+    return cdm_forward_impl(wp, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, workspace, workspace_bytes, side_stream, stream);
 }

@@ -447,6 +447,11 @@ int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
 int afm_cdm_forward(const afm_cdm_weights* w, const float* feat, const float* x_t, const int64_t* t,
                     const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
                     const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes, void* stream);
+/* Same, with the decoder-adapter GEMM enqueued on `side_stream` underneath the per-sample latent chain (fork / join by events on
+ * `stream`; results identical).  side_stream == NULL behaves like afm_cdm_forward. */
+int afm_cdm_forward_overlap(const afm_cdm_weights* w, const float* feat, const float* x_t, const int64_t* t,
+                    const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
+                    const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes, void* side_stream, void* stream);
 
 /* Latent-token precomputation (step-invariant, off the per-step path): for n input rows `in` [n, text_dim] (which = 0,
  * language_adapter) or [n, time_dim] (which = 1, time_embedding_adapter) compute the latent's enc_q0 row
