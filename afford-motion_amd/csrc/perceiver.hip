@@ -329,39 +329,64 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
     const float* cb = P + NJH * 256;
     const int per = (N + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
-    for (int n = n0 + wave; n < n1; n += 4) {
-        const int64_t row = ((int64_t)b * N + n) * 256 + c0;
-        const float4 x = *reinterpret_cast<const float4*>(dec_q0 + row);
-        float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
-        float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
-        float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
-        const float y0 = d0 * rstd * g1.x + b1.x, y1 = d1 * rstd * g1.y + b1.y, y2 = d2 * rstd * g1.z + b1.z, y3 = d3 * rstd * g1.w + b1.w;
-        float sc[NJH];
+    // PP points per wave iteration: the folded key / value rows (G, P: 32 x ds_read_b128 per point) are read from LDS once
+    // and used for PP points - the kernel is LDS-issue bound, not HBM bound
+    constexpr int PP = 2;
+    for (int nb = n0 + wave * PP; nb < n1; nb += 4 * PP) {
+        float4 x[PP];
+        float y[PP][4], sc[PP][NJH];
+        bool ok[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            ok[u] = nb + u < n1;
+            const int64_t row = ((int64_t)b * N + min(nb + u, n1 - 1)) * 256 + c0;
+            x[u] = *reinterpret_cast<const float4*>(dec_q0 + row);
+        }
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const float mean = wave_sum((x[u].x + x[u].y) + (x[u].z + x[u].w)) * (1.0f / 256.0f);
+            const float d0 = x[u].x - mean, d1 = x[u].y - mean, d2 = x[u].z - mean, d3 = x[u].w - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
+            y[u][0] = d0 * rstd * g1.x + b1.x; y[u][1] = d1 * rstd * g1.y + b1.y; y[u][2] = d2 * rstd * g1.z + b1.z; y[u][3] = d3 * rstd * g1.w + b1.w;
+        }
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
             const float4 gv = *reinterpret_cast<const float4*>(G + jh * 256 + c0);
-            sc[jh] = (y0 * gv.x + y1 * gv.y) + (y2 * gv.z + y3 * gv.w);
+#pragma unroll
+            for (int u = 0; u < PP; ++u) sc[u][jh] = (y[u][0] * gv.x + y[u][1] * gv.y) + (y[u][2] * gv.z + y[u][3] * gv.w);
         }
-        // lane owns score jh = j*HD + h (j <-> lane bit 5); its softmax partner (other key, same head) is lane ^ 32
-        const float s_own = wave_reduce_multi<NJH>(sc, lane) + cb[multi_owned_index<NJH>(lane)];
-        const float s_oth = __shfl_xor(s_own, 32);
-        const float mx = fmaxf(s_own, s_oth);
-        const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
-        const float w_own = e_own / (e_own + e_oth);
-        float o0 = ob.x, o1 = ob.y, o2 = ob.z, o3 = ob.w;
+        float w_own[PP], o[PP][4];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            // lane owns score jh = j*HD + h (j <-> lane bit 5); its softmax partner (other key, same head) is lane ^ 32
+            const float s_own = wave_reduce_multi<NJH>(sc[u], lane) + cb[multi_owned_index<NJH>(lane)];
+            const float s_oth = __shfl_xor(s_own, 32);
+            const float mx = fmaxf(s_own, s_oth);
+            const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
+            w_own[u] = e_own / (e_own + e_oth);
+            o[u][0] = ob.x; o[u][1] = ob.y; o[u][2] = ob.z; o[u][3] = ob.w;
+        }
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
-            const float wj = lane_bcast(w_own, multi_owner_lane<NJH>(jh));
             const float4 pv = *reinterpret_cast<const float4*>(P + jh * 256 + c0);
-            o0 += wj * pv.x; o1 += wj * pv.y; o2 += wj * pv.z; o3 += wj * pv.w;
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const float wj = lane_bcast(w_own[u], multi_owner_lane<NJH>(jh));
+                o[u][0] += wj * pv.x; o[u][1] += wj * pv.y; o[u][2] += wj * pv.z; o[u][3] += wj * pv.w;
+            }
         }
-        const float r0 = o0 + x.x, r1 = o1 + x.y, r2 = o2 + x.z, r3 = o3 + x.w;            // Residual adds the raw query
-        *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
-        mean = wave_sum((r0 + r1) + (r2 + r3)) * (1.0f / 256.0f);
-        d0 = r0 - mean; d1 = r1 - mean; d2 = r2 - mean; d3 = r3 - mean;
-        rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
-        *reinterpret_cast<float4*>(z + row) =
-            make_float4(d0 * rstd * g2.x + b2.x, d1 * rstd * g2.y + b2.y, d2 * rstd * g2.z + b2.z, d3 * rstd * g2.w + b2.w);
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = ((int64_t)b * N + nb + u) * 256 + c0;
+            const float r0 = o[u][0] + x[u].x, r1 = o[u][1] + x[u].y, r2 = o[u][2] + x[u].z, r3 = o[u][3] + x[u].w;   // Residual adds the raw query
+            *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
+            const float mean = wave_sum((r0 + r1) + (r2 + r3)) * (1.0f / 256.0f);
+            const float d0 = r0 - mean, d1 = r1 - mean, d2 = r2 - mean, d3 = r3 - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
+            *reinterpret_cast<float4*>(z + row) =
+                make_float4(d0 * rstd * g2.x + b2.x, d1 * rstd * g2.y + b2.y, d2 * rstd * g2.z + b2.z, d3 * rstd * g2.w + b2.w);
+        }
     }
 }
 
