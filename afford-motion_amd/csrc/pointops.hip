@@ -70,9 +70,17 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
 
 constexpr int KNN_TILE = 1024;
 
+// One lane per query, candidates tiled through LDS.  A candidate that beats the lane's current k-th distance is NOT inserted
+// at once: a wave executes a divergent branch whenever ANY of its 64 lanes takes it, and with 64 independent queries some lane
+// nearly always does, so the 6K-instruction sorted insert would run for almost every candidate.  Instead qualifying candidates
+// are appended (predicated, branch-free) to a 3-entry per-lane buffer (3 measured best of 2, 3, 4, 8) and the wave flushes the buffers with one wave-uniform
+// branch when any lane's buffer is full - the insert cost is paid every ~i/(2K) candidates instead of every candidate.
+// Insertion order per lane is still the scan order and uses strict '<', so the result is identical to the direct form:
+// neighbours ordered by (d2, index).
 template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, const float* __restrict__ qxyz, int n, int m,
                                                   int* __restrict__ idx_out, float* __restrict__ d2_out) {
+    constexpr int BUF = 3;
     __shared__ float tile[3 * KNN_TILE];             // interleaved x,y,z exactly as in memory (coalesced fill)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int q = blockIdx.x * blockDim.x + tid;
@@ -80,31 +88,52 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
     const float* Q = qxyz + ((int64_t)b * m + (valid ? q : 0)) * 3;
     const float qx = Q[0], qy = Q[1], qz = Q[2];
     const float* P = xyz + (int64_t)b * n * 3;
-    float bd[K];
-    int bi[K];
+    float bd[K], cd[BUF];
+    int bi[K], ci[BUF];
+    int cnt = 0;
 #pragma unroll
     for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = -1; }
+#pragma unroll
+    for (int j = 0; j < BUF; ++j) { cd[j] = INFINITY; ci[j] = -1; }
+    auto flush = [&]() {
+#pragma unroll
+        for (int e = 0; e < BUF; ++e) {
+            const float d = e < cnt ? cd[e] : INFINITY;              // unused slots can never beat anything
+            const int id = ci[e];
+            // sorted insert; strict '<' keeps the earlier (lower) index in front on equal distances
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool up = d < bd[j - 1];
+                const bool here = d < bd[j];
+                bd[j] = up ? bd[j - 1] : (here ? d : bd[j]);
+                bi[j] = up ? bi[j - 1] : (here ? id : bi[j]);
+            }
+            const bool first = d < bd[0];
+            bd[0] = first ? d : bd[0];
+            bi[0] = first ? id : bi[0];
+        }
+        cnt = 0;
+    };
     for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
-        const int cnt = min(KNN_TILE, n - t0);
-        for (int f = tid; f < cnt * 3; f += blockDim.x) tile[f] = P[(int64_t)t0 * 3 + f];
+        const int tc = min(KNN_TILE, n - t0);
+        for (int f = tid; f < tc * 3; f += blockDim.x) tile[f] = P[(int64_t)t0 * 3 + f];
         __syncthreads();
-        for (int i = 0; i < cnt; ++i) {
+        for (int i = 0; i < tc; ++i) {
             const float dx = qx - tile[3 * i], dy = qy - tile[3 * i + 1], dz = qz - tile[3 * i + 2];
             const float d = (dx * dx + dy * dy) + dz * dz;
-            if (d < bd[K - 1]) {
-                // sorted insert; strict '<' keeps the earlier (lower) index in front on equal distances
+            const bool take = d < bd[K - 1];                          // threshold may be stale until the next flush: re-checked there
 #pragma unroll
-                for (int j = K - 1; j > 0; --j) {
-                    const bool up = d < bd[j - 1];
-                    const bool here = d < bd[j];
-                    bd[j] = up ? bd[j - 1] : (here ? d : bd[j]);
-                    bi[j] = up ? bi[j - 1] : (here ? (t0 + i) : bi[j]);
-                }
-                if (d < bd[0]) { bd[0] = d; bi[0] = t0 + i; }
+            for (int e = 0; e < BUF; ++e) {
+                const bool w = take && cnt == e;
+                cd[e] = w ? d : cd[e];
+                ci[e] = w ? (t0 + i) : ci[e];
             }
+            cnt += take ? 1 : 0;
+            if (__any(cnt == BUF)) flush();
         }
         __syncthreads();
     }
+    flush();
     if (valid) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
