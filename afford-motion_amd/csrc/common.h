@@ -69,6 +69,41 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {      // src
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+// Wave-wide maximum of a 64-bit key without touching the LDS crossbar: four DPP steps inside each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - every lane of a row ends with the row maximum), then
+// the four row results are read into SGPRs (v_readlane) and combined on the scalar unit.  Returns a wave-uniform value.
+// (__shfl_xor on 64-bit values is 2 x ds_bpermute per step, ~100+ cycles of dependent latency each.)
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v, const int ctrl_tag) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    switch (ctrl_tag) {
+        case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true); break;
+        case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true); break;
+        default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, true); break;
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const unsigned long long o = dpp_u64(v, st);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = row_max_u64(v);
+    unsigned long long r = 0ull;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, row * 16);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), row * 16);
+        const unsigned long long k = ((unsigned long long)hi << 32) | lo;
+        r = k > r ? k : r;
+    }
+    return r;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -11,7 +11,7 @@
 // gfx950 design
 //   * FPS is latency-bound (m-1 dependent rounds): one workgroup per sample, every point and its
 //     running min-distance live in registers, arg-max = 64-bit (dist bits | ~index) keys reduced with
-//     6 cross-lane steps per wave + one LDS hop across <= 16 waves, ONE barrier per round.
+//     4 DPP row steps + 4 readlanes per wave (no ds_bpermute), one LDS hop across <= 16 waves, ONE barrier per round.
 //   * kNN: one lane per query, candidates streamed through an LDS tile (broadcast reads), the k best
 //     kept as a sorted register array with a branch-free insertion.
 #include "common.h"
@@ -20,49 +20,62 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Per-point work is kept minimal (the round's VALU time is 16 waves x PPT points on ONE CU): coordinates of two slots are
+// processed as packed f32 pairs (v_pk_add / v_pk_mul: same IEEE results, half the instructions), the per-thread arg-max is a
+// 32-bit (distance bits, slot) select - slots are visited in increasing point index, so a strict '>' keeps the lowest index on
+// ties - and the 64-bit (dist | ~index) key that the wave / workgroup reduction orders by is built once per thread per round.
 template <int PPT>
-__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out, int xyz_in_lds) {
+    constexpr int NP = (PPT + 1) / 2;                 // packed pairs (PPT == 1: second half is a dead slot)
     __shared__ unsigned long long keys[2][16];
+    extern __shared__ float pts[];                    // [3n] copy of the sample for the winner's coordinates (critical path)
     const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     const float* P = xyz + (int64_t)b * n * 3;
-    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    f32x2 px[NP], py[NP], pz[NP], tmp[NP];
+    bool ok[2 * NP];
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
+    for (int s = 0; s < 2 * NP; ++s) {
         const int i = s * T + tid;
-        const bool ok = i < n;
-        px[s] = ok ? P[i * 3 + 0] : 0.f; py[s] = ok ? P[i * 3 + 1] : 0.f; pz[s] = ok ? P[i * 3 + 2] : 0.f;
-        tmp[s] = 1e10f;
+        ok[s] = (s < PPT) && (i < n);
+        px[s >> 1][s & 1] = ok[s] ? P[i * 3 + 0] : 0.f; py[s >> 1][s & 1] = ok[s] ? P[i * 3 + 1] : 0.f; pz[s >> 1][s & 1] = ok[s] ? P[i * 3 + 2] : 0.f;
+        tmp[s >> 1][s & 1] = 1e10f;
     }
+    if (xyz_in_lds) {
+        for (int i = tid; i < 3 * n; i += T) pts[i] = P[i];
+        __syncthreads();
+    }
+    const float* C = xyz_in_lds ? pts : P;
     int cur = 0;
     if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
     for (int j = 1; j < m; ++j) {
-        const float cx = P[cur * 3 + 0], cy = P[cur * 3 + 1], cz = P[cur * 3 + 2];
-        unsigned long long best = 0ull;
+        const float cx = C[cur * 3 + 0], cy = C[cur * 3 + 1], cz = C[cur * 3 + 2];
+        const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+        unsigned bd = 0u, bs = 0u;                    // best distance bits (distances are >= 0: bits order like values), its slot
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int i = s * T + tid;
-            if (i < n) {
-                const float dx = px[s] - cx, dy = py[s] - cy, dz = pz[s] - cz;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                tmp[s] = fminf(tmp[s], d);
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(tmp[s]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-                best = key > best ? key : best;
+        for (int p2 = 0; p2 < NP; ++p2) {
+            const f32x2 dx = px[p2] - cx2, dy = py[p2] - cy2, dz = pz[p2] - cz2;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = 2 * p2 + h;
+                if (s < PPT) {
+                    tmp[p2][h] = fminf(tmp[p2][h], d[h]);
+                    const unsigned db = ok[s] ? __float_as_uint(tmp[p2][h]) : 0u;
+                    const bool better = db > bd;
+                    bd = better ? db : bd;
+                    bs = better ? (unsigned)s : bs;
+                }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o);
-            best = other > best ? other : best;
-        }
+        // slot 0 wins an all-zero tie, which is also the lowest index of this thread; invalid threads carry key 0
+        const unsigned bi = bs * (unsigned)T + (unsigned)tid;
+        unsigned long long best = ok[0] ? (((unsigned long long)bd << 32) | (unsigned long long)(0xFFFFFFFFu - bi)) : 0ull;
+        best = wave_max_u64(best);                    // DPP + readlane: no LDS-crossbar shuffles on the round's critical path
         if (lane == 0) keys[j & 1][wave] = best;
         __syncthreads();
-        unsigned long long k = keys[j & 1][(lane < nw) ? lane : 0];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(k, o);
-            k = other > k ? other : k;
-        }
+        const unsigned long long k = row_max_u64(keys[j & 1][((lane & 15) < nw) ? (lane & 15) : 0]);   // <= 16 waves: one DPP row
         cur = __builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)));
         if (tid == 0) idx_out[(int64_t)b * m + j] = b * n + cur;
     }
@@ -216,7 +229,16 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
     if (T > 1024) T = 1024;
     const int ppt = (n + T - 1) / T;
     AfmProf prof(AFM_PROF_FPS, (double)B * (m - 1) * n, s);
-#define AFM_FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(T), 0, s, xyz, n, m, idx_out)
+    const size_t lds = (size_t)3 * n * sizeof(float);
+    const int in_lds = lds <= 150 * 1024 ? 1 : 0;
+#define AFM_FPS(P)                                                                                                                  \
+    do {                                                                                                                            \
+        if (in_lds && lds > 48 * 1024) {                                                                                            \
+            hipError_t e__ = hipFuncSetAttribute((const void*)fps_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            if (e__ != hipSuccess) return (int)e__;                                                                                 \
+        }                                                                                                                           \
+        hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(T), in_lds ? lds : 0, s, xyz, n, m, idx_out, in_lds);                        \
+    } while (0)
     if (ppt <= 1) AFM_FPS(1);
     else if (ppt <= 2) AFM_FPS(2);
     else if (ppt <= 4) AFM_FPS(4);
