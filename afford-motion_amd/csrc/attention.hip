@@ -12,6 +12,7 @@
 //     its K row as 8 x ds_read_b128; K rows are padded to 68 floats (conflict-free 16-lane groups).
 //   * online softmax in f32 (running max / sum per query), masked keys get -inf exactly like
 //     masked_fill(-inf) in the reference; fully masked 32-key blocks are skipped (their weight is 0).
+#include <atomic>
 #include "common.h"
 #include "profile.h"
 #include <math.h>
@@ -197,15 +198,15 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nkb * KB) * sizeof(float) + (size_t)nkb * sizeof(int);
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~30000 keys
     if (lds > 64 * 1024) {                                     // long memories (cross-attention over N = 8192 points): opt in once
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<bool> attr_set{false};      // idempotent attribute: a race only repeats the call
+        if (!attr_set.load(std::memory_order_acquire)) {
             const void* fns[4] = {(const void*)mha_fwd_kernel<2, false>, (const void*)mha_fwd_kernel<4, false>, (const void*)mha_fwd_kernel<2, true>,
                                   (const void*)mha_fwd_kernel<4, true>};
             for (int i = 0; i < 4; ++i) {
                 hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return (int)e;
             }
-            attr_set = true;
+            attr_set.store(true, std::memory_order_release);
         }
     }
     const float scale = 1.0f / sqrtf((float)dh);

@@ -17,6 +17,7 @@
 //       dV^T += dO^T P_drop, dK^T += Q^T dS   (A = dO / Q columns from LDS, B = the P / dS registers)
 //   Two passes recompute S twice (7 products instead of 5) but need no atomics and no cross-wave reduction: every
 //   gradient element has exactly one owner, so the result is deterministic.
+#include <atomic>
 #include "common.h"
 #include "profile.h"
 #include <math.h>
@@ -375,14 +376,14 @@ extern "C" int afm_mha_bwd(const float* qkv, const uint8_t* key_mask, const floa
     const float scale = 1.0f / sqrtf((float)dh);
     hipStream_t s = (hipStream_t)stream;
     const double flops_prod = 2.0 * B * H * (double)T * T * dh;
-    static bool attr_set = false;                     // > 64 KB of dynamic LDS must be opted into once per kernel
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};         // > 64 KB of dynamic LDS must be opted into once per kernel (idempotent)
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipSuccess;
         const void* fns[4] = {(const void*)mha_bwd_dkv_kernel<2, false>, (const void*)mha_bwd_dkv_kernel<4, false>,
                               (const void*)mha_bwd_dkv_kernel<2, true>, (const void*)mha_bwd_dkv_kernel<4, true>};
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const bool drop = drop_p > 0.0f;
 #define AFM_DQ(NST, DR) hipLaunchKernelGGL((mha_bwd_dq_kernel<NST, DR>), dim3(B * H), dim3(nw * 64), lds1, s, qkv, key_mask, out, dout, lse, dqkv, Dws, T, H, scale, drop_p, drop_seed, drop_id)
