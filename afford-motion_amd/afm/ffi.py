@@ -175,6 +175,9 @@ EXPORTS = {
                                   C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p]),
     "afm_cdm_forward_overlap": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.POINTER(DdpmArgs), i32, i32, C.c_void_p, i64, C.c_void_p, C.c_void_p]),
+    "afm_cdm_loop_workspace_bytes": (i64, [C.POINTER(CdmWeights), i32, i32, i32]),
+    "afm_cdm_sample_loop": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p,
+                                      i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, i32, C.POINTER(C.c_void_p), C.c_void_p]),
     "afm_cdm_latent_tokens": (C.c_int, [C.POINTER(CdmWeights), i32, c_f32p, i32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "afm_profile_enable": (C.c_int, [i32]),
     "afm_profile_read": (C.c_int, [C.POINTER(ProfileEntry), i32]),

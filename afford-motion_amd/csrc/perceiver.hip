@@ -541,3 +541,138 @@ extern "C" int afm_cdm_forward_overlap(const afm_cdm_weights* wp, const float* f
                                        void* side_stream, void* stream) {
     return cdm_forward_impl(wp, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, workspace, workspace_bytes, side_stream, stream);
 }
+
+// ------------------------------------------------------------------------------------------------ native sampling loop
+namespace {
+
+__global__ void cdm_expand_schedule_kernel(const int64_t* __restrict__ tmap, const float* __restrict__ c1, const float* __restrict__ c2,
+                                           const float* __restrict__ sg, int n_steps, int B, int64_t* __restrict__ t_all,
+                                           float* __restrict__ c1_all, float* __restrict__ c2_all, float* __restrict__ sg_all) {
+    const int64_t n = (int64_t)n_steps * B;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = n_steps - 1 - (int)(e / B);
+        t_all[e] = tmap[i]; c1_all[e] = c1[i]; c2_all[e] = c2[i]; sg_all[e] = sg[i];
+    }
+}
+
+// feat[r, 0:cd] = x[r, :]  (the noisy contact map is the leading block of the encoder input, cdm.py:167-171)
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x, float* __restrict__ feat, int64_t rows, int cd, int fd) {
+    const int64_t n = rows * cd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cd;
+        feat[r * fd + (i - r * cd)] = x[i];
+    }
+}
+
+inline void cdm_sub_range(int B, int nsub, int s, int* start, int* count) {
+    const int base = B / nsub, extra = B % nsub;
+    *start = s * base + (s < extra ? s : extra);
+    *count = base + (s < extra ? 1 : 0);
+}
+
+}  // namespace
+
+extern "C" int64_t afm_cdm_loop_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N, int32_t n_sub) {
+    if (validate(w, B, N) != 0 || n_sub < 0) return AFM_E_BADARG;
+    int nsub = n_sub > 1 ? (n_sub < B ? n_sub : B) : 1;
+    if (nsub > 8) nsub = 8;
+    int64_t total = 0;
+    for (int s = 0; s < nsub; ++s) {
+        int st, cnt;
+        cdm_sub_range(B, nsub, s, &st, &cnt);
+        total += carve(*w, cnt, N, nullptr).bytes + align256((int64_t)cnt * N * w->contact_dim * 4);
+    }
+    return total;
+}
+
+// Whole p_sample_loop of the ADM (gaussian_diffusion.py:442-536) enqueued natively: x [B,N,contact_dim] holds x_T on entry and the
+// sample on exit; feat [B,N,feat_dim] holds the step-invariant columns (point features, xyz) - its leading contact_dim columns are
+// rewritten from x every step.  Sub-batch s runs on streams[2s] with streams[2s+1] as the side stream of its decoder-adapter GEMM
+// (n_sub <= 1: everything on `stream`, streams[0] = optional side stream).
+extern "C" int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
+                                   const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                                   const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0, int32_t B,
+                                   int32_t N, void* sched_scratch, void* workspace, int64_t workspace_bytes, int32_t n_sub, void* const* streams,
+                                   void* stream) {
+    AFM_TRY(validate(w, B, N));
+    if (!x || !feat || !text_q0 || !text_u || !text_cu || !d_timestep_map || !d_c1 || !d_c2 || !d_sigma || n_steps <= 0 || !sched_scratch ||
+        !workspace || n_sub < 0 || (n_sub > 1 && !streams))
+        return AFM_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s0 = (hipStream_t)stream;
+    int nsub = n_sub > 1 ? (n_sub < B ? n_sub : B) : 1;
+    if (nsub > 8) nsub = 8;
+    const int cd = w->contact_dim, fd = w->feat_dim, He = w->enc_heads, dkv = w->dkv, dq = w->dq;
+
+    char* sp = (char*)sched_scratch;
+    const int64_t nb = (int64_t)n_steps * B;
+    int64_t* t_all = (int64_t*)sp; sp += align256(nb * 8);
+    float* c1_all = (float*)sp; sp += align256(nb * 4);
+    float* c2_all = (float*)sp; sp += align256(nb * 4);
+    float* sg_all = (float*)sp;
+    hipLaunchKernelGGL(cdm_expand_schedule_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s0, d_timestep_map, d_c1, d_c2, d_sigma, n_steps, B,
+                       t_all, c1_all, c2_all, sg_all);
+    AFM_CHECK_LAUNCH();
+
+    int start[8], count[8];
+    char* wsp[8];
+    int64_t wsb[8];
+    float* noise[8];
+    hipStream_t mainst[8], sidest[8];
+    {
+        char* base = (char*)workspace;
+        int64_t off = 0;
+        for (int s = 0; s < nsub; ++s) {
+            cdm_sub_range(B, nsub, s, &start[s], &count[s]);
+            wsb[s] = carve(*w, count[s], N, nullptr).bytes;
+            wsp[s] = base + off; off += wsb[s];
+            noise[s] = (float*)(base + off); off += align256((int64_t)count[s] * N * cd * 4);
+            if (nsub > 1) { mainst[s] = (hipStream_t)streams[2 * s]; sidest[s] = (hipStream_t)streams[2 * s + 1]; }
+            else { mainst[s] = s0; sidest[s] = streams ? (hipStream_t)streams[0] : nullptr; }
+        }
+        if (off > workspace_bytes) return AFM_E_WORKSPACE;
+    }
+    hipEvent_t fork = nullptr;
+    if (nsub > 1) {
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        (void)hipEventRecord(fork, s0);
+        for (int s = 0; s < nsub; ++s) (void)hipStreamWaitEvent(mainst[s], fork, 0);
+    }
+    const int64_t per = (int64_t)N * cd;
+    int rc = 0;
+    for (int j = 0; j < n_steps && rc == 0; ++j) {
+        for (int s = 0; s < nsub && rc == 0; ++s) {
+            if (count[s] == 0) continue;
+            float* xs = x + (int64_t)start[s] * per;
+            float* fs = feat + (int64_t)start[s] * N * fd;
+            const int64_t rows = (int64_t)count[s] * N;
+            int64_t gx = (rows * cd + 255) / 256; if (gx > 2048) gx = 2048;
+            hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)gx), dim3(256), 0, mainst[s], xs, fs, rows, cd, fd);
+            afm_ddpm_args dd = {};
+            if (step_noise) dd.noise = step_noise + ((int64_t)j * B + start[s]) * per;
+            else {
+                rc = afm_randn(noise[s], count[s], per, seed, sample_index0 + start[s], j, mainst[s]);
+                if (rc) break;
+                dd.noise = noise[s];
+            }
+            dd.x_next = xs;                               // in place: each element is read then written by the same lane
+            dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s]; dd.sigma = sg_all + (int64_t)j * B + start[s];
+            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = j;
+            rc = cdm_forward_impl(w, fs, xs, t_all + (int64_t)j * B + start[s], text_q0 + (int64_t)start[s] * dq,
+                                  text_u + (int64_t)start[s] * He * dkv, text_cu + (int64_t)start[s] * He, nullptr, &dd, count[s], N, wsp[s], wsb[s],
+                                  sidest[s], mainst[s]);
+        }
+    }
+    if (nsub > 1) {
+        for (int s = 0; s < nsub; ++s) {
+            hipEvent_t done;
+            if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) {
+                (void)hipEventRecord(done, mainst[s]);
+                (void)hipStreamWaitEvent(s0, done, 0);
+                (void)hipEventDestroy(done);
+            }
+        }
+        (void)hipEventDestroy(fork);
+    }
+    return rc;
+}

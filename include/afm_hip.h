@@ -453,6 +453,21 @@ int afm_cdm_forward_overlap(const afm_cdm_weights* w, const float* feat, const f
                     const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
                     const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes, void* side_stream, void* stream);
 
+/* Whole ADM p_sample_loop (gaussian_diffusion.py:442-536 with the CDM Perceiver denoiser) enqueued natively, no host synchronisation:
+ *   x [B,N,contact_dim]: x_T on entry, the sample on exit.  feat [B,N,feat_dim]: the encoder input; its step-invariant columns
+ *   (per-point features, xyz) are filled by the caller, the leading contact_dim columns are rewritten from x every step.
+ *   text_q0 / text_u / text_cu: afm_cdm_latent_tokens of the text features.  step_noise [n_steps,B,N,contact_dim] or NULL (Philox
+ *   keyed by (seed, sample_index0 + b, step)).  Schedule rows / sched_scratch as for afm_cmdm_sample_loop
+ *   (afm_cmdm_sched_scratch_bytes).  Sub-batching: n_sub > 1 splits the batch; sub-batch s runs on streams[2s] and uses streams[2s+1]
+ *   as the side stream of its decoder-adapter GEMM (one half's per-sample latent chain overlaps the other half's GEMMs);
+ *   n_sub <= 1: everything on `stream`, streams[0] (if given) = side stream.  workspace >= afm_cdm_loop_workspace_bytes. */
+int64_t afm_cdm_loop_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N, int32_t n_sub);
+int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
+                        const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                        const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0,
+                        int32_t B, int32_t N, void* sched_scratch, void* workspace, int64_t workspace_bytes, int32_t n_sub,
+                        void* const* streams, void* stream);
+
 /* Latent-token precomputation (step-invariant, off the per-step path): for n input rows `in` [n, text_dim] (which = 0,
  * language_adapter) or [n, time_dim] (which = 1, time_embedding_adapter) compute the latent's enc_q0 row
  * q0_out [n, dq], q = dp_scale * q_proj(LN_q(q0)) folded through k_proj: u_out [n, enc_heads, dkv], cu_out [n, enc_heads]. */
