@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
                     s[4 * g + 0] += ma.x; s[4 * g + 1] += ma.y; s[4 * g + 2] += ma.z; s[4 * g + 3] += ma.w;
                     mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = fmaxf(mx, xor32(mx));
                 const float m_new = fmaxf(m_run, mx);
                 const float m_safe = (m_new == NEG_INF) ? 0.0f : m_new;
                 const float alpha = __expf(m_run - m_safe);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
                     s[r] = __expf(s[r] - m_safe);
                     rs += s[r];
                 }
-                rs += __shfl_xor(rs, 32);
+                rs += xor32(rs);
                 l_run = l_run * alpha + rs;
                 m_run = m_new;
 #pragma unroll

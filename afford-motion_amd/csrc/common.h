@@ -22,9 +22,33 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// The value held by lane (l ^ 32), as one VALU instruction: v_permlane32_swap (gfx950) exchanges the upper half of one register with
+// the lower half of another, so swapping two copies of v leaves {v_lo, v_lo} and {v_hi, v_hi}; the lane picks the half it does not own.
+// (__shfl_xor(v, 32) is a ds_bpermute: an LDS-crossbar round trip on the critical path of the softmax.)
+__device__ __forceinline__ float xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+__device__ __forceinline__ float xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 64 lanes, result in every lane, entirely on the VALU: four DPP steps inside each row of 16 lanes (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror), then v_permlane16_swap / v_permlane32_swap across rows.  No ds_bpermute: the
+// LayerNorm-style kernels (two to four of these per row on the critical path) were bound by the LDS crossbar round trips.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    v += xor16(v);
+    v += xor32(v);
     return v;
 }
 
