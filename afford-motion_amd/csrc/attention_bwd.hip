@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
                 const float4 o = *reinterpret_cast<const float4*>(op + i * 4);
                 dsum += (g.x * o.x + g.y * o.y) + (g.z * o.z + g.w * o.w);
             }
-            D_q = dsum + __shfl_xor(dsum, 32);
+            D_q = dsum + xor32(dsum);
             lse_q = lse[(int64_t)blockIdx.x * T + qrow];
             if (active && hh == 0 && qb * 32 + r32 < T) Dws[(int64_t)blockIdx.x * T + qrow] = D_q;
         }

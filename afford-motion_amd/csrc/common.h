@@ -55,25 +55,36 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Reduce NV per-lane values over the 64 lanes with a halving butterfly: NV/2 + NV/4 + ... + 1 exchanges, then
 // log2(64/NV) plain steps (17 cross-lane ops for NV = 16 instead of 96).  On return v[0] of lane l holds the wave
 // total of value index  owner(l) = sum_b bit(l, 5-b) * (NV >> (b+1))  (NV = 16: bits 5,4,3,2 -> 8,4,2,1).
-template <int N>
-__device__ __forceinline__ void halve_step(float* v, int lane, int mask) {
-    const bool up = (lane & mask) != 0;
+// value of lane (l ^ M) on the VALU (DPP inside a row, v_permlane*_swap across rows)
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "M");
+    if (M == 1) return dpp_f32<0xB1>(v);
+    if (M == 2) return dpp_f32<0x4E>(v);
+    if (M == 4) { const float a = dpp_f32<0x124>(v), b = dpp_f32<0x12C>(v); return (threadIdx.x & 4) ? a : b; }   // row_ror:4 / row_ror:12
+    if (M == 8) return dpp_f32<0x128>(v);                                                                              // row_ror:8
+    if (M == 16) return xor16(v);
+    return xor32(v);
+}
+template <int N, int MASK>
+__device__ __forceinline__ void halve_step(float* v, int lane) {
+    const bool up = (lane & MASK) != 0;
 #pragma unroll
     for (int q = 0; q < N / 2; ++q) {
         const float keep = up ? v[q + N / 2] : v[q];
         const float send = up ? v[q] : v[q + N / 2];
-        v[q] = keep + __shfl_xor(send, mask);
+        v[q] = keep + lane_xor<MASK>(send);
     }
 }
 template <int NV>
 __device__ __forceinline__ float wave_reduce_multi(float (&v)[NV], int lane) {
     static_assert(NV == 16 || NV == 8 || NV == 4, "NV");
-    if (NV == 16) { halve_step<16>(v, lane, 32); halve_step<8>(v, lane, 16); halve_step<4>(v, lane, 8); halve_step<2>(v, lane, 4);
-                    v[0] += __shfl_xor(v[0], 2); v[0] += __shfl_xor(v[0], 1); }
-    if (NV == 8) { halve_step<8>(v, lane, 32); halve_step<4>(v, lane, 16); halve_step<2>(v, lane, 8);
-                   v[0] += __shfl_xor(v[0], 4); v[0] += __shfl_xor(v[0], 2); v[0] += __shfl_xor(v[0], 1); }
-    if (NV == 4) { halve_step<4>(v, lane, 32); halve_step<2>(v, lane, 16);
-                   v[0] += __shfl_xor(v[0], 8); v[0] += __shfl_xor(v[0], 4); v[0] += __shfl_xor(v[0], 2); v[0] += __shfl_xor(v[0], 1); }
+    if (NV == 16) { halve_step<16, 32>(v, lane); halve_step<8, 16>(v, lane); halve_step<4, 8>(v, lane); halve_step<2, 4>(v, lane);
+                    v[0] += lane_xor<2>(v[0]); v[0] += lane_xor<1>(v[0]); }
+    if (NV == 8) { halve_step<8, 32>(v, lane); halve_step<4, 16>(v, lane); halve_step<2, 8>(v, lane);
+                   v[0] += lane_xor<4>(v[0]); v[0] += lane_xor<2>(v[0]); v[0] += lane_xor<1>(v[0]); }
+    if (NV == 4) { halve_step<4, 32>(v, lane); halve_step<2, 16>(v, lane);
+                   v[0] += lane_xor<8>(v[0]); v[0] += lane_xor<4>(v[0]); v[0] += lane_xor<2>(v[0]); v[0] += lane_xor<1>(v[0]); }
     return v[0];
 }
 // lane that owns value index q after wave_reduce_multi<NV> (its low bits are free: use the lowest such lane)

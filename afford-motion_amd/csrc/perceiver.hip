@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
         for (int u = 0; u < PP; ++u) {
             // lane owns score jh = j*HD + h (j <-> lane bit 5); its softmax partner (other key, same head) is lane ^ 32
             const float s_own = wave_reduce_multi<NJH>(sc[u], lane) + cb[multi_owned_index<NJH>(lane)];
-            const float s_oth = __shfl_xor(s_own, 32);
+            const float s_oth = xor32(s_own);
             const float mx = fmaxf(s_own, s_oth);
             const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
             w_own[u] = e_own / (e_own + e_oth);

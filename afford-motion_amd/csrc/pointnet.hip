@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void transition_down_kernel(const float* __
             for (int r = 0; r < 8; ++r) mA = fmaxf(mA, acc[tm][r] * sc + sh);
 #pragma unroll
             for (int r = 8; r < 16; ++r) mB = fmaxf(mB, acc[tm][r] * sc + sh);
-            mA = fmaxf(mA, __shfl_xor(mA, 32));
-            mB = fmaxf(mB, __shfl_xor(mB, 32));
+            mA = fmaxf(mA, xor32(mA));
+            mB = fmaxf(mB, xor32(mB));
             const int pA = (bm * BM + wm * 64 + tm * 32) >> 4;
             if (hh == 0) {
                 if (pA < M) out[(int64_t)pA * cout + col] = mA;

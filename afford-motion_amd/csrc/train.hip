@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const float* __restri
                 if (n < N && k < K) pw[(int64_t)n * K + k] = acc[i][j][r];
             }
         }
-        const float t = bsum[i] + __shfl_xor(bsum[i], 32);
+        const float t = bsum[i] + xor32(bsum[i]);
         if (part_b && hh == 0 && i * 32 + r32 < N) part_b[(int64_t)gw * N + i * 32 + r32] = t;
     }
 }
