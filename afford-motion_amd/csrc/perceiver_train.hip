@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void xq_dots_kernel(const float* __restrict__ 
             float s = 0.f;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) s += q[t][v] * x[v];
-            for (int o = gl >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            s += lane_xor<4>(s); s += lane_xor<2>(s); s += lane_xor<1>(s);          // gl == 8 lanes per head (checked on the host)
             d[t] = s;
         }
         if ((lane % gl) == 0) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void xk_attn_kernel(const float* __restrict__ 
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < VPL; ++e) a += q[e] * k[j][e];
-            for (int o = gl >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            a += lane_xor<4>(a); a += lane_xor<2>(a); a += lane_xor<1>(a);
             s[j] = a * scale;
         }
         const float mx = fmaxf(s[0], s[1]);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void xk_attn_kernel(const float* __restrict__ 
                 float a = 0.f;
 #pragma unroll
                 for (int e = 0; e < VPL; ++e) a += g[e] * v[j][e];
-                for (int o = gl >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                a += lane_xor<4>(a); a += lane_xor<2>(a); a += lane_xor<1>(a);
                 dp[j] = a * keep[j];
             }
             const float dot = p[0] * dp[0] + p[1] * dp[1];
@@ -268,7 +268,7 @@ extern "C" int64_t afm_xq_workspace_bytes(int32_t B, int32_t N, int32_t C) {
 extern "C" int afm_xq_attention_fwd(const float* Q, const float* K, const float* V, float* P, float* O, int32_t B, int32_t N, int32_t H, int32_t C,
                                     float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream) {
     if (B == 0) return 0;
-    if (!Q || !K || !V || !P || !O || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H || drop_p < 0.0f || drop_p >= 1.0f) return AFM_E_BADARG;
+    if (!Q || !K || !V || !P || !O || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H || (C / H) / (C / 64) != 8 || drop_p < 0.0f || drop_p >= 1.0f) return AFM_E_BADARG;
     const int chunks = xq_chunks(N);
     if (!ws || ws_bytes < (int64_t)B * chunks * TQ * C * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -290,7 +290,7 @@ extern "C" int afm_xq_attention_bwd(const float* Q, const float* K, const float*
                                     float* dV, int32_t B, int32_t N, int32_t H, int32_t C, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws,
                                     int64_t ws_bytes, void* stream) {
     if (B == 0) return 0;
-    if (!Q || !K || !V || !P || !dO || !dS || !dQ || !dK || !dV || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H) return AFM_E_BADARG;
+    if (!Q || !K || !V || !P || !dO || !dS || !dQ || !dK || !dV || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H || (C / H) / (C / 64) != 8) return AFM_E_BADARG;
     const int chunks = xq_chunks(N);
     if (!ws || ws_bytes < (int64_t)B * chunks * TQ * C * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -322,7 +322,7 @@ extern "C" int64_t afm_xk_workspace_bytes(int32_t B, int32_t N, int32_t C) {
 extern "C" int afm_xk_attention_fwd(const float* Q, const float* K, const float* V, float* O, int32_t B, int32_t N, int32_t H, int32_t C, float drop_p,
                                     uint64_t drop_seed, uint32_t drop_id, void* stream) {
     if (B == 0) return 0;
-    if (!Q || !K || !V || !O || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H || drop_p < 0.0f || drop_p >= 1.0f) return AFM_E_BADARG;
+    if (!Q || !K || !V || !O || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H || (C / H) / (C / 64) != 8 || drop_p < 0.0f || drop_p >= 1.0f) return AFM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)(C / H));
     AfmProf prof(AFM_PROF_CDM_TRAIN, 0.0, s);
@@ -336,7 +336,7 @@ extern "C" int afm_xk_attention_fwd(const float* Q, const float* K, const float*
 extern "C" int afm_xk_attention_bwd(const float* Q, const float* K, const float* V, const float* dO, float* dQ, float* dK, float* dV, int32_t B, int32_t N,
                                     int32_t H, int32_t C, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream) {
     if (B == 0) return 0;
-    if (!Q || !K || !V || !dO || !dQ || !dK || !dV || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H) return AFM_E_BADARG;
+    if (!Q || !K || !V || !dO || !dQ || !dK || !dV || B < 0 || N <= 0 || H <= 0 || (C != 512 && C != 256) || C % H || (C / H) / (C / 64) != 8) return AFM_E_BADARG;
     const int blocks = xk_blocks(N);
     if (!ws || ws_bytes < (int64_t)B * blocks * 4 * C * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
