@@ -218,6 +218,11 @@ class ContactPerceiver(nn.Module):
         self.decoder_cross_attn = nn.Sequential(_Wrap(_CrossAttention(self.dkv, self.dq)), _Wrap(_mlp(self.dkv, 1)))
 
 
+def _dist_rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 @Model.register()
 class CDM(TextEncoderMixin, nn.Module):
     def __init__(self, cfg, *args, **kwargs):
@@ -542,7 +547,7 @@ class CDM(TextEncoderMixin, nn.Module):
         p_enc = float(a.encoder_dropout) if self.training else 0.0
         p_dec = float(a.decoder_dropout) if self.training else 0.0
         self._drop_calls = getattr(self, "_drop_calls", 0) + 1
-        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls) & (2**64 - 1)
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls + 0xD1B54A32D192ED03 * _dist_rank()) & (2**64 - 1)   # per call, per rank
         te = self.timestep_embedder
         t_idx = timesteps.to(device=dev, dtype=torch.int64)
         time_emb = AG.linear(AG.linear(te.pe[t_idx, 0, :], te.time_embed[0].weight, te.time_embed[0].bias, act=ffi.ACT_SILU),

@@ -82,6 +82,11 @@ def _param_version(module: nn.Module) -> int:
     return sum(p._version for p in module.parameters()) + sum(b._version for b in module.buffers())
 
 
+def _dist_rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 @Model.register()
 class CMDM(TextEncoderMixin, nn.Module):
     """`Model.get('CMDM')(cfg.model, device=...)` - see module docstring."""
@@ -343,7 +348,7 @@ class CMDM(TextEncoderMixin, nn.Module):
         p_drop = self.dropout_p if self.training else 0.0
         p_pe = float(self.positional_encoder.dropout.p) if self.training else 0.0
         self._drop_calls += 1
-        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls) & (2**64 - 1)
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls + 0xD1B54A32D192ED03 * _dist_rank()) & (2**64 - 1)   # per call, per rank
 
         # time token: pe[t] -> Linear -> SiLU -> Linear (modules.py:48-53)
         te = self.timestep_embedder
