@@ -257,12 +257,12 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NSTG = 3>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p, int nbm, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int STAGE = (BM + BN) * BK;            // floats per stage: A tile then W tile, 32 floats per row
     constexpr int LDC = BN + 4;
-    constexpr int LDS_FLOATS = (3 * STAGE > BM * LDC) ? 3 * STAGE : BM * LDC;
+    constexpr int LDS_FLOATS = (NSTG * STAGE > BM * LDC) ? NSTG * STAGE : BM * LDC;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int nblk = nbm * nbn;
@@ -312,15 +312,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p
 
     const int nk = p.K / BK;
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    if (NSTG == 3 && nk > 1) issue(1, 1);
     const int swz = r32 & 7;
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's part of tile kt has landed once at most one newer tile (kt+1) is still in flight
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        if (NSTG == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                // every wave's part landed; every wave is done with tile kt-1
-        if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);       // (kt+2) % 3 == (stage + 2) % 3
+        if (NSTG == 3) { if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1); }      // (kt+2) % 3 == (stage + 2) % 3
+        else if (kt + 1 < nk) issue(kt + 1, stage ^ 1);                                     // 2-stage ring: 32 KB, more workgroups per CU
         // LDS operand reads are issued through inline asm: with an LDS-DMA in flight hipcc otherwise guards every
         // ds_read with `s_waitcnt vmcnt(0)` (it cannot prove the DMA target does not alias), which drains the ring.
         // All reads of the K-tile are issued up front (they return in order), then each MFMA group waits for exactly
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(af[j][tm][e], bf[j][tn][e], acc[tm][tn]);
         }
-        stage = stage == 2 ? 0 : stage + 1;
+        stage = NSTG == 3 ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
     }
     __syncthreads();                                  // all waves done reading the last stage before it is reused
 
@@ -381,7 +382,10 @@ int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
     const int tag = BM == 128 ? (dma ? AFM_PROF_GEMM128_DMA : AFM_PROF_GEMM128)
                               : (BN == 128 ? (dma ? AFM_PROF_GEMM64x128_DMA : AFM_PROF_GEMM64x128) : (dma ? AFM_PROF_GEMM64_DMA : AFM_PROF_GEMM64));
     AfmProf prof(tag, 2.0 * a.M * a.N * a.K, s);
-    if (dma)
+    static const bool two_stage = getenv("AFM_GEMM_STAGES") && atoi(getenv("AFM_GEMM_STAGES")) == 2;       // tuning knob
+    if (dma && two_stage)
+        hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, 2>), grid, block, 0, s, a, nbm, nbn);
+    else if (dma)
         hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN>), grid, block, 0, s, a, nbm, nbn);
     else if (vec)
         hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, true>), grid, block, 0, s, a, nbm, nbn);
