@@ -68,3 +68,26 @@ def test_attention_random_lengths(B, T, H, seed, masked):
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, d)
     got = ops.mha(qkv.to(dev()), None if mask is None else mask.to(dev()), H)
     assert (got.cpu().double() - ref).abs().max().item() <= 2e-5
+
+
+@settings(max_examples=25, deadline=None)
+@given(B=st.integers(1, 3), n=st.integers(1, 700), frac=st.floats(0.05, 1.0), k=st.sampled_from([3, 8, 16]), seed=st.integers(0, 10**6),
+       dup=st.booleans())
+def test_fps_knn_random_sizes_bit_exact(B, n, frac, k, seed, dup):
+    """FPS / kNN indices vs the oracle on ragged sizes (n < k, m not a multiple of the workgroup, duplicated points)."""
+    from afm import pointops
+    from oracle import pointops_ref as po
+    m = max(1, int(n * frac))
+    p = _rand((B * n, 3), seed)
+    if dup and n > 4:
+        p[1::3] = p[0::3][: p[1::3].shape[0]]                      # exact duplicates -> ties in both operators
+    o = (torch.arange(1, B + 1, dtype=torch.int32) * n)
+    no = (torch.arange(1, B + 1, dtype=torch.int32) * m)
+    idx_ref = po.furthest_sampling(p, o, no)
+    idx = pointops.furthest_point_sampling(p.to(dev()), B, n, m)
+    assert torch.equal(idx.cpu().int(), idx_ref.int())
+    q = p[idx_ref.long()]
+    ki_ref, d_ref = po.knn_query(k, p, q, o, no)
+    ki, d2 = pointops.knn(k, p.to(dev()), q.to(dev()), B, n, m)
+    assert torch.equal(ki.cpu().int(), ki_ref.int())
+    assert torch.equal(d2.cpu(), d_ref)
