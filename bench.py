@@ -114,7 +114,8 @@ def main():
     rank, world, local = adist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
-    dev = torch.device(f"cuda:{local}")
+    # AFM_BENCH_SHARE_GPU=1 (testing only, with AFM_DIST_BACKEND=gloo): every rank uses cuda:0, to exercise the N > 1 control flow
+    dev = torch.device("cuda:0" if os.environ.get("AFM_BENCH_SHARE_GPU") else f"cuda:{local}")
     torch.cuda.set_device(dev)
     ffi.load()
 
@@ -143,9 +144,9 @@ def main():
     setup_ms_steady = 1e3 * (time.perf_counter() - t0)
     model.condition_tokens(**kw)
 
-    def run(diffusion, seed):
+    def run(diffusion, seed, gather=True):
         x = diffusion.p_sample_loop(model, (B, L, D), clip_denoised=False, model_kwargs=kw, seed=seed, sample_index0=rank * B)
-        if world > 1:                                  # the path's only collective: gather the shards at the end
+        if world > 1 and gather:                       # the path's only collective: gather the shards at the end
             out = [torch.empty_like(x) for _ in range(world)]
             dist.all_gather(out, x)
         return x
@@ -174,10 +175,10 @@ def main():
     if rank == 0:
         streams_timed = model.loop_streams
         model.loop_streams = 1
-        run(diff_w, 1)
+        run(diff_w, 1, gather=False)                  # rank 0 only: no collective in this pass
         ffi.profile_enable(True)
         ffi.profile_read()
-        run(diff_k, 2)
+        run(diff_k, 2, gather=False)
         prof = ffi.profile_read()
         ffi.profile_enable(False)
         model.loop_streams = streams_timed
@@ -222,6 +223,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                                 # rank 0 is still in its roofline pass: leave together
         dist.destroy_process_group()
 
 
