@@ -202,3 +202,17 @@ def test_evaluator_file_formats_round_trip(tmp_path):
     rec = aio.load_motion_sample(p)
     assert set(rec) == {"name", "text", "tokens", "motion", "m_len"} and rec["m_len"] == 12
     np.testing.assert_allclose(rec["motion"], motion.numpy() * 2.0 + 1.0, rtol=1e-6)
+
+
+def test_all_four_task_configs_compose():
+    """configs/task/*.yaml mirror the reference's four tasks (HumanML3D + HUMANISE, ADM + AMDM) with the keys the path reads."""
+    for task, model, ov in (("contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver", "model.scene_model.pretrained_weight=''"]),
+                            ("contact_motion_gen", "cmdm", ["model.data_repr=pos", "model.input_feats=66"]),
+                            ("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver", "model.scene_model.use_scene_model=False"]),
+                            ("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263"])):
+        cfg = load_config(task, model, ov)
+        assert float(cfg.task.train.lr) == 1e-4 and cfg.task.train.batch_size == 32 and cfg.task.dataset.num_points == 8192
+        m = base.create_model(cfg, device="cpu")
+        assert sum(p.numel() for p in m.parameters()) > 0
+    humanise = load_config("contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver", "model.scene_model.pretrained_weight=''"])
+    assert humanise.model.scene_model.use_color is True and hasattr(base.create_model(humanise, device="cpu"), "scene_model")
