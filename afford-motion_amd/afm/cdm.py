@@ -255,6 +255,10 @@ class CDM(TextEncoderMixin, nn.Module):
                 if os.path.exists(pw):
                     sd = torch.load(pw, map_location="cpu")
                     self.scene_model.load_state_dict({k: v for k, v in sd.items() if "enc" in k or "dec" in k})
+            self.freeze_scene_model = bool(sm.freeze)          # read by TrainLoop._freeze_scene_model_batchnorm (utils/training.py:111-116)
+            if not self.freeze_scene_model:
+                raise NotImplementedError("scene_model.freeze=False: fine-tuning the PointTransformerSeg backbone is not built "
+                                          "(every reference config freezes it)")
             self.scene_model.eval().requires_grad_(False)
             self.point_feat_dim = sm.point_feat_dim
             self._scene_cache = None

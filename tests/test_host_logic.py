@@ -216,3 +216,24 @@ def test_all_four_task_configs_compose():
         assert sum(p.numel() for p in m.parameters()) > 0
     humanise = load_config("contact_gen", "cdm", ["model.input_feats=6", "model.arch=Perceiver", "model.scene_model.pretrained_weight=''"])
     assert humanise.model.scene_model.use_color is True and hasattr(base.create_model(humanise, device="cpu"), "scene_model")
+
+
+def test_shim_packages_fall_through_to_a_reference_checkout(tmp_path):
+    """`utils` / `diffusion` / `models` shadow the reference's directories; modules that are NOT on the hot path (utils.io,
+    utils.training, diffusion.resample ...) must still resolve to the reference checkout that follows on sys.path.  A fake
+    checkout stands in for /root/reference (which does not exist on the GPU box)."""
+    import subprocess
+    import sys
+    fake = tmp_path / "ref"
+    for pkg, mod, body in (("utils", "io", "MARK = 'ref-utils-io'"), ("diffusion", "resample", "MARK = 'ref-resample'"),
+                           ("utils", "misc", "MARK = 'must-not-win'")):
+        (fake / pkg).mkdir(parents=True, exist_ok=True)
+        (fake / pkg / f"{mod}.py").write_text(body + "\n")
+    code = ("import utils.io, diffusion.resample, utils.misc, models.base, diffusion.gaussian_diffusion as gd;"
+            "assert utils.io.MARK == 'ref-utils-io' and diffusion.resample.MARK == 'ref-resample';"
+            "assert hasattr(utils.misc, 'compute_repr_dimesion') and not hasattr(utils.misc, 'MARK');"
+            "assert 'afford-motion_amd' in models.base.__file__ and 'afford-motion_amd' in gd.__file__;"
+            "from models.modules import PositionalEncoding, TimestepEmbedder; print('fall-through ok')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "afford-motion_amd"), str(fake)]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "fall-through ok" in r.stdout, r.stdout + r.stderr
