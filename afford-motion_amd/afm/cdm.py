@@ -431,8 +431,9 @@ class CDM(TextEncoderMixin, nn.Module):
         return out
 
     # ------------------------------------------------------------------ native sampling loop
-    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0):
-        """Whole p_sample_loop of the ADM on the device (afm_cdm_sample_loop): x holds x_T on entry, returns the sample.  The batch
+    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False):
+        """Whole p_sample_loop of the ADM on the device (afm_cdm_sample_loop): x holds x_T on entry, returns the sample.  ``progress``
+        slices the chain (afm_cdm_sample_loop_range) so a tqdm bar can advance, with bit-identical results.  The batch
         can run as `loop_sub_batches` sub-batches on their own stream pairs (AFM_CDM_LOOP_SUBBATCH; default 1: the M = B*N GEMMs are
         already efficient and the latent chain is hidden by the side stream, splitting only costs)."""
         if self.arch != "Perceiver":
@@ -464,10 +465,17 @@ class CDM(TextEncoderMixin, nn.Module):
             if step_noise is not None:
                 step_noise = ffi.f32c(step_noise.to(dev))
                 assert step_noise.shape == (n,) + tuple(x.shape), step_noise.shape
-            ffi.check(lib.afm_cdm_sample_loop(C.byref(w), x.data_ptr(), feat.data_ptr(), tq0.data_ptr(), tu.data_ptr(), tcu.data_ptr(),
-                                              ffi.ptr(step_noise), tab.timestep_map.data_ptr(), tab.coef1.data_ptr(), tab.coef2.data_ptr(),
-                                              tab.sigma.data_ptr(), n, seed & (2**64 - 1), sample_index0, B, N, sched.data_ptr(), ws.data_ptr(),
-                                              ws.numel(), nsub, handles, ffi.stream_of(x)), "afm_cdm_sample_loop")
+            stream = ffi.stream_of(x)
+
+            def enqueue(j0, j1):        # executed steps j0..j1-1 = timestep indices n-j1 .. n-1-j0
+                lo, cnt = n - j1, j1 - j0
+                ffi.check(lib.afm_cdm_sample_loop_range(
+                    C.byref(w), x.data_ptr(), feat.data_ptr(), tq0.data_ptr(), tu.data_ptr(), tcu.data_ptr(),
+                    None if step_noise is None else step_noise[j0:j1].data_ptr(), tab.timestep_map[lo:].data_ptr(),
+                    tab.coef1[lo:].data_ptr(), tab.coef2[lo:].data_ptr(), tab.sigma[lo:].data_ptr(), cnt, j0, seed & (2**64 - 1),
+                    sample_index0, B, N, sched.data_ptr(), ws.data_ptr(), ws.numel(), nsub, handles, stream), "afm_cdm_sample_loop_range")
+
+            ffi.run_slices(ffi.progress_slices(n, progress), enqueue, progress, dev)
             self._last_loop_scratch = (sched, step_noise, feat, tq0, tu, tcu)
         return x
 

@@ -200,7 +200,7 @@ class GaussianDiffusion:
         run the whole loop natively without host synchronisation."""
         native = getattr(model, "afm_native_loop", None)
         switches = any(k in (model_kwargs or {}) for k in ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase"))
-        if native is not None and not clip_denoised and denoised_fn is None and cond_fn is None and not progress \
+        if native is not None and not clip_denoised and denoised_fn is None and cond_fn is None \
                 and not self.rescale_timesteps and not switches:
             if device is None:
                 device = next(model.parameters()).device
@@ -209,7 +209,8 @@ class GaussianDiffusion:
                                                                    sample_index0=sample_index0, step=-1)
             if isinstance(step_noise, (list, tuple)):
                 step_noise = torch.stack(list(step_noise), 0)
-            return native(self, x, model_kwargs or {}, step_noise=step_noise, seed=seed, sample_index0=sample_index0)
+            return native(self, x, model_kwargs or {}, step_noise=step_noise, seed=seed, sample_index0=sample_index0,
+                          progress=bool(progress))
         final = None
         for final in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                     denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,

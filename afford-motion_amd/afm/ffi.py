@@ -178,6 +178,9 @@ EXPORTS = {
     "afm_cdm_loop_workspace_bytes": (i64, [C.POINTER(CdmWeights), i32, i32, i32]),
     "afm_cdm_sample_loop": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p,
                                       i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, i32, C.POINTER(C.c_void_p), C.c_void_p]),
+    "afm_cdm_sample_loop_range": (C.c_int, [C.POINTER(CdmWeights), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p,
+                                            c_f32p, i32, i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, i32, C.POINTER(C.c_void_p),
+                                            C.c_void_p]),
     "afm_cdm_latent_tokens": (C.c_int, [C.POINTER(CdmWeights), i32, c_f32p, i32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "afm_profile_enable": (C.c_int, [i32]),
     "afm_profile_read": (C.c_int, [C.POINTER(ProfileEntry), i32]),
@@ -189,6 +192,9 @@ EXPORTS = {
     "afm_cmdm_sample_loop": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
                                        c_f32p, c_f32p, i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, i32,
                                        C.POINTER(C.c_void_p), C.c_void_p]),
+    "afm_cmdm_sample_loop_range": (C.c_int, [C.POINTER(CmdmWeights), c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p,
+                                             c_f32p, c_f32p, i32, i32, u64, i64, i32, i32, C.c_void_p, C.c_void_p, i64, i32,
+                                             C.POINTER(C.c_void_p), C.c_void_p]),
 }
 
 
@@ -252,3 +258,36 @@ def profile_read():
         check(n, "afm_profile_read")
     return {buf[i].name.decode(): dict(launches=buf[i].launches, total_ms=buf[i].total_ms, total_work=buf[i].total_work)
             for i in range(n)}
+
+
+def progress_slices(n_steps: int, progress: bool, slices: int = 50):
+    """Executed-step ranges [(j0, j1), ...] of a native sampling loop: one range without a progress bar, ~`slices` ranges with one
+    (the bar advances between native enqueues; gaussian_diffusion.py:520-523's tqdm over the step indices)."""
+    if not progress:
+        return [(0, n_steps)]
+    per = max(1, -(-n_steps // slices))
+    return [(j, min(j + per, n_steps)) for j in range(0, n_steps, per)]
+
+
+def run_slices(ranges, enqueue, progress: bool, device):
+    """Enqueue every slice; with a progress bar, advance it as the device finishes each slice (one event per slice, the next slice is
+    already queued while the host waits, so the GPU never idles on the bar)."""
+    import torch
+    if not progress:
+        for j0, j1 in ranges:
+            enqueue(j0, j1)
+        return
+    from tqdm.auto import tqdm
+    bar = tqdm(total=ranges[-1][1])
+    pending = None
+    for j0, j1 in ranges:
+        enqueue(j0, j1)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        if pending is not None:
+            pending[0].synchronize()
+            bar.update(pending[1])
+        pending = (ev, j1 - j0)
+    pending[0].synchronize()
+    bar.update(pending[1])
+    bar.close()

@@ -219,11 +219,11 @@ extern "C" int64_t afm_cmdm_loop_workspace_bytes(const afm_cmdm_weights* w, int3
     return total;
 }
 
-extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_tokens, const uint8_t* frame_mask,
-                                    const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
-                                    const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed,
-                                    int64_t sample_index0, int32_t B, int32_t L, void* sched_scratch, void* workspace,
-                                    int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream) {
+static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* cond_tokens, const uint8_t* frame_mask,
+                            const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                            const float* d_c2, const float* d_sigma, int32_t n_steps, int32_t first_step, uint64_t seed,
+                            int64_t sample_index0, int32_t B, int32_t L, void* sched_scratch, void* workspace,
+                            int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream) {
     AFM_TRY(validate(w, B, L));
     if (!x || (w->n_cond > 0 && !cond_tokens) || !d_timestep_map || !d_c1 || !d_c2 || !d_sigma || n_steps <= 0 ||
         !sched_scratch || !workspace || n_streams < 0 || (n_streams > 1 && !side_streams))
@@ -277,7 +277,7 @@ extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const f
             dd.x_next = x + (int64_t)start[s] * row;      // in place: each element is read then written by the same lane
             dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s];
             dd.sigma = sg_all + (int64_t)j * B + start[s];
-            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = j;
+            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = first_step + j;
             rc = forward_impl(*w, x + (int64_t)start[s] * row, t_all + (int64_t)j * B + start[s],
                               cond_tokens ? cond_tokens + (int64_t)start[s] * w->n_cond * w->d : nullptr,
                               frame_mask ? frame_mask + (int64_t)start[s] * L : nullptr, nullptr, &dd, count[s], L, ws[s], j == 0,
@@ -296,4 +296,24 @@ extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const f
         (void)hipEventDestroy(fork);
     }
     return rc;
+}
+
+extern "C" int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_tokens, const uint8_t* frame_mask,
+                                    const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                                    const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed,
+                                    int64_t sample_index0, int32_t B, int32_t L, void* sched_scratch, void* workspace,
+                                    int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream) {
+    return sample_loop_impl(w, x, cond_tokens, frame_mask, step_noise, d_timestep_map, d_c1, d_c2, d_sigma, n_steps, 0, seed,
+                            sample_index0, B, L, sched_scratch, workspace, workspace_bytes, n_streams, side_streams, stream);
+}
+
+extern "C" int afm_cmdm_sample_loop_range(const afm_cmdm_weights* w, float* x, const float* cond_tokens,
+                                          const uint8_t* frame_mask, const float* step_noise, const int64_t* d_timestep_map,
+                                          const float* d_c1, const float* d_c2, const float* d_sigma, int32_t n_steps,
+                                          int32_t first_step, uint64_t seed, int64_t sample_index0, int32_t B, int32_t L,
+                                          void* sched_scratch, void* workspace, int64_t workspace_bytes, int32_t n_streams,
+                                          void* const* side_streams, void* stream) {
+    if (first_step < 0) return AFM_E_BADARG;
+    return sample_loop_impl(w, x, cond_tokens, frame_mask, step_noise, d_timestep_map, d_c1, d_c2, d_sigma, n_steps, first_step,
+                            seed, sample_index0, B, L, sched_scratch, workspace, workspace_bytes, n_streams, side_streams, stream);
 }

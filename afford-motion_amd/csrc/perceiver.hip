@@ -589,11 +589,11 @@ extern "C" int64_t afm_cdm_loop_workspace_bytes(const afm_cdm_weights* w, int32_
 // sample on exit; feat [B,N,feat_dim] holds the step-invariant columns (point features, xyz) - its leading contact_dim columns are
 // rewritten from x every step.  Sub-batch s runs on streams[2s] with streams[2s+1] as the side stream of its decoder-adapter GEMM
 // (n_sub <= 1: everything on `stream`, streams[0] = optional side stream).
-extern "C" int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
-                                   const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
-                                   const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0, int32_t B,
-                                   int32_t N, void* sched_scratch, void* workspace, int64_t workspace_bytes, int32_t n_sub, void* const* streams,
-                                   void* stream) {
+static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
+                                const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                                const float* d_c2, const float* d_sigma, int32_t n_steps, int32_t first_step, uint64_t seed,
+                                int64_t sample_index0, int32_t B, int32_t N, void* sched_scratch, void* workspace, int64_t workspace_bytes,
+                                int32_t n_sub, void* const* streams, void* stream) {
     AFM_TRY(validate(w, B, N));
     if (!x || !feat || !text_q0 || !text_u || !text_cu || !d_timestep_map || !d_c1 || !d_c2 || !d_sigma || n_steps <= 0 || !sched_scratch ||
         !workspace || n_sub < 0 || (n_sub > 1 && !streams))
@@ -651,13 +651,13 @@ extern "C" int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* fe
             afm_ddpm_args dd = {};
             if (step_noise) dd.noise = step_noise + ((int64_t)j * B + start[s]) * per;
             else {
-                rc = afm_randn(noise[s], count[s], per, seed, sample_index0 + start[s], j, mainst[s]);
+                rc = afm_randn(noise[s], count[s], per, seed, sample_index0 + start[s], first_step + j, mainst[s]);
                 if (rc) break;
                 dd.noise = noise[s];
             }
             dd.x_next = xs;                               // in place: each element is read then written by the same lane
             dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s]; dd.sigma = sg_all + (int64_t)j * B + start[s];
-            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = j;
+            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = first_step + j;
             rc = cdm_forward_impl(w, fs, xs, t_all + (int64_t)j * B + start[s], text_q0 + (int64_t)start[s] * dq,
                                   text_u + (int64_t)start[s] * He * dkv, text_cu + (int64_t)start[s] * He, nullptr, &dd, count[s], N, wsp[s], wsb[s],
                                   sidest[s], mainst[s]);
@@ -675,4 +675,23 @@ extern "C" int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* fe
         (void)hipEventDestroy(fork);
     }
     return rc;
+}
+
+extern "C" int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
+                                   const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                                   const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0, int32_t B,
+                                   int32_t N, void* sched_scratch, void* workspace, int64_t workspace_bytes, int32_t n_sub, void* const* streams,
+                                   void* stream) {
+    return cdm_sample_loop_impl(w, x, feat, text_q0, text_u, text_cu, step_noise, d_timestep_map, d_c1, d_c2, d_sigma, n_steps, 0, seed,
+                                sample_index0, B, N, sched_scratch, workspace, workspace_bytes, n_sub, streams, stream);
+}
+
+extern "C" int afm_cdm_sample_loop_range(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
+                                         const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                                         const float* d_c2, const float* d_sigma, int32_t n_steps, int32_t first_step, uint64_t seed,
+                                         int64_t sample_index0, int32_t B, int32_t N, void* sched_scratch, void* workspace,
+                                         int64_t workspace_bytes, int32_t n_sub, void* const* streams, void* stream) {
+    if (first_step < 0) return AFM_E_BADARG;
+    return cdm_sample_loop_impl(w, x, feat, text_q0, text_u, text_cu, step_noise, d_timestep_map, d_c1, d_c2, d_sigma, n_steps, first_step,
+                                seed, sample_index0, B, N, sched_scratch, workspace, workspace_bytes, n_sub, streams, stream);
 }

@@ -403,6 +403,19 @@ int afm_cmdm_sample_loop(const afm_cmdm_weights* w, float* x, const float* cond_
                          int32_t B, int32_t L, void* sched_scratch, void* workspace,
                          int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream);
 
+/* A contiguous slice of the same loop: runs executed steps first_step .. first_step+n_steps-1 of a longer chain (the
+ * Philox step counter continues at first_step, so chunks chained over [0, T) reproduce afm_cmdm_sample_loop bit for bit).
+ * The schedule rows and step_noise passed in are the SLICE's: d_*[i] for the slice's timesteps in ascending order (the
+ * slice walks them from index n_steps-1 down to 0), step_noise row 0 = the slice's first executed step.  This is what
+ * `progress=True` in the reference's test.py maps to (gaussian_diffusion.py:520-523: tqdm over the step indices): the host
+ * advances the progress bar between slices while each slice stays one native enqueue. */
+int afm_cmdm_sample_loop_range(const afm_cmdm_weights* w, float* x, const float* cond_tokens,
+                               const uint8_t* frame_mask, const float* step_noise,
+                               const int64_t* d_timestep_map, const float* d_c1, const float* d_c2,
+                               const float* d_sigma, int32_t n_steps, int32_t first_step, uint64_t seed,
+                               int64_t sample_index0, int32_t B, int32_t L, void* sched_scratch, void* workspace,
+                               int64_t workspace_bytes, int32_t n_streams, void* const* side_streams, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CDM (`Perceiver`) denoiser forward.  Replaces CDM.forward + ContactPerceiver.forward
  * (models/cdm.py:474-513,155-188) and the Perceiver-IO blocks it uses (models/modules.py:234-661:
@@ -467,6 +480,12 @@ int afm_cdm_sample_loop(const afm_cdm_weights* w, float* x, float* feat, const f
                         const float* d_c2, const float* d_sigma, int32_t n_steps, uint64_t seed, int64_t sample_index0,
                         int32_t B, int32_t N, void* sched_scratch, void* workspace, int64_t workspace_bytes, int32_t n_sub,
                         void* const* streams, void* stream);
+/* Slice of the loop, as afm_cmdm_sample_loop_range. */
+int afm_cdm_sample_loop_range(const afm_cdm_weights* w, float* x, float* feat, const float* text_q0, const float* text_u,
+                              const float* text_cu, const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
+                              const float* d_c2, const float* d_sigma, int32_t n_steps, int32_t first_step, uint64_t seed,
+                              int64_t sample_index0, int32_t B, int32_t N, void* sched_scratch, void* workspace,
+                              int64_t workspace_bytes, int32_t n_sub, void* const* streams, void* stream);
 
 /* Latent-token precomputation (step-invariant, off the per-step path): for n input rows `in` [n, text_dim] (which = 0,
  * language_adapter) or [n, time_dim] (which = 1, time_embedding_adapter) compute the latent's enc_q0 row

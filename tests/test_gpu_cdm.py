@@ -133,8 +133,16 @@ def test_native_loop_matches_stepwise_and_is_sub_batch_invariant(cdm):
         outs.append(d8.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=11, sample_index0=7))
     cdm.loop_sub_batches = 2
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    step = d8.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=11, sample_index0=7, progress=True)
+    step = None
+    for o in d8.p_sample_loop_progressive(cdm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=11, sample_index0=7):
+        step = o["sample"]
     report("CDM native loop vs step-by-step (8 steps)", outs[0], step, 1e-4)
+    # test.py's call pattern (progress=True, non-tensor info_* entries): sliced native loop, bit-identical to the unsliced one
+    d60 = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="60"))
+    kwi = dict(kw, info_index=list(range(B)), c_text=["walk"] * B)
+    whole = d60.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, noise=None, model_kwargs=kwi, seed=3, sample_index0=7)
+    sliced = d60.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, noise=None, model_kwargs=kwi, seed=3, sample_index0=7, progress=True)
+    assert torch.equal(whole, sliced)
     # sharding invariance: samples 2..4 computed alone with their global indices give the same rows
     kw2 = {k: v[2:] for k, v in kw.items()}
     part = d8.p_sample_loop(cdm, (3, N, 6), clip_denoised=False, model_kwargs=kw2, seed=11, sample_index0=9)

@@ -76,6 +76,15 @@ def test_sample_loop_vs_reference_golden(cmdm, steps, resp, tag):
         generic = out["sample"]
     report(f"generic loop {tag}", generic, want, 1e-3)
     report(f"native vs generic {tag}", native, generic.cpu(), 1e-5)
+    # test.py:94-101 passes progress=True: the sliced native loop is bit-identical, with recorded noise and with Philox noise
+    sliced = diff.p_sample_loop(model, (2, 16, 263), noise=xT, clip_denoised=False, model_kwargs=_kw(g), step_noise=nz, progress=True)
+    assert torch.equal(native, sliced)
+    if tag == "r5":
+        d70 = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="70"))
+        kwi = dict(_kw(g), info_set_split=["test", "test"], c_text=["a", "b"])
+        a = d70.p_sample_loop(model, (2, 16, 263), clip_denoised=False, noise=None, model_kwargs=kwi, seed=5, sample_index0=3)
+        b = d70.p_sample_loop(model, (2, 16, 263), clip_denoised=False, noise=None, model_kwargs=kwi, seed=5, sample_index0=3, progress=True)
+        assert torch.equal(a, b)
 
 
 def test_training_losses_vs_reference_golden(cmdm):
