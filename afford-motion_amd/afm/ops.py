@@ -62,6 +62,15 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def set_gemm_split(products: int) -> int:
+    """Arithmetic mode of `linear` for large GEMMs (afm_linear_set_split): 0 = native f32 MFMA (default), 9 / 6 = exact three-way bf16
+    operand split on the bf16 matrix pipe with all nine / the six largest cross products.  Returns the previous mode."""
+    prev = ffi.load().afm_linear_set_split(int(products))
+    if prev < 0:
+        ffi.check(prev, "afm_linear_set_split")
+    return prev
+
+
 def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
     """qkv [B, T, 3*d] (packed in_proj output) -> softmax(QK^T/sqrt(dh) + mask) V, [B, T, d]."""
     lib = ffi.load()

@@ -1,0 +1,274 @@
+// afm_linear on the bf16 matrix pipe with f32 results: every f32 operand is split EXACTLY into three bf16 terms
+// (x = x1 + x2 + x3, 8 + 8 + 8 significant bits, round-to-nearest residual chain), the products x_i * w_j are exact in
+// f32 inside v_mfma_f32_32x32x16_bf16 and accumulate in f32, so the sum of all nine products is the f32 dot product
+// with f32 accumulation - the arithmetic of v_mfma_f32_32x32x2_f32 up to summation order.  gfx950's f32 MFMA runs at
+// 1/16 of the bf16 rate (157 vs 2500 TF), so nine bf16 MFMAs cost 9/16 of one f32 MFMA's time.
+//   NPROD = 9: all products (error = f32 accumulation order only).
+//   NPROD = 6: drops x2*w3, x3*w2, x3*w3 (each <= 2^-24 relative to |x||w|, zero-mean because the split rounds to nearest).
+// Measured against float64 (tools/gemm_bench.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
+// native f32 MFMA kernel.  OPT-IN (AFM_GEMM_SPLIT=9|6 or afm_linear_set_split): on MI355X the in-kernel split makes the 9-product variant
+// only ~10 % faster than the native kernels (102 vs 92 TF in the sampling loop, 398 vs 399 steps/s end to end) because VALU and MFMA
+// time on a SIMD add up rather than overlap (profiles/r01_gemm_investigation.md); the 6-product variant reaches 447 steps/s.
+//
+// Kernel: 256 threads = 2x2 waves, wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, K consumed BK at a time.
+//   global f32 -> registers (next K-tile, issued before the MFMAs of the current one) -> split in VALU, interleaved with
+//   the MFMA stream -> three bf16 planes in LDS ([row][BK] bf16, rows padded by 16 B: ds_read_b128 / ds_write_b128 of a
+//   16-lane group hit 16 distinct 16-byte bank groups) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
+//   One barrier per K-tile (double-buffered LDS), shared epilogue of gemm.hip.
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "profile.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // first-class 16-byte value (HIP's uint4 struct copies can pin arrays in scratch)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// v_cvt_pk_bf16_f32 (round to nearest even); a builtin conversion, not inline asm, so the machine scheduler can place it
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// two f32 -> three packed bf16 pairs; every residual subtraction is exact (|x - bf16(x)| <= half a bf16 ulp of x)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(p2 << 16);
+    r1 -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = cvt_pk_bf16(r0, r1);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// product order: small terms first inside every K16 step
+__device__ constexpr int PA[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0};
+__device__ constexpr int PB[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+
+template <int BM, int BN, int BKS, int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int CPR = BKS / 8;                      // 8-float chunks per row of a K-tile
+    constexpr int ROWB = BKS * 2 + 16;                // LDS row bytes (bf16 + pad)
+    constexpr int ROWS = BM + BN;                     // A rows then W rows
+    constexpr int PLANE = ROWS * ROWB;
+    constexpr int STAGE = 3 * PLANE;
+    constexpr int NI = ROWS * CPR / 256;              // (row, chunk) items per thread
+    static_assert(ROWS * CPR % 256 == 0, "tile does not divide over 256 threads");
+    constexpr int LDC = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* lds = lds_raw;
+
+    const int nblk = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / nbn, bn = bid % nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off};
+    const float* src[NI];
+    int dst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int it = tid + 256 * i, row = it / CPR, ch = it % CPR;
+        src[i] = (row < BM ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
+                           : p.W + (int64_t)min(bn * BN + row - BM, p.N - 1) * p.ldw) + ch * 8;
+        dst[i] = row * ROWB + ch * 16;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Two register sets, always indexed with compile-time constants: at the top of K-tile kt the set (kt & 1) is free (its
+    // tile went to LDS during kt - 1) and receives tile kt + 2; the other set holds tile kt + 1 (loaded one full K-tile
+    // ago) and is split into the other LDS stage between the MFMAs of tile kt.
+    float4 g[2][NI][2];
+    const int nk = p.K / BKS;
+    auto load = [&](auto SETC, int kt) {
+        constexpr int S = decltype(SETC)::value;
+        const int k = min(kt, nk - 1) * BKS;          // past the end: re-load the last tile (never consumed)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            g[S][i][0] = *reinterpret_cast<const float4*>(src[i] + k);
+            g[S][i][1] = *reinterpret_cast<const float4*>(src[i] + k + 4);
+        }
+    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    load(Set0{}, 0);
+    load(Set1{}, 1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        uint4 q1, q2, q3;
+        split2(g[0][i][0].x, g[0][i][0].y, q1.x, q2.x, q3.x);
+        split2(g[0][i][0].z, g[0][i][0].w, q1.y, q2.y, q3.y);
+        split2(g[0][i][1].x, g[0][i][1].y, q1.z, q2.z, q3.z);
+        split2(g[0][i][1].z, g[0][i][1].w, q1.w, q2.w, q3.w);
+        unsigned char* d = lds + dst[i];
+        *reinterpret_cast<uint4*>(d) = q1;
+        *reinterpret_cast<uint4*>(d + PLANE) = q2;
+        *reinterpret_cast<uint4*>(d + 2 * PLANE) = q3;
+    }
+    __syncthreads();
+
+    const int a_off = (wm * (BM / 2) + r32) * ROWB + hh * 16;
+    const int w_off = (BM + wn * (BN / 2) + r32) * ROWB + hh * 16;
+    constexpr int NMFMA = (BKS / 16) * NPROD * TM * TN;      // MFMAs per wave per K-tile
+    constexpr int NPIECE = NI * 4 * 3;                        // split pieces per thread per K-tile (pair of floats x residual level)
+
+    // One K-tile.  The instruction order is written out and pinned with sched_barrier fences (hipcc otherwise hoists all
+    // MFMAs in front of the split and chains the nine MFMAs of one accumulator back to back): after every MFMA a piece of
+    // the next tile's split (~5 VALU) issues in the shadow of the 32-cycle matrix op.
+    auto body = [&](auto CURC, int kt) {          // K-tile kt with kt & 1 == cur: register set cur is free, set cur ^ 1 holds tile kt + 1
+        constexpr int cur = decltype(CURC)::value;
+        load(CURC, kt + 2);
+        const unsigned char* base = lds + cur * STAGE;
+        unsigned char* wbase = lds + (cur ^ 1) * STAGE;
+        float r0[NI * 4], r1[NI * 4];
+        uint32_t sp[NI * 4][3];
+        int piece = 0, m = 0;
+        auto do_piece = [&](int t) {
+            const int u = t / 3, lvl = t % 3, i = u / 4, c = u % 4;
+            if (lvl == 0) {
+                const float4 v = g[cur ^ 1][i][c >> 1];
+                r0[u] = (c & 1) ? v.z : v.x;
+                r1[u] = (c & 1) ? v.w : v.y;
+            }
+            const uint32_t pk = cvt_pk_bf16(r0[u], r1[u]);
+            sp[u][lvl] = pk;
+            if (lvl < 2) {
+                r0[u] -= __uint_as_float(pk << 16);
+                r1[u] -= __uint_as_float(pk & 0xffff0000u);
+            } else if (c == 3) {
+                unsigned char* d = wbase + dst[i];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<uint4*>(d + pl * PLANE) = make_uint4(sp[4 * i][pl], sp[4 * i + 1][pl], sp[4 * i + 2][pl], sp[4 * i + 3][pl]);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < BKS / 16; ++s) {
+            uint4 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + a_off + i * 32 * ROWB + s * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + w_off + j * 32 * ROWB + s * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 9 - NPROD; q < 9; ++q)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn] = mfma_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn]);
+                        ++m;
+#pragma unroll
+                        for (int t = 0; t < NPIECE; ++t)
+                            if (t >= piece && t < (m * NPIECE) / NMFMA) do_piece(t);
+                        piece = (m * NPIECE) / NMFMA;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        body(Set0{}, kt);
+        if (kt + 1 < nk) body(Set1{}, kt + 1);
+    }
+
+    float* ldsf = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
+    __syncthreads();
+    gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid);
+}
+
+template <int BM, int BN, int BKS, int NPROD>
+int launch_split(const afm_linear_args& a, hipStream_t s) {
+    constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
+    constexpr int LDS_BYTES = 2 * STAGE > BM * (BN + 4) * 4 ? 2 * STAGE : BM * (BN + 4) * 4;
+    static const int attr = []() {
+        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16<BM, BN, BKS, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }();
+    if (attr != 0) return attr;
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    AfmProf prof(BM == 128 ? AFM_PROF_GEMM_SPLIT128 : AFM_PROF_GEMM_SPLIT64, 2.0 * a.M * a.N * a.K, s);
+    hipLaunchKernelGGL((gemm_f32_split_bf16<BM, BN, BKS, NPROD>), dim3(nbm * nbn), dim3(256), LDS_BYTES, s, a, nbm, nbn);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NPROD>
+int dispatch_split(const afm_linear_args& a, hipStream_t s) {
+    static const int tile = []() { const char* e = getenv("AFM_GEMM_SPLIT_TILE"); return e ? atoi(e) : 0; }();      // tuning knob
+    // 128x128 amortises the split best (each thread splits 16 floats per 36 MFMAs of its wave); with fewer 128x128 tiles
+    // than CUs, 64x64 tiles fill the chip better (measured on M = 5216, N = 512: 34.8 vs 41.3 us)
+    const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (tile == 2 || (tile == 0 && tiles128 < 256)) return launch_split<64, 64, 16, NPROD>(a, s);
+    return launch_split<128, 128, 16, NPROD>(a, s);
+}
+
+}  // namespace
+
+// Products per f32 product used by afm_linear: 0 = native f32 MFMA kernels (default), 9 / 6 = split-bf16 path.
+// Initial value from AFM_GEMM_SPLIT; afm_linear_set_split changes it at run time (returns the previous value).
+static std::atomic<int> g_split_mode{-1};
+
+static int split_mode_now() {
+    int m = g_split_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("AFM_GEMM_SPLIT");
+        m = e ? atoi(e) : 0;
+        if (m != 9 && m != 6) m = 0;
+        g_split_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+extern "C" int afm_linear_set_split(int products) {
+    if (products != 0 && products != 6 && products != 9) return AFM_E_BADARG;
+    const int prev = split_mode_now();
+    g_split_mode.store(products, std::memory_order_relaxed);
+    return prev;
+}
+
+// The split path pays for shapes with enough K to amortise its prologue and enough rows to fill the chip; everything else
+// (the K = 3..64 point-cloud layers, per-sample vectors, unaligned operands) stays on the native kernels.
+int afm_linear_split_mode(const afm_linear_args& a) {
+    const int mode = split_mode_now();
+    if (!mode) return 0;
+    const bool ok = (a.K % 16 == 0) && a.K >= 128 && a.M >= 512 && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
+                    (((uintptr_t)a.W & 15) == 0);
+    return ok ? mode : 0;
+}
+
+int afm_linear_split(const afm_linear_args& a, int mode, hipStream_t s) {
+    return mode == 9 ? dispatch_split<9>(a, s) : dispatch_split<6>(a, s);
+}

@@ -29,6 +29,35 @@ def test_linear_shapes(M, N, K):
     report(f"linear {M}x{N}x{K}", got, want, 2e-4)
 
 
+@pytest.mark.parametrize("products", [9, 6])
+@pytest.mark.parametrize("M,N,K", [(10432, 512, 1024), (9000, 1500, 256), (1000, 1536, 512), (5216, 512, 512), (777, 263, 512), (640, 96, 144)])
+def test_linear_split_bf16_mode(products, M, N, K):
+    """afm_linear_set_split: f32 operands split exactly into three bf16 terms, products on the bf16 matrix pipe, f32 accumulate.
+    The error against float64 must stay at the native f32 MFMA kernel's level (same products, different summation order), on
+    both tile variants (128x128 / 64x64), with ragged M / N edges and every epilogue input."""
+    lib = ffi.load()
+    x = synth.gaussian("sp_x", (M, K)); w = synth.gaussian("sp_w", (N, K)) / math.sqrt(K); b = synth.gaussian("sp_b", (N,))
+    res = synth.gaussian("sp_r", (M, N))
+    x[::7] *= 50.0                                        # mixed magnitudes: the residual terms matter
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + res.double()
+    scale = (x.double().abs() @ w.double().abs().t()) + b.double().abs() + 1e-30
+    args = (x.to(dev()), w.to(dev()), b.to(dev()))
+    native = ops.linear(*args, act=ffi.ACT_GELU, residual=res.to(dev()))
+    prev = lib.afm_linear_set_split(products)
+    try:
+        assert prev == 0
+        got = ops.linear(*args, act=ffi.ACT_GELU, residual=res.to(dev()))
+    finally:
+        assert lib.afm_linear_set_split(prev) == products
+    e_split = ((got.double().cpu() - ref).abs() / scale).max().item()
+    e_native = ((native.double().cpu() - ref).abs() / scale).max().item()
+    print(f"split x{products} {M}x{N}x{K}: max err / sum|a||w| = {e_split:.2e} (native f32 MFMA {e_native:.2e})")
+    assert e_split <= max(1.5 * e_native, 3e-7)
+    assert (got - native).abs().max().item() <= 1e-5 * native.abs().max().item()
+    assert lib.afm_linear_set_split(5) == -1              # AFM_E_BADARG, mode unchanged
+    assert lib.afm_linear_set_split(0) == 0
+
+
 def test_linear_detects_transposed_layouts():
     # asymmetric operands + identity A (guide: always A=I-check with asymmetric B)
     K = N = 64
