@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--latency-runs", type=int, default=3, help="full 1000-step loops for the p50 sample latency (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-gemm", action="store_true", help="skip the informational passes with the split-bf16 GEMM modes")
     ap.add_argument("--streams", type=int, default=None, help="sub-batch HIP streams of the native loop (default: model default, 2)")
     args = ap.parse_args()
 
@@ -123,6 +124,7 @@ def main():
     model, diff_k, cfg = build(dev, str(K))
     if args.streams is not None:
         model.loop_streams = args.streams
+    streams_default = model.loop_streams
     from afm.base import create_gaussian_diffusion
     cfg.diffusion.timestep_respacing = str(max(W, 1))
     diff_w = create_gaussian_diffusion(cfg)
@@ -212,6 +214,28 @@ def main():
             ts.append(1e3 * (time.perf_counter() - t0))
         lat = {"p50_ms": round(statistics.median(ts), 1), "runs": args.latency_runs, "steps": 1000, "batch": B}
 
+    # informational only (never `value`): the same K steps with afm_linear's opt-in arithmetic modes - f32 operands split exactly
+    # into three bf16 terms, products on the bf16 matrix pipe, f32 accumulate (9 = all cross products, 6 = the six largest)
+    alt = None
+    if rank == 0 and world == 1 and not args.no_alt_gemm:
+        from afm import ops as afm_ops
+        alt = {}
+        for products in (9, 6):
+            prev = afm_ops.set_gemm_split(products)
+            try:
+                for streams in (1, 2):
+                    model.loop_streams = streams
+                    run(diff_w, 1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    run(diff_k, 2)
+                    torch.cuda.synchronize()
+                    alt[f"split_bf16x3_{products}_products_{streams}_streams"] = round(K / (time.perf_counter() - t0), 2)
+            finally:
+                afm_ops.set_gemm_split(prev)
+                model.loop_streams = streams_default
+        alt["unit"] = "steps/s"
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -227,7 +251,7 @@ def main():
                        "conditions": "hoisted (step-invariant, computed once: setup_ms)", "parallelism": f"batch-shard x{world}", "sub_batch_streams": model.loop_streams},
             "algorithmic_tflops": round(step_flops(B) * world * K / dt / 1e12, 2),
             "setup_ms": round(setup_ms, 2), "setup_ms_steady": round(setup_ms_steady, 2),
-            "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat,
+            "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat, "alt_gemm_modes": alt,
         }
         print(json.dumps(line))
     if world > 1:

@@ -112,6 +112,33 @@ def test_full_size_vs_oracle():
     report("CMDM forward L=196 T=326 vs oracle", got, want, 3e-4)
 
 
+def test_split_bf16_gemm_modes_track_native_f32_over_a_sampling_run():
+    """afm_linear_set_split(9 | 6): the exact three-way bf16 operand split on the bf16 matrix pipe is f32 arithmetic in another
+    summation order, so a 200-step sampling run (full-size tokens, shared Philox noise) stays within f32 drift of the native run."""
+    from afm import ops as afm_ops
+    cfg = cmdm_cfg(num_points=8192, steps=1000, respacing="200")
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    B, L = 4, 196
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("full_cont", (B, 128, 256)).to(dev()),
+              x_mask=synth.frame_mask(B, L, seed=3).to(dev()))
+    runs = {}
+    for products in (0, 9, 6):
+        prev = afm_ops.set_gemm_split(products)
+        try:
+            runs[products] = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=21)
+        finally:
+            afm_ops.set_gemm_split(prev)
+    valid = ~kw["x_mask"]
+    scale = runs[0][valid].abs().max().item()
+    for products in (9, 6):
+        drift = (runs[products] - runs[0])[valid].abs().max().item()
+        print(f"split x{products}: max |x_0 - native| after 200 steps = {drift:.2e} (max |x_0| = {scale:.2f})")
+        assert drift <= 2e-4 * max(scale, 1.0)
+    assert not torch.equal(runs[9], runs[0])             # the mode really switched kernels
+
+
 def test_sharding_invariance_of_native_loop(cmdm):
     """Philox noise is keyed by the global sample index: sampling 2 samples at once equals sampling
     them one by one with sample_index0 = 0 / 1 (what rank r does for its shard)."""
