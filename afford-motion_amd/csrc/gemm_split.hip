@@ -4,8 +4,8 @@
 // with f32 accumulation - the arithmetic of v_mfma_f32_32x32x2_f32 up to summation order.  gfx950's f32 MFMA runs at
 // 1/16 of the bf16 rate (157 vs 2500 TF), so nine bf16 MFMAs cost 9/16 of one f32 MFMA's time.
 //   NPROD = 9: all products (error = f32 accumulation order only).
-//   NPROD = 6: drops x2*w3, x3*w2, x3*w3 (|x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|: each dropped product <= 2^-26 |x||w|, zero-mean because the
-//              split rounds to nearest - an order of magnitude below the rounding noise of the f32 accumulation itself).
+//   NPROD = 6: drops x2*w3, x3*w2, x3*w3 (|x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|: each dropped product <= 2^-24 |x||w|, rms ~2^-26, zero-mean because
+//              the split rounds to nearest - an order of magnitude below the rounding noise of the f32 accumulation itself).
 // Measured against float64 (tools/gemm_bench.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
 // native f32 MFMA kernel.  OPT-IN (AFM_GEMM_SPLIT=9|6 or afm_linear_set_split): on MI355X the in-kernel split makes the 9-product variant
 // only ~10 % faster than the native kernels (102 vs 92 TF in the sampling loop, 390-410 vs 390-401 steps/s end to end) because VALU and MFMA

@@ -91,7 +91,7 @@ int afm_linear(const afm_linear_args* args, void* stream);
  *   9            every f32 operand is split exactly into three bf16 terms inside the kernel and all nine cross products run on
  *                the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak) with f32 accumulation: the same products, exact,
  *                in a different summation order (measured error vs float64 <= the native kernel's, tools/gemm_bench.cpp);
- *   6            as 9 without the three smallest products (each <= 2^-26 |a||w|; what oneMKL calls float_to_bf16x3).
+ *   6            as 9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3).
  * Process-wide; initial value from the environment variable AFM_GEMM_SPLIT.  Returns the previous mode, or AFM_E_BADARG. */
 int afm_linear_set_split(int products);
 
