@@ -118,6 +118,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     "afm_version": (C.c_int, []),
     "afm_linear_set_split": (C.c_int, [C.c_int]),
+    "afm_linear_set_split_min_n": (C.c_int, [C.c_int]),
     "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_cross_fwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),

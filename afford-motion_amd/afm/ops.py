@@ -62,13 +62,30 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
-def set_gemm_split(products: int) -> int:
-    """Arithmetic mode of `linear` for large GEMMs (afm_linear_set_split): 0 = native f32 MFMA (default), 9 / 6 = exact three-way bf16
-    operand split on the bf16 matrix pipe with all nine / the six largest cross products.  Returns the previous mode."""
-    prev = ffi.load().afm_linear_set_split(int(products))
+def set_gemm_split(products: int, min_n: Optional[int] = None):
+    """Arithmetic of `linear`'s wide GEMMs (afm_linear_set_split): 9 = exact three-way bf16 operand split on the bf16 matrix pipe with all
+    nine cross products (default, for N >= 1024), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N
+    threshold.  Returns the previous setting in the same form (products, or (products, min_n) when ``min_n`` was given)."""
+    lib = ffi.load()
+    prev = lib.afm_linear_set_split(int(products))
     if prev < 0:
         ffi.check(prev, "afm_linear_set_split")
-    return prev
+    if min_n is None:
+        return prev
+    prev_n = lib.afm_linear_set_split_min_n(int(min_n))
+    if prev_n < 0:
+        ffi.check(prev_n, "afm_linear_set_split_min_n")
+    return prev, prev_n
+
+
+def get_gemm_split():
+    """Current (products, min_n) of `linear`'s wide-GEMM arithmetic."""
+    lib = ffi.load()
+    products = lib.afm_linear_set_split(0)
+    lib.afm_linear_set_split(products)
+    min_n = lib.afm_linear_set_split_min_n(0)
+    lib.afm_linear_set_split_min_n(min_n)
+    return products, min_n
 
 
 def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:

@@ -7,9 +7,10 @@
 //   NPROD = 6: drops x2*w3, x3*w2, x3*w3 (|x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|: each dropped product <= 2^-24 |x||w|, rms ~2^-26, zero-mean because
 //              the split rounds to nearest - an order of magnitude below the rounding noise of the f32 accumulation itself).
 // Measured against float64 (tools/gemm_bench.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
-// native f32 MFMA kernel.  OPT-IN (AFM_GEMM_SPLIT=9|6 or afm_linear_set_split): on MI355X the in-kernel split makes the 9-product variant
-// only ~10 % faster than the native kernels (102 vs 92 TF in the sampling loop, 390-410 vs 390-401 steps/s end to end) because VALU and MFMA
-// time on a SIMD add up rather than overlap (profiles/r01_gemm_investigation.md); the 6-product variant reaches 470-505 steps/s (bench.py `alt_gemm_modes`).
+// native f32 MFMA kernel.  Default: the exact 9-product variant on the wide GEMMs (N >= 1024: in_proj, linear1), where it is 1.26x faster than
+// the native kernel stand-alone and +10 % end to end (443 vs 402 steps/s); the N = 512 GEMMs stay native (the split gains less there and the
+// bf16 pipe's power draw lowers the clock for everything around it, profiles/r01_gemm_investigation.md).  AFM_GEMM_SPLIT=0 restores the native
+// kernels everywhere; AFM_GEMM_SPLIT=6 with AFM_GEMM_SPLIT_MIN_N=0 is the fastest setting (534 steps/s).
 //
 // Kernel: 256 threads = 2x2 waves, wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, K consumed BK at a time.
 //   global f32 -> registers (next K-tile, issued before the MFMAs of the current one) -> split in VALU, interleaved with
@@ -85,7 +86,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
     int dst[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int it = tid + 256 * i, row = it / CPR, ch = it % CPR;
+        // item -> (row, chunk): inside every block of 8 rows, an 8-lane group (the unit ds_write_b128 is serviced in) takes the four
+        // even rows and the next group the four odd rows, so its eight 16-byte stores fall on eight different slots of the 128-byte
+        // bank window (with row stride 48 B, rows r and r + 3 would meet); lanes 2k, 2k+1 still read one row's 64 contiguous bytes
+        const int it = tid + 256 * i, blk = it >> 4, j = it & 15;
+        const int row = CPR == 2 ? blk * 8 + 2 * ((j & 7) >> 1) + (j >> 3) : it / CPR, ch = CPR == 2 ? (j & 1) : it % CPR;
         src[i] = (row < BM ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
                            : p.W + (int64_t)min(bn * BN + row - BM, p.N - 1) * p.ldw) + ch * 8;
         dst[i] = row * ROWB + ch * 16;
@@ -238,19 +243,31 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
 
 }  // namespace
 
-// Products per f32 product used by afm_linear: 0 = native f32 MFMA kernels (default), 9 / 6 = split-bf16 path.
-// Initial value from AFM_GEMM_SPLIT; afm_linear_set_split changes it at run time (returns the previous value).
+// Products per f32 product used by afm_linear for its wide GEMMs: 9 (default, exact), 6, or 0 = native f32 MFMA kernels everywhere.
+// Initial values from AFM_GEMM_SPLIT / AFM_GEMM_SPLIT_MIN_N; afm_linear_set_split / afm_linear_set_split_min_n change them at run time.
 static std::atomic<int> g_split_mode{-1};
+static std::atomic<int> g_split_min_n{-1};
 
 static int split_mode_now() {
     int m = g_split_mode.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("AFM_GEMM_SPLIT");
-        m = e ? atoi(e) : 0;
+        m = e ? atoi(e) : 9;
         if (m != 9 && m != 6) m = 0;
         g_split_mode.store(m, std::memory_order_relaxed);
     }
     return m;
+}
+
+static int split_min_n_now() {
+    int n = g_split_min_n.load(std::memory_order_relaxed);
+    if (n < 0) {
+        const char* e = getenv("AFM_GEMM_SPLIT_MIN_N");
+        n = e ? atoi(e) : 1024;
+        if (n < 0) n = 0;
+        g_split_min_n.store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 extern "C" int afm_linear_set_split(int products) {
@@ -260,12 +277,20 @@ extern "C" int afm_linear_set_split(int products) {
     return prev;
 }
 
-// The split path pays for shapes with enough K to amortise its prologue and enough rows to fill the chip; everything else
-// (the K = 3..64 point-cloud layers, per-sample vectors, unaligned operands) stays on the native kernels.
+extern "C" int afm_linear_set_split_min_n(int min_n) {
+    if (min_n < 0) return AFM_E_BADARG;
+    const int prev = split_min_n_now();
+    g_split_min_n.store(min_n, std::memory_order_relaxed);
+    return prev;
+}
+
+// Which GEMMs take the split path is a function of (N, K) and operand alignment only - never of M - so a batch and its shards run the
+// same arithmetic (sharding / sub-batch invariance stays bit-exact).  Measured in the sampling loop (B = 32, two sub-batch streams):
+// native everywhere 402 steps/s, x9 on the N >= 1024 GEMMs (in_proj, linear1) 443, x9 everywhere 427, x6 everywhere 534.
 int afm_linear_split_mode(const afm_linear_args& a) {
     const int mode = split_mode_now();
     if (!mode) return 0;
-    const bool ok = (a.K % 16 == 0) && a.K >= 128 && a.M >= 512 && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
+    const bool ok = (a.K % 16 == 0) && a.K >= 128 && a.N >= split_min_n_now() && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
                     (((uintptr_t)a.W & 15) == 0);
     return ok ? mode : 0;
 }

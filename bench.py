@@ -37,15 +37,20 @@ def step_flops(batch: int, frames: int = L, groups: int = NPTS // 64) -> float:
     return batch * (5 * T * (4194304 + 2048 * T) + 2 * (2 * 263 * 512 * frames) + 2 * 2 * 512 * 512)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, corrected as
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes and calibrated on layernorm_kernel): written by tools/summarize_profiles.py into
     profiles/traffic.json on the GPU box; counters cannot be read from inside the process, so null when absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)
+            tr = json.load(f)
     except (OSError, ValueError):
         return None
+    want = kernel.replace(" ", "").rstrip(">")
+    for name, v in tr.get("kernels", {}).items():        # rocprof names carry every template argument: match on the prefix
+        if name.replace(" ", "").startswith(want):
+            return dict(v, kernel=name, source=tr.get("source"))
+    return None
 
 
 def build(dev, steps_cfg: str):
@@ -189,14 +194,15 @@ def main():
         if g:
             ach = g["total_work"] / (g["total_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(name),
                     "avg_launch_us": round(1e3 * g["total_ms"] / g["launches"], 2), "launches": g["launches"],
                     "flops_per_launch": g["total_work"] / g["launches"],
                     "all_kernels_ms_per_step": {k: round(v["total_ms"] / K, 4) for k, v in prof.items()}}
             if "split_bf16" in name:
                 # f32 results computed as 9 exact bf16 x bf16 products per f32 product on the bf16 matrix pipe: `achieved` / `peak` above
                 # are ALGORITHMIC f32 FLOPs against the f32 MFMA peak (the dtype's peak); the pipe actually used is priced here
-                nprod = int(os.environ.get("AFM_GEMM_SPLIT", "9") or 9)
+                from afm import ops as afm_ops
+                nprod = afm_ops.get_gemm_split()[0]
                 roof["matrix_pipe"] = {"instruction": "v_mfma_f32_32x32x16_bf16", "bf16_products_per_f32_product": nprod,
                                        "issued_tflops": round(ach * nprod, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                                        "frac": round(ach * nprod / BF16_MFMA_PEAK_TFLOPS, 4)}
@@ -214,26 +220,25 @@ def main():
             ts.append(1e3 * (time.perf_counter() - t0))
         lat = {"p50_ms": round(statistics.median(ts), 1), "runs": args.latency_runs, "steps": 1000, "batch": B}
 
-    # informational only (never `value`): the same K steps with afm_linear's opt-in arithmetic modes - f32 operands split exactly
-    # into three bf16 terms, products on the bf16 matrix pipe, f32 accumulate (9 = all cross products, 6 = the six largest)
+    # informational only (never `value`): the same K steps with afm_linear's other arithmetic settings.  Default (the timed run above):
+    # the exact nine-product bf16x3 split on the wide GEMMs (N >= 1024), native f32 MFMA kernels elsewhere.
     alt = None
     if rank == 0 and world == 1 and not args.no_alt_gemm:
         from afm import ops as afm_ops
         alt = {}
-        for products in (9, 6):
-            prev = afm_ops.set_gemm_split(products)
-            try:
-                for streams in (1, 2):
-                    model.loop_streams = streams
-                    run(diff_w, 1)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    run(diff_k, 2)
-                    torch.cuda.synchronize()
-                    alt[f"split_bf16x3_{products}_products_{streams}_streams"] = round(K / (time.perf_counter() - t0), 2)
-            finally:
-                afm_ops.set_gemm_split(prev)
-                model.loop_streams = streams_default
+        saved = afm_ops.get_gemm_split()
+        try:
+            for tag, (products, min_n) in (("native_f32_mfma_everywhere", (0, 0)), ("split9_all_gemms", (9, 0)),
+                                           ("split6_wide_gemms", (6, 1024)), ("split6_all_gemms", (6, 0))):
+                afm_ops.set_gemm_split(products, min_n)
+                run(diff_w, 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(diff_k, 2)
+                torch.cuda.synchronize()
+                alt[tag] = round(K / (time.perf_counter() - t0), 2)
+        finally:
+            afm_ops.set_gemm_split(*saved)
         alt["unit"] = "steps/s"
 
     cpu = None
@@ -247,6 +252,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CMDM trans_enc p_sample_loop, HumanML3D t2m_contact_motion config (BASELINE configs[1])",
+                       "gemm_arithmetic": "f32 in / f32 accumulate; N >= 1024 GEMMs: exact 3-way bf16 operand split, all 9 cross products on the bf16 MFMA pipe; others: f32 MFMA",
                        "batch_per_gpu": B, "frames": L, "motion_dim": D, "scene_points": NPTS, "tokens": 2 + NPTS // 64 + L,
                        "conditions": "hoisted (step-invariant, computed once: setup_ms)", "parallelism": f"batch-shard x{world}", "sub_batch_streams": model.loop_streams},
             "algorithmic_tflops": round(step_flops(B) * world * K / dt / 1e12, 2),

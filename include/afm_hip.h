@@ -86,14 +86,17 @@ typedef struct {
 
 int afm_linear(const afm_linear_args* args, void* stream);
 
-/* Optional arithmetic mode of afm_linear for K >= 128, M >= 512, 16-byte aligned operands (other calls are unaffected):
- *   0 (default)  native f32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak on gfx950);
- *   9            every f32 operand is split exactly into three bf16 terms inside the kernel and all nine cross products run on
- *                the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak) with f32 accumulation: the same products, exact,
- *                in a different summation order (measured error vs float64 <= the native kernel's, tools/gemm_bench.cpp);
- *   6            as 9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3).
- * Process-wide; initial value from the environment variable AFM_GEMM_SPLIT.  Returns the previous mode, or AFM_E_BADARG. */
+/* Arithmetic of afm_linear's wide GEMMs (N >= min_n, K >= 128, K % 16 == 0, 16-byte aligned operands; everything else always runs
+ * the native f32 MFMA kernels, v_mfma_f32_32x32x2_f32, 157 TF peak on gfx950):
+ *   9 (default)  every f32 operand is split exactly into three bf16 terms inside the kernel and all nine cross products run on the
+ *                bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak) with f32 accumulation: the same exact products as the
+ *                f32 MFMA in a different summation order (measured error vs float64 <= the native kernel's, tools/gemm_bench.cpp);
+ *   6            as 9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3);
+ *   0            native f32 MFMA everywhere.
+ * The choice never depends on M, so a batch and its shards compute identical bits.  Process-wide; initial values from the
+ * environment variables AFM_GEMM_SPLIT (9) and AFM_GEMM_SPLIT_MIN_N (1024).  Both return the previous value, or AFM_E_BADARG. */
 int afm_linear_set_split(int products);
+int afm_linear_set_split_min_n(int min_n);
 
 /* ------------------------------------------------------------------------------------------
  * afm_mha_fwd: multi-head self-attention core, softmax(QK^T / sqrt(dh) + key mask) V.

@@ -113,7 +113,7 @@ def test_full_size_vs_oracle():
 
 
 def test_split_bf16_gemm_modes_track_native_f32_over_a_sampling_run():
-    """afm_linear_set_split(9 | 6): the exact three-way bf16 operand split on the bf16 matrix pipe is f32 arithmetic in another
+    """afm_linear_set_split(9 | 6) vs 0: the exact three-way bf16 operand split on the bf16 matrix pipe is f32 arithmetic in another
     summation order, so a 200-step sampling run (full-size tokens, shared Philox noise) stays within f32 drift of the native run."""
     from afm import ops as afm_ops
     cfg = cmdm_cfg(num_points=8192, steps=1000, respacing="200")
@@ -124,12 +124,13 @@ def test_split_bf16_gemm_modes_track_native_f32_over_a_sampling_run():
     kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("full_cont", (B, 128, 256)).to(dev()),
               x_mask=synth.frame_mask(B, L, seed=3).to(dev()))
     runs = {}
-    for products in (0, 9, 6):
-        prev = afm_ops.set_gemm_split(products)
-        try:
+    saved = afm_ops.get_gemm_split()
+    try:
+        for products in (0, 9, 6):                       # every eligible GEMM (min_n = 0), not only the default's wide ones
+            afm_ops.set_gemm_split(products, 0)
             runs[products] = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=21)
-        finally:
-            afm_ops.set_gemm_split(prev)
+    finally:
+        afm_ops.set_gemm_split(*saved)
     valid = ~kw["x_mask"]
     scale = runs[0][valid].abs().max().item()
     for products in (9, 6):

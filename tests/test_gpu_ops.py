@@ -35,27 +35,39 @@ def test_linear_split_bf16_mode(products, M, N, K):
     """afm_linear_set_split: f32 operands split exactly into three bf16 terms, products on the bf16 matrix pipe, f32 accumulate.
     The error against float64 must stay at the native f32 MFMA kernel's level (same products, different summation order), on
     both tile variants (128x128 / 64x64), with ragged M / N edges and every epilogue input."""
-    lib = ffi.load()
     x = synth.gaussian("sp_x", (M, K)); w = synth.gaussian("sp_w", (N, K)) / math.sqrt(K); b = synth.gaussian("sp_b", (N,))
     res = synth.gaussian("sp_r", (M, N))
     x[::7] *= 50.0                                        # mixed magnitudes: the residual terms matter
     ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + res.double()
     scale = (x.double().abs() @ w.double().abs().t()) + b.double().abs() + 1e-30
     args = (x.to(dev()), w.to(dev()), b.to(dev()))
-    native = ops.linear(*args, act=ffi.ACT_GELU, residual=res.to(dev()))
-    prev = lib.afm_linear_set_split(products)
+    saved = ops.get_gemm_split()
     try:
-        assert prev == 0
+        ops.set_gemm_split(0, 0)
+        native = ops.linear(*args, act=ffi.ACT_GELU, residual=res.to(dev()))
+        assert ops.set_gemm_split(products, 0) == (0, 0)
         got = ops.linear(*args, act=ffi.ACT_GELU, residual=res.to(dev()))
+        assert ops.get_gemm_split() == (products, 0)
     finally:
-        assert lib.afm_linear_set_split(prev) == products
+        ops.set_gemm_split(*saved)
     e_split = ((got.double().cpu() - ref).abs() / scale).max().item()
     e_native = ((native.double().cpu() - ref).abs() / scale).max().item()
     print(f"split x{products} {M}x{N}x{K}: max err / sum|a||w| = {e_split:.2e} (native f32 MFMA {e_native:.2e})")
     assert e_split <= max(1.5 * e_native, 3e-7)
     assert (got - native).abs().max().item() <= 1e-5 * native.abs().max().item()
-    assert lib.afm_linear_set_split(5) == -1              # AFM_E_BADARG, mode unchanged
-    assert lib.afm_linear_set_split(0) == 0
+    assert not torch.equal(got, native)                   # a different kernel really ran
+    lib = ffi.load()
+    assert lib.afm_linear_set_split(5) == -1 and lib.afm_linear_set_split_min_n(-3) == -1      # AFM_E_BADARG, state unchanged
+    assert ops.get_gemm_split() == saved
+
+
+def test_linear_split_dispatch_is_independent_of_m():
+    """The split path is chosen from (N, K) only, so rows computed in a small batch equal the same rows of a large batch bit for bit."""
+    x = synth.gaussian("spm_x", (4096, 512)); w = synth.gaussian("spm_w", (1536, 512)) / math.sqrt(512)
+    big = ops.linear(x.to(dev()), w.to(dev()))            # 128x128-tile instantiation; the slices below run the 64x64 one
+    for rows in (1, 33, 200, 640):
+        part = ops.linear(x[:rows].to(dev()), w.to(dev()))
+        assert torch.equal(part, big[:rows]), rows
 
 
 def test_linear_detects_transposed_layouts():

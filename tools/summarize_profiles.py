@@ -30,16 +30,24 @@ for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     print("| kernel | launches | mean KiB | mean MB (raw) |\n|---|---|---|---|")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:10]:
         print(f"| `{k}` | {len(v)} | {sum(v)/len(v):.0f} | {sum(v)/len(v)*1024/1e6:.2f} |")
-# machine-readable traffic of the dominant GEMM kernel for bench.py's roofline.traffic
+# machine-readable HBM traffic of every GEMM kernel for bench.py's roofline.traffic (it picks the entry of its dominant kernel)
 try:
-    tr = {}
+    per = collections.defaultdict(dict)
     for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         fl = glob.glob(os.path.join(out, tag, "*", "*counter_collection.csv"))
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fl[0])) if r["Counter_Name"] == ctr and "gemm_f32_mfma_dma<64, 64>" in r["Kernel_Name"]]
-        tr[ctr] = sum(vals) / len(vals) * 1024
-    json.dump({"kernel": "gemm_f32_mfma_dma<64,64>", "read_bytes_per_launch": 2 * tr["FETCH_SIZE"], "write_bytes_per_launch": tr["WRITE_SIZE"],
-               "bytes_per_launch": 2 * tr["FETCH_SIZE"] + tr["WRITE_SIZE"], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), tools/pmc_target.py"},
-              open(os.path.join(out, "traffic.json"), "w"))
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fl[0])):
+            if r["Counter_Name"] == ctr and "gemm" in r["Kernel_Name"]:
+                agg[short(r["Kernel_Name"]).replace(" ", "")].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            per[k][ctr] = sum(v) / len(v) * 1024
+            per[k]["launches"] = len(v)
+    kernels = {k: {"read_bytes_per_launch": 2 * v["FETCH_SIZE"], "write_bytes_per_launch": v["WRITE_SIZE"],
+                   "bytes_per_launch": 2 * v["FETCH_SIZE"] + v["WRITE_SIZE"], "launches": v["launches"]}
+               for k, v in per.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    json.dump({"kernels": kernels, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), tools/pmc_target.py "
+                                             "(12 native steps, B = 32, one stream: launches of M = 10432 rows)"},
+              open(os.path.join(out, "traffic.json"), "w"), indent=1)
 except Exception as e:   # noqa
     print(f"(traffic.json not written: {e})")
 f = glob.glob(os.path.join(out, "pmc_sq", "*", "*counter_collection.csv"))
