@@ -8,14 +8,15 @@
 //              the split rounds to nearest - an order of magnitude below the rounding noise of the f32 accumulation itself).
 // Measured against float64 (tools/gemm_bench.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
 // native f32 MFMA kernel.  Default: the exact 9-product variant on the wide GEMMs (N >= 1024: in_proj, linear1), where it is 1.26x faster than
-// the native kernel stand-alone and +10 % end to end (443 vs 402 steps/s); the N = 512 GEMMs stay native (the split gains less there and the
+// the native kernel stand-alone and +7..10 % end to end (435-441 vs 400-406 steps/s, tools/ab_gemm_modes.py); the N = 512 GEMMs stay native (the split gains less there and the
 // bf16 pipe's power draw lowers the clock for everything around it, profiles/r01_gemm_investigation.md).  AFM_GEMM_SPLIT=0 restores the native
-// kernels everywhere; AFM_GEMM_SPLIT=6 with AFM_GEMM_SPLIT_MIN_N=0 is the fastest setting (534 steps/s).
+// kernels everywhere; AFM_GEMM_SPLIT=6 with AFM_GEMM_SPLIT_MIN_N=0 is the fastest setting (522-529 steps/s).
 //
 // Kernel: 256 threads = 2x2 waves, wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, K consumed BK at a time.
 //   global f32 -> registers (next K-tile, issued before the MFMAs of the current one) -> split in VALU, interleaved with
-//   the MFMA stream -> three bf16 planes in LDS ([row][BK] bf16, rows padded by 16 B: ds_read_b128 / ds_write_b128 of a
-//   16-lane group hit 16 distinct 16-byte bank groups) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
+//   the MFMA stream -> three bf16 planes in LDS ([row][BK] bf16, rows padded to 48 B: the 16 rows of each ds_read_b128 lane group
+//   {0-3,12-15,20-27} / {4-11,16-19,28-31} hit 16 distinct 16-byte slots; stores go even rows / odd rows per 8-lane group, also
+//   conflict-free: SQ_LDS_BANK_CONFLICT = 0) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
 //   One barrier per K-tile (double-buffered LDS), shared epilogue of gemm.hip.
 #include <atomic>
 #include <cstdlib>
@@ -286,7 +287,8 @@ extern "C" int afm_linear_set_split_min_n(int min_n) {
 
 // Which GEMMs take the split path is a function of (N, K) and operand alignment only - never of M - so a batch and its shards run the
 // same arithmetic (sharding / sub-batch invariance stays bit-exact).  Measured in the sampling loop (B = 32, two sub-batch streams):
-// native everywhere 402 steps/s, x9 on the N >= 1024 GEMMs (in_proj, linear1) 443, x9 everywhere 427, x6 everywhere 534.
+// native everywhere 406 steps/s, x9 on the N >= 1024 GEMMs (in_proj, linear1) 435, x9 everywhere 447 (385 on a box with less power
+// headroom, where the wide-only default still matched native), x6 everywhere 529.
 int afm_linear_split_mode(const afm_linear_args& a) {
     const int mode = split_mode_now();
     if (!mode) return 0;
