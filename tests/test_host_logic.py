@@ -180,6 +180,33 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert ffi.load().afm_version() == 2            # pure host call, no GPU needed
 
 
+def test_gemm_arithmetic_switches_are_host_state():
+    """afm_linear_set_split / _min_n are plain host state (no GPU): defaults (or the AFM_GEMM_SPLIT* environment), validation, round trip."""
+    if not os.path.exists(ffi.lib_path()):
+        pytest.skip("libafm_hip.so not built")
+    from afm import ops
+    want = (int(os.environ.get("AFM_GEMM_SPLIT", "9")), int(os.environ.get("AFM_GEMM_SPLIT_MIN_N", "1024")))
+    saved = ops.get_gemm_split()
+    assert saved == want
+    try:
+        assert ops.set_gemm_split(6, 0) == saved and ops.get_gemm_split() == (6, 0)
+        assert ops.set_gemm_split(0) == 6 and ops.get_gemm_split() == (0, 0)
+        lib = ffi.load()
+        assert lib.afm_linear_set_split(7) == -1 and lib.afm_linear_set_split_min_n(-1) == -1
+        assert ops.get_gemm_split() == (0, 0)
+    finally:
+        ops.set_gemm_split(*saved)
+
+
+def test_progress_slices_cover_the_chain():
+    """`progress=True` (test.py:94-101) runs the native loop as chained slices: contiguous, complete, ~50 of them."""
+    assert ffi.progress_slices(1000, False) == [(0, 1000)]
+    for n in (1, 7, 50, 51, 500, 1000):
+        sl = ffi.progress_slices(n, True)
+        assert sl[0][0] == 0 and sl[-1][1] == n and len(sl) <= 50
+        assert all(a[1] == b[0] for a, b in zip(sl, sl[1:])) and all(j1 > j0 for j0, j1 in sl)
+
+
 def test_evaluator_file_formats_round_trip(tmp_path):
     """ADM -> file -> AMDM hand-off (utils/evaluate.py:41-82, datasets/humanml3d.py:763-774) and the motion pickle; the glue
     values are pinned by the reference-generated golden."""
