@@ -10,6 +10,7 @@
 //   buffer, +bias +positional rows) -> n_layers x { in_proj GEMM, flash MHA, out_proj GEMM(+bias
 //   +residual), LN, FFN1 GEMM(+bias+GELU), FFN2 GEMM(+bias+residual), LN } -> motion_layer GEMM
 //   (gather motion tokens, +bias, fused DDPM posterior update).
+#include <cstdlib>
 #include "common.h"
 
 extern "C" int afm_linear(const afm_linear_args*, void*);
@@ -23,7 +24,7 @@ namespace {
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 struct Workspace {
-    float *seq0, *y, *x1, *tmp, *qkv, *att, *hid, *noise;
+    float *seq0, *y, *x1, *tmp, *qkv, *qkv0, *att, *hid, *noise;
     uint8_t* keymask;
     int64_t bytes;
 };
@@ -39,6 +40,7 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.x1 = (float*)take(M * d * 4);
     ws.tmp = (float*)take(M * d * 4);
     ws.qkv = (float*)take(M * 3 * d * 4);
+    ws.qkv0 = (float*)take(M * 3 * d * 4);            // layer 0's in_proj output: its condition-token rows persist across the steps of a loop
     ws.att = (float*)take(M * d * 4);
     ws.hid = (float*)take(M * (int64_t)w.ff * 4);
     ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
@@ -112,11 +114,24 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
     const float* X = ws.seq0;
     for (int li = 0; li < w.n_layers; ++li) {
         const afm_encoder_layer_weights& lw = w.layer[li];
+        // Layer 0 reads the token buffer itself, whose condition rows (text + contact groups) do not change between the steps of a
+        // sampling loop: their q | k | v rows are computed on the loop's first step only (copy_cond) and kept in qkv0; afterwards the
+        // in_proj runs on the time-token rows and the motion rows (a GEMM row depends on its own input row only: bit-identical).
+        float* qkv = li == 0 ? ws.qkv0 : ws.qkv;
         afm_linear_args a = {};
-        a.A = X; a.lda = d; a.W = lw.in_proj_w; a.ldw = d; a.C = ws.qkv; a.ldc = 3 * d;
-        a.M = M; a.N = 3 * d; a.K = d; a.bias = lw.in_proj_b;
-        AFM_TRY(afm_linear(&a, s));
-        AFM_TRY(afm_mha_fwd(ws.qkv, keymask, ws.att, B, T, w.heads, d / w.heads, s));
+        a.A = X; a.lda = d; a.W = lw.in_proj_w; a.ldw = d; a.C = qkv; a.ldc = 3 * d;
+        a.N = 3 * d; a.K = d; a.bias = lw.in_proj_b;
+        static const bool no_l0_cache = getenv("AFM_CMDM_NO_L0_CACHE") != nullptr;      // measurement knob
+        if (li == 0 && !copy_cond && w.n_cond > 0 && !no_l0_cache) {
+            a.M = B; a.a_grp = 1; a.a_stride = T; a.a_off = 0; a.c_grp = 1; a.c_stride = T; a.c_off = 0;                 // time tokens
+            AFM_TRY(afm_linear(&a, s));
+            a.M = B * L; a.a_grp = L; a.a_stride = T; a.a_off = 1 + w.n_cond; a.c_grp = L; a.c_stride = T; a.c_off = 1 + w.n_cond;   // motion tokens
+            AFM_TRY(afm_linear(&a, s));
+        } else {
+            a.M = M;
+            AFM_TRY(afm_linear(&a, s));
+        }
+        AFM_TRY(afm_mha_fwd(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, s));
         // After the LAST layer only the L motion tokens of each sample are read (motion_layer, cmdm.py:169,195), and
         // everything after the attention is row-local: run it on the B*L motion rows only (token rows gathered /
         // scattered by the row maps; the other rows of tmp/x1/y keep stale values nobody reads).
