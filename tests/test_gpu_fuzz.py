@@ -9,7 +9,7 @@ from afm import ffi, ops
 from gpu_util import dev
 
 pytestmark = pytest.mark.gpu
-SET = dict(max_examples=40, deadline=None)
+SET = dict(max_examples=40, deadline=None, derandomize=True)      # fixed example set: the round-end run must be reproducible
 
 
 def _rand(shape, seed):
@@ -52,7 +52,7 @@ def test_layernorm_random_shapes(rows, dim, seed):
     assert (got.cpu().double() - ref).abs().max().item() <= 2e-5
 
 
-@settings(max_examples=20, deadline=None)
+@settings(max_examples=20, deadline=None, derandomize=True)
 @given(B=st.integers(1, 3), T=st.integers(1, 150), H=st.sampled_from([1, 2, 8]), seed=st.integers(0, 10**6), masked=st.booleans())
 def test_attention_random_lengths(B, T, H, seed, masked):
     d = 64 * H
@@ -70,7 +70,7 @@ def test_attention_random_lengths(B, T, H, seed, masked):
     assert (got.cpu().double() - ref).abs().max().item() <= 2e-5
 
 
-@settings(max_examples=25, deadline=None)
+@settings(max_examples=25, deadline=None, derandomize=True)
 @given(B=st.integers(1, 3), n=st.integers(1, 700), frac=st.floats(0.05, 1.0), k=st.sampled_from([3, 8, 16]), seed=st.integers(0, 10**6),
        dup=st.booleans())
 def test_fps_knn_random_sizes_bit_exact(B, n, frac, k, seed, dup):
