@@ -49,7 +49,10 @@ def test_layernorm_random_shapes(rows, dim, seed):
     g, b = 1 + 0.1 * _rand((dim,), seed + 1), 0.1 * _rand((dim,), seed + 2)
     ref = torch.nn.functional.layer_norm(x.double(), (dim,), g.double(), b.double(), 1e-5)
     got = ops.layernorm(x.to(dev()), g.to(dev()), b.to(dev()))
-    assert (got.cpu().double() - ref).abs().max().item() <= 2e-5
+    # a row of nearly equal values (tiny variance next to eps) amplifies the f32 rounding of x - mean by rstd: allow that much
+    rstd = (x.double().var(dim=1, unbiased=False) + 1e-5).rsqrt()
+    tol = 2e-5 + 8 * 2.0 ** -24 * x.double().abs().amax(dim=1) * rstd * g.double().abs().max()
+    assert ((got.cpu().double() - ref).abs().amax(dim=1) <= tol).all()
 
 
 @settings(max_examples=20, deadline=None, derandomize=True)
