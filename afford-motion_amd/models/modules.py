@@ -6,6 +6,7 @@ module inside its own autograd optimisation.  (The reference's file cannot be im
 `pointops_cuda` extension.)"""
 import torch
 
+from afm._shim import reference_fallback
 from afm.cmdm import PositionalEncoding as _PositionalEncodingBuffers
 from afm.cmdm import TimestepEmbedder  # noqa: F401
 from afm.scene import SceneMapEncoder, SceneMapEncoderDecoder  # noqa: F401
@@ -16,3 +17,7 @@ class PositionalEncoding(_PositionalEncodingBuffers):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.dropout(x + self.pe[: x.shape[0], :].to(x))
+
+
+# any other name (CrossAttentionLayer, SelfAttentionBlock ... used only by the reference's own models/cdm.py) -> the checkout's file
+__getattr__ = reference_fallback(__name__, __file__)

@@ -1,1 +1,6 @@
+"""Drop-in `utils.registry` (reference utils/registry.py:10-92): `Registry` is ours (same observable behaviour); any other name
+falls through to the reference checkout's file."""
+from afm._shim import reference_fallback
 from afm.registry import Registry  # noqa: F401
+
+__getattr__ = reference_fallback(__name__, __file__)

@@ -247,20 +247,57 @@ def test_all_four_task_configs_compose():
 
 def test_shim_packages_fall_through_to_a_reference_checkout(tmp_path):
     """`utils` / `diffusion` / `models` shadow the reference's directories; modules that are NOT on the hot path (utils.io,
-    utils.training, diffusion.resample ...) must still resolve to the reference checkout that follows on sys.path.  A fake
-    checkout stands in for /root/reference (which does not exist on the GPU box)."""
+    utils.training, diffusion.resample ...) must still resolve to the reference checkout that follows on sys.path, and so must
+    NAMES the shim modules do not define (`utils.misc.smplx_neutral_model` for utils/evaluate.py:15).  A fake checkout stands in
+    for /root/reference (which does not exist on the GPU box)."""
     import subprocess
     import sys
     fake = tmp_path / "ref"
     for pkg, mod, body in (("utils", "io", "MARK = 'ref-utils-io'"), ("diffusion", "resample", "MARK = 'ref-resample'"),
-                           ("utils", "misc", "MARK = 'must-not-win'")):
+                           ("utils", "misc", "MARK = 'ref-misc'\ncompute_repr_dimesion = 'must-not-win'\n"
+                                             "def get_meshes_from_smplx():\n    return 'ref-meshes'")):
         (fake / pkg).mkdir(parents=True, exist_ok=True)
         (fake / pkg / f"{mod}.py").write_text(body + "\n")
     code = ("import utils.io, diffusion.resample, utils.misc, models.base, diffusion.gaussian_diffusion as gd;"
             "assert utils.io.MARK == 'ref-utils-io' and diffusion.resample.MARK == 'ref-resample';"
-            "assert hasattr(utils.misc, 'compute_repr_dimesion') and not hasattr(utils.misc, 'MARK');"
-            "assert 'afford-motion_amd' in models.base.__file__ and 'afford-motion_amd' in gd.__file__;"
+            "assert callable(utils.misc.compute_repr_dimesion) and utils.misc.compute_repr_dimesion('h3d') == 263;"
+            "from utils.misc import get_meshes_from_smplx, MARK; assert MARK == 'ref-misc' and get_meshes_from_smplx() == 'ref-meshes';"
+            "assert 'afford-motion_amd' in models.base.__file__ and 'afford-motion_amd' in gd.__file__ and 'afford-motion_amd' in utils.misc.__file__;"
             "from models.modules import PositionalEncoding, TimestepEmbedder; print('fall-through ok')")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "afford-motion_amd"), str(fake)]))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
     assert r.returncode == 0 and "fall-through ok" in r.stdout, r.stdout + r.stderr
+    # without any checkout a missing name is a clear ImportError, not a crash at import of the shim
+    code = ("import utils.misc\ntry:\n    from utils.misc import smplx_neutral_model\nexcept ImportError as e:\n    print('clean', e)")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "afford-motion_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "clean" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="needs the reference checkout (build container only)")
+def test_reference_entry_scripts_import_through_the_shims():
+    """The REAL reference tree behind the shims: test.py:1-12 / train.py / train_ddp.py import completely (utils/evaluate.py:13-16 and
+    utils/joints_to_smplx.py:14-16 get their names from the checkout's utils/misc.py through the shim's fall-through), while every
+    hot-path module still resolves to the product."""
+    import json
+    import subprocess
+    import sys
+    ref = "/root/reference"
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "afford-motion_amd"), ref, os.path.join(ROOT, "oracle", "stubs")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "import_reference_scripts.py"), ref],
+                       capture_output=True, text=True, env=env, cwd=ref)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    ours = os.path.join(ROOT, "afford-motion_amd")
+    for m in ("utils.misc", "models.base", "models.cmdm", "models.cdm", "diffusion.gaussian_diffusion", "diffusion.respace", "utils.registry"):
+        assert out[m].startswith(ours), (m, out[m])
+    for m in ("utils.training", "utils.evaluate", "utils.joints_to_smplx", "utils.io", "diffusion.resample", "datasets.base"):
+        assert out[m].startswith(ref), (m, out[m])
+    assert out["compute_repr_dimesion"] == "afm.cmdm" and out["get_meshes_from_smplx"] == "utils._reference_misc"
+    assert out["PositionalEncoding"] == "models.modules|afm.cmdm"
+    for script in ("test.py", "train.py", "train_ddp.py"):
+        assert out[script][0] == "afm.base" and out[script][1] == "afm.cmdm" and out[script][3] == "utils.training", out[script]
+    assert out["test.py"][2] == "utils.evaluate"
+    assert out["registry"] == ["CDM", "CMDM"]
+    assert not any("__pycache__" in d for d, _, _ in os.walk(ref)), "the import dropped bytecode into the reference tree"
