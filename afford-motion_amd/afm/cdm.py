@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import autograd as AG
 from . import ffi, ops
 from .base import Model
+from ._cache import HeldKey
 from .cmdm import TimestepEmbedder, _param_version
 from .text import TextEncoderMixin, lang_feat_dim_type
 
@@ -250,11 +251,14 @@ class CDM(TextEncoderMixin, nn.Module):
             self.scene_model_dim = 3 + int(sm.use_color) * 3
             self.scene_model = PointTransformerSeg(c=self.scene_model_dim, num_points=sm.num_points)
             pw = getattr(sm, "pretrained_weight", None)
-            if pw:
+            if pw:                                               # '' / None = explicit opt-out (tests, synthetic benches)
                 import os
-                if os.path.exists(pw):
-                    sd = torch.load(pw, map_location="cpu")
-                    self.scene_model.load_state_dict({k: v for k, v in sd.items() if "enc" in k or "dec" in k})
+                if not os.path.exists(pw):                       # pointtransformer.py:203-205 raises too: a frozen, randomly
+                    raise FileNotFoundError(                     # initialised backbone would produce garbage features silently
+                        f"Can't find pretrained point-transformer weights: scene_model.pretrained_weight={pw!r} "
+                        "(set it to '' to build the frozen backbone without loading weights)")
+                sd = torch.load(pw, map_location="cpu")
+                self.scene_model.load_state_dict({k: v for k, v in sd.items() if "enc" in k or "dec" in k})
             self.freeze_scene_model = bool(sm.freeze)          # read by TrainLoop._freeze_scene_model_batchnorm (utils/training.py:111-116)
             if not self.freeze_scene_model:
                 raise NotImplementedError("scene_model.freeze=False: fine-tuning the PointTransformerSeg backbone is not built "
@@ -350,13 +354,22 @@ class CDM(TextEncoderMixin, nn.Module):
     def _text_latent(self, w, kwargs, device):
         """Text latent of every sample; cached while the same text tensor / strings are passed (the sampling loop)."""
         tf = kwargs.get("c_text_feat")
-        key = (tf.data_ptr(), tf._version, tuple(tf.shape)) if isinstance(tf, torch.Tensor) else tuple(kwargs["c_text"])
-        if getattr(self, "_text_cache", None) is not None and self._text_cache[0] == key:
+        extra = (None if isinstance(tf, torch.Tensor) else tuple(kwargs["c_text"]), _param_version(self))
+        if getattr(self, "_text_cache", None) is not None and self._text_cache[0].matches((tf,), extra):
             return self._text_cache[1]
         text = ffi.f32c(self.encode_text(kwargs).to(device))
         lat = self._latent_tokens(w, 0, text)
-        self._text_cache = (key, lat, text)
+        self._text_cache = (HeldKey((tf,), extra), lat, text)
         return lat
+
+    def _scene_features(self, xyz, col, like) -> torch.Tensor:
+        """Frozen PointTransformerSeg features of the scene batch; step-invariant (the reference re-runs the backbone in every step,
+        cdm.py:508), so cached while the SAME live tensors are passed again (`HeldKey` keeps them alive: a freed batch's address
+        handed to the next batch can therefore never match)."""
+        ver = (_param_version(self.scene_model),)
+        if self._scene_cache is None or not self._scene_cache[0].matches((xyz, col), ver):
+            self._scene_cache = (HeldKey((xyz, col), ver), self.scene_model((xyz.to(like), None if col is None else col.to(like))))
+        return self._scene_cache[1]
 
     def _features(self, x, kwargs) -> torch.Tensor:
         """cat(x_t, per-point features, xyz) exactly as cdm.py:495-505 + ContactPerceiver.forward :167-171."""
@@ -364,10 +377,7 @@ class CDM(TextEncoderMixin, nn.Module):
         if hasattr(self, "scene_model"):
             # step-invariant: the reference re-runs the frozen backbone in every step (cdm.py:508); cache per scene batch
             xyz, col = kwargs["c_pc_xyz"], kwargs.get("c_pc_feat")
-            key = (xyz.data_ptr(), xyz._version, None if col is None else (col.data_ptr(), col._version), tuple(xyz.shape))
-            if self._scene_cache is None or self._scene_cache[0] != key:
-                self._scene_cache = (key, self.scene_model((xyz.to(x), None if col is None else col.to(x))))
-            parts.append(self._scene_cache[1])
+            parts.append(self._scene_features(xyz, col, x))
         elif self.point_feat_dim > 0:
             pf = kwargs["c_pc_feat"]
             if self.point_feat_dim == 1 and pf.shape[-1] != 1:
@@ -484,10 +494,7 @@ class CDM(TextEncoderMixin, nn.Module):
         """pc_emb of CDM.forward (cdm.py:495-508): frozen scene backbone output, given per-point features, or None."""
         if hasattr(self, "scene_model"):
             xyz, col = kwargs["c_pc_xyz"], kwargs.get("c_pc_feat")
-            key = (xyz.data_ptr(), xyz._version, None if col is None else (col.data_ptr(), col._version), tuple(xyz.shape))
-            if self._scene_cache is None or self._scene_cache[0] != key:
-                self._scene_cache = (key, self.scene_model((xyz.to(x), None if col is None else col.to(x))))
-            return self._scene_cache[1]
+            return self._scene_features(xyz, col, x)
         if self.point_feat_dim > 0:
             pf = kwargs["c_pc_feat"]
             if self.point_feat_dim == 1 and pf.shape[-1] != 1:

@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from . import autograd as AG
 from . import ffi, ops
+from ._cache import HeldKey
 from .base import Model
 from .scene import SceneMapEncoder, SceneMapEncoderDecoder
 from .text import TextEncoderMixin, lang_feat_dim_type
@@ -199,9 +200,8 @@ class CMDM(TextEncoderMixin, nn.Module):
         """[B, 1 + G, d]: language_adapter(text) and contact_adapter(SceneMapEncoder(xyz, contact)),
         positional encoding of sequence positions 1 .. 1+G already added (cmdm.py:134-156,161-162)."""
         tensors = [kwargs.get(k) for k in ("c_pc_xyz", "c_pc_contact", "c_text_feat", "c_cont_emb")]
-        key = (tuple((t.data_ptr(), t._version, tuple(t.shape)) if isinstance(t, torch.Tensor) else None for t in tensors),
-               tuple(kwargs["c_text"]) if "c_text" in kwargs and "c_text_feat" not in kwargs else None, _param_version(self))
-        if self.hoist_conditions and self._cond_cache is not None and self._cond_cache[0] == key:
+        extra = (tuple(kwargs["c_text"]) if "c_text" in kwargs and "c_text_feat" not in kwargs else None, _param_version(self))
+        if self.hoist_conditions and self._cond_cache is not None and self._cond_cache[0].matches(tensors, extra):
             return self._cond_cache[1]
         text_feat = self.encode_text(kwargs)                                          # [B, text_dim]
         cont_emb = kwargs["c_cont_emb"] if "c_cont_emb" in kwargs else \
@@ -214,7 +214,7 @@ class CMDM(TextEncoderMixin, nn.Module):
                    out=flat, c_map=(1, 1 + G, 0))
         ops.linear(cont_emb.reshape(B * G, -1), self.contact_adapter.weight, self.contact_adapter.bias, rowtab=pe[2:2 + G],
                    out=flat, c_map=(G, 1 + G, 1))
-        self._cond_cache = (key, tok) if self.hoist_conditions else None
+        self._cond_cache = (HeldKey(tensors, extra), tok) if self.hoist_conditions else None
         return tok
 
     # ------------------------------------------------------------------ forward
@@ -281,8 +281,8 @@ class CMDM(TextEncoderMixin, nn.Module):
         """Step-invariant part of trans_dec: SceneMapEncoderDecoder features -> kv_mappling (Linear + LayerNorm) -> the packed
         K | V projections of every cross-attention layer; cached per scene batch like the trans_enc condition tokens."""
         tensors = [kwargs.get(k) for k in ("c_pc_xyz", "c_pc_contact", "c_pc_erase")]
-        key = (tuple((t.data_ptr(), t._version, tuple(t.shape)) if isinstance(t, torch.Tensor) else None for t in tensors), _param_version(self))
-        if self.hoist_conditions and self._cond_cache is not None and self._cond_cache[0] == key:
+        extra = ("trans_dec", _param_version(self))
+        if self.hoist_conditions and self._cond_cache is not None and self._cond_cache[0].matches(tensors, extra):
             return self._cond_cache[1]
         feats = self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])                     # [x4, x3, x2, x1]
         d, out = self.latent_dim, []
@@ -295,7 +295,7 @@ class CMDM(TextEncoderMixin, nn.Module):
             m = ops.layernorm(ops.linear(mem.reshape(B * n, c), km[0].weight, km[0].bias), km[1].weight, km[1].bias, km[1].eps)
             ca = layer.multihead_attn
             out.append(ops.linear(m, ca.in_proj_weight[d:], ca.in_proj_bias[d:]).view(B, n, 2 * d))
-        self._cond_cache = (key, out) if self.hoist_conditions else None
+        self._cond_cache = (HeldKey(tensors, extra), out) if self.hoist_conditions else None
         return out
 
     def forward_trans_dec(self, x, timesteps, **kwargs):

@@ -151,6 +151,14 @@ class GaussianDiffusion:
         tab = self.tables(x_start.device)
         return ops.ddpm_step(x_start, x_start, noise, tab.sqrt_ac[t], tab.zeros[t], tab.sqrt_1mac[t], seed=seed, step=-1)
 
+    def _fresh_seed(self, counter: str) -> int:
+        """Default noise seed when the caller passes none: like `th.randn_like` in the reference, every call draws NEW noise
+        (test.py:88-101 calls p_sample_loop k_sample times and expects k different samples), reproducible from `torch.manual_seed`.
+        The per-object call counter advances identically on every rank, so sharded runs still agree on the seed."""
+        n = getattr(self, counter, 0) + 1
+        setattr(self, counter, n)
+        return (torch.initial_seed() * 6364136223846793005 + n * 1442695040888963407 + (17 if counter == "_loss_calls" else 0)) & (2**63 - 1)
+
     # ------------------------------------------------------------------ reverse process
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, *,
                  noise: Optional[torch.Tensor] = None, seed: int = 0, sample_index0: int = 0, step: int = 0):
@@ -175,7 +183,7 @@ class GaussianDiffusion:
         """Generator over the T steps (reference gaussian_diffusion.py:488-536)."""
         if device is None:
             device = next(model.parameters()).device
-        seed = int(torch.initial_seed()) if seed is None else seed
+        seed = self._fresh_seed("_sample_calls") if seed is None else seed
         img = noise if noise is not None else ops.randn(tuple(shape), device, seed=seed, sample_index0=sample_index0, step=-1)
         tvec = self.tables(device).timesteps(shape[0])
         steps: Iterable[int] = range(self.num_timesteps - 1, -1, -1)
@@ -204,7 +212,7 @@ class GaussianDiffusion:
                 and not self.rescale_timesteps and not switches:
             if device is None:
                 device = next(model.parameters()).device
-            seed = int(torch.initial_seed()) if seed is None else seed
+            seed = self._fresh_seed("_sample_calls") if seed is None else seed
             x = noise.clone() if noise is not None else ops.randn(tuple(shape), device, seed=seed,
                                                                    sample_index0=sample_index0, step=-1)
             if isinstance(step_noise, (list, tuple)):
@@ -230,8 +238,7 @@ class GaussianDiffusion:
         tab = self.tables(x_start.device)
         seed = kwargs.get("seed")
         if seed is None:       # th.randn_like of the reference: fresh noise on every call, reproducible from torch's seed
-            self._loss_calls = getattr(self, "_loss_calls", 0) + 1
-            seed = (torch.initial_seed() * 6364136223846793005 + self._loss_calls) & (2**63 - 1)
+            seed = self._fresh_seed("_loss_calls")
         with torch.no_grad():
             x_t = self.q_sample(x_start, t, noise=noise, seed=seed)
         train = torch.is_grad_enabled() and any(p.requires_grad for p in getattr(model, "parameters", lambda: [])())

@@ -28,7 +28,7 @@ class TextEncoderMixin:
         if self.text_feat_type not in ("clip", "bert"):
             raise NotImplementedError(self.text_feat_type)
         self.text_encoder = None
-        self._clip = None
+        object.__setattr__(self, "_clip", None)
 
     def _clip_encode(self, texts, device):
         if self._clip is None:
@@ -38,9 +38,12 @@ class TextEncoderMixin:
                 raise RuntimeError(
                     "no text encoder available: pass `c_text_feat` ([B, text_dim] pooled text feature), set "
                     "`model.text_encoder`, or install openai/CLIP (the reference's frozen text model)") from e
-            self._clip_mod = clip
-            self._clip, _ = clip.load(self.text_model_name, device="cpu", jit=False)
-            self._clip.eval().requires_grad_(False)
+            model, _ = clip.load(self.text_model_name, device="cpu", jit=False)
+            model.eval().requires_grad_(False)
+            # NOT a submodule: plain attribute writes bypass nn.Module.__setattr__, so the frozen text model never enters
+            # state_dict() / parameters() (the reference keeps it out of checkpoints by key filter, utils/training.py:97)
+            object.__setattr__(self, "_clip_mod", clip)
+            object.__setattr__(self, "_clip", model)
         clip = self._clip_mod
         ctx = self.text_max_length + 2          # reference models/functions.py:73-79: truncate, then zero-pad to 77
         tok = clip.tokenize(texts, context_length=ctx, truncate=True)

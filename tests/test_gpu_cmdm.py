@@ -278,3 +278,48 @@ def test_cross_attention_kernel_vs_float64():
     sc = sp1(q[:1]) @ sp1(kv[..., :d]).transpose(-1, -2) / 8.0
     ref = (torch.softmax(sc, -1) @ sp1(kv[..., d:])).transpose(1, 2).reshape(1, Tq, d)
     report("cross-attention (Tk=8192, >64 KB LDS)", ops.mha_cross(q[:1].to(dev()), kv.to(dev()), None, H), ref, 2e-5)
+
+
+def test_default_seed_draws_fresh_noise_per_call(cmdm):
+    """test.py:95-102 calls p_sample_loop(model, shape, noise=None, ...) k_sample times without a seed and expects k
+    DIFFERENT samples (th.randn advances the global RNG); reproducible from torch.manual_seed like the reference."""
+    model, _ = cmdm
+    g = golden("cmdm_forward_N1024_L16")
+    kw = _kw(g)
+
+    def three():
+        torch.manual_seed(2023)
+        diff = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="4"))
+        return [diff.p_sample_loop(model, (2, 16, 263), clip_denoised=False, model_kwargs=kw).cpu() for _ in range(3)]
+
+    a, b = three(), three()
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[1], a[2]) and not torch.equal(a[0], a[2])
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert (a[0] - a[1]).abs().max() > 1e-2
+
+
+def test_condition_cache_is_not_fooled_by_a_recycled_address(cmdm):
+    """a dataloader loop frees batch k's device tensors; the caching allocator gives batch k+1 the same address with
+    version 0 and the same shape.  The condition tokens must be recomputed for the new batch."""
+    model, _ = cmdm
+    g = golden("cmdm_forward_N1024_L16")
+    x, t = g["x"].to(dev()), g["t"].to(dev())
+    base_kw = _kw(g, with_encoder=True)
+    hits = 0
+    for trial in range(6):
+        xyz = base_kw["c_pc_xyz"].clone()
+        kw = dict(base_kw, c_pc_xyz=xyz)
+        ptr = xyz.data_ptr()
+        out_a = model(x, t, **kw).clone()
+        del xyz, kw
+        xyz2 = (base_kw["c_pc_xyz"] * 0.5 + 0.1).contiguous()        # another scene, same shape
+        hits += int(xyz2.data_ptr() == ptr)
+        kw2 = dict(base_kw, c_pc_xyz=xyz2)
+        out_b = model(x, t, **kw2)
+        model.hoist_conditions = False
+        want_b = model(x, t, **kw2)
+        model.hoist_conditions = True
+        assert torch.equal(out_b, want_b), f"trial {trial}: stale condition tokens reused"
+        assert not torch.equal(out_a, out_b)
+        del xyz2, kw2
+    print(f"[cache] allocator handed back the freed address in {hits}/6 trials (held keys make that impossible: expected 0)")

@@ -145,7 +145,7 @@ def test_cdm_state_dict_keys_match_reference():
             want[k] = tuple(int(v) for v in shp.strip("()").split(",") if v.strip())
         assert have == want, (arch, set(have) ^ set(want))
     with pytest.raises(NotImplementedError):                                 # unknown variants fail loudly
-        base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Nope"]), device="cpu")
+        base.create_model(load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.arch=Nope", "model.scene_model.pretrained_weight=''"]), device="cpu")
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -301,3 +301,72 @@ def test_reference_entry_scripts_import_through_the_shims():
     assert out["test.py"][2] == "utils.evaluate"
     assert out["registry"] == ["CDM", "CMDM"]
     assert not any("__pycache__" in d for d, _, _ in os.walk(ref)), "the import dropped bytecode into the reference tree"
+
+
+def test_step_invariant_cache_keys_hold_their_tensors():
+    """a cache keyed on (address, version, shape) alone matches the NEXT batch when the allocator recycles the
+    freed address.  HeldKey keeps the keyed tensors alive, so an equal address always means the same live storage."""
+    from afm._cache import HeldKey
+    recycled = 0
+    for _ in range(20):
+        a = torch.randn(4, 64, 3)
+        key = HeldKey((a, None), ("v", 1))
+        assert key.matches((a, None), ("v", 1)) and key.matches((a.view(4, 64, 3), None), ("v", 1))     # same storage, same layout
+        assert not key.matches((a, None), ("v", 2)) and not key.matches((a[:2], None), ("v", 1))
+        ptr = a.data_ptr()
+        del a                                   # the caller drops its batch; the key still owns it
+        b = torch.randn(4, 64, 3)               # "next batch": same shape, fresh version counter
+        recycled += int(b.data_ptr() == ptr)
+        assert not key.matches((b, None), ("v", 1))
+        b.add_(1.0)
+        key2 = HeldKey((b,), ())
+        b.mul_(2.0)                             # in-place edits invalidate through the version counter
+        assert not key2.matches((b,), ())
+    assert recycled == 0                        # the address cannot come back while the key lives
+
+
+def test_default_noise_seed_is_fresh_per_call():
+    """with seed=None (how test.py:95-102 calls p_sample_loop inside its k_sample loop) every call must draw new noise,
+    reproducibly from torch.manual_seed, and identically on every rank (no per-process hash randomisation)."""
+    cfg = load_config("text_to_motion_contact_motion_gen", "cmdm", [])
+    torch.manual_seed(2023)
+    d1 = base.create_gaussian_diffusion(cfg)
+    s = [d1._fresh_seed("_sample_calls") for _ in range(4)] + [d1._fresh_seed("_loss_calls")]
+    assert len(set(s)) == 5 and all(0 <= v < 2**63 for v in s)
+    torch.manual_seed(2023)
+    d2 = base.create_gaussian_diffusion(cfg)
+    assert [d2._fresh_seed("_sample_calls") for _ in range(4)] + [d2._fresh_seed("_loss_calls")] == s
+    torch.manual_seed(7)
+    assert base.create_gaussian_diffusion(cfg)._fresh_seed("_sample_calls") != s[0]
+
+
+def test_missing_pretrained_scene_weights_raise(tmp_path):
+    """reference pointtransformer.py:203-205 raises when the frozen backbone's weights are missing."""
+    ov = ["model.input_feats=6", "model.arch=Perceiver", "task.dataset.use_color=True"]
+    with pytest.raises(FileNotFoundError, match="pretrained point-transformer"):
+        base.create_model(load_config("text_to_motion_contact_gen", "cdm", ov + [f"model.scene_model.pretrained_weight={tmp_path}/nope.pth"]),
+                          device="cpu")
+
+
+def test_clip_text_model_is_not_a_submodule(tmp_path, monkeypatch):
+    """the lazily loaded CLIP model must not change state_dict() keys after the first text encode."""
+    import sys
+    import types
+    fake = types.ModuleType("clip")
+
+    class _Clip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Embedding(50000, 512)
+
+        def encode_text(self, tok):
+            return self.emb(tok.clamp(max=49999)).mean(1)
+
+    fake.load = lambda name, device="cpu", jit=False: (_Clip(), None)
+    fake.tokenize = lambda texts, context_length=77, truncate=True: torch.ones(len(texts), context_length, dtype=torch.long)
+    monkeypatch.setitem(sys.modules, "clip", fake)
+    model = base.create_model(load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263"]), device="cpu")
+    before = set(model.state_dict())
+    feat = model.encode_text({"c_text": ["a person walks", "sits down"]})
+    assert feat.shape == (2, 512)
+    assert set(model.state_dict()) == before and not any("clip" in n for n, _ in model.named_modules())
