@@ -20,7 +20,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import ffi
+from . import ffi, ops
 
 RowMap = Tuple[int, int, int]
 
@@ -52,6 +52,7 @@ def _gemm(A, W, out, M, N, K, *, lda=None, bias=None, residual=None, act=0, prea
         a.a_grp, a.a_stride, a.a_off = a_map
     if c_map:
         a.c_grp, a.c_stride, a.c_off = c_map
+    ops.fill_arith(a)
     ffi.check(ffi.load().afm_linear(C.byref(a), _st(out)), "afm_linear")
     return out
 

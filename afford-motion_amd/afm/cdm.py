@@ -294,7 +294,9 @@ class CDM(TextEncoderMixin, nn.Module):
     def _weights(self) -> ffi.CdmWeights:
         ver = _param_version(self)
         if self._pack is not None and self._pack[0] == ver:
-            return self._pack[1]
+            w = self._pack[1]
+            w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
+            return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
         keep: List[torch.Tensor] = []
@@ -318,6 +320,7 @@ class CDM(TextEncoderMixin, nn.Module):
 
         cm = self.contact_model
         w = ffi.CdmWeights()
+        w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
         w.contact_dim, w.feat_dim, w.dq, w.dkv = self.contact_dim, cm.feat_dim, cm.dq, cm.dkv
         w.enc_heads, w.dec_heads, w.n_self = cm.enc_heads, cm.dec_heads, cm.n_self
         w.text_dim, w.time_dim, w.n_timesteps = self.text_feat_dim, self.time_emb_dim, self.timestep_embedder.pe.shape[0]
@@ -340,6 +343,7 @@ class CDM(TextEncoderMixin, nn.Module):
         w.time_q0, w.time_u, w.time_cu = q0.data_ptr(), u.data_ptr(), cu.data_ptr()
         self._pack = (ver, w, keep)
         self._text_cache = None
+        w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):

@@ -149,6 +149,8 @@ class CMDM(TextEncoderMixin, nn.Module):
         # sub-batches of the native sampling loop, each on its own HIP stream (AFM_LOOP_STREAMS overrides)
         self.loop_streams = int(os.environ.get("AFM_LOOP_STREAMS", "2"))
         self._side_streams: List[torch.cuda.Stream] = []
+        self.attn_group_waves = 0  # afm_mha_fwd_grouped workgroup shape (0 = library heuristic; results do not depend on it)
+        self.no_l0_cache = bool(os.environ.get("AFM_CMDM_NO_L0_CACHE"))      # measurement knob (host state, passed in the pack)
         self._pack = None          # (version, CmdmWeights, keep-alive tensors)
         self._cond_cache = None    # (key, cond_tokens)
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -157,7 +159,7 @@ class CMDM(TextEncoderMixin, nn.Module):
     def _weights(self) -> ffi.CmdmWeights:
         ver = _param_version(self)
         if self._pack is not None and self._pack[0] == ver:
-            return self._pack[1]
+            return self._stamp(self._pack[1])
         dev = self.motion_adapter.weight.device
         if dev.type != "cuda":
             raise ffi.AfmError("CMDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -184,6 +186,13 @@ class CMDM(TextEncoderMixin, nn.Module):
             lw.lin1_w, lw.lin1_b, lw.lin2_w, lw.lin2_b = P(l.linear1.weight), P(l.linear1.bias), P(l.linear2.weight), P(l.linear2.bias)
             lw.norm1_w, lw.norm1_b, lw.norm2_w, lw.norm2_b = P(l.norm1.weight), P(l.norm1.bias), P(l.norm2.weight), P(l.norm2.bias)
         self._pack = (ver, w, keep)
+        return self._stamp(w)
+
+    def _stamp(self, w: ffi.CmdmWeights) -> ffi.CmdmWeights:
+        """Per-call settings of the pack: the host's GEMM arithmetic (afm.ops.set_gemm_split) and bit-neutral tuning fields."""
+        w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
+        w.attn_group_waves = int(self.attn_group_waves)
+        w.flags = ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0
         return w
 
     def _workspace(self, w: ffi.CmdmWeights, B: int, L: int, device) -> torch.Tensor:
@@ -392,7 +401,7 @@ class CMDM(TextEncoderMixin, nn.Module):
         return out.view(B, L, self.motion_dim)
 
     # ------------------------------------------------------------------ native sampling loop
-    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False):
+    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False, snapshots=None):
         """Whole p_sample_loop on the device: x holds x_T on entry, returns the final sample.  ``progress`` (test.py:85 passes
         True) splits the chain into ~50 native slices (afm_cmdm_sample_loop_range) and advances a tqdm bar between them; the
         result is bit-identical to the unsliced loop."""
@@ -435,7 +444,19 @@ class CMDM(TextEncoderMixin, nn.Module):
                     cnt, j0, seed & (2**64 - 1), sample_index0, B, L, sched.data_ptr(), ws.data_ptr(), ws.numel(),
                     nsub if nsub > 1 else 0, handles if nsub > 1 else None, stream), "afm_cmdm_sample_loop_range")
 
-            ffi.run_slices(ffi.progress_slices(n, progress), enqueue, progress, x.device)
+            slices = ffi.progress_slices(n, progress)
+            if snapshots is not None:
+                # `snapshots` = {executed step count: None}: the chain is cut at those counts and x is cloned there (stream-ordered
+                # device copies, no host synchronisation) - the intermediate states p_sample_loop_progressive would yield
+                slices = ffi.cut_slices(slices, sorted(k for k in snapshots if 0 < k < n))
+
+                def enqueue_snap(j0, j1, _inner=enqueue):
+                    _inner(j0, j1)
+                    if j1 in snapshots:
+                        snapshots[j1] = x.clone()
+                ffi.run_slices(slices, enqueue_snap, progress, x.device)
+            else:
+                ffi.run_slices(slices, enqueue, progress, x.device)
             # keep scratch alive until the stream has consumed it
             self._last_loop_scratch = (sched, step_noise, cond, fm)
         return x

@@ -199,13 +199,14 @@ class GaussianDiffusion:
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, *,
-                      step_noise=None, seed: Optional[int] = None, sample_index0: int = 0):
+                      step_noise=None, seed: Optional[int] = None, sample_index0: int = 0, snapshots: Optional[dict] = None):
         """Full ancestral sampling (reference gaussian_diffusion.py:442-486).
 
         Extra keyword-only arguments: ``step_noise`` ([T, *shape] tensor or list, row j = j-th
         executed step) replaces the `randn_like` draws; otherwise Philox noise keyed by
         (seed, sample_index0 + b, step).  Denoisers exposing ``afm_native_loop`` (our CMDM / CDM)
-        run the whole loop natively without host synchronisation."""
+        run the whole loop natively without host synchronisation.  ``snapshots`` = {executed-step count: None} is filled with
+        clones of x after those steps (what iterating p_sample_loop_progressive would have shown)."""
         native = getattr(model, "afm_native_loop", None)
         switches = any(k in (model_kwargs or {}) for k in ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase"))
         if native is not None and not clip_denoised and denoised_fn is None and cond_fn is None \
@@ -217,14 +218,17 @@ class GaussianDiffusion:
                                                                    sample_index0=sample_index0, step=-1)
             if isinstance(step_noise, (list, tuple)):
                 step_noise = torch.stack(list(step_noise), 0)
+            extra = {} if snapshots is None else {"snapshots": snapshots}
             return native(self, x, model_kwargs or {}, step_noise=step_noise, seed=seed, sample_index0=sample_index0,
-                          progress=bool(progress))
-        final = None
+                          progress=bool(progress), **extra)
+        final, done = None, 0
         for final in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                     denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
                                                     device=device, progress=progress, step_noise=step_noise, seed=seed,
                                                     sample_index0=sample_index0):
-            pass
+            done += 1
+            if snapshots is not None and done in snapshots:
+                snapshots[done] = final["sample"].clone()
         return final["sample"]
 
     # ------------------------------------------------------------------ loss

@@ -43,6 +43,18 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, count
 
 
+def job_shard(scaling: str, batch: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(first global sample, samples on this rank, samples in the whole job) for the two ways a node is used:
+    "weak"   every rank owns `batch` samples (the job grows with the node: 32 per GPU, the metric's configuration);
+    "strong" ONE job of `batch` samples (k_sample = 32 of test.py:88-101) is sharded contiguously over the ranks."""
+    if scaling == "weak":
+        return rank * batch, batch, batch * world
+    if scaling != "strong":
+        raise ValueError(f"scaling must be 'weak' or 'strong', got {scaling!r}")
+    start, count = shard_range(batch, rank, world)
+    return start, count, batch
+
+
 def shard_kwargs(kwargs: Dict[str, Any], start: int, count: int, total: int) -> Dict[str, Any]:
     """Slice every per-sample entry (tensor or list whose leading size is `total`) of a batch dict."""
     out = {}

@@ -17,6 +17,10 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libafm_hip
 _lib = None
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+ARITH_DEFAULT, ARITH_F32, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
+TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
+CMDM_NO_L0_CACHE = 0x1
+ABI_VERSION = 3
 MAX_LAYERS = 16
 
 c_f32p = C.c_void_p
@@ -40,6 +44,8 @@ class LinearArgs(C.Structure):
         # training hooks (ABI v2)
         ("preact", c_f32p), ("ldp", i64), ("dact_z", c_f32p), ("ldz", i64), ("dact", i32),
         ("drop_p", C.c_float), ("drop_seed", u64), ("drop_id", C.c_uint32), ("drop_after", i32),
+        # arithmetic of the product + bit-neutral tuning (ABI v3: fields instead of a process-wide switch)
+        ("arith", i32), ("arith_min_n", i32), ("tune", i32),
     ]
 
 
@@ -86,6 +92,7 @@ class CdmWeights(C.Structure):
         ("self_norm", Ln * 4), ("self_attn", MhaW * 4), ("self_mlp", MlpW * 4),
         ("dec_q_norm", Ln), ("dec_kv_norm", Ln), ("dec_attn", MhaW), ("dec_mlp", MlpW),
         ("contact_layer", Lin),
+        ("gemm_arith", i32), ("gemm_arith_min_n", i32),
     ]
 
 
@@ -106,6 +113,7 @@ class CmdmWeights(C.Structure):
         ("motion_layer_w", c_f32p), ("motion_layer_b", c_f32p),
         ("time_table", c_f32p), ("n_timesteps", i32), ("pos_table", c_f32p),
         ("layer", EncoderLayerWeights * MAX_LAYERS),
+        ("gemm_arith", i32), ("gemm_arith_min_n", i32), ("attn_group_waves", i32), ("flags", i32),
     ]
 
 
@@ -117,10 +125,9 @@ class DdpmArgs(C.Structure):
 EXPORTS = {
     # name: (restype, argtypes)
     "afm_version": (C.c_int, []),
-    "afm_linear_set_split": (C.c_int, [C.c_int]),
-    "afm_linear_set_split_min_n": (C.c_int, [C.c_int]),
     "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
+    "afm_mha_fwd_grouped": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_cross_fwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, C.c_void_p]),
     "afm_layernorm_rows": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, i32, i32, i32, C.c_void_p]),
@@ -269,6 +276,18 @@ def progress_slices(n_steps: int, progress: bool, slices: int = 50):
         return [(0, n_steps)]
     per = max(1, -(-n_steps // slices))
     return [(j, min(j + per, n_steps)) for j in range(0, n_steps, per)]
+
+
+def cut_slices(ranges, cuts):
+    """Split the (j0, j1) ranges at every executed-step count in `cuts` (chained slices stay bit-identical to the whole loop)."""
+    out = []
+    for j0, j1 in ranges:
+        for c in cuts:
+            if j0 < c < j1:
+                out.append((j0, c))
+                j0 = c
+        out.append((j0, j1))
+    return out
 
 
 def run_slices(ranges, enqueue, progress: bool, device):

@@ -58,38 +58,72 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         a.a_grp, a.a_stride, a.a_off = a_map
     if c_map:
         a.c_grp, a.c_stride, a.c_off = c_map
+    fill_arith(a)
     ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
     return out
 
 
+# ---- arithmetic of the GEMMs: HOST state (this module), written into every afm_linear_args / weight pack that is built.
+# The library itself has no switch and reads no environment (ABI v3).  Initial value: AFM_GEMM_SPLIT / AFM_GEMM_SPLIT_MIN_N in the
+# environment of the Python process, else the library default (exact nine-product bf16 split for N >= 1024, f32 MFMA elsewhere).
+def _initial_split():
+    import os
+    p = os.environ.get("AFM_GEMM_SPLIT")
+    products = int(p) if p is not None else 9
+    if products not in (0, 6, 9):
+        products = 0
+    n = os.environ.get("AFM_GEMM_SPLIT_MIN_N")
+    return products, max(0, int(n)) if n is not None else 1024
+
+
+_gemm_split = list(_initial_split())
+_gemm_tune = 0
+
+
+def gemm_arith() -> Tuple[int, int]:
+    """(arith, arith_min_n) for afm_linear_args / afm_c(m)dm_weights from the host setting."""
+    products, min_n = _gemm_split
+    if products == 0:
+        return ffi.ARITH_F32, 0
+    return (ffi.ARITH_BF16X9 if products == 9 else ffi.ARITH_BF16X6), min_n
+
+
 def set_gemm_split(products: int, min_n: Optional[int] = None):
-    """Arithmetic of `linear`'s wide GEMMs (afm_linear_set_split): 9 = exact three-way bf16 operand split on the bf16 matrix pipe with all
-    nine cross products (default, for N >= 1024), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N
-    threshold.  Returns the previous setting in the same form (products, or (products, min_n) when ``min_n`` was given)."""
-    lib = ffi.load()
-    prev = lib.afm_linear_set_split(int(products))
-    if prev < 0:
-        ffi.check(prev, "afm_linear_set_split")
+    """Arithmetic of `linear`'s GEMMs: 9 = exact three-way bf16 operand split on the bf16 matrix pipe with all nine cross products
+    (default, for N >= 1024), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N threshold.
+    Returns the previous setting in the same form (products, or (products, min_n) when ``min_n`` was given)."""
+    if int(products) not in (0, 6, 9):
+        raise ffi.AfmError(f"set_gemm_split: products must be 0, 6 or 9 (got {products})")
+    if min_n is not None and int(min_n) < 0:
+        raise ffi.AfmError(f"set_gemm_split: min_n must be >= 0 (got {min_n})")
+    prev = tuple(_gemm_split)
+    _gemm_split[0] = int(products)
     if min_n is None:
-        return prev
-    prev_n = lib.afm_linear_set_split_min_n(int(min_n))
-    if prev_n < 0:
-        ffi.check(prev_n, "afm_linear_set_split_min_n")
-    return prev, prev_n
+        return prev[0]
+    _gemm_split[1] = int(min_n)
+    return prev
 
 
 def get_gemm_split():
-    """Current (products, min_n) of `linear`'s wide-GEMM arithmetic."""
-    lib = ffi.load()
-    products = lib.afm_linear_set_split(0)
-    lib.afm_linear_set_split(products)
-    min_n = lib.afm_linear_set_split_min_n(0)
-    lib.afm_linear_set_split_min_n(min_n)
-    return products, min_n
+    """Current (products, min_n) of the GEMM arithmetic."""
+    return tuple(_gemm_split)
 
 
-def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
-    """qkv [B, T, 3*d] (packed in_proj output) -> softmax(QK^T/sqrt(dh) + mask) V, [B, T, d]."""
+def set_gemm_tune(tune: int) -> int:
+    """Bit-neutral performance knobs of afm_linear for experiments (afm_linear_args.tune, AFM_TUNE_*); returns the previous value."""
+    global _gemm_tune
+    prev, _gemm_tune = _gemm_tune, int(tune)
+    return prev
+
+
+def fill_arith(a) -> None:
+    a.arith, a.arith_min_n = gemm_arith()
+    a.tune = _gemm_tune
+
+
+def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int, group_waves: int = 0) -> torch.Tensor:
+    """qkv [B, T, 3*d] (packed in_proj output) -> softmax(QK^T/sqrt(dh) + mask) V, [B, T, d].  ``group_waves``: workgroup shape of
+    afm_mha_fwd_grouped (0 = the library's choice); results do not depend on it."""
     lib = ffi.load()
     ffi.require_gpu(qkv)
     qkv = ffi.f32c(qkv)
@@ -100,8 +134,8 @@ def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torc
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
         assert km.shape == (B, T)
-    ffi.check(lib.afm_mha_fwd(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, ffi.stream_of(qkv)),
-              "afm_mha_fwd")
+    ffi.check(lib.afm_mha_fwd_grouped(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, int(group_waves),
+                                      ffi.stream_of(qkv)), "afm_mha_fwd_grouped")
     return out
 
 

@@ -1,8 +1,11 @@
 // afm_mha_fwd: softmax(Q K^T / sqrt(dh) + key_mask) V for the CMDM encoder (T <= ~330 tokens, dh = 64).
 //
 // gfx950 design
-//   * one workgroup per (sample, head); one wave per 32-query block (T = 326 -> 11 waves = 704 threads,
-//     B*H = 256 workgroups = one per CU at the headline batch of 32).
+//   * grid = (sample, head, query group); a workgroup is a group of 1 / 2 / 4 / 8 / 12 waves, one wave per 32-query block.
+//     T = 326 -> 11 query blocks per (sample, head): groups of 4 waves give 3 workgroups per (sample, head) = 768 workgroups at
+//     B = 32 (3 co-resident per CU, each with its own barriers, so one group's softmax phase overlaps another's MFMA phase);
+//     at B = 4 per GPU (strong scaling over 8 GPUs) single-wave groups give 352 workgroups instead of 32.  A query row's
+//     arithmetic does not depend on the grouping (bit-identical results).
 //   * K/V are streamed in 32-key blocks through a double-buffered LDS stage shared by all waves
 //     (coalesced float4 global loads, one barrier per block); Q lives in registers for the whole pass.
 //   * "Swapped" products on v_mfma_f32_32x32x2_f32 so that nothing is ever transposed or shuffled:
@@ -27,10 +30,10 @@ constexpr int MAX_WAVES = 12;      // 3 waves per SIMD -> 168 VGPRs each, no spi
 // TRAIN: also writes lse[b,h,q] = log-sum-exp of the scaled, masked logits (saved for afm_mha_bwd) and applies
 // attention-probability dropout to the P used in P V (the softmax normaliser uses the undropped P, as in torch).
 template <int NST, bool TRAIN>
-__global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
+__global__ __launch_bounds__(NST == 16 ? 64 : NST == 8 ? 128 : NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
                                                        const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
                                                        float* __restrict__ out, int Tq, int T, int H, float scale,
-                                                       float* __restrict__ lse, float drop_p, uint64_t drop_seed, uint32_t drop_id) {
+                                                       float* __restrict__ lse, float drop_p, uint64_t drop_seed, uint32_t drop_id, int nchunk) {
     // Tq queries (rows of qp_, stride ldq) attend over T keys / values (rows of kp_ / vp_, stride ldkv): self-attention passes the
     // packed in_proj output three times (q | k | v, ld = 3D, Tq == T), cross-attention a [B,Tq,D] query and a packed [B,T,2D] memory.
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -39,7 +42,15 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
     float* madd = Vs + 2 * KB * DH;                 // [nkb*KB] additive mask (0 / -inf)
     int* blk_valid = reinterpret_cast<int*>(madd + ((T + KB - 1) / KB) * KB);   // [nkb]
 
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // XCD-aware order: block i runs on XCD i % 8; give each XCD a contiguous range of (sample, head, group) so the groups that
+    // share one (sample, head)'s K / V read them through the same L2
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bh = bid / nchunk, chunk = bid % nchunk;
+    const int b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
     const int D = H * DH;
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
         }
     };
 
-    for (int q0 = 0; q0 < nqb; q0 += nw) {
+    for (int q0 = chunk * nw; q0 < nqb; q0 += nw * nchunk) {
         const int qb = q0 + wave;
         const bool active = qb < nqb;
         // Q fragment: query row (clamped), head dims 32*hh .. 32*hh+31, pre-scaled
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
                 // ---- O^T += V^T P^T : step r multiplies key (r&3) + 8*(r>>2) + 4*hh
                 if (TRAIN && drop_p > 0.0f) {
                     const DropKey dk(drop_p, drop_seed, drop_id);
-                    const uint32_t row_ix = blockIdx.x * Tq + min(qb * 32 + r32, Tq - 1), col0 = kb * KB + 4 * hh;
+                    const uint32_t row_ix = (uint32_t)bh * Tq + min(qb * 32 + r32, Tq - 1), col0 = kb * KB + 4 * hh;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] *= dk(row_ix, col0 + (r & 3) + 8 * (r >> 2));
                 }
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
         if (active) {
             const int qrow = qb * 32 + r32;
             if (qrow < Tq) {
-                if (TRAIN && hh == 0) lse[(int64_t)blockIdx.x * Tq + qrow] = m_run + __logf(l_run);
+                if (TRAIN && hh == 0) lse[(int64_t)bh * Tq + qrow] = m_run + __logf(l_run);
                 const float inv = 1.0f / l_run;
                 float* op = out + ((int64_t)b * Tq + qrow) * D + h * DH + 4 * hh;
 #pragma unroll
@@ -186,23 +197,38 @@ __global__ __launch_bounds__(NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kerne
     }
 }
 
+// group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 8 / 12; 0 = choose from the launch size; < 0 = one workgroup per
+// (sample, head) that walks all query blocks (long-query cross-attention, training).
 int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, float* lse, int32_t B,
-                   int32_t Tq, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, void* stream) {
+                   int32_t Tq, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, int group_waves,
+                   void* stream) {
     if (dh != DH) return AFM_E_UNSUPPORTED;
     if (B == 0) return 0;                                     // empty batch (pointers may be null)
     if (!q || !k || !v || !out || B < 0 || T <= 0 || Tq <= 0 || H <= 0) return AFM_E_BADARG;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return AFM_E_BADARG;
     if (train && (!lse || drop_p < 0.0f || drop_p >= 1.0f)) return AFM_E_BADARG;
     const int nqb = (Tq + 31) / 32, nkb = (T + 31) / 32;
-    int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
+    int nw, nchunk = 1;
+    if (group_waves < 0) {
+        nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
+    } else {
+        if (group_waves != 0 && group_waves != 1 && group_waves != 2 && group_waves != 4 && group_waves != 8 && group_waves != 12) return AFM_E_BADARG;
+        nw = group_waves;
+        if (nw == 0) {          // largest group that still gives >= 2 workgroups per CU (256 CUs); measured table in profiles/r02_small_batch.md
+            const int64_t bh = (int64_t)B * H;
+            nw = bh * ((nqb + 3) / 4) >= 512 ? 4 : (bh * ((nqb + 1) / 2) >= 512 ? 2 : 1);
+        }
+        if (nw > nqb) nw = nqb >= 8 ? nqb : (nqb >= 4 ? 4 : (nqb >= 2 ? 2 : 1));      // never more waves than query blocks
+        nchunk = (nqb + nw - 1) / nw;
+    }
     const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nkb * KB) * sizeof(float) + (size_t)nkb * sizeof(int);
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~30000 keys
     if (lds > 64 * 1024) {                                     // long memories (cross-attention over N = 8192 points): opt in once
         static std::atomic<bool> attr_set{false};      // idempotent attribute: a race only repeats the call
         if (!attr_set.load(std::memory_order_acquire)) {
-            const void* fns[4] = {(const void*)mha_fwd_kernel<2, false>, (const void*)mha_fwd_kernel<4, false>, (const void*)mha_fwd_kernel<2, true>,
-                                  (const void*)mha_fwd_kernel<4, true>};
-            for (int i = 0; i < 4; ++i) {
+            const void* fns[6] = {(const void*)mha_fwd_kernel<2, false>, (const void*)mha_fwd_kernel<4, false>, (const void*)mha_fwd_kernel<2, true>,
+                                  (const void*)mha_fwd_kernel<4, true>, (const void*)mha_fwd_kernel<8, false>, (const void*)mha_fwd_kernel<16, false>};
+            for (int i = 0; i < 6; ++i) {
                 hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return (int)e;
             }
@@ -212,9 +238,12 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     const float scale = 1.0f / sqrtf((float)dh);
     hipStream_t s = (hipStream_t)stream;
     AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
-#define AFM_MHA(NST, TR) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR>), dim3(B * H), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id)
+#define AFM_MHA(NST, TR) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR>), dim3(B * H * nchunk), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id, nchunk)
     if (train) { if (nw >= 8) AFM_MHA(2, true); else AFM_MHA(4, true); }
-    else { if (nw >= 8) AFM_MHA(2, false); else AFM_MHA(4, false); }
+    else if (nw >= 8) AFM_MHA(2, false);
+    else if (nw >= 4) AFM_MHA(4, false);
+    else if (nw == 2) AFM_MHA(8, false);
+    else AFM_MHA(16, false);
 #undef AFM_MHA
     AFM_CHECK_LAUNCH();
     return 0;
@@ -222,22 +251,28 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
 
 }  // namespace
 
-extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
-                           int32_t dh, void* stream) {
+extern "C" int afm_mha_fwd_grouped(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
+                                   int32_t dh, int32_t group_waves, void* stream) {
+    if (group_waves < 0) return AFM_E_BADARG;
     const int D = H * dh;
     return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, nullptr, B, T, T, H, dh, 0.0f, 0, 0, false,
-                          stream);
+                          group_waves, stream);
+}
+
+extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,
+                           int32_t dh, void* stream) {
+    return afm_mha_fwd_grouped(qkv, key_mask, out, B, T, H, dh, 0, stream);
 }
 
 extern "C" int afm_mha_fwd_train(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t T, int32_t H,
                                  int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream) {
     const int D = H * dh;
     return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, lse, B, T, T, H, dh, drop_p, drop_seed,
-                          drop_id, true, stream);
+                          drop_id, true, -1, stream);
 }
 
 extern "C" int afm_mha_cross_fwd(const float* q, const float* kv, const uint8_t* key_mask, float* out, int32_t B, int32_t Tq, int32_t Tk, int32_t H,
                                  int32_t dh, void* stream) {
     const int D = H * dh;
-    return mha_fwd_launch(q, D, kv, kv ? kv + D : nullptr, 2 * D, key_mask, out, nullptr, B, Tq, Tk, H, dh, 0.0f, 0, 0, false, stream);
+    return mha_fwd_launch(q, D, kv, kv ? kv + D : nullptr, 2 * D, key_mask, out, nullptr, B, Tq, Tk, H, dh, 0.0f, 0, 0, false, -1, stream);
 }

@@ -10,11 +10,10 @@
 //   buffer, +bias +positional rows) -> n_layers x { in_proj GEMM, flash MHA, out_proj GEMM(+bias
 //   +residual), LN, FFN1 GEMM(+bias+GELU), FFN2 GEMM(+bias+residual), LN } -> motion_layer GEMM
 //   (gather motion tokens, +bias, fused DDPM posterior update).
-#include <cstdlib>
 #include "common.h"
 
 extern "C" int afm_linear(const afm_linear_args*, void*);
-extern "C" int afm_mha_fwd(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, void*);
+extern "C" int afm_mha_fwd_grouped(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_layernorm(const float*, const float*, const float*, float*, int64_t, int32_t, float, void*);
 extern "C" int afm_layernorm_rows(const float*, const float*, const float*, float*, int64_t, int32_t, float, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_randn(float*, int32_t, int64_t, uint64_t, int64_t, int32_t, void*);
@@ -90,6 +89,12 @@ __global__ void expand_schedule_kernel(const int64_t* __restrict__ tmap, const f
 
 #define AFM_TRY(expr) do { int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
 
+// every nn.Linear of the denoiser runs with the arithmetic the caller put into the weight pack (ABI v3: no process-wide switch)
+inline int run_linear(const afm_cmdm_weights& w, afm_linear_args& a, hipStream_t s) {
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    return afm_linear(&a, s);
+}
+
 int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, const float* cond,
                  const uint8_t* frame_mask, float* x0_out, const afm_ddpm_args* ddpm, int B, int L, const Workspace& ws,
                  bool copy_cond, hipStream_t s) {
@@ -108,7 +113,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.bias = w.motion_adapter_b;
         a.rowtab = w.pos_table + (int64_t)(1 + w.n_cond) * d; a.rowtab_period = L;
         a.c_grp = L; a.c_stride = T; a.c_off = 1 + w.n_cond;
-        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(run_linear(w, a, s));
     }
 
     const float* X = ws.seq0;
@@ -121,17 +126,17 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         afm_linear_args a = {};
         a.A = X; a.lda = d; a.W = lw.in_proj_w; a.ldw = d; a.C = qkv; a.ldc = 3 * d;
         a.N = 3 * d; a.K = d; a.bias = lw.in_proj_b;
-        static const bool no_l0_cache = getenv("AFM_CMDM_NO_L0_CACHE") != nullptr;      // measurement knob
+        const bool no_l0_cache = (w.flags & AFM_CMDM_NO_L0_CACHE) != 0;                  // measurement knob
         if (li == 0 && !copy_cond && w.n_cond > 0 && !no_l0_cache) {
             a.M = B; a.a_grp = 1; a.a_stride = T; a.a_off = 0; a.c_grp = 1; a.c_stride = T; a.c_off = 0;                 // time tokens
-            AFM_TRY(afm_linear(&a, s));
+            AFM_TRY(run_linear(w, a, s));
             a.M = B * L; a.a_grp = L; a.a_stride = T; a.a_off = 1 + w.n_cond; a.c_grp = L; a.c_stride = T; a.c_off = 1 + w.n_cond;   // motion tokens
-            AFM_TRY(afm_linear(&a, s));
+            AFM_TRY(run_linear(w, a, s));
         } else {
             a.M = M;
-            AFM_TRY(afm_linear(&a, s));
+            AFM_TRY(run_linear(w, a, s));
         }
-        AFM_TRY(afm_mha_fwd(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, s));
+        AFM_TRY(afm_mha_fwd_grouped(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, w.attn_group_waves, s));
         // After the LAST layer only the L motion tokens of each sample are read (motion_layer, cmdm.py:169,195), and
         // everything after the attention is row-local: run it on the B*L motion rows only (token rows gathered /
         // scattered by the row maps; the other rows of tmp/x1/y keep stale values nobody reads).
@@ -142,18 +147,18 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.A = ws.att; a.lda = d; a.W = lw.out_proj_w; a.ldw = d; a.C = ws.tmp; a.ldc = d;
         a.M = rows; a.N = d; a.K = d; a.bias = lw.out_proj_b; a.residual = X; a.ldr = d;
         a.a_grp = g; a.a_stride = gs; a.a_off = go; a.c_grp = g; a.c_stride = gs; a.c_off = go;
-        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(run_linear(w, a, s));
         AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, rows, d, 1e-5f, g, gs, go, s));
         a = {};
         a.A = ws.x1; a.lda = d; a.W = lw.lin1_w; a.ldw = d; a.C = ws.hid; a.ldc = w.ff;
         a.M = rows; a.N = w.ff; a.K = d; a.bias = lw.lin1_b; a.act = AFM_ACT_GELU;
         a.a_grp = g; a.a_stride = gs; a.a_off = go;                       // hid is written compactly [rows, ff]
-        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(run_linear(w, a, s));
         a = {};
         a.A = ws.hid; a.lda = w.ff; a.W = lw.lin2_w; a.ldw = w.ff; a.C = ws.tmp; a.ldc = d;
         a.M = rows; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.x1; a.ldr = d;
         a.c_grp = g; a.c_stride = gs; a.c_off = go;
-        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(run_linear(w, a, s));
         AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm2_w, lw.norm2_b, ws.y, rows, d, 1e-5f, g, gs, go, s));
         X = ws.y;
     }
@@ -173,7 +178,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
             a.ddpm_xt = x_t; a.ddpm_noise = nz; a.ddpm_out = ddpm->x_next; a.ldx = w.motion_dim;
             a.ddpm_c1 = ddpm->c1; a.ddpm_c2 = ddpm->c2; a.ddpm_sigma = ddpm->sigma; a.rows_per_sample = L;
         }
-        AFM_TRY(afm_linear(&a, s));
+        AFM_TRY(run_linear(w, a, s));
     }
     return 0;
 }
@@ -183,6 +188,9 @@ int validate(const afm_cmdm_weights* w, int B, int L) {
     if (w->d <= 0 || (w->d & 3) || w->heads <= 0 || w->d % w->heads || w->ff <= 0 || (w->ff & 3)) return AFM_E_BADARG;
     if (w->n_layers <= 0 || w->n_layers > AFM_MAX_LAYERS || w->n_cond < 0 || w->motion_dim <= 0) return AFM_E_BADARG;
     if (w->d / w->heads != 64) return AFM_E_UNSUPPORTED;
+    if (w->gemm_arith != AFM_ARITH_DEFAULT && w->gemm_arith != AFM_ARITH_F32 && w->gemm_arith != AFM_ARITH_BF16X6 && w->gemm_arith != AFM_ARITH_BF16X9)
+        return AFM_E_BADARG;
+    if (w->gemm_arith_min_n < 0 || w->attn_group_waves < 0) return AFM_E_BADARG;
     if (!w->motion_adapter_w || !w->motion_layer_w || !w->time_table || !w->pos_table) return AFM_E_BADARG;
     return 0;
 }

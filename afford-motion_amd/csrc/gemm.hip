@@ -13,7 +13,6 @@
 //     written to the other LDS buffer afterwards: one barrier per K tile.
 //   * XCD-aware tile order: the 8 XCDs each walk a contiguous range of tiles (A row-panels are
 //     reused out of the XCD's own L2; W (<= 3 MB) stays L2 resident).
-#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 #include "gemm_epilogue.h"
@@ -191,9 +190,15 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BM, int BN, int NSTG = 3>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p, int nbm, int nbn) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+// Workgroup = WM x WN waves, each wave owns TM x TN MFMA tiles of 32x32: tile BM x BN = 32 WM TM x 32 WN TN.  Every shape sums an
+// output element in the same order (K-tiles of 32 in sequence, the permuted k inside a tile), so shapes are interchangeable bit for
+// bit and the dispatcher may pick one from M (small batches: 32x32 single-wave workgroups keep 256 CUs busy at B*T = 1304 rows).
+template <int WM, int WN, int TM, int TN, int NSTG = 3>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_linear_args p, int nbm, int nbn) {
+    constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int RP = NT / 8;                       // rows one DMA pass of the whole workgroup covers (8 x 16 B per row)
+    constexpr int PA = BM / RP, PW = BN / RP;        // passes per K-tile for the A / W panels
+    static_assert(BM % RP == 0 && BN % RP == 0, "panel rows must be a multiple of the rows per DMA pass");
     constexpr int STAGE = (BM + BN) * BK;            // floats per stage: A tile then W tile, 32 floats per row
     constexpr int LDC = BN + 4;
     constexpr int LDS_FLOATS = (NSTG * STAGE > BM * LDC) ? NSTG * STAGE : BM * LDC;
@@ -207,22 +212,22 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p
     }
     const int bm = bid / nbn, bn = bid % nbn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r32 = lane & 31, hh = lane >> 5;
     const int c8 = tid & 7, r0 = tid >> 3;           // this thread's (row-in-pass, 16-byte slot) of every DMA pass
 
     const RowMap amap{p.a_grp, p.a_stride, p.a_off};
     // per-pass source pointers with the swizzle folded in: slot c8 of row r receives logical chunk c8 ^ ((r >> 1) & 7)
-    const float* asrc[BM / 32];
-    const float* wsrc[BN / 32];
+    const float* asrc[PA];
+    const float* wsrc[PW];
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-        const int r = r0 + 32 * i;
+    for (int i = 0; i < PA; ++i) {
+        const int r = r0 + RP * i;
         asrc[i] = p.A + amap(min(bm * BM + r, p.M - 1)) * p.lda + ((c8 ^ ((r >> 1) & 7)) << 2);
     }
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-        const int r = r0 + 32 * i;
+    for (int i = 0; i < PW; ++i) {
+        const int r = r0 + RP * i;
         wsrc[i] = p.W + (int64_t)min(bn * BN + r, p.N - 1) * p.ldw + ((c8 ^ ((r >> 1) & 7)) << 2);
     }
     const int wave_off = __builtin_amdgcn_readfirstlane(wave) * 256;     // floats: 8 rows x 32 per wave per pass
@@ -230,11 +235,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p
         float* a_dst = lds + stage * STAGE + wave_off;
         float* w_dst = lds + stage * STAGE + BM * BK + wave_off;
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) glds16(asrc[i] + kt * BK, a_dst + i * 32 * BK);
+        for (int i = 0; i < PA; ++i) glds16(asrc[i] + kt * BK, a_dst + i * RP * BK);
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) glds16(wsrc[i] + kt * BK, w_dst + i * 32 * BK);
+        for (int i = 0; i < PW; ++i) glds16(wsrc[i] + kt * BK, w_dst + i * RP * BK);
     };
-    constexpr int PER_TILE = BM / 32 + BN / 32;      // DMA instructions per thread per K-tile
+    constexpr int PER_TILE = PA + PW;                // DMA instructions per thread per K-tile
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -260,8 +265,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p
         // ds_read with `s_waitcnt vmcnt(0)` (it cannot prove the DMA target does not alias), which drains the ring.
         // All reads of the K-tile are issued up front (they return in order), then each MFMA group waits for exactly
         // the reads it needs (counted lgkmcnt) - guide section 5.7 forms (ii)/(iii), rule 18 (sched_barrier after a wait).
-        const unsigned a_addr = (unsigned)((stage * STAGE + (wm * (BM / 2) + r32) * BK) * 4);
-        const unsigned w_addr = (unsigned)((stage * STAGE + BM * BK + (wn * (BN / 2) + r32) * BK) * 4);
+        const unsigned a_addr = (unsigned)((stage * STAGE + (wm * TM * 32 + r32) * BK) * 4);
+        const unsigned w_addr = (unsigned)((stage * STAGE + BM * BK + (wn * TN * 32 + r32) * BK) * 4);
         f32x4 af[4][TM], bf[4][TN];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -302,29 +307,26 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_dma(const afm_linear_args p
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                lds[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
+                lds[(wm * TM * 32 + tm * 32 + mfma_row(r, lane)) * LDC + wn * TN * 32 + tn * 32 + r32] = acc[tm][tn][r];
     __syncthreads();
-    gemm_epilogue<BM, BN>(p, lds, bm, bn, tid);
+    gemm_epilogue<BM, BN, NT>(p, lds, bm, bn, tid);
 }
 
-template <int BM, int BN>
-int launch(const afm_linear_args& a, bool vec, hipStream_t s) {
+template <int WM, int WN, int TM, int TN>
+int launch_dma(const afm_linear_args& a, int tag, hipStream_t s) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    dim3 grid(nbm * nbn), block(256);
-    static const bool no_dma = getenv("AFM_GEMM_NO_DMA") != nullptr;      // tuning knob
-    const bool dma = vec && (a.K % BK) == 0 && !no_dma;
-    const int tag = BM == 128 ? (dma ? AFM_PROF_GEMM128_DMA : AFM_PROF_GEMM128)
-                              : (BN == 128 ? (dma ? AFM_PROF_GEMM64x128_DMA : AFM_PROF_GEMM64x128) : (dma ? AFM_PROF_GEMM64_DMA : AFM_PROF_GEMM64));
     AfmProf prof(tag, 2.0 * a.M * a.N * a.K, s);
-    static const bool two_stage = getenv("AFM_GEMM_STAGES") && atoi(getenv("AFM_GEMM_STAGES")) == 2;       // tuning knob
-    if (dma && two_stage)
-        hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN, 2>), grid, block, 0, s, a, nbm, nbn);
-    else if (dma)
-        hipLaunchKernelGGL((gemm_f32_mfma_dma<BM, BN>), grid, block, 0, s, a, nbm, nbn);
-    else if (vec)
-        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, true>), grid, block, 0, s, a, nbm, nbn);
-    else
-        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, false>), grid, block, 0, s, a, nbm, nbn);
+    hipLaunchKernelGGL((gemm_f32_mfma_dma<WM, WN, TM, TN>), dim3(nbm * nbn), dim3(64 * WM * WN), 0, s, a, nbm, nbn);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_regs(const afm_linear_args& a, bool vec, hipStream_t s) {       // register-staged 64x64 kernel: any K, any alignment
+    const int nbm = (a.M + 63) / 64, nbn = (a.N + 63) / 64;
+    AfmProf prof(AFM_PROF_GEMM64, 2.0 * a.M * a.N * a.K, s);
+    if (vec) hipLaunchKernelGGL((gemm_f32_mfma<64, 64, true>), dim3(nbm * nbn), dim3(256), 0, s, a, nbm, nbn);
+    else hipLaunchKernelGGL((gemm_f32_mfma<64, 64, false>), dim3(nbm * nbn), dim3(256), 0, s, a, nbm, nbn);
     AFM_CHECK_LAUNCH();
     return 0;
 }
@@ -343,18 +345,31 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
-    if (a.M == 0) return 0;
+    if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9) return AFM_E_BADARG;
+    if (a.arith_min_n < 0) return AFM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                      (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
-    // Tile choice (measured on MI355X, tools/probe_*.py, profiles/round1_notes.md): with the 64-cycle f32 MFMA
-    // neither LDS nor L2 bandwidth limits; what limits is keeping every SIMD's matrix pipe busy across the
-    // barrier / load phases of its waves.  64x64 tiles (72 VGPRs, 36 KB LDS -> 4 workgroups = 4 waves per SIMD,
-    // fine-grained tails) beat 64x128 and 128x128 on every GEMM shape of the encoder (2.79 vs 2.95 vs 3.30
-    // ms/step), so they are the default; the larger instantiations stay selectable for experiments.
     if (const int mode = afm_linear_split_mode(a)) return afm_linear_split(a, mode, s);
-    static const int forced = []() { const char* e = getenv("AFM_GEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 1) return launch<128, 128>(a, vec, s);
-    if (forced == 2) return launch<64, 128>(a, vec, s);
-    return launch<64, 64>(a, vec, s);
+    // Native f32 MFMA.  Tile choice (measured on MI355X, profiles/r01_gemm_investigation.md): with the 64-cycle f32 MFMA neither LDS
+    // nor L2 bandwidth limits; what limits is keeping every SIMD's matrix pipe busy across the barrier / load phases of its waves
+    // and filling 256 CUs.  64x64 tiles (4 workgroups = 4 waves per SIMD, fine-grained tails) beat 64x128 and 128x128 on every
+    // encoder shape at B = 32 (2.79 vs 2.95 vs 3.30 ms/step); with few rows (strong scaling: B = 4 per GPU -> M = 1304) the same
+    // kernel runs with 2-wave 32x64 or single-wave 32x32 workgroups so that the launch still covers the chip.  All shapes are
+    // bit-identical (same summation order per output element), which is why M may enter this choice.
+    const bool dma = vec && (a.K % BK) == 0 && !(a.tune & AFM_TUNE_NO_DMA);
+    if (!dma) return launch_regs(a, vec, s);
+    int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;
+    if (tile == 0) {
+        const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64), t3264 = (int64_t)((a.M + 31) / 32) * ((a.N + 63) / 64);
+        tile = t64 >= 512 ? 3 : (t3264 >= 512 ? 2 : 1);
+    }
+    switch (tile) {
+        case 1: return launch_dma<1, 1, 1, 1>(a, AFM_PROF_GEMM32_DMA, s);
+        case 2: return launch_dma<1, 2, 1, 1>(a, AFM_PROF_GEMM32x64_DMA, s);
+        case 3: return launch_dma<2, 2, 1, 1>(a, AFM_PROF_GEMM64_DMA, s);
+        case 4: return launch_dma<2, 2, 1, 2>(a, AFM_PROF_GEMM64x128_DMA, s);
+        case 5: return launch_dma<2, 2, 2, 2>(a, AFM_PROF_GEMM128_DMA, s);
+        default: return AFM_E_BADARG;
+    }
 }

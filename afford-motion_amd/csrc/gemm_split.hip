@@ -6,11 +6,11 @@
 //   NPROD = 9: all products (error = f32 accumulation order only).
 //   NPROD = 6: drops x2*w3, x3*w2, x3*w3 (|x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|: each dropped product <= 2^-24 |x||w|, rms ~2^-26, zero-mean because
 //              the split rounds to nearest - an order of magnitude below the rounding noise of the f32 accumulation itself).
-// Measured against float64 (tools/gemm_bench.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
+// Measured against float64 (tools/kernel_sweep.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
 // native f32 MFMA kernel.  Default: the exact 9-product variant on the wide GEMMs (N >= 1024: in_proj, linear1), where it is 1.26x faster than
 // the native kernel stand-alone and +7..10 % end to end (435-441 vs 400-406 steps/s, tools/ab_gemm_modes.py); the N = 512 GEMMs stay native (the split gains less there and the
-// bf16 pipe's power draw lowers the clock for everything around it, profiles/r01_gemm_investigation.md).  AFM_GEMM_SPLIT=0 restores the native
-// kernels everywhere; AFM_GEMM_SPLIT=6 with AFM_GEMM_SPLIT_MIN_N=0 is the fastest setting (522-529 steps/s).
+// bf16 pipe's power draw lowers the clock for everything around it, profiles/r01_gemm_investigation.md).  afm_linear_args.arith = AFM_ARITH_F32 selects the native
+// kernels everywhere; AFM_ARITH_BF16X6 with arith_min_n = 0 is the fastest setting (522-529 steps/s).
 //
 // Kernel: 256 threads = 2x2 waves, wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, K consumed BK at a time.
 //   global f32 -> registers (next K-tile, issued before the MFMAs of the current one) -> split in VALU, interleaved with
@@ -18,8 +18,6 @@
 //   {0-3,12-15,20-27} / {4-11,16-19,28-31} hit 16 distinct 16-byte slots; stores go even rows / odd rows per 8-lane group, also
 //   conflict-free: SQ_LDS_BANK_CONFLICT = 0) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
 //   One barrier per K-tile (double-buffered LDS), shared epilogue of gemm.hip.
-#include <atomic>
-#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "profile.h"
@@ -234,65 +232,30 @@ int launch_split(const afm_linear_args& a, hipStream_t s) {
 
 template <int NPROD>
 int dispatch_split(const afm_linear_args& a, hipStream_t s) {
-    static const int tile = []() { const char* e = getenv("AFM_GEMM_SPLIT_TILE"); return e ? atoi(e) : 0; }();      // tuning knob
+    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 0 = heuristic
     // 128x128 amortises the split best (each thread splits 16 floats per 36 MFMAs of its wave); with fewer 128x128 tiles
-    // than CUs, 64x64 tiles fill the chip better (measured on M = 5216, N = 512: 34.8 vs 41.3 us)
+    // than CUs, 64x64 tiles fill the chip better (measured on M = 5216, N = 512: 34.8 vs 41.3 us).  Both tile shapes add
+    // the products of an output element in the same order (bit-identical), so M may enter the choice.
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tile == 2 || (tile == 0 && tiles128 < 256)) return launch_split<64, 64, 16, NPROD>(a, s);
+    if (tile == 3 || (tile != 5 && tiles128 < 256)) return launch_split<64, 64, 16, NPROD>(a, s);
     return launch_split<128, 128, 16, NPROD>(a, s);
 }
 
 }  // namespace
 
-// Products per f32 product used by afm_linear for its wide GEMMs: 9 (default, exact), 6, or 0 = native f32 MFMA kernels everywhere.
-// Initial values from AFM_GEMM_SPLIT / AFM_GEMM_SPLIT_MIN_N; afm_linear_set_split / afm_linear_set_split_min_n change them at run time.
-static std::atomic<int> g_split_mode{-1};
-static std::atomic<int> g_split_min_n{-1};
-
-static int split_mode_now() {
-    int m = g_split_mode.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char* e = getenv("AFM_GEMM_SPLIT");
-        m = e ? atoi(e) : 9;
-        if (m != 9 && m != 6) m = 0;
-        g_split_mode.store(m, std::memory_order_relaxed);
-    }
-    return m;
-}
-
-static int split_min_n_now() {
-    int n = g_split_min_n.load(std::memory_order_relaxed);
-    if (n < 0) {
-        const char* e = getenv("AFM_GEMM_SPLIT_MIN_N");
-        n = e ? atoi(e) : 1024;
-        if (n < 0) n = 0;
-        g_split_min_n.store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
-
-extern "C" int afm_linear_set_split(int products) {
-    if (products != 0 && products != 6 && products != 9) return AFM_E_BADARG;
-    const int prev = split_mode_now();
-    g_split_mode.store(products, std::memory_order_relaxed);
-    return prev;
-}
-
-extern "C" int afm_linear_set_split_min_n(int min_n) {
-    if (min_n < 0) return AFM_E_BADARG;
-    const int prev = split_min_n_now();
-    g_split_min_n.store(min_n, std::memory_order_relaxed);
-    return prev;
-}
-
-// Which GEMMs take the split path is a function of (N, K) and operand alignment only - never of M - so a batch and its shards run the
-// same arithmetic (sharding / sub-batch invariance stays bit-exact).  Measured in the sampling loop (B = 32, two sub-batch streams):
-// native everywhere 406 steps/s, x9 on the N >= 1024 GEMMs (in_proj, linear1) 435, x9 everywhere 447 (385 on a box with less power
-// headroom, where the wide-only default still matched native), x6 everywhere 529.
+// Which GEMMs take the split path is a function of (arith, arith_min_n, N, K) and operand alignment only - never of M - so a batch
+// and its shards run the same arithmetic (sharding / sub-batch invariance stays bit-exact).  Measured in the sampling loop (B = 32,
+// two sub-batch streams): native everywhere 406 steps/s, x9 on the N >= 1024 GEMMs (in_proj, linear1) 435, x9 everywhere 447 (385 on
+// a box with less power headroom, where the wide-only default still matched native), x6 everywhere 529.
 int afm_linear_split_mode(const afm_linear_args& a) {
-    const int mode = split_mode_now();
-    if (!mode) return 0;
-    const bool ok = (a.K % 16 == 0) && a.K >= 128 && a.N >= split_min_n_now() && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
+    int mode, min_n;
+    switch (a.arith) {
+        case AFM_ARITH_DEFAULT: mode = 9; min_n = 1024; break;
+        case AFM_ARITH_BF16X9: mode = 9; min_n = a.arith_min_n; break;
+        case AFM_ARITH_BF16X6: mode = 6; min_n = a.arith_min_n; break;
+        default: return 0;
+    }
+    const bool ok = (a.K % 16 == 0) && a.K >= 128 && a.N >= min_n && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
                     (((uintptr_t)a.W & 15) == 0);
     return ok ? mode : 0;
 }

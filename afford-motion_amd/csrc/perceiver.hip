@@ -459,6 +459,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     afm_linear_args a = {};
     a.A = feat; a.lda = w.feat_dim; a.W = w.encoder_adapter.w; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = w.feat_dim; a.bias = w.encoder_adapter.b;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));
     // The decoder adapter GEMM (34 GFLOP at B = 32) only needs enc_kv, while the latent chain (enc_reduce -> latent_post: one
     // workgroup per SAMPLE, a serial 0.5 ms dependency chain that leaves the chip idle) only produces the 2 latent tokens:
@@ -488,6 +489,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
         afm_linear_args d = {};
         d.A = ws.enc_kv; d.lda = dkv; d.W = w.decoder_adapter.w; d.ldw = dkv; d.C = ws.bufB; d.ldc = dkv;
         d.M = M; d.N = dkv; d.K = dkv; d.bias = w.decoder_adapter.b;
+        d.arith = w.gemm_arith; d.arith_min_n = w.gemm_arith_min_n;
         const int rc = afm_linear(&d, side);
         (void)hipEventRecord(ev_join, side);
         if (rc) { (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); return rc; }
@@ -499,7 +501,8 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
         a = {};
         a.A = ws.enc_kv; a.lda = dkv; a.W = w.decoder_adapter.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
         a.M = M; a.N = dkv; a.K = dkv; a.bias = w.decoder_adapter.b;
-        AFM_TRY(afm_linear(&a, s));
+        a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    AFM_TRY(afm_linear(&a, s));
     }
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
@@ -512,10 +515,12 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     a = {};
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));
     a = {};
     a.A = ws.bufB; a.lda = dkv; a.W = w.dec_mlp.fc2.w; a.ldw = dkv; a.C = ws.z; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc2.b; a.residual = ws.h1; a.ldr = dkv;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));
     a = {};
     a.A = ws.z; a.lda = dkv; a.W = w.contact_layer.w; a.ldw = dkv; a.C = x0_out; a.ldc = w.contact_dim;
@@ -524,6 +529,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
         a.ddpm_xt = x_t; a.ddpm_noise = ddpm->noise; a.ddpm_out = ddpm->x_next; a.ldx = w.contact_dim;
         a.ddpm_c1 = ddpm->c1; a.ddpm_c2 = ddpm->c2; a.ddpm_sigma = ddpm->sigma; a.rows_per_sample = N;
     }
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));
     return 0;
 }

@@ -8,8 +8,10 @@
 One "step" = one `p_sample` (CMDM denoiser forward over the rank's batch + DDPM posterior update) of
 BASELINE.json configs[1]: B = 32 samples per GPU, L = 196 frames, D = 263, N = 8192 scene points
 (128 contact-group tokens), hoisted step-invariant conditions, synthetic inputs, name-keyed random weights.
-Weak scaling: every rank runs its own 32 samples (global sample indices rank*32 ...), one all_gather at
-the end; value = (ranks x K steps) / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
+Weak scaling (default): every rank runs its own 32 samples (global sample indices rank*32 ...), one all_gather at
+the end; value = (ranks x K steps) / max-over-ranks wall time.  `--scaling strong`: ONE 32-sample job (k_sample = 32,
+reference test.py:88-101) is sharded over the ranks (32 / N samples per GPU), value = K / max-over-ranks wall time; with
+N > 1 the line carries the OTHER mode as well (`other_scaling_mode`).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -35,6 +37,16 @@ def step_flops(batch: int, frames: int = L, groups: int = NPTS // 64) -> float:
     """Algorithmic FLOPs of one CMDM step: 5 encoder layers + motion adapters + time MLP."""
     T = 2 + groups + frames
     return batch * (5 * T * (4194304 + 2048 * T) + 2 * (2 * 263 * 512 * frames) + 2 * 2 * 512 * 512)
+
+
+def elided_flops(batch: int, frames: int = L, groups: int = NPTS // 64) -> float:
+    """FLOPs of the algorithmic step that the loop does NOT execute (bit-neutral): after the LAST layer's attention only the motion
+    rows are used (out_proj + FFN on the other 2 + groups rows per sample are skipped), and layer 0's in_proj rows of the 1 + groups
+    step-invariant condition tokens are computed on the first step of a loop only."""
+    other_rows = 2 + groups
+    last_layer = other_rows * (2 * 512 * 512 + 2 * 2 * 512 * 1024)
+    layer0_qkv = (1 + groups) * 2 * 512 * 1536
+    return batch * float(last_layer + layer0_qkv)
 
 
 def pmc_traffic(kernel: str):
@@ -65,13 +77,15 @@ def build(dev, steps_cfg: str):
     return model.to(dev).eval(), diff, cfg
 
 
-def cpu_baseline(n_steps: int = 3):
+def cpu_baseline(n_steps: int = 20, reps: int = 3):
     """The reference's CPU path = its PyTorch-CPU math (oracle restatement, checked against the reference
-    by tests/test_oracle_golden.py) on this host's cores, same B/L/T, conditions hoisted."""
+    by tests/test_oracle_golden.py) on this host's cores, same B/L/T, conditions hoisted: `reps` repetitions of
+    `n_steps` chained p_sample steps at the fastest thread count (the faithful variant - contact encoder
+    recomputed every step - is timed at configs[0]'s size by tools/bench_configs.py)."""
     from afm import synth
     from oracle import denoiser_ref as dr, diffusion_ref as df, shapes as sh
     sd = sh.weights(sh.cmdm())
-    x = synth.gaussian("bench_x", (B_PER_GPU, L, D))
+    x0 = synth.gaussian("bench_x", (B_PER_GPU, L, D))
     text, cont = synth.text_feature(B_PER_GPU), synth.gaussian("bench_cont", (B_PER_GPU, NPTS // 64, 256))
     mask = synth.frame_mask(B_PER_GPU, L, all_valid=True)
     s = df.Schedule(1000)
@@ -86,23 +100,32 @@ def cpu_baseline(n_steps: int = 3):
     with torch.no_grad():
         for c in cands:
             torch.set_num_threads(c)
-            df.p_sample(s, model, x, t, nz)                               # warm-up at this thread count
+            df.p_sample(s, model, x0, t, nz)                              # warm-up at this thread count
             t0 = time.perf_counter()
-            df.p_sample(s, model, x, t, nz)
+            df.p_sample(s, model, x0, t, nz)
             d1 = time.perf_counter() - t0
             if d1 < best[1]:
                 best = (c, d1)
             if d1 > 4 * best[1]:
                 break
         torch.set_num_threads(best[0])
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            x = df.p_sample(s, model, x, t, nz)["sample"]
-        dt = (time.perf_counter() - t0) / n_steps
+        per_rep = []
+        for _ in range(reps):
+            x = x0
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                x = df.p_sample(s, model, x, t, nz)["sample"]
+            per_rep.append((time.perf_counter() - t0) / n_steps)
+    dt = statistics.median(per_rep)
+    try:
+        cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        cpu_model = "unknown"
     return {"value": round(1.0 / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_steps} p_sample steps at B={B_PER_GPU}, L={L}, T=326 tokens, f32, conditions hoisted "
-                      f"(torch-CPU restatement of the reference, {1e3 * dt:.0f} ms/step; best of thread counts {cands}, "
-                      f"{avail} logical CPUs available)"}
+            "sample": f"{reps} x {n_steps} chained p_sample steps at B={B_PER_GPU}, L={L}, T=326 tokens, f32, conditions hoisted "
+                      f"(torch-CPU restatement of the reference; median {1e3 * dt:.0f} ms/step, per repetition "
+                      f"{[round(1e3 * v) for v in per_rep]} ms/step; best of thread counts {cands}, {avail} logical CPUs available)",
+            "host": {"cpu": cpu_model, "logical_cpus": avail, "torch": torch.__version__, "threads_used": torch.get_num_threads()}}
 
 
 def main():
@@ -110,10 +133,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--latency-runs", type=int, default=3, help="full 1000-step loops for the p50 sample latency (N=1 only)")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="samples per GPU (weak) / in the whole job (strong); the headline is 32")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("AFM_BENCH_SCALING", "weak"),
+                    help="weak: --batch samples on EVERY GPU (the metric's B=32 per GPU); strong: ONE --batch-sample job (k_sample = 32 of "
+                         "test.py:88-101) sharded over the GPUs, value = steps/s of that job")
+    ap.add_argument("--latency-runs", type=int, default=5, help="full 1000-step loops at B=32 for the p50 sample latency (N=1 only)")
+    ap.add_argument("--latency-runs-b1", type=int, default=20, help="full 1000-step loops at B=1 for the p50 sample latency (N=1 only)")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="p_sample steps per repetition of the CPU baseline")
+    ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-gemm", action="store_true", help="skip the informational passes with the split-bf16 GEMM modes")
-    ap.add_argument("--streams", type=int, default=None, help="sub-batch HIP streams of the native loop (default: model default, 2)")
+    ap.add_argument("--no-alt-gemm", action="store_true", help="skip the informational passes with the other GEMM arithmetic settings")
+    ap.add_argument("--streams", type=int, default=None, help="sub-batch HIP streams of the native loop (default: model default)")
     args = ap.parse_args()
 
     from afm import dist as adist, ffi, synth
@@ -129,15 +159,25 @@ def main():
     model, diff_k, cfg = build(dev, str(K))
     if args.streams is not None:
         model.loop_streams = args.streams
-    streams_default = model.loop_streams
     from afm.base import create_gaussian_diffusion
     cfg.diffusion.timestep_respacing = str(max(W, 1))
     diff_w = create_gaussian_diffusion(cfg)
+    # the schedule tables are built at construction in the reference (gaussian_diffusion.py:119-170, "init only"); ours are uploaded
+    # lazily per device, so touch them here instead of inside the timed region
+    diff_k.tables(dev); diff_w.tables(dev)
 
-    # synthetic batch of this rank (global sample indices rank*B ...), resident in HBM before any timing
-    B = B_PER_GPU
-    kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, NPTS).to(dev),
-              c_pc_contact=synth.contact_map(B, NPTS).to(dev), x_mask=synth.frame_mask(B, L, all_valid=True).to(dev))
+    # this rank's shard [i0, i0 + B) of the job, resident in HBM before any timing.  weak: every rank owns --batch samples (global
+    # sample indices rank * batch ...); strong: the --batch samples of ONE job are sharded contiguously (afm.dist.shard_range)
+    def shard(scaling):
+        return adist.job_shard(scaling, args.batch, rank, world)
+
+    def batch_kwargs(total, i0, cnt):
+        full = dict(c_text_feat=synth.text_feature(total), c_pc_xyz=synth.scene_cloud(total, NPTS),
+                    c_pc_contact=synth.contact_map(total, NPTS), x_mask=synth.frame_mask(total, L, all_valid=True))
+        return {k: v[i0:i0 + cnt].contiguous().to(dev) for k, v in full.items()}
+
+    i0, B, total = shard(args.scaling)
+    kw = batch_kwargs(total, i0, B)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     model.condition_tokens(**kw)                      # one-off: SceneMapEncoder (FPS, kNN, set abstraction, attention)
@@ -151,28 +191,48 @@ def main():
     setup_ms_steady = 1e3 * (time.perf_counter() - t0)
     model.condition_tokens(**kw)
 
-    def run(diffusion, seed, gather=True):
-        x = diffusion.p_sample_loop(model, (B, L, D), clip_denoised=False, model_kwargs=kw, seed=seed, sample_index0=rank * B)
+    def run(diffusion, seed, kwargs=None, nb=None, index0=None, gather=True):
+        kwargs, nb, index0 = kwargs or kw, B if nb is None else nb, i0 if index0 is None else index0
+        x = diffusion.p_sample_loop(model, (nb, L, D), clip_denoised=False, model_kwargs=kwargs, seed=seed, sample_index0=index0)
         if world > 1 and gather:                       # the path's only collective: gather the shards at the end
             out = [torch.empty_like(x) for _ in range(world)]
             dist.all_gather(out, x)
         return x
 
-    if W > 0:
-        run(diff_w, 1)
-    torch.cuda.synchronize()
+    def timed(kwargs=None, nb=None, index0=None):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+        if W > 0:
+            run(diff_w, 1, kwargs, nb, index0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run(diff_k, 2, kwargs, nb, index0)             # exactly K steps
+        t_enq = time.perf_counter() - t0               # host time to enqueue the K steps (the loop never synchronises)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt, t_enq
+
+    dt, t_enq = timed()
+
+    # the other scaling mode in the same invocation (N > 1 only; informational): the driver calls bench.py without --scaling, so a
+    # weak run also reports the strong-scaling rate of ONE 32-sample job sharded over the ranks (B/N samples per GPU), and vice versa
+    other = None
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run(diff_k, 2)                                     # exactly K steps
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+        o_mode = "strong" if args.scaling == "weak" else "weak"
+        o_i0, o_B, o_total = shard(o_mode)
+        o_kw = batch_kwargs(o_total, o_i0, o_B)
+        o_dt, _ = timed(o_kw, o_B, o_i0)
+        o_steps = (world if o_mode == "weak" else 1) * K
+        other = {"scaling": o_mode, "value": round(o_steps / o_dt, 2), "unit": "steps/s", "ms_per_step": round(1e3 * o_dt / K, 4),
+                 "batch_per_gpu": o_B, "job_samples": o_total,
+                 "note": "steps/s of the whole job; strong = one 32-sample job (k_sample = 32) sharded over the GPUs, one all_gather at the end"}
 
     # roofline of the dominant kernel: the same K steps again with every launch bracketed by HIP events on its
     # stream.  Sub-batch streams are switched OFF for this pass so a launch's elapsed time is the kernel's own
@@ -197,7 +257,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(name),
                     "avg_launch_us": round(1e3 * g["total_ms"] / g["launches"], 2), "launches": g["launches"],
                     "flops_per_launch": g["total_work"] / g["launches"],
-                    "all_kernels_ms_per_step": {k: round(v["total_ms"] / K, 4) for k, v in prof.items()}}
+                    "all_kernels_ms_per_step": {k: round(v["total_ms"] / K, 4) for k, v in prof.items()},
+                    "all_kernels_tflops": {k: round(v["total_work"] / (v["total_ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["total_work"] > 0}}
             if "split_bf16" in name:
                 # f32 results computed as 9 exact bf16 x bf16 products per f32 product on the bf16 matrix pipe: `achieved` / `peak` above
                 # are ALGORITHMIC f32 FLOPs against the f32 MFMA peak (the dtype's peak); the pipe actually used is priced here
@@ -207,18 +268,27 @@ def main():
                                        "issued_tflops": round(ach * nprod, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                                        "frac": round(ach * nprod / BF16_MFMA_PEAK_TFLOPS, 4)}
 
+    # p50 sequence-sample latency: full 1000-step p_sample_loop, wall time of the whole call incl. the final synchronise
     lat = None
-    if rank == 0 and world == 1 and args.latency_runs > 0:
+    if rank == 0 and world == 1 and (args.latency_runs > 0 or args.latency_runs_b1 > 0):
         cfg.diffusion.timestep_respacing = ""
         diff_full = create_gaussian_diffusion(cfg)
-        ts = []
-        for i in range(args.latency_runs):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(diff_full, 10 + i)
-            torch.cuda.synchronize()
-            ts.append(1e3 * (time.perf_counter() - t0))
-        lat = {"p50_ms": round(statistics.median(ts), 1), "runs": args.latency_runs, "steps": 1000, "batch": B}
+        diff_full.tables(dev)
+        lat = {"steps": 1000, "warmups": 1}
+        for nb, runs in ((args.batch, args.latency_runs), (1, args.latency_runs_b1)):
+            if runs <= 0:
+                continue
+            kwb = kw if nb == B else {k: v[:nb].contiguous() for k, v in kw.items()}
+            run(diff_w, 3, kwb, nb, 0)                 # warm-up at this batch size (condition tokens, workspaces)
+            ts = []
+            for i in range(runs):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(diff_full, 10 + i, kwb, nb, 0)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - t0))
+            lat[f"B{nb}"] = {"p50_ms": round(statistics.median(ts), 1), "min_ms": round(min(ts), 1), "max_ms": round(max(ts), 1), "runs": runs}
+        model.condition_tokens(**kw)
 
     # informational only (never `value`): the same K steps with afm_linear's other arithmetic settings.  Default (the timed run above):
     # the exact nine-product bf16x3 split on the wide GEMMs (N >= 1024), native f32 MFMA kernels elsewhere.
@@ -243,21 +313,31 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.cpu_steps, args.cpu_reps)
 
     if rank == 0:
         ms = 1e3 * dt / K
+        job_steps = (world if args.scaling == "weak" else 1) * K
+        flops = step_flops(args.batch * (world if args.scaling == "weak" else 1))
+        elided = elided_flops(args.batch * (world if args.scaling == "weak" else 1))
         line = {
-            "metric": "denoising steps/sec (B=32, L=196, N=8192)", "value": round(world * K / dt, 2), "unit": "steps/s",
+            "metric": f"denoising steps/sec (B={args.batch}, L=196, N=8192)", "value": round(job_steps / dt, 2), "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CMDM trans_enc p_sample_loop, HumanML3D t2m_contact_motion config (BASELINE configs[1])",
                        "gemm_arithmetic": "f32 in / f32 accumulate; N >= 1024 GEMMs: exact 3-way bf16 operand split, all 9 cross products on the bf16 MFMA pipe; others: f32 MFMA",
-                       "batch_per_gpu": B, "frames": L, "motion_dim": D, "scene_points": NPTS, "tokens": 2 + NPTS // 64 + L,
-                       "conditions": "hoisted (step-invariant, computed once: setup_ms)", "parallelism": f"batch-shard x{world}", "sub_batch_streams": model.loop_streams},
-            "algorithmic_tflops": round(step_flops(B) * world * K / dt / 1e12, 2),
+                       "batch_per_gpu": B, "job_samples": total, "frames": L, "motion_dim": D, "scene_points": NPTS, "tokens": 2 + NPTS // 64 + L,
+                       "conditions": "hoisted (step-invariant, computed once: setup_ms)",
+                       "parallelism": f"batch-shard x{world} ({args.scaling})", "sub_batch_streams": model.loop_streams},
+            "algorithmic_tflops": round(flops * K / dt / 1e12, 2),
+            "executed_tflops": round((flops - elided) * K / dt / 1e12, 2),
+            "elided_gflop_per_step": round(elided / 1e9, 2),
+            "elided_note": "bit-neutral eliminations inside the timed step: the last layer's out_proj / FFN run on the motion rows only, layer 0's "
+                           "q|k|v rows of the step-invariant condition tokens are computed once per loop; algorithmic_tflops prices the full "
+                           "SURVEY 8d step (257 GFLOP at B=32), executed_tflops what the kernels really did",
+            "host_enqueue_ms_per_step": round(1e3 * t_enq / K, 4),
             "setup_ms": round(setup_ms, 2), "setup_ms_steady": round(setup_ms_steady, 2),
-            "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat, "alt_gemm_modes": alt,
+            "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat, "alt_gemm_modes": alt, "other_scaling_mode": other,
         }
         print(json.dumps(line))
     if world > 1:

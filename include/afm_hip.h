@@ -12,7 +12,9 @@
  *   - every function returns 0 on success, a positive hipError_t, or a negative AFM_E_* code.
  *   - no allocation, no host synchronisation, no global state: work is enqueued on `stream`
  *     (a hipStream_t passed as void*); the caller owns all memory and keeps it alive until the
- *     stream is synchronised.  Thread-safe by construction.
+ *     stream is synchronised.  Thread-safe by construction.  In particular the library reads NO
+ *     environment variables and has no setters: every arithmetic or tuning choice is a field of
+ *     the argument structs (ABI v3; the one exception is the opt-in measurement profiler at the end).
  *   - all matrices are row-major float32; indices int32; masks uint8 (1 = padded/ignored).
  */
 #ifndef AFM_HIP_H
@@ -24,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 2
+#define AFM_ABI_VERSION 3
 
 #define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
 #define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
@@ -82,21 +84,34 @@ typedef struct {
     float* preact; int64_t ldp;
     const float* dact_z; int64_t ldz; int32_t dact;
     float drop_p; uint64_t drop_seed; uint32_t drop_id; int32_t drop_after;
+    /* ---- arithmetic of the product (ABI v3; replaces the process-wide afm_linear_set_split of v2).  A GEMM is ELIGIBLE for the
+     * bf16-split path when K >= 128, K % 16 == 0 and A / W are 16-byte aligned with lda / ldw % 4 == 0; everything else always runs
+     * the native f32 MFMA kernels (v_mfma_f32_32x32x2_f32, 157 TF peak on gfx950).
+     *   AFM_ARITH_DEFAULT  eligible GEMMs with N >= 1024 take AFM_ARITH_BF16X9, all others AFM_ARITH_F32 (arith_min_n ignored);
+     *   AFM_ARITH_F32      native f32 MFMA;
+     *   AFM_ARITH_BF16X9   eligible GEMMs with N >= arith_min_n: every f32 operand is split exactly into three bf16 terms inside the
+     *                      kernel and all nine cross products run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak)
+     *                      with f32 accumulation: the same exact products as the f32 MFMA in a different summation order
+     *                      (measured error vs float64 <= the native kernel's, tools/kernel_sweep.cpp);
+     *   AFM_ARITH_BF16X6   as X9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3).
+     * The kernel choice is a function of (arith, arith_min_n, N, K, alignment) - never of M - and every tile shape of one
+     * arithmetic sums a given output element in the same order, so a batch and its shards compute identical bits. */
+    int32_t arith; int32_t arith_min_n;
+    /* performance-only knobs for experiments (bit-neutral; 0 = the library's heuristics): AFM_TUNE_* bits */
+    int32_t tune;
 } afm_linear_args;
+
+#define AFM_ARITH_DEFAULT 0
+#define AFM_ARITH_F32     1
+#define AFM_ARITH_BF16X6  6
+#define AFM_ARITH_BF16X9  9
+
+#define AFM_TUNE_NO_DMA      0x1     /* register-staged operand loads instead of global_load_lds                         */
+#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128 */
+#define AFM_TUNE_TILE_MASK   0xF0
 
 int afm_linear(const afm_linear_args* args, void* stream);
 
-/* Arithmetic of afm_linear's wide GEMMs (N >= min_n, K >= 128, K % 16 == 0, 16-byte aligned operands; everything else always runs
- * the native f32 MFMA kernels, v_mfma_f32_32x32x2_f32, 157 TF peak on gfx950):
- *   9 (default)  every f32 operand is split exactly into three bf16 terms inside the kernel and all nine cross products run on the
- *                bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak) with f32 accumulation: the same exact products as the
- *                f32 MFMA in a different summation order (measured error vs float64 <= the native kernel's, tools/gemm_bench.cpp);
- *   6            as 9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3);
- *   0            native f32 MFMA everywhere.
- * The choice never depends on M, so a batch and its shards compute identical bits.  Process-wide; initial values from the
- * environment variables AFM_GEMM_SPLIT (9) and AFM_GEMM_SPLIT_MIN_N (1024).  Both return the previous value, or AFM_E_BADARG. */
-int afm_linear_set_split(int products);
-int afm_linear_set_split_min_n(int min_n);
 
 /* ------------------------------------------------------------------------------------------
  * afm_mha_fwd: multi-head self-attention core, softmax(QK^T / sqrt(dh) + key mask) V.
@@ -108,6 +123,11 @@ int afm_linear_set_split_min_n(int min_n);
  */
 int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out,
                 int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
+/* Same with an explicit workgroup shape: group_waves in {1, 2, 4, 8, 12} 32-query waves per workgroup (the grid is
+ * (sample, head, query group)); 0 = the library's choice from B*H and T (small batches get small groups so that the
+ * launch still fills 256 CUs).  A query row's arithmetic does not depend on the grouping: results are bit-identical. */
+int afm_mha_fwd_grouped(const float* qkv, const uint8_t* key_mask, float* out,
+                        int32_t B, int32_t T, int32_t H, int32_t dh, int32_t group_waves, void* stream);
 
 /* Cross-attention core of nn.TransformerDecoderLayer (CMDM `trans_dec`, cmdm.py:78-113,171-191): Tq queries q [B*Tq, H*dh] over a
  * packed memory kv [B*Tk, 2*H*dh] (k | v), key_mask [B,Tk] or NULL.  Same kernel as afm_mha_fwd (dh = 64). */
@@ -365,7 +385,13 @@ typedef struct {
     int32_t n_timesteps;
     const float* pos_table;                /* [>= 1+n_cond+L, d] sinusoid table (modules.py:10-26)    */
     afm_encoder_layer_weights layer[AFM_MAX_LAYERS];
+    /* ABI v3: arithmetic of every nn.Linear of the denoiser (afm_linear_args.arith / arith_min_n) and bit-neutral tuning */
+    int32_t gemm_arith, gemm_arith_min_n;
+    int32_t attn_group_waves;              /* afm_mha_fwd_grouped's group_waves (0 = auto)                              */
+    int32_t flags;                         /* AFM_CMDM_* bits                                                           */
 } afm_cmdm_weights;
+
+#define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
 
 /* bytes of workspace afm_cmdm_forward needs for (B, L). */
 int64_t afm_cmdm_workspace_bytes(const afm_cmdm_weights* w, int32_t B, int32_t L);
@@ -460,6 +486,7 @@ typedef struct {
     afm_ln self_norm[4]; afm_mha_w self_attn[4]; afm_mlp_w self_mlp[4];             /* encoder_self_attn.{l}.{0,1}.module */
     afm_ln dec_q_norm, dec_kv_norm; afm_mha_w dec_attn; afm_mlp_w dec_mlp;          /* decoder_cross_attn.{0,1}.module */
     afm_lin contact_layer;     /* [contact_dim, dkv]                                               */
+    int32_t gemm_arith, gemm_arith_min_n;   /* ABI v3: afm_linear_args.arith / arith_min_n of the dense per-point layers */
 } afm_cdm_weights;
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);

@@ -20,6 +20,49 @@ def test_shard_range_covers_everything():
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
 
 
+def test_job_shard_weak_and_strong():
+    """bench.py's two node modes: weak = 32 samples on every rank, strong = one 32-sample job split over the ranks."""
+    for world in (1, 2, 4, 8):
+        weak = [adist.job_shard("weak", 32, r, world) for r in range(world)]
+        assert [w[0] for w in weak] == [32 * r for r in range(world)] and all(w[1] == 32 and w[2] == 32 * world for w in weak)
+        strong = [adist.job_shard("strong", 32, r, world) for r in range(world)]
+        assert sum(c for _, c, _ in strong) == 32 and all(t == 32 for _, _, t in strong)
+        assert [s0 for s0, _, _ in strong] == [sum(c for _, c, _ in strong[:r]) for r in range(world)]
+        assert all(c == 32 // world for _, c, _ in strong)                   # B = 4 per GPU at 8 GPUs
+    with pytest.raises(ValueError):
+        adist.job_shard("both", 32, 0, 1)
+
+
+def _strong_worker(rank, world, port, total, q):
+    """One `total`-sample job sharded over the ranks exactly as `bench.py --scaling strong` does it: job_shard -> local run keyed by
+    the GLOBAL sample index -> one all_gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_process_group("gloo")
+    i0, cnt, job = adist.job_shard("strong", total, rank, world)
+    cond = (torch.arange(job, dtype=torch.float32) * 0.5)[i0:i0 + cnt]
+    local = _fake_sampler(dict(cond=cond), cnt, i0)
+    out = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(out, local)
+    q.put((rank, torch.cat(out, 0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_two_ranks_equal_one_process():
+    total = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, 29655, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _fake_sampler(dict(cond=torch.arange(total, dtype=torch.float32) * 0.5), total, 0)
+    assert torch.equal(got[0], want) and torch.equal(got[1], want)
+
+
 def test_shard_kwargs_slices_only_per_sample_entries():
     kw = dict(x_mask=torch.zeros(6, 4), c_text=["a"] * 6, sigma=0.8, table=torch.zeros(3, 2))
     out = adist.shard_kwargs(kw, 2, 3, 6)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loaded_and_versioned():
     lib = ffi.load()
-    assert lib.afm_version() == 2
+    assert lib.afm_version() == ffi.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (326, 512, 512), (1000, 1536, 512), (777, 263, 512),
@@ -32,7 +32,7 @@ def test_linear_shapes(M, N, K):
 @pytest.mark.parametrize("products", [9, 6])
 @pytest.mark.parametrize("M,N,K", [(10432, 512, 1024), (9000, 1500, 256), (1000, 1536, 512), (5216, 512, 512), (777, 263, 512), (640, 96, 144)])
 def test_linear_split_bf16_mode(products, M, N, K):
-    """afm_linear_set_split: f32 operands split exactly into three bf16 terms, products on the bf16 matrix pipe, f32 accumulate.
+    """afm_linear_args.arith = AFM_ARITH_BF16X9 / X6: f32 operands split exactly into three bf16 terms, products on the bf16 matrix pipe, f32 accumulate.
     The error against float64 must stay at the native f32 MFMA kernel's level (same products, different summation order), on
     both tile variants (128x128 / 64x64), with ragged M / N edges and every epilogue input."""
     x = synth.gaussian("sp_x", (M, K)); w = synth.gaussian("sp_w", (N, K)) / math.sqrt(K); b = synth.gaussian("sp_b", (N,))
@@ -56,9 +56,16 @@ def test_linear_split_bf16_mode(products, M, N, K):
     assert e_split <= max(1.5 * e_native, 3e-7)
     assert (got - native).abs().max().item() <= 1e-5 * native.abs().max().item()
     assert not torch.equal(got, native)                   # a different kernel really ran
-    lib = ffi.load()
-    assert lib.afm_linear_set_split(5) == -1 and lib.afm_linear_set_split_min_n(-3) == -1      # AFM_E_BADARG, state unchanged
+    with pytest.raises(ffi.AfmError):                      # invalid settings are rejected on the host, state unchanged
+        ops.set_gemm_split(5)
+    with pytest.raises(ffi.AfmError):
+        ops.set_gemm_split(9, -3)
     assert ops.get_gemm_split() == saved
+    import ctypes as C                                     # and by the library: the arithmetic is a validated field of the arguments
+    bad = ffi.LinearArgs()
+    bad.A, bad.W, bad.C, bad.M, bad.N, bad.K, bad.lda, bad.ldw, bad.ldc = args[0].data_ptr(), args[1].data_ptr(), got.data_ptr(), 4, N, K, K, K, N
+    bad.arith = 5
+    assert ffi.load().afm_linear(C.byref(bad), None) == -1      # AFM_E_BADARG
 
 
 def test_linear_split_dispatch_is_independent_of_m():
@@ -68,6 +75,35 @@ def test_linear_split_dispatch_is_independent_of_m():
     for rows in (1, 33, 200, 640):
         part = ops.linear(x[:rows].to(dev()), w.to(dev()))
         assert torch.equal(part, big[:rows]), rows
+
+
+@pytest.mark.parametrize("M,N,K", [(1304, 512, 512), (1304, 512, 1024), (784, 263, 512), (2608, 512, 512), (10432, 512, 512), (97, 96, 64)])
+def test_linear_tile_shapes_are_bit_identical(M, N, K):
+    """Strong scaling runs B = 4 per GPU (M = 1304 rows): afm_linear then picks 32x32 / 32x64 workgroup tiles so the launch still fills
+    256 CUs.  Every tile shape of one arithmetic sums an output element in the same order, so the choice (which depends on M) must not
+    change a single bit - the sharding / sub-batch invariance of the loop rests on it."""
+    x = synth.gaussian("tile_x", (M, K)).to(dev()); w = (synth.gaussian("tile_w", (N, K)) / math.sqrt(K)).to(dev())
+    b = synth.gaussian("tile_b", (N,)).to(dev()); res = synth.gaussian("tile_r", (M, N)).to(dev())
+    saved, saved_tune = ops.get_gemm_split(), ops.set_gemm_tune(0)
+    try:
+        for products, tiles in ((0, (0, 1, 2, 3, 4, 5)), (9, (0, 3, 5)), (6, (0, 3, 5))):
+            ops.set_gemm_split(products, 0)
+            outs = []
+            for tile in tiles:
+                ops.set_gemm_tune(tile << ffi.TUNE_TILE_SHIFT)
+                outs.append(ops.linear(x, w, b, act=ffi.ACT_GELU, residual=res))
+            for tile, o in zip(tiles[1:], outs[1:]):
+                assert torch.equal(o, outs[0]), f"arith {products}: tile {tile} differs from the heuristic's choice on {M}x{N}x{K}"
+            ops.set_gemm_tune(ffi.TUNE_NO_DMA)              # register-staged operand path: same k order as the LDS-DMA kernels
+            if products == 0:
+                assert torch.equal(ops.linear(x, w, b, act=ffi.ACT_GELU, residual=res), outs[0])
+            # a shard of the rows computes the same bits as the whole matrix (other tile shape chosen from the smaller M)
+            ops.set_gemm_tune(0)
+            part = ops.linear(x[: M // 3], w, b, act=ffi.ACT_GELU, residual=res[: M // 3])
+            assert torch.equal(part, outs[0][: M // 3])
+    finally:
+        ops.set_gemm_split(*saved)
+        ops.set_gemm_tune(saved_tune)
 
 
 def test_linear_detects_transposed_layouts():
@@ -137,6 +173,24 @@ def test_mha(B, T, masked):
     want = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, H * dh).float()
     got = ops.mha(qkv.to(dev()), None if mask is None else mask.to(dev()), H)
     report(f"mha B{B} T{T} masked={masked}", got, want, 2e-5)
+
+
+@pytest.mark.parametrize("B,T", [(4, 326), (1, 326), (2, 196), (3, 61)])
+def test_mha_workgroup_groupings_are_bit_identical(B, T):
+    """grid = (sample, head, query group): groups of 1 / 2 / 4 / 8 / 12 waves (and the automatic choice, which depends on B) must give the
+    same bits - a query row's arithmetic never depends on which workgroup it ran in."""
+    H, dh = 8, 64
+    qkv = synth.gaussian("mha_grp", (B, T, 3 * H * dh)).to(dev())
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for b in range(B):
+        mask[b, T - 1 - 11 * b:] = True
+    mask = mask.to(dev())
+    for km in (None, mask):
+        outs = [ops.mha(qkv, km, H, group_waves=g) for g in (0, 1, 2, 4, 8, 12)]
+        for g, o in zip((1, 2, 4, 8, 12), outs[1:]):
+            assert torch.equal(o, outs[0]), f"group_waves={g} differs (B={B}, T={T}, masked={km is not None})"
+    with pytest.raises(ffi.AfmError):
+        ops.mha(qkv, None, H, group_waves=3)
 
 
 def test_mha_softmax_rescale_branch():

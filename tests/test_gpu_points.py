@@ -133,3 +133,22 @@ def test_cdm_with_scene_backbone_vs_oracle():
     want = dr.cdm_forward(sh.weights(sh.cdm(point_feat_dim=32)), x, t, text, xyz, pc_emb=emb)
     got = m(x.to(dev()), t.to(dev()), c_text_feat=text.to(dev()), c_pc_xyz=xyz.to(dev()), c_pc_feat=col.to(dev()))
     report("CDM + frozen scene backbone vs oracle", got, want, 3e-4)
+
+
+def test_scene_map_encoder_full_size_vs_oracle():
+    """VERDICT r1 #4b: the WHOLE SceneMapEncoder (models/modules.py:124-167) at the shape t2m_contact_motion really runs - N = 8192 points,
+    planes [32, 64, 128, 256], strides [1, 4, 4, 4] -> 128 groups of 256 channels - HIP path vs the CPU oracle, one sample
+    (FPS 8192 -> 2048 -> 512 -> 128, 11 kNN calls, 4 set abstractions, 8 vector-attention blocks)."""
+    from afm import scene as S
+    from oracle import scene_ref as sr, shapes as sh
+    enc = S.SceneMapEncoder(point_feat_dim=6, planes=[32, 64, 128, 256], blocks=[2, 2, 2, 2], num_points=8192)
+    sd = {k[len("contact_encoder."):]: v for k, v in sh.weights(sh.cmdm()).items() if k.startswith("contact_encoder.")}
+    res = enc.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys), res
+    enc = enc.to(dev()).eval()
+    B, N = 1, 8192
+    xyz, contact = synth.scene_cloud(B, N, seed=77), synth.contact_map(B, N, seed=77)
+    want = sr.scene_map_encoder({"contact_encoder." + k: v for k, v in sd.items()}, "contact_encoder", xyz, contact, blocks=(2, 2, 2, 2))
+    got = enc(xyz.to(dev()), contact.to(dev()))
+    assert got.shape == (B, 128, 256)
+    report("SceneMapEncoder N=8192 vs oracle", got, want, 2e-4)

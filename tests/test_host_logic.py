@@ -177,25 +177,37 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(ffi.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"missing export {name}"
-    assert ffi.load().afm_version() == 2            # pure host call, no GPU needed
+    assert ffi.load().afm_version() == ffi.ABI_VERSION == 3     # pure host call, no GPU needed
 
 
 def test_gemm_arithmetic_switches_are_host_state():
-    """afm_linear_set_split / _min_n are plain host state (no GPU): defaults (or the AFM_GEMM_SPLIT* environment), validation, round trip."""
-    if not os.path.exists(ffi.lib_path()):
-        pytest.skip("libafm_hip.so not built")
+    """ABI v3: the GEMM arithmetic is a field of afm_linear_args / the weight packs; the switch lives in the Python host (afm.ops),
+    initialised from AFM_GEMM_SPLIT* in the host's environment.  The library exports no setter and reads no environment."""
     from afm import ops
     want = (int(os.environ.get("AFM_GEMM_SPLIT", "9")), int(os.environ.get("AFM_GEMM_SPLIT_MIN_N", "1024")))
     saved = ops.get_gemm_split()
     assert saved == want
     try:
-        assert ops.set_gemm_split(6, 0) == saved and ops.get_gemm_split() == (6, 0)
-        assert ops.set_gemm_split(0) == 6 and ops.get_gemm_split() == (0, 0)
-        lib = ffi.load()
-        assert lib.afm_linear_set_split(7) == -1 and lib.afm_linear_set_split_min_n(-1) == -1
+        assert ops.set_gemm_split(6, 0) == saved and ops.get_gemm_split() == (6, 0) and ops.gemm_arith() == (ffi.ARITH_BF16X6, 0)
+        assert ops.set_gemm_split(0) == 6 and ops.get_gemm_split() == (0, 0) and ops.gemm_arith() == (ffi.ARITH_F32, 0)
+        with pytest.raises(ffi.AfmError):
+            ops.set_gemm_split(7)
+        with pytest.raises(ffi.AfmError):
+            ops.set_gemm_split(9, -1)
         assert ops.get_gemm_split() == (0, 0)
+        ops.set_gemm_split(9, 1024)
+        a = ffi.LinearArgs()
+        ops.fill_arith(a)
+        assert (a.arith, a.arith_min_n, a.tune) == (ffi.ARITH_BF16X9, 1024, 0)
     finally:
         ops.set_gemm_split(*saved)
+    if os.path.exists(ffi.lib_path()):
+        import subprocess
+        syms = subprocess.run(["nm", "-D", "--defined-only", ffi.lib_path()], capture_output=True, text=True).stdout
+        assert "afm_linear_set_split" not in syms                      # no process-wide switch left in the library
+        imports = subprocess.run(["nm", "-D", "--undefined-only", ffi.lib_path()], capture_output=True, text=True).stdout
+        assert " getenv" not in imports and "secure_getenv" not in imports, "libafm_hip.so must not read the environment"
+        assert ffi.load().afm_version() == ffi.ABI_VERSION == 3
 
 
 def test_progress_slices_cover_the_chain():
