@@ -148,6 +148,7 @@ class CMDM(TextEncoderMixin, nn.Module):
         self.hoist_conditions = True
         # sub-batches of the native sampling loop, each on its own HIP stream (AFM_LOOP_STREAMS overrides)
         self.loop_streams = int(os.environ.get("AFM_LOOP_STREAMS", "2"))
+        self.loop_streams_auto = "AFM_LOOP_STREAMS" not in os.environ       # an explicit setting is taken literally
         self._side_streams: List[torch.cuda.Stream] = []
         self.attn_group_waves = 0  # afm_mha_fwd_grouped workgroup shape (0 = library heuristic; results do not depend on it)
         self.no_l0_cache = bool(os.environ.get("AFM_CMDM_NO_L0_CACHE"))      # measurement knob (host state, passed in the pack)
@@ -419,7 +420,9 @@ class CMDM(TextEncoderMixin, nn.Module):
             tab = diffusion.tables(x.device)
             n = diffusion.num_timesteps
             sched = torch.empty(lib.afm_cmdm_sched_scratch_bytes(n, B), dtype=torch.uint8, device=x.device)
-            nsub = max(1, min(int(self.loop_streams), B))
+            # sub-batch streams fill the wave-quantisation tails of B >= 16 launches; below that every launch is latency-bound and a
+            # second stream only adds launches (B = 4: 1311 steps/s on one stream vs 1159 on two, profiles/r02_small_batch.md)
+            nsub = max(1, min(int(self.loop_streams), B // 8 if self.loop_streams_auto else B))
             while len(self._side_streams) < nsub:
                 self._side_streams.append(torch.cuda.Stream(device=x.device))
             handles = (C.c_void_p * nsub)(*[s.cuda_stream for s in self._side_streams[:nsub]])

@@ -65,7 +65,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 # ---- arithmetic of the GEMMs: HOST state (this module), written into every afm_linear_args / weight pack that is built.
 # The library itself has no switch and reads no environment (ABI v3).  Initial value: AFM_GEMM_SPLIT / AFM_GEMM_SPLIT_MIN_N in the
-# environment of the Python process, else the library default (exact nine-product bf16 split for N >= 1024, f32 MFMA elsewhere).
+# environment of the Python process, else the library default (exact nine-product bf16 split on every eligible GEMM).
 def _initial_split():
     import os
     p = os.environ.get("AFM_GEMM_SPLIT")
@@ -73,7 +73,7 @@ def _initial_split():
     if products not in (0, 6, 9):
         products = 0
     n = os.environ.get("AFM_GEMM_SPLIT_MIN_N")
-    return products, max(0, int(n)) if n is not None else 1024
+    return products, max(0, int(n)) if n is not None else 0
 
 
 _gemm_split = list(_initial_split())
@@ -90,7 +90,7 @@ def gemm_arith() -> Tuple[int, int]:
 
 def set_gemm_split(products: int, min_n: Optional[int] = None):
     """Arithmetic of `linear`'s GEMMs: 9 = exact three-way bf16 operand split on the bf16 matrix pipe with all nine cross products
-    (default, for N >= 1024), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N threshold.
+    (default, every eligible GEMM: K >= 128, K % 16 == 0, aligned), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N threshold.
     Returns the previous setting in the same form (products, or (products, min_n) when ``min_n`` was given)."""
     if int(products) not in (0, 6, 9):
         raise ffi.AfmError(f"set_gemm_split: products must be 0, 6 or 9 (got {products})")

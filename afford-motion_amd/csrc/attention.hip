@@ -29,8 +29,10 @@ constexpr int MAX_WAVES = 12;      // 3 waves per SIMD -> 168 VGPRs each, no spi
 
 // TRAIN: also writes lse[b,h,q] = log-sum-exp of the scaled, masked logits (saved for afm_mha_bwd) and applies
 // attention-probability dropout to the P used in P V (the softmax normaliser uses the undropped P, as in torch).
-template <int NST, bool TRAIN>
-__global__ __launch_bounds__(NST == 16 ? 64 : NST == 8 ? 128 : NST == 4 ? 512 : 64 * MAX_WAVES) void mha_fwd_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
+// NWC: waves per workgroup when known at compile time (NST * 64 * NWC == 1024: every thread stages exactly NST float4 of each K / V
+// block, no predicates), 0 = read from blockDim (NST * blockDim >= 1024, predicated).
+template <int NST, bool TRAIN, int NWC>
+__global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES)) void mha_fwd_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
                                                        const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
                                                        float* __restrict__ out, int Tq, int T, int H, float scale,
                                                        float* __restrict__ lse, float drop_p, uint64_t drop_seed, uint32_t drop_id, int nchunk) {
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(NST == 16 ? 64 : NST == 8 ? 128 : NST == 4 ? 512 : 
     }
     const int bh = bid / nchunk, chunk = bid % nchunk;
     const int b = bh / H, h = bh % H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NWC ? NWC : (int)(blockDim.x >> 6);
+    const int nthreads = NWC ? 64 * NWC : (int)blockDim.x;
     const int r32 = lane & 31, hh = lane >> 5;
     const int D = H * DH;
     const int nkb = (T + KB - 1) / KB, nqb = (Tq + 31) / 32;
@@ -60,37 +63,36 @@ __global__ __launch_bounds__(NST == 16 ? 64 : NST == 8 ? 128 : NST == 4 ? 512 : 
     const float* vbase = vp_ + (int64_t)b * T * ldkv + h * DH;
     const float NEG_INF = -INFINITY;
 
-    for (int i = tid; i < nkb; i += blockDim.x) blk_valid[i] = 0;
+    for (int i = tid; i < nkb; i += nthreads) blk_valid[i] = 0;
     __syncthreads();
-    for (int i = tid; i < nkb * KB; i += blockDim.x) {
+    for (int i = tid; i < nkb * KB; i += nthreads) {
         const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
         madd[i] = ok ? 0.0f : NEG_INF;
         if (ok) blk_valid[i / KB] = 1;              // benign race: every writer stores 1
     }
 
-    // cooperative K/V block loader: 1024 float4 per block (512 K + 512 V), NST per thread (NST * blockDim >= 1024)
-    float4 stage[NST];
+    // cooperative K/V block loader: 1024 float4 per block (512 K + 512 V), NST per thread (NST * threads >= 1024).  Loads are
+    // UNCONDITIONAL: rows past the last key are clamped to key T-1 (real, finite data) - those keys carry an additive -inf, so their
+    // probabilities are exactly 0 whatever K / V hold.  (A predicated load made hipcc put `s_waitcnt vmcnt(0)` between the loads of
+    // a block, i.e. a full memory round trip in front of every block's MFMAs.)
+    f32x4 stage[NST];      // ext_vector_type, not HIP's float4 struct: struct copies in a register array can pin it in scratch
     auto load_block = [&](int kb) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * blockDim.x;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < 1024) {
-                const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
-                const int key = kb * KB + row;
-                if (key < T) v = *reinterpret_cast<const float4*>((isv ? vbase : kbase) + (int64_t)key * ldkv + c4 * 4);
-            }
-            stage[i] = v;
+            const int e = NWC ? tid + i * nthreads : min(tid + i * nthreads, 1023);
+            const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
+            const int key = min(kb * KB + row, T - 1);
+            stage[i] = *reinterpret_cast<const f32x4*>((isv ? vbase : kbase) + (int64_t)key * ldkv + c4 * 4);
         }
     };
     auto store_block = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * blockDim.x;
-            if (e < 1024) {
+            const int e = tid + i * nthreads;
+            if (NWC || e < 1024) {
                 const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
                 float* dst = isv ? (Vs + (buf * KB + row) * DH + c4 * 4) : (Ks + (buf * KB + row) * LDKK + c4 * 4);
-                *reinterpret_cast<float4*>(dst) = stage[i];
+                *reinterpret_cast<f32x4*>(dst) = stage[i];
             }
         }
     };
@@ -214,10 +216,10 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     } else {
         if (group_waves != 0 && group_waves != 1 && group_waves != 2 && group_waves != 4 && group_waves != 8 && group_waves != 12) return AFM_E_BADARG;
         nw = group_waves;
-        if (nw == 0) {          // largest group that still gives >= 2 workgroups per CU (256 CUs); measured table in profiles/r02_small_batch.md
-            const int64_t bh = (int64_t)B * H;
-            nw = bh * ((nqb + 3) / 4) >= 512 ? 4 : (bh * ((nqb + 1) / 2) >= 512 ? 2 : 1);
-        }
+        // 4-wave groups everywhere (profiles/r02_kernel_sweep.txt, T = 326, us for 12 / 8 / 4 / 2 / 1 waves per group): B = 32: 93 / 119 / 94 / 128 / 150,
+        // B = 16: 85 / 62 / 63 / 69 / 98, B = 4: 79 / 57 / 36 / 41 / 49, B = 1: 78 / 56 / 36 / 40 / 48 - the four waves share every K / V
+        // tile they stage (smaller groups re-stage it per wave), and three groups fit one CU (larger ones leave SIMDs unevenly loaded)
+        if (nw == 0) nw = 4;
         if (nw > nqb) nw = nqb >= 8 ? nqb : (nqb >= 4 ? 4 : (nqb >= 2 ? 2 : 1));      // never more waves than query blocks
         nchunk = (nqb + nw - 1) / nw;
     }
@@ -226,9 +228,10 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     if (lds > 64 * 1024) {                                     // long memories (cross-attention over N = 8192 points): opt in once
         static std::atomic<bool> attr_set{false};      // idempotent attribute: a race only repeats the call
         if (!attr_set.load(std::memory_order_acquire)) {
-            const void* fns[6] = {(const void*)mha_fwd_kernel<2, false>, (const void*)mha_fwd_kernel<4, false>, (const void*)mha_fwd_kernel<2, true>,
-                                  (const void*)mha_fwd_kernel<4, true>, (const void*)mha_fwd_kernel<8, false>, (const void*)mha_fwd_kernel<16, false>};
-            for (int i = 0; i < 6; ++i) {
+            const void* fns[8] = {(const void*)mha_fwd_kernel<2, false, 0>, (const void*)mha_fwd_kernel<4, false, 0>, (const void*)mha_fwd_kernel<2, true, 0>,
+                                  (const void*)mha_fwd_kernel<4, true, 0>, (const void*)mha_fwd_kernel<8, false, 2>, (const void*)mha_fwd_kernel<16, false, 1>,
+                                  (const void*)mha_fwd_kernel<2, false, 8>, (const void*)mha_fwd_kernel<4, false, 4>};
+            for (int i = 0; i < 8; ++i) {
                 hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return (int)e;
             }
@@ -238,12 +241,14 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     const float scale = 1.0f / sqrtf((float)dh);
     hipStream_t s = (hipStream_t)stream;
     AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
-#define AFM_MHA(NST, TR) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR>), dim3(B * H * nchunk), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id, nchunk)
-    if (train) { if (nw >= 8) AFM_MHA(2, true); else AFM_MHA(4, true); }
-    else if (nw >= 8) AFM_MHA(2, false);
-    else if (nw >= 4) AFM_MHA(4, false);
-    else if (nw == 2) AFM_MHA(8, false);
-    else AFM_MHA(16, false);
+#define AFM_MHA(NST, TR, NWC) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR, NWC>), dim3(B * H * nchunk), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id, nchunk)
+    if (train) { if (nw >= 8) AFM_MHA(2, true, 0); else AFM_MHA(4, true, 0); }
+    else if (nw == 8) AFM_MHA(2, false, 8);
+    else if (nw > 8) AFM_MHA(2, false, 0);
+    else if (nw == 4) AFM_MHA(4, false, 4);
+    else if (nw > 4) AFM_MHA(4, false, 0);
+    else if (nw == 2) AFM_MHA(8, false, 2);
+    else AFM_MHA(16, false, 1);
 #undef AFM_MHA
     AFM_CHECK_LAUNCH();
     return 0;

@@ -193,9 +193,17 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // Workgroup = WM x WN waves, each wave owns TM x TN MFMA tiles of 32x32: tile BM x BN = 32 WM TM x 32 WN TN.  Every shape sums an
 // output element in the same order (K-tiles of 32 in sequence, the permuted k inside a tile), so shapes are interchangeable bit for
 // bit and the dispatcher may pick one from M (small batches: 32x32 single-wave workgroups keep 256 CUs busy at B*T = 1304 rows).
+#ifdef AFM_TIMELINE          // tools/gemm_timeline.hip only: per-workgroup (start, end, hardware id) records; never compiled into the library
+struct AfmTimelineRec { unsigned long long t0, t1; unsigned hw_id, xcc_id; };
+__device__ AfmTimelineRec* afm_timeline = nullptr;
+#endif
+
 template <int WM, int WN, int TM, int TN, int NSTG = 3>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_linear_args p, int nbm, int nbn) {
     constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
+#ifdef AFM_TIMELINE
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int RP = NT / 8;                       // rows one DMA pass of the whole workgroup covers (8 x 16 B per row)
     constexpr int PA = BM / RP, PW = BN / RP;        // passes per K-tile for the A / W panels
     static_assert(BM % RP == 0 && BN % RP == 0, "panel rows must be a multiple of the rows per DMA pass");
@@ -310,6 +318,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
                 lds[(wm * TM * 32 + tm * 32 + mfma_row(r, lane)) * LDC + wn * TN * 32 + tn * 32 + r32] = acc[tm][tn][r];
     __syncthreads();
     gemm_epilogue<BM, BN, NT>(p, lds, bm, bn, tid);
+#ifdef AFM_TIMELINE
+    if (afm_timeline && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), hw, xcc};
+    }
+#endif
 }
 
 template <int WM, int WN, int TM, int TN>

@@ -233,11 +233,15 @@ int launch_split(const afm_linear_args& a, hipStream_t s) {
 template <int NPROD>
 int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 0 = heuristic
-    // 128x128 amortises the split best (each thread splits 16 floats per 36 MFMAs of its wave); with fewer 128x128 tiles
-    // than CUs, 64x64 tiles fill the chip better (measured on M = 5216, N = 512: 34.8 vs 41.3 us).  Both tile shapes add
-    // the products of an output element in the same order (bit-identical), so M may enter the choice.
+    // 128x128 amortises the split best (each thread splits 16 floats per 36 MFMAs of its wave) but holds 2 workgroups per CU = 512
+    // resident tiles, so it only pays when its last resident round is nearly full; otherwise 64x64 tiles fill the chip better.
+    // Measured (profiles/r02_kernel_sweep.txt, x9, us): N=1536 M=10432 (984 tiles, 96 % full) 161 vs 174 for 64x64; M=5216 (492, 96 %) 80 vs 86;
+    // M=2608 (252, 49 %) 51 vs 47; N=1024 M=10432 (656, 64 %) 118 vs 113; N=512 (328, 64 %) 73 vs 65.  Both tile shapes add the
+    // products of an output element in the same order (bit-identical), so M may enter the choice.
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tile == 3 || (tile != 5 && tiles128 < 256)) return launch_split<64, 64, 16, NPROD>(a, s);
+    const int64_t resident = 512, rounds = (tiles128 + resident - 1) / resident;
+    const bool full_rounds = tiles128 * 10 >= rounds * resident * 9;              // >= 90 % of the resident slots used over all rounds
+    if (tile == 3 || (tile != 5 && !full_rounds)) return launch_split<64, 64, 16, NPROD>(a, s);
     return launch_split<128, 128, 16, NPROD>(a, s);
 }
 
@@ -250,7 +254,7 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
 int afm_linear_split_mode(const afm_linear_args& a) {
     int mode, min_n;
     switch (a.arith) {
-        case AFM_ARITH_DEFAULT: mode = 9; min_n = 1024; break;
+        case AFM_ARITH_DEFAULT: mode = 9; min_n = 0; break;
         case AFM_ARITH_BF16X9: mode = 9; min_n = a.arith_min_n; break;
         case AFM_ARITH_BF16X6: mode = 6; min_n = a.arith_min_n; break;
         default: return 0;

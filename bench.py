@@ -158,7 +158,7 @@ def main():
     K, W = args.steps, args.warmup
     model, diff_k, cfg = build(dev, str(K))
     if args.streams is not None:
-        model.loop_streams = args.streams
+        model.loop_streams, model.loop_streams_auto = args.streams, False
     from afm.base import create_gaussian_diffusion
     cfg.diffusion.timestep_respacing = str(max(W, 1))
     diff_w = create_gaussian_diffusion(cfg)
@@ -291,14 +291,14 @@ def main():
         model.condition_tokens(**kw)
 
     # informational only (never `value`): the same K steps with afm_linear's other arithmetic settings.  Default (the timed run above):
-    # the exact nine-product bf16x3 split on the wide GEMMs (N >= 1024), native f32 MFMA kernels elsewhere.
+    # the exact nine-product bf16x3 split on every eligible GEMM (K >= 128, K % 16 == 0); the motion adapter (K = 263) runs the native f32 MFMA kernel.
     alt = None
     if rank == 0 and world == 1 and not args.no_alt_gemm:
         from afm import ops as afm_ops
         alt = {}
         saved = afm_ops.get_gemm_split()
         try:
-            for tag, (products, min_n) in (("native_f32_mfma_everywhere", (0, 0)), ("split9_all_gemms", (9, 0)),
+            for tag, (products, min_n) in (("native_f32_mfma_everywhere", (0, 0)), ("split9_wide_gemms_only", (9, 1024)),
                                            ("split6_wide_gemms", (6, 1024)), ("split6_all_gemms", (6, 0))):
                 afm_ops.set_gemm_split(products, min_n)
                 run(diff_w, 1)
@@ -325,10 +325,11 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CMDM trans_enc p_sample_loop, HumanML3D t2m_contact_motion config (BASELINE configs[1])",
-                       "gemm_arithmetic": "f32 in / f32 accumulate; N >= 1024 GEMMs: exact 3-way bf16 operand split, all 9 cross products on the bf16 MFMA pipe; others: f32 MFMA",
+                       "gemm_arithmetic": "f32 in / f32 accumulate; every GEMM with K % 16 == 0: exact 3-way bf16 operand split of both operands, all 9 cross products "
+                                          "(exact in f32) on the bf16 MFMA pipe, f32 accumulation; motion adapter (K = 263): f32 MFMA",
                        "batch_per_gpu": B, "job_samples": total, "frames": L, "motion_dim": D, "scene_points": NPTS, "tokens": 2 + NPTS // 64 + L,
                        "conditions": "hoisted (step-invariant, computed once: setup_ms)",
-                       "parallelism": f"batch-shard x{world} ({args.scaling})", "sub_batch_streams": model.loop_streams},
+                       "parallelism": f"batch-shard x{world} ({args.scaling})", "sub_batch_streams": max(1, min(model.loop_streams, B // 8 if model.loop_streams_auto else B))},
             "algorithmic_tflops": round(flops * K / dt / 1e12, 2),
             "executed_tflops": round((flops - elided) * K / dt / 1e12, 2),
             "elided_gflop_per_step": round(elided / 1e9, 2),

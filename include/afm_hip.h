@@ -87,7 +87,7 @@ typedef struct {
     /* ---- arithmetic of the product (ABI v3; replaces the process-wide afm_linear_set_split of v2).  A GEMM is ELIGIBLE for the
      * bf16-split path when K >= 128, K % 16 == 0 and A / W are 16-byte aligned with lda / ldw % 4 == 0; everything else always runs
      * the native f32 MFMA kernels (v_mfma_f32_32x32x2_f32, 157 TF peak on gfx950).
-     *   AFM_ARITH_DEFAULT  eligible GEMMs with N >= 1024 take AFM_ARITH_BF16X9, all others AFM_ARITH_F32 (arith_min_n ignored);
+     *   AFM_ARITH_DEFAULT  every eligible GEMM takes AFM_ARITH_BF16X9, all others AFM_ARITH_F32 (arith_min_n ignored);
      *   AFM_ARITH_F32      native f32 MFMA;
      *   AFM_ARITH_BF16X9   eligible GEMMs with N >= arith_min_n: every f32 operand is split exactly into three bf16 terms inside the
      *                      kernel and all nine cross products run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak)

@@ -174,10 +174,11 @@ def test_sub_batch_streams_are_bit_identical(cmdm):
     g = golden("cmdm_forward_N1024_L16")
     kw = _kw(g)
     outs = []
+    model.loop_streams_auto = False              # take the stream count literally (the automatic rule uses one stream below B = 16)
     for n in (1, 2):
         model.loop_streams = n
         outs.append(diff.p_sample_loop(model, (2, 16, 263), clip_denoised=False, model_kwargs=kw, seed=5).cpu())
-    model.loop_streams = 2
+    model.loop_streams, model.loop_streams_auto = 2, True
     assert torch.equal(outs[0], outs[1])
 
 

@@ -184,7 +184,7 @@ def test_gemm_arithmetic_switches_are_host_state():
     """ABI v3: the GEMM arithmetic is a field of afm_linear_args / the weight packs; the switch lives in the Python host (afm.ops),
     initialised from AFM_GEMM_SPLIT* in the host's environment.  The library exports no setter and reads no environment."""
     from afm import ops
-    want = (int(os.environ.get("AFM_GEMM_SPLIT", "9")), int(os.environ.get("AFM_GEMM_SPLIT_MIN_N", "1024")))
+    want = (int(os.environ.get("AFM_GEMM_SPLIT", "9")), int(os.environ.get("AFM_GEMM_SPLIT_MIN_N", "0")))
     saved = ops.get_gemm_split()
     assert saved == want
     try:

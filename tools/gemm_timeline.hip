@@ -1,0 +1,93 @@
+// Per-workgroup timeline of one afm_linear launch (native f32 MFMA LDS-DMA kernel): every workgroup records s_memrealtime (100 MHz,
+// chip-global) at entry and exit plus its hardware id.  Answers "where does a launch's time go": how long tiles of the first
+// resident round take vs the tail round, how many workgroups are resident over time, when the last CU goes idle.
+// Compiles the library's own gemm sources with -DAFM_TIMELINE (instrumentation that is never part of libafm_hip.so):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAFM_TIMELINE -Iinclude -Iafford-motion_amd/csrc tools/gemm_timeline.hip \
+//         afford-motion_amd/csrc/gemm_split.hip afford-motion_amd/csrc/profile.hip -o tools/gemm_timeline
+//   tools/gemm_timeline [M N K [tile]]
+#include "../afford-motion_amd/csrc/gemm.hip"
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+static void one(int M, int N, int K, int tile) {
+    float *dA, *dW, *dC, *dR;
+    CK(hipMalloc(&dA, (size_t)M * K * 4)); CK(hipMalloc(&dW, (size_t)N * K * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dR, (size_t)M * N * 4));
+    CK(hipMemset(dA, 0x11, (size_t)M * K * 4)); CK(hipMemset(dW, 0x11, (size_t)N * K * 4)); CK(hipMemset(dR, 0, (size_t)M * N * 4));
+    const int maxwg = ((M + 31) / 32) * ((N + 31) / 32);
+    AfmTimelineRec* drec;
+    CK(hipMalloc(&drec, (size_t)maxwg * sizeof(AfmTimelineRec)));
+    CK(hipMemset(drec, 0, (size_t)maxwg * sizeof(AfmTimelineRec)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(afm_timeline), &drec, sizeof drec));
+    afm_linear_args a = {};
+    a.A = dA; a.lda = K; a.W = dW; a.ldw = K; a.C = dC; a.ldc = N; a.residual = dR; a.ldr = N; a.M = M; a.N = N; a.K = K;
+    a.arith = AFM_ARITH_F32; a.tune = tile << AFM_TUNE_TILE_SHIFT;
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) afm_linear(&a, st);
+    CK(hipStreamSynchronize(st));
+    CK(hipMemset(drec, 0, (size_t)maxwg * sizeof(AfmTimelineRec)));
+    CK(hipEventRecord(e0, st));
+    afm_linear(&a, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<AfmTimelineRec> rec(maxwg);
+    CK(hipMemcpy(rec.data(), drec, (size_t)maxwg * sizeof(AfmTimelineRec), hipMemcpyDeviceToHost));
+    std::vector<AfmTimelineRec> r;
+    for (auto& x : rec) if (x.t1) r.push_back(x);
+    const int n = (int)r.size();
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (auto& x : r) { tmin = std::min(tmin, x.t0); tmax = std::max(tmax, x.t1); }
+    const double tick_us = 0.01;                       // s_memrealtime: 100 MHz
+    printf("== M=%d N=%d K=%d tile=%d: %d workgroups, event time %.1f us, first entry -> last exit %.1f us, %.1f TF\n", M, N, K, tile, n, ms * 1e3,
+           (tmax - tmin) * tick_us, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+    std::map<unsigned, int> cus;
+    for (auto& x : r) cus[(x.xcc_id & 0xF) << 16 | (x.hw_id & 0xFF00)]++;           // (xcc, se, sh, cu)
+    int mn = 1 << 30, mx = 0;
+    for (auto& kv : cus) { mn = std::min(mn, kv.second); mx = std::max(mx, kv.second); }
+    printf("   distinct CUs %zu, workgroups per CU min %d max %d\n", cus.size(), mn, mx);
+    // durations by start order: first resident round vs later
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return r[x].t0 < r[y].t0; });
+    auto stats = [&](int lo, int hi, const char* name) {
+        if (hi <= lo) return;
+        std::vector<double> d;
+        double last_end = 0, first_start = 1e30;
+        for (int i = lo; i < hi; ++i) { const auto& x = r[order[i]]; d.push_back((x.t1 - x.t0) * tick_us); last_end = std::max(last_end, (x.t1 - tmin) * tick_us); first_start = std::min(first_start, (x.t0 - tmin) * tick_us); }
+        std::sort(d.begin(), d.end());
+        printf("   %-22s n=%4d  start %6.1f..  last end %6.1f us   duration min %5.1f  p50 %5.1f  p90 %5.1f  max %5.1f us\n", name, hi - lo, first_start, last_end,
+               d.front(), d[d.size() / 2], d[d.size() * 9 / 10], d.back());
+    };
+    int first_round = 0;
+    for (int i = 0; i < n; ++i) if ((r[order[i]].t0 - tmin) * tick_us < 3.0) first_round++;
+    stats(0, first_round, "started in first 3 us");
+    stats(first_round, n, "started later");
+    const double span = (tmax - tmin) * tick_us, bucket = span / 24;
+    printf("   resident workgroups over time (24 buckets of %.1f us):", bucket);
+    for (int b = 0; b < 24; ++b) {
+        const double t = (b + 0.5) * bucket;
+        int c = 0;
+        for (auto& x : r) if ((x.t0 - tmin) * tick_us <= t && (x.t1 - tmin) * tick_us > t) c++;
+        printf(" %d", c);
+    }
+    printf("\n");
+    CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(drec));
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 4) { one(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 0); return 0; }
+    for (int tile : {3, 4, 5}) one(10432, 512, 512, tile);
+    one(10432, 512, 1024, 3);
+    one(8192, 512, 512, 3);          // exactly 1024 tiles of 64x64: one full resident round
+    one(16384, 512, 512, 3);         // exactly two rounds
+    for (int tile : {1, 2, 3}) one(1304, 512, 512, tile);
+    return 0;
+}

@@ -1,14 +1,38 @@
-"""Lean target for rocprofv3 --pmc passes: 12 native CMDM steps at the bench shape, single stream, no profiler events."""
-import sys, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/afford-motion_amd')
-from afm import synth
-from afm.base import create_model_and_diffusion
-from afm.config import load_config
-dev = torch.device('cuda:0')
-cfg = load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263", "diffusion.timestep_respacing='12'"])
-model, diff = create_model_and_diffusion(cfg, device=dev)
-synth.fill_module_(model); model = model.to(dev).eval(); model.loop_streams = 1
-B, L = 32, 196
-kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_cont_emb=synth.gaussian("c", (B, 128, 256)).to(dev), x_mask=synth.frame_mask(B, L, all_valid=True).to(dev))
-diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=1)
+"""Lean target for rocprofv3 --pmc / --kernel-trace passes: 12 native steps at the bench shape, single stream, no profiler events.
+    python tools/pmc_target.py          -> CMDM trans_enc loop (BASELINE configs[1]: B = 32, L = 196, T = 326)
+    python tools/pmc_target.py cdm      -> CDM Perceiver loop  (BASELINE configs[2]: B = 32, N = 8192 points + text token)"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "afford-motion_amd"))
+from afm import synth  # noqa: E402
+from afm.base import create_model_and_diffusion  # noqa: E402
+from afm.config import load_config  # noqa: E402
+
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "cmdm"
+B = 32
+if which == "cdm":
+    N = 8192
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.scene_model.use_scene_model=False", "model.input_feats=6",
+                                                            "model.text_model.max_length=20", "diffusion.steps=500", "diffusion.timestep_respacing='12'"])
+    model, diff = create_model_and_diffusion(cfg, device=dev)
+    synth.fill_module_(model)
+    model = model.to(dev).eval()
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev))
+    for _ in range(2):
+        diff.p_sample_loop(model, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=1)
+else:
+    L = 196
+    cfg = load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263", "diffusion.timestep_respacing='12'"])
+    model, diff = create_model_and_diffusion(cfg, device=dev)
+    synth.fill_module_(model)
+    model = model.to(dev).eval()
+    model.loop_streams = 1
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_cont_emb=synth.gaussian("c", (B, 128, 256)).to(dev), x_mask=synth.frame_mask(B, L, all_valid=True).to(dev))
+    diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=1)
 torch.cuda.synchronize()

@@ -37,7 +37,7 @@ try:
         fl = glob.glob(os.path.join(out, tag, "*", "*counter_collection.csv"))
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(fl[0])):
-            if r["Counter_Name"] == ctr and "gemm" in r["Kernel_Name"]:
+            if r["Counter_Name"] == ctr:
                 agg[short(r["Kernel_Name"]).replace(" ", "")].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             per[k][ctr] = sum(v) / len(v) * 1024
