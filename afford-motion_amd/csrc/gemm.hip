@@ -13,6 +13,7 @@
 //     written to the other LDS buffer afterwards: one barrier per K tile.
 //   * XCD-aware tile order: the 8 XCDs each walk a contiguous range of tiles (A row-panels are
 //     reused out of the XCD's own L2; W (<= 3 MB) stays L2 resident).
+#include <type_traits>
 #include "common.h"
 #include "profile.h"
 #include "gemm_epilogue.h"
@@ -186,15 +187,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
 // Two 128-byte rows share a 256-byte bank row and ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}
 // (+32): (row & 1, (row >> 1) & 7) is distinct for the 16 rows of each group, row & 7 alone was a 2-way conflict on every read
 // (SQ_LDS_BANK_CONFLICT 3.4 M cycles per launch).
+// Stage layout: every wave owns one contiguous region of PT = PA + PW pieces of 1 KiB (8 rows x 128 B): [A pass 0 .. | W pass 0 ..].
+// The instruction's immediate offset is added to BOTH the global and the LDS address, so the pieces of one group of four share ONE
+// LDS base: M0 is written once per group instead of once per instruction (the global pointer is pre-decremented by the same offset).
+// With one M0 write per piece the issue phase measured ~290 cycles per DMA instruction (tools/gemm_timeline, 20.9 k of a workgroup's
+// 69.8 k cycles at M = 10432, N = K = 512: an M0 write waits for the LDS-DMA instructions in flight that still need the old value).
+template <int OFF>
 __device__ __forceinline__ void glds16(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    static_assert(OFF >= 0 && OFF < 4096, "immediate offset range of global_load_lds");
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g) - OFF),
+                                     (__attribute__((address_space(3))) void*)l, 16, OFF, 0);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
 // Workgroup = WM x WN waves, each wave owns TM x TN MFMA tiles of 32x32: tile BM x BN = 32 WM TM x 32 WN TN.  Every shape sums an
 // output element in the same order (K-tiles of 32 in sequence, the permuted k inside a tile), so shapes are interchangeable bit for
 // bit and the dispatcher may pick one from M (small batches: 32x32 single-wave workgroups keep 256 CUs busy at B*T = 1304 rows).
 #ifdef AFM_TIMELINE          // tools/gemm_timeline.hip only: per-workgroup (start, end, hardware id) records; never compiled into the library
-struct AfmTimelineRec { unsigned long long t0, t1; unsigned hw_id, xcc_id; };
+struct AfmTimelineRec { unsigned long long t0, t1; unsigned hw_id, xcc_id; unsigned long long c0, c1, wait_c, barrier_c, issue_c, mfma_c; };
+__device__ __forceinline__ unsigned long long afm_cycles() {      // shader clock; drained immediately so hand-counted lgkmcnt waits stay valid
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 __device__ AfmTimelineRec* afm_timeline = nullptr;
 #endif
 
@@ -202,7 +220,8 @@ template <int WM, int WN, int TM, int TN, int NSTG = 3>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_linear_args p, int nbm, int nbn) {
     constexpr int NT = 64 * WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN;
 #ifdef AFM_TIMELINE
-    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = afm_cycles();
+    unsigned long long tl_wait = 0, tl_barrier = 0, tl_issue = 0, tl_mfma = 0;
 #endif
     constexpr int RP = NT / 8;                       // rows one DMA pass of the whole workgroup covers (8 x 16 B per row)
     constexpr int PA = BM / RP, PW = BN / RP;        // passes per K-tile for the A / W panels
@@ -238,16 +257,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
         const int r = r0 + RP * i;
         wsrc[i] = p.W + (int64_t)min(bn * BN + r, p.N - 1) * p.ldw + ((c8 ^ ((r >> 1) & 7)) << 2);
     }
-    const int wave_off = __builtin_amdgcn_readfirstlane(wave) * 256;     // floats: 8 rows x 32 per wave per pass
+    constexpr int PT = PA + PW;                      // 1-KiB pieces per wave per K-tile = DMA instructions per thread per K-tile
+    constexpr int PER_TILE = PT;
+    const int wave_off = __builtin_amdgcn_readfirstlane(wave) * (PT * 256);      // floats: this wave's region of a stage
     auto issue = [&](int kt, int stage) {
-        float* a_dst = lds + stage * STAGE + wave_off;
-        float* w_dst = lds + stage * STAGE + BM * BK + wave_off;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(asrc[i] + kt * BK, a_dst + i * RP * BK);
-#pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(wsrc[i] + kt * BK, w_dst + i * RP * BK);
+        float* dst = lds + stage * STAGE + wave_off;
+        static_for<0, PT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float* src = i < PA ? asrc[i < PA ? i : 0] : wsrc[i < PA ? 0 : i - PA];
+            glds16<(i & 3) * 1024>(src + kt * BK, dst + (i >> 2) * 1024);            // group base every 4 KiB, piece = immediate offset
+        });
     };
-    constexpr int PER_TILE = PA + PW;                // DMA instructions per thread per K-tile
+    // LDS float offset of logical row R of the A tile (piece0 = 0) / the W tile (piece0 = PA): the wave that staged it, the pass, the row of 8
+    auto row_off = [&](int R, int piece0) { return ((R % RP) >> 3) * (PT * 256) + (piece0 + R / RP) * 256 + (R & 7) * BK; };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -261,30 +283,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
     issue(0, 0);
     if (NSTG == 3 && nk > 1) issue(1, 1);
     const int swz = (r32 >> 1) & 7;
+    unsigned a_row[TM], w_row[TN];                   // byte offsets (inside a stage) of the rows this lane feeds to the MFMAs
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_row[i] = (unsigned)(row_off((wm * TM + i) * 32 + r32, 0) * 4);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) w_row[i] = (unsigned)(row_off((wn * TN + i) * 32 + r32, PA) * 4);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef AFM_TIMELINE
+        const unsigned long long tl_a = afm_cycles();
+#endif
         // this wave's part of tile kt has landed once at most one newer tile (kt+1) is still in flight
         if (NSTG == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AFM_TIMELINE
+        const unsigned long long tl_b = afm_cycles();
+#endif
         __builtin_amdgcn_s_barrier();                // every wave's part landed; every wave is done with tile kt-1
+#ifdef AFM_TIMELINE
+        const unsigned long long tl_c = afm_cycles();
+#endif
         if (NSTG == 3) { if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1); }      // (kt+2) % 3 == (stage + 2) % 3
         else if (kt + 1 < nk) issue(kt + 1, stage ^ 1);                                     // 2-stage ring: 32 KB, more workgroups per CU
+#ifdef AFM_TIMELINE
+        const unsigned long long tl_d = afm_cycles();
+#endif
         // LDS operand reads are issued through inline asm: with an LDS-DMA in flight hipcc otherwise guards every
         // ds_read with `s_waitcnt vmcnt(0)` (it cannot prove the DMA target does not alias), which drains the ring.
         // All reads of the K-tile are issued up front (they return in order), then each MFMA group waits for exactly
         // the reads it needs (counted lgkmcnt) - guide section 5.7 forms (ii)/(iii), rule 18 (sched_barrier after a wait).
-        const unsigned a_addr = (unsigned)((stage * STAGE + (wm * TM * 32 + r32) * BK) * 4);
-        const unsigned w_addr = (unsigned)((stage * STAGE + BM * BK + (wn * TN * 32 + r32) * BK) * 4);
+        const unsigned st_addr = (unsigned)(stage * STAGE * 4);
         f32x4 af[4][TM], bf[4][TN];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned slot = (unsigned)((((hh * 4 + j) ^ swz) << 2) * 4);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(af[j][i]) : "v"(a_addr + slot + (unsigned)(i * 32 * BK * 4)));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[j][i]) : "v"(st_addr + a_row[i] + slot));
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bf[j][i]) : "v"(w_addr + slot + (unsigned)(i * 32 * BK * 4)));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bf[j][i]) : "v"(st_addr + w_row[i] + slot));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -306,6 +344,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
                     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(af[j][tm][e], bf[j][tn][e], acc[tm][tn]);
         }
         stage = NSTG == 3 ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
+#ifdef AFM_TIMELINE
+        const unsigned long long tl_e = afm_cycles();
+        tl_wait += tl_b - tl_a; tl_barrier += tl_c - tl_b; tl_issue += tl_d - tl_c; tl_mfma += tl_e - tl_d;
+#endif
     }
     __syncthreads();                                  // all waves done reading the last stage before it is reused
 
@@ -323,7 +365,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), hw, xcc};
+        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), hw, xcc, tl_c0, afm_cycles(), tl_wait, tl_barrier, tl_issue, tl_mfma};
     }
 #endif
 }

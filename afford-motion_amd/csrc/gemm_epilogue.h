@@ -29,9 +29,8 @@ __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int
 }
 
 // Shared epilogue: the accumulators were staged in `lds` as a [BM][BN + 4] tile; stream rows out with 16-byte accesses.
-template <int BM, int BN, int NT = 256>
+template <int BM, int BN, int NT = 256, int LDC = BN + 4>
 __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const float* lds, int bm, int bn, int tid) {
-    constexpr int LDC = BN + 4;
     const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
     const int col0 = bn * BN;
     const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && ((p.ldp & 3) == 0) && ((p.ldz & 3) == 0) && !p.ddpm_out &&

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
     constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char* lds = lds_raw;
+#ifdef AFM_TIMELINE          // tools/gemm_timeline.hip only (single translation unit with gemm.hip, which defines the record type)
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = afm_cycles();
+#endif
 
     const int nblk = nbm * nbn;
     int bid = blockIdx.x;
@@ -213,6 +216,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
                 ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
     __syncthreads();
     gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid);
+#ifdef AFM_TIMELINE
+    if (afm_timeline && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), hw, xcc, tl_c0, afm_cycles(), 0, 0, 0, 0};
+    }
+#endif
 }
 
 template <int BM, int BN, int BKS, int NPROD>
@@ -241,6 +252,7 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t resident = 512, rounds = (tiles128 + resident - 1) / resident;
     const bool full_rounds = tiles128 * 10 >= rounds * resident * 9;              // >= 90 % of the resident slots used over all rounds
+    if (tile == 6) return launch_split<64, 64, 32, NPROD>(a, s);                  // experiment: K-tiles of 32 (half the barriers, same product order)
     if (tile == 3 || (tile != 5 && !full_rounds)) return launch_split<64, 64, 16, NPROD>(a, s);
     return launch_split<128, 128, 16, NPROD>(a, s);
 }

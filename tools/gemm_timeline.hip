@@ -3,9 +3,10 @@
 // resident round take vs the tail round, how many workgroups are resident over time, when the last CU goes idle.
 // Compiles the library's own gemm sources with -DAFM_TIMELINE (instrumentation that is never part of libafm_hip.so):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAFM_TIMELINE -Iinclude -Iafford-motion_amd/csrc tools/gemm_timeline.hip \
-//         afford-motion_amd/csrc/gemm_split.hip afford-motion_amd/csrc/profile.hip -o tools/gemm_timeline
-//   tools/gemm_timeline [M N K [tile]]
+//         afford-motion_amd/csrc/profile.hip -o tools/gemm_timeline
+//   tools/gemm_timeline [M N K [tile [arith]]]        arith: 1 = f32 MFMA (default), 9 / 6 = bf16 split
 #include "../afford-motion_amd/csrc/gemm.hip"
+#include "../afford-motion_amd/csrc/gemm_split.hip"
 #include <algorithm>
 #include <cstdio>
 #include <map>
@@ -13,18 +14,19 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-static void one(int M, int N, int K, int tile) {
+static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pad = 0, int flags = 0) {
+    const int lda = K + pad, ldw = K + pad;           // pad != 0: row strides that are not a power of two (L2 channel spread)
     float *dA, *dW, *dC, *dR;
-    CK(hipMalloc(&dA, (size_t)M * K * 4)); CK(hipMalloc(&dW, (size_t)N * K * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dR, (size_t)M * N * 4));
-    CK(hipMemset(dA, 0x11, (size_t)M * K * 4)); CK(hipMemset(dW, 0x11, (size_t)N * K * 4)); CK(hipMemset(dR, 0, (size_t)M * N * 4));
+    CK(hipMalloc(&dA, (size_t)M * lda * 4)); CK(hipMalloc(&dW, (size_t)N * ldw * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dR, (size_t)M * N * 4));
+    CK(hipMemset(dA, 0x11, (size_t)M * lda * 4)); CK(hipMemset(dW, 0x11, (size_t)N * ldw * 4)); CK(hipMemset(dR, 0, (size_t)M * N * 4));
     const int maxwg = ((M + 31) / 32) * ((N + 31) / 32);
     AfmTimelineRec* drec;
     CK(hipMalloc(&drec, (size_t)maxwg * sizeof(AfmTimelineRec)));
     CK(hipMemset(drec, 0, (size_t)maxwg * sizeof(AfmTimelineRec)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(afm_timeline), &drec, sizeof drec));
     afm_linear_args a = {};
-    a.A = dA; a.lda = K; a.W = dW; a.ldw = K; a.C = dC; a.ldc = N; a.residual = dR; a.ldr = N; a.M = M; a.N = N; a.K = K;
-    a.arith = AFM_ARITH_F32; a.tune = tile << AFM_TUNE_TILE_SHIFT;
+    a.A = dA; a.lda = lda; a.W = dW; a.ldw = ldw; a.C = dC; a.ldc = N; a.residual = dR; a.ldr = N; a.M = M; a.N = N; a.K = K;
+    a.arith = arith; a.tune = (tile << AFM_TUNE_TILE_SHIFT) | flags;
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -46,7 +48,7 @@ static void one(int M, int N, int K, int tile) {
     unsigned long long tmin = ~0ull, tmax = 0;
     for (auto& x : r) { tmin = std::min(tmin, x.t0); tmax = std::max(tmax, x.t1); }
     const double tick_us = 0.01;                       // s_memrealtime: 100 MHz
-    printf("== M=%d N=%d K=%d tile=%d: %d workgroups, event time %.1f us, first entry -> last exit %.1f us, %.1f TF\n", M, N, K, tile, n, ms * 1e3,
+    printf("== arith=%d flags=%d pad=%d M=%d N=%d K=%d tile=%d: %d workgroups, event time %.1f us, first entry -> last exit %.1f us, %.1f TF\n", arith, flags, pad, M, N, K, tile, n, ms * 1e3,
            (tmax - tmin) * tick_us, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
     std::map<unsigned, int> cus;
     for (auto& x : r) cus[(x.xcc_id & 0xF) << 16 | (x.hw_id & 0xFF00)]++;           // (xcc, se, sh, cu)
@@ -70,6 +72,17 @@ static void one(int M, int N, int K, int tile) {
     for (int i = 0; i < n; ++i) if ((r[order[i]].t0 - tmin) * tick_us < 3.0) first_round++;
     stats(0, first_round, "started in first 3 us");
     stats(first_round, n, "started later");
+    // shader-clock view of wave 0 of every workgroup: effective clock and where the K loop's cycles go
+    auto phases = [&](int lo, int hi, const char* name) {
+        if (hi <= lo) return;
+        double cyc = 0, us = 0, w = 0, b = 0, is = 0, mf = 0;
+        for (int i = lo; i < hi; ++i) { const auto& x = r[order[i]]; cyc += (double)(x.c1 - x.c0); us += (x.t1 - x.t0) * tick_us; w += x.wait_c; b += x.barrier_c; is += x.issue_c; mf += x.mfma_c; }
+        const int m = hi - lo;
+        printf("   %-22s shader clock %.2f GHz; per workgroup: %.0f cycles = vmcnt wait %.0f + barrier %.0f + DMA issue %.0f + ds_read/MFMA section %.0f + prologue/epilogue %.0f  (MFMA-only floor per wave: %d)\n",
+               name, cyc / us / 1e3, cyc / m, w / m, b / m, is / m, mf / m, (cyc - w - b - is - mf) / m, 64 * (K / 2) * (tile == 5 ? 4 : tile == 4 ? 2 : 1));
+    };
+    phases(0, first_round, "started in first 3 us");
+    phases(first_round, n, "started later");
     const double span = (tmax - tmin) * tick_us, bucket = span / 24;
     printf("   resident workgroups over time (24 buckets of %.1f us):", bucket);
     for (int b = 0; b < 24; ++b) {
@@ -83,11 +96,15 @@ static void one(int M, int N, int K, int tile) {
 }
 
 int main(int argc, char** argv) {
-    if (argc >= 4) { one(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 0); return 0; }
-    for (int tile : {3, 4, 5}) one(10432, 512, 512, tile);
+    if (argc >= 4) { one(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 0, argc > 5 ? atoi(argv[5]) : AFM_ARITH_F32, argc > 6 ? atoi(argv[6]) : 0); return 0; }
+    for (int tile : {3, 5}) one(10432, 512, 512, tile);
     one(10432, 512, 1024, 3);
-    one(8192, 512, 512, 3);          // exactly 1024 tiles of 64x64: one full resident round
-    one(16384, 512, 512, 3);         // exactly two rounds
-    for (int tile : {1, 2, 3}) one(1304, 512, 512, tile);
+    one(10432, 1536, 512, 3);
+    one(6144, 512, 512, 3);          // exactly 768 tiles of 64x64: one full resident round (3 workgroups per CU)
+    for (int tile : {1, 3}) one(1304, 512, 512, tile);
+    for (int tile : {3, 5}) one(10432, 512, 512, tile, AFM_ARITH_BF16X9);
+    for (int tile : {3, 5}) one(10432, 1536, 512, tile, AFM_ARITH_BF16X9);
+    one(10432, 512, 1024, 3, AFM_ARITH_BF16X9);
+    one(1304, 512, 512, 3, AFM_ARITH_BF16X9);
     return 0;
 }

@@ -38,13 +38,13 @@ static double time_us(F&& launch, int reps = 15) {
     return ts[ts.size() / 2];
 }
 
-struct GemmCfg { int arith, min_n, tile; const char* name; };
+struct GemmCfg { int arith, min_n, tile; const char* name; int flags = 0; };
 
 static void gemm_sweep(const std::vector<int>& batches) {
     const int T = 326, L = 196;
     const GemmCfg cfgs[] = {{AFM_ARITH_F32, 0, 0, "f32 auto"},   {AFM_ARITH_F32, 0, 1, "f32 32x32"},   {AFM_ARITH_F32, 0, 2, "f32 32x64"},
                             {AFM_ARITH_F32, 0, 3, "f32 64x64"},  {AFM_ARITH_F32, 0, 4, "f32 64x128"},  {AFM_ARITH_F32, 0, 5, "f32 128x128"},
-                            {AFM_ARITH_BF16X9, 0, 0, "x9 auto"}, {AFM_ARITH_BF16X9, 0, 3, "x9 64x64"}, {AFM_ARITH_BF16X9, 0, 5, "x9 128x128"},
+                            {AFM_ARITH_BF16X9, 0, 0, "x9 auto"}, {AFM_ARITH_BF16X9, 0, 3, "x9 64x64"}, {AFM_ARITH_BF16X9, 0, 6, "x9 64x64 BK32"}, {AFM_ARITH_BF16X9, 0, 5, "x9 128x128"},
                             {AFM_ARITH_BF16X6, 0, 0, "x6 auto"}};
     std::mt19937 rng(7);
     std::normal_distribution<float> nd(0.f, 1.f);
@@ -69,7 +69,7 @@ static void gemm_sweep(const std::vector<int>& batches) {
                 afm_linear_args a;
                 memset(&a, 0, sizeof a);
                 a.A = dA; a.lda = sh.K; a.W = dW; a.ldw = sh.K; a.C = dC; a.ldc = sh.N; a.bias = dB; a.residual = dR; a.ldr = sh.N;
-                a.M = sh.M; a.N = sh.N; a.K = sh.K; a.arith = c.arith; a.arith_min_n = c.min_n; a.tune = c.tile << AFM_TUNE_TILE_SHIFT;
+                a.M = sh.M; a.N = sh.N; a.K = sh.K; a.arith = c.arith; a.arith_min_n = c.min_n; a.tune = (c.tile << AFM_TUNE_TILE_SHIFT) | c.flags;
                 CK(hipMemsetAsync(dC, 0xFF, nc * 4, st));
                 int rc = afm_linear(&a, st);
                 if (rc) { printf("B=%-2d %-15s %-11s rc=%d\n", B, sh.name, c.name, rc); continue; }
@@ -88,7 +88,7 @@ static void gemm_sweep(const std::vector<int>& batches) {
                     }
                     worst = std::fmax(worst, std::fabs((double)out[(size_t)m * sh.N + n] - ref) / scale);
                 }
-                printf("B=%-2d %-15s M=%5d N=%4d K=%4d  %-11s %8.1f us %6.1f TF  err %.1e  %s\n", B, sh.name, sh.M, sh.N, sh.K, c.name, us,
+                printf("B=%-2d %-15s M=%5d N=%4d K=%4d  %-18s %8.1f us %6.1f TF  err %.1e  %s\n", B, sh.name, sh.M, sh.N, sh.K, c.name, us,
                        2.0 * sh.M * sh.N * sh.K / (us * 1e-6) / 1e12, worst, same);
             }
             CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR));
