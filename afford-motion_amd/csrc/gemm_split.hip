@@ -252,7 +252,6 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t resident = 512, rounds = (tiles128 + resident - 1) / resident;
     const bool full_rounds = tiles128 * 10 >= rounds * resident * 9;              // >= 90 % of the resident slots used over all rounds
-    if (tile == 6) return launch_split<64, 64, 32, NPROD>(a, s);                  // experiment: K-tiles of 32 (half the barriers, same product order)
     if (tile == 3 || (tile != 5 && !full_rounds)) return launch_split<64, 64, 16, NPROD>(a, s);
     return launch_split<128, 128, 16, NPROD>(a, s);
 }

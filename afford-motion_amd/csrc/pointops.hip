@@ -18,6 +18,10 @@
 #include "profile.h"
 #pragma clang fp contract(off)
 
+#ifdef AFM_PROBE
+int afm_probe_fps_threads = 0;
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -26,8 +30,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // processed as packed f32 pairs (v_pk_add / v_pk_mul: same IEEE results, half the instructions), the per-thread arg-max is a
 // 32-bit (distance bits, slot) select - slots are visited in increasing point index, so a strict '>' keeps the lowest index on
 // ties - and the 64-bit (dist | ~index) key that the wave / workgroup reduction orders by is built once per thread per round.
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out, int xyz_in_lds) {
+template <int PPT, int MAXT = 1024>
+__global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out, int xyz_in_lds) {
     constexpr int NP = (PPT + 1) / 2;                 // packed pairs (PPT == 1: second half is a dead slot)
     __shared__ unsigned long long keys[2][16];
     extern __shared__ float pts[];                    // [3n] copy of the sample for the winner's coordinates (critical path)
@@ -85,34 +89,38 @@ constexpr int KNN_TILE = 1024;
 
 // One lane per query, candidates tiled through LDS.  A candidate that beats the lane's current k-th distance is NOT inserted
 // at once: a wave executes a divergent branch whenever ANY of its 64 lanes takes it, and with 64 independent queries some lane
-// nearly always does, so the 6K-instruction sorted insert would run for almost every candidate.  Instead qualifying candidates
-// are appended (predicated, branch-free) to a 3-entry per-lane buffer (3 measured best of 2, 3, 4, 8) and the wave flushes the buffers with one wave-uniform
-// branch when any lane's buffer is full - the insert cost is paid every ~i/(2K) candidates instead of every candidate.
+// nearly always does (each query takes ~K ln(n / K) ~ 100 candidates of 8192, i.e. ~0.8 takes per candidate per wave), so the 6K-instruction
+// sorted insert would run for almost every candidate.  Instead a qualifying candidate is APPENDED to a per-lane buffer in LDS: one
+// branch-free ds_write_b64 whose row is the lane's fill count (non-qualifying lanes write to a dump row), and the wave drains the
+// buffers with one wave-uniform branch when some lane is nearly full.  Round 1 kept a 3-entry buffer in registers (six v_cndmask per
+// candidate); the LDS form costs 4 VALU + 1 LDS store per candidate and leaves room for 8 entries, so the drain runs half as often.
+// Candidates are consumed four per trip (three broadcast ds_read_b128, four independent distance chains): the kernel runs ONE wave
+// per SIMD (65536 queries are 1024 waves), so instruction-level parallelism is all the latency hiding there is.
 // Insertion order per lane is still the scan order and uses strict '<', so the result is identical to the direct form:
 // neighbours ordered by (d2, index).
 template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, const float* __restrict__ qxyz, int n, int m,
                                                   int* __restrict__ idx_out, float* __restrict__ d2_out) {
-    constexpr int BUF = 3;
-    __shared__ float tile[3 * KNN_TILE];             // interleaved x,y,z exactly as in memory (coalesced fill)
+    constexpr int BUF = 8;
+    __shared__ __attribute__((aligned(16))) float tile[3 * KNN_TILE];      // interleaved x,y,z exactly as in memory (coalesced fill)
+    __shared__ float2 buf[BUF + 1][256];                                    // [entry][thread] (conflict-free), row BUF = dump row
     const int b = blockIdx.y, tid = threadIdx.x;
     const int q = blockIdx.x * blockDim.x + tid;
     const bool valid = q < m;
     const float* Q = qxyz + ((int64_t)b * m + (valid ? q : 0)) * 3;
     const float qx = Q[0], qy = Q[1], qz = Q[2];
     const float* P = xyz + (int64_t)b * n * 3;
-    float bd[K], cd[BUF];
-    int bi[K], ci[BUF];
+    float bd[K];
+    int bi[K];
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = -1; }
-#pragma unroll
-    for (int j = 0; j < BUF; ++j) { cd[j] = INFINITY; ci[j] = -1; }
     auto flush = [&]() {
-#pragma unroll
         for (int e = 0; e < BUF; ++e) {
-            const float d = e < cnt ? cd[e] : INFINITY;              // unused slots can never beat anything
-            const int id = ci[e];
+            if (!__any(e < cnt)) break;                              // wave-uniform
+            const float2 v = buf[e][tid];
+            const float d = e < cnt ? v.x : INFINITY;                // unused slots can never beat anything
+            const int id = __float_as_int(v.y);
             // sorted insert; strict '<' keeps the earlier (lower) index in front on equal distances
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
@@ -127,22 +135,32 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
         }
         cnt = 0;
     };
+    auto offer = [&](float d, int id) {                              // append if it beats the (possibly stale) k-th distance: re-checked at the drain
+        const bool take = d < bd[K - 1];
+        buf[take ? cnt : BUF][tid] = make_float2(d, __int_as_float(id));
+        cnt += take ? 1 : 0;
+    };
     for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
         const int tc = min(KNN_TILE, n - t0);
         for (int f = tid; f < tc * 3; f += blockDim.x) tile[f] = P[(int64_t)t0 * 3 + f];
         __syncthreads();
-        for (int i = 0; i < tc; ++i) {
+        int i = 0;
+        for (; i + 4 <= tc; i += 4) {
+            const float4 c0 = *reinterpret_cast<const float4*>(tile + 3 * i), c1 = *reinterpret_cast<const float4*>(tile + 3 * i + 4),
+                         c2 = *reinterpret_cast<const float4*>(tile + 3 * i + 8);
+            const float ax = qx - c0.x, ay = qy - c0.y, az = qz - c0.z;
+            const float bx = qx - c0.w, by = qy - c1.x, bz = qz - c1.y;
+            const float ex = qx - c1.z, ey = qy - c1.w, ez = qz - c2.x;
+            const float fx = qx - c2.y, fy = qy - c2.z, fz = qz - c2.w;
+            const float d0 = (ax * ax + ay * ay) + az * az, d1 = (bx * bx + by * by) + bz * bz;
+            const float d2 = (ex * ex + ey * ey) + ez * ez, d3 = (fx * fx + fy * fy) + fz * fz;
+            offer(d0, t0 + i); offer(d1, t0 + i + 1); offer(d2, t0 + i + 2); offer(d3, t0 + i + 3);
+            if (__any(cnt > BUF - 4)) flush();                       // room for the next four appends in every lane
+        }
+        for (; i < tc; ++i) {
             const float dx = qx - tile[3 * i], dy = qy - tile[3 * i + 1], dz = qz - tile[3 * i + 2];
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const bool take = d < bd[K - 1];                          // threshold may be stale until the next flush: re-checked there
-#pragma unroll
-            for (int e = 0; e < BUF; ++e) {
-                const bool w = take && cnt == e;
-                cd[e] = w ? d : cd[e];
-                ci[e] = w ? (t0 + i) : ci[e];
-            }
-            cnt += take ? 1 : 0;
-            if (__any(cnt == BUF)) flush();
+            offer((dx * dx + dy * dy) + dz * dz, t0 + i);
+            if (__any(cnt > BUF - 4)) flush();
         }
         __syncthreads();
     }
@@ -225,25 +243,36 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
     if (!xyz || !idx_out || B < 0 || n <= 0 || m < 0 || m > n) return AFM_E_BADARG;
     if (B == 0 || m == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    int T = ((n + 63) / 64) * 64;
-    if (T > 1024) T = 1024;
+    // Threads per workgroup: a round is a dependent chain (per-thread scan -> wave arg-max -> LDS hop -> barrier -> broadcast), and the
+    // chain gets SHORTER with fewer, fatter threads: n = 8192 measured 1.18 / 1.06 / 1.00 / 1.65 us per round with 1024 / 512 / 256 / 128
+    // threads (8 / 16 / 32 / 64 points per thread; profiles/r02_points_probe.txt) - 4 waves = one per SIMD pay the cheapest barrier and
+    // cross-wave step while 32 independent distance chains per thread still fill the VALU.  Results do not depend on the split.
+    int T = (((n + 31) / 32 + 63) / 64) * 64;
+    if (T < 64) T = 64;
+    if (T > 512) T = 512;
+    if ((n + T - 1) / T > 32) T = 1024;              // n > 16384: the round-1 shape (up to 16 points per thread)
+#ifdef AFM_PROBE               // tools/points_probe.hip only: threads per workgroup override for experiments
+    if (afm_probe_fps_threads > 0) T = afm_probe_fps_threads;
+#endif
     const int ppt = (n + T - 1) / T;
     AfmProf prof(AFM_PROF_FPS, (double)B * (m - 1) * n, s);
     const size_t lds = (size_t)3 * n * sizeof(float);
     const int in_lds = lds <= 150 * 1024 ? 1 : 0;
-#define AFM_FPS(P)                                                                                                                  \
+#define AFM_FPS(P, MT)                                                                                                              \
     do {                                                                                                                            \
         if (in_lds && lds > 48 * 1024) {                                                                                            \
-            hipError_t e__ = hipFuncSetAttribute((const void*)fps_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            hipError_t e__ = hipFuncSetAttribute((const void*)fps_kernel<P, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             if (e__ != hipSuccess) return (int)e__;                                                                                 \
         }                                                                                                                           \
-        hipLaunchKernelGGL(fps_kernel<P>, dim3(B), dim3(T), in_lds ? lds : 0, s, xyz, n, m, idx_out, in_lds);                        \
+        hipLaunchKernelGGL((fps_kernel<P, MT>), dim3(B), dim3(T), in_lds ? lds : 0, s, xyz, n, m, idx_out, in_lds);                  \
     } while (0)
-    if (ppt <= 1) AFM_FPS(1);
-    else if (ppt <= 2) AFM_FPS(2);
-    else if (ppt <= 4) AFM_FPS(4);
-    else if (ppt <= 8) AFM_FPS(8);
-    else if (ppt <= 16) AFM_FPS(16);
+    if (T <= 128 && ppt > 32 && ppt <= 64) AFM_FPS(64, 128);
+    else if (T <= 512 && ppt > 16 && ppt <= 32) AFM_FPS(32, 512);
+    else if (ppt <= 1) AFM_FPS(1, 1024);
+    else if (ppt <= 2) AFM_FPS(2, 1024);
+    else if (ppt <= 4) AFM_FPS(4, 1024);
+    else if (ppt <= 8) AFM_FPS(8, 1024);
+    else if (ppt <= 16) AFM_FPS(16, 1024);
     else return AFM_E_UNSUPPORTED;
 #undef AFM_FPS
     AFM_CHECK_LAUNCH();

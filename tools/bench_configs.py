@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Secondary measurements for the BASELINE.json configs that bench.py's headline line does not cover
-(configs[2] CDM Perceiver, configs[3] set abstraction, configs[4] two-stage ADM -> AMDM at k_sample = 32),
+(configs[0] the reference's CPU case B=4 / L=60 / 100 steps, faithful and hoisted, CPU oracle next to the HIP path; configs[2] CDM Perceiver,
+configs[3] set abstraction, configs[4] two-stage ADM -> AMDM at k_sample = 32),
 one JSON object per line.  Single GPU; the per-stage timings come from the library's HIP-event profiler.
 
     python tools/bench_configs.py [--quick] > profiles/rNN_configs.jsonl
@@ -47,6 +48,77 @@ def cdm_models(steps_adm="", steps_amdm=""):
     adm, amdm = create_model(ca, device=dev), create_model(cm, device=dev)
     synth.fill_module_(adm); synth.fill_module_(amdm)
     return adm.to(dev).eval(), create_gaussian_diffusion(ca), amdm.to(dev).eval(), create_gaussian_diffusion(cm)
+
+
+def config0(quick):
+    """BASELINE configs[0]: CMDM trans_enc, t2m_contact_motion settings, synthetic B=4, L=60, D=263, N=8192, 100 DDPM steps - the reference's CPU
+    path next to the HIP path, both variants: *faithful* (the contact encoder re-run every step, as models/cmdm.py:149-156
+    does) and *hoisted* (step-invariant conditions once).  CPU = the oracle restatement (torch-CPU, pinned to the reference by tests/golden) on this
+    box's host cores; its faithful variant is timed on a bounded sample of steps (the SceneMapEncoder over 4 x 8192 points takes seconds per step)."""
+    import statistics
+    from oracle import denoiser_ref as dr, diffusion_ref as df, shapes as sh
+    Bc, Lc, steps = 4, 60, 100
+    cm = load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263", "diffusion.steps=100"])
+    amdm = create_model(cm, device=dev)
+    synth.fill_module_(amdm)
+    amdm = amdm.to(dev).eval()
+    diff = create_gaussian_diffusion(cm)
+    text, xyz, contact = synth.text_feature(Bc), synth.scene_cloud(Bc, N), synth.contact_map(Bc, N)
+    mask = synth.frame_mask(Bc, Lc, seed=9)
+    kw = dict(c_text_feat=text.to(dev), c_pc_xyz=xyz.to(dev), c_pc_contact=contact.to(dev), x_mask=mask.to(dev))
+    run = lambda: diff.p_sample_loop(amdm, (Bc, Lc, 263), clip_denoised=False, model_kwargs=kw, seed=1)
+    hip_hoisted = timed(run, 3) / steps                                   # native loop: conditions computed once per run (cache warm: 0 times)
+    amdm.hoist_conditions = False
+
+    def run_faithful():                                                    # per-step path: CMDM.forward re-encodes the scene every step
+        x = torch.randn(Bc, Lc, 263, device=dev)
+        tvec = diff.tables(dev).timesteps(Bc)
+        for i in range(steps - 1, -1, -1):
+            x = diff.p_sample(amdm, x, tvec[i], clip_denoised=False, model_kwargs=kw, seed=1, step=steps - 1 - i)["sample"]
+        return x
+    hip_faithful = timed(run_faithful, 1) / steps
+    amdm.hoist_conditions = True
+    # ---- CPU (oracle)
+    sd = sh.weights(sh.cmdm())
+    s100 = df.Schedule(100)
+    avail = len(os.sched_getaffinity(0))
+    torch.set_num_threads(min(avail, 16))                                  # 16 threads were the fastest on the headline shape (bench.py probes)
+    x = synth.gaussian("c0b_x", (Bc, Lc, 263)); nz = synth.gaussian("c0b_nz", (Bc, Lc, 263)); t = torch.full((Bc,), 50)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        cont = None
+        from oracle import scene_ref as sr
+        cont = sr.scene_map_encoder({k: v for k, v in sd.items() if k.startswith("contact_encoder.")}, "contact_encoder", xyz, contact, blocks=(2, 2, 2, 2))
+        enc_s = time.perf_counter() - t0
+        hoisted = lambda xx, tt, **k: dr.cmdm_forward(sd, xx, tt, text, x_mask=mask, cont_emb=cont)
+        df.p_sample(s100, hoisted, x, t, nz)
+        reps = []
+        n_h = 20 if quick else steps
+        for _ in range(1 if quick else 3):
+            xx = x
+            t0 = time.perf_counter()
+            for i in range(n_h):
+                xx = df.p_sample(s100, hoisted, xx, torch.full((Bc,), steps - 1 - i % steps), nz)["sample"]
+            reps.append((time.perf_counter() - t0) / n_h)
+        cpu_hoisted = statistics.median(reps)
+        faithful = lambda xx, tt, **k: dr.cmdm_forward(sd, xx, tt, text, xyz, contact, mask)
+        n_f = 1 if quick else 2
+        t0 = time.perf_counter()
+        xx = x
+        for _ in range(n_f):
+            xx = df.p_sample(s100, faithful, xx, t, nz)["sample"]
+        cpu_faithful = (time.perf_counter() - t0) / n_f
+    flops = Bc * (5 * 190 * (4194304 + 2048 * 190) + 2 * (2 * 263 * 512 * Lc) + 2 * 2 * 512 * 512)
+    return {"config": "configs[0] CMDM trans_enc, t2m_contact_motion, B=4, L=60, D=263, N=8192, 100 DDPM steps",
+            "cpu_oracle": {"hoisted_steps_per_s": round(1 / cpu_hoisted, 2), "hoisted_ms_per_step": round(1e3 * cpu_hoisted, 1),
+                           "hoisted_sample": f"{len(reps)} x {n_h} chained p_sample steps", "hoisted_gflops": round(flops / cpu_hoisted / 1e9, 1),
+                           "faithful_steps_per_s": round(1 / cpu_faithful, 3), "faithful_ms_per_step": round(1e3 * cpu_faithful, 1),
+                           "faithful_sample": f"{n_f} steps (the contact encoder alone: {enc_s:.2f} s per call for 4 scenes)",
+                           "threads": torch.get_num_threads(), "logical_cpus": avail},
+            "hip": {"hoisted_steps_per_s": round(1 / hip_hoisted, 1), "hoisted_ms_per_step": round(1e3 * hip_hoisted, 4),
+                    "faithful_steps_per_s": round(1 / hip_faithful, 1), "faithful_ms_per_step": round(1e3 * hip_faithful, 4),
+                    "note": "hoisted = native sync-free loop; faithful = per-step CMDM.forward with hoist_conditions=False (SceneMapEncoder re-run every step)"},
+            "algorithmic_gflop_per_step_hoisted": round(flops / 1e9, 2)}
 
 
 def config2(quick):
@@ -105,11 +177,11 @@ def main():
     a = ap.parse_args()
     ffi.load()
     results = []
-    for fn in (config4, config2, config3):        # the long two-stage run first, on a fresh allocator state
+    for fn in (config4, config2, config3, config0):        # the long two-stage run first, on a fresh allocator state
         r = fn(a.quick)
         results.append(r if isinstance(r, list) else [r])
         torch.cuda.empty_cache()
-    for r in (results[1], results[2], results[0]):
+    for r in (results[3], results[1], results[2], results[0]):
         for line in r:
             print(json.dumps(line), flush=True)
 
