@@ -55,9 +55,17 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x
 __device__ constexpr int PA[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0};
 __device__ constexpr int PB[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
 
-template <int BM, int BN, int BKS, int NPROD>
-__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
+// K is summed in SEGMENTS of KSEG = 256: every segment accumulates from zero and the segment sums are added left to right,
+// ((s0 + s1) + s2) + s3.  With KG == 1 a workgroup walks all segments itself (a second accumulator set, one add per segment: free);
+// with KG > 1 (small launches: strong scaling runs 4 samples per GPU, M = 1304) KG groups of 256 threads take one segment each and
+// the sums meet in LDS - the serial chain of a 32x32 MFMA tile drops from K to 256 deep.  Both forms add exactly the same numbers in
+// the same order, so a shard computed by the split form is bit-identical to the full batch computed by the sequential form.
+constexpr int KSEG = 256;
+
+template <int BM, int BN, int BKS, int NPROD, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
+    static_assert(KG == 1 || (BM == 64 && BN == 64), "the split-K form exists for 64x64 tiles");
     constexpr int CPR = BKS / 8;                      // 8-float chunks per row of a K-tile
     constexpr int ROWB = BKS * 2 + 16;                // LDS row bytes (bf16 + pad)
     constexpr int ROWS = BM + BN;                     // A rows then W rows
@@ -67,7 +75,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
     static_assert(ROWS * CPR % 256 == 0, "tile does not divide over 256 threads");
     constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned char* lds = lds_raw;
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // K segment of this 256-thread group
+    unsigned char* lds = lds_raw + grp * (2 * STAGE);
 #ifdef AFM_TIMELINE          // tools/gemm_timeline.hip only (single translation unit with gemm.hip, which defines the record type)
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = afm_cycles();
 #endif
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int bm = bid / nbn, bn = bid % nbn;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // position inside the 256-thread group
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
 
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
         const int it = tid + 256 * i, blk = it >> 4, j = it & 15;
         const int row = CPR == 2 ? blk * 8 + 2 * ((j & 7) >> 1) + (j >> 3) : it / CPR, ch = CPR == 2 ? (j & 1) : it % CPR;
         src[i] = (row < BM ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
-                           : p.W + (int64_t)min(bn * BN + row - BM, p.N - 1) * p.ldw) + ch * 8;
+                           : p.W + (int64_t)min(bn * BN + row - BM, p.N - 1) * p.ldw) + ch * 8 + grp * KSEG;
         dst[i] = row * ROWB + ch * 16;
     }
 
@@ -110,7 +119,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
     // tile went to LDS during kt - 1) and receives tile kt + 2; the other set holds tile kt + 1 (loaded one full K-tile
     // ago) and is split into the other LDS stage between the MFMAs of tile kt.
     float4 g[2][NI][2];
-    const int nk = p.K / BKS;
+    const int nk = KG > 1 ? KSEG / BKS : p.K / BKS;
+    constexpr int SEGT = KSEG / BKS;                  // K-tiles per segment
+    f32x16 tot[TM][TN];                               // sum of the finished segments (KG == 1 with K > KSEG only)
+    bool have_tot = false;
     auto load = [&](auto SETC, int kt) {
         constexpr int S = decltype(SETC)::value;
         const int k = min(kt, nk - 1) * BKS;          // past the end: re-load the last tile (never consumed)
@@ -199,6 +211,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
                         __builtin_amdgcn_sched_barrier(0);
                     }
         }
+        if (KG == 1 && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {        // segment finished, more to come: bank it, restart from zero
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tot[tm][tn][r] = have_tot ? tot[tm][tn][r] + acc[tm][tn][r] : acc[tm][tn][r];
+                        acc[tm][tn][r] = 0.f;
+                    }
+            have_tot = true;
+        }
         __syncthreads();
     };
     for (int kt = 0; kt < nk; kt += 2) {
@@ -206,18 +230,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
         if (kt + 1 < nk) body(Set1{}, kt + 1);
     }
 
-    float* ldsf = reinterpret_cast<float*>(lds);
+    if (KG == 1 && have_tot) {                        // ((s0 + s1) + ...) + s_last
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = tot[tm][tn][r] + acc[tm][tn][r];
+    }
+    if (KG > 1) {
+        // groups 1 .. KG-1 hand their segment sums to group 0 through their own (now idle) operand regions: [r / 4][thread] float4
+        f32x4* part = reinterpret_cast<f32x4*>(lds);
+        if (grp > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[q * 256 + tid] = f32x4{acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+        }
+        __syncthreads();
+        if (grp == 0) {
+            for (int gI = 1; gI < KG; ++gI) {
+                const f32x4* pg = reinterpret_cast<const f32x4*>(lds_raw + gI * (2 * STAGE));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = pg[q * 256 + tid];
+                    acc[0][0][4 * q] += v[0]; acc[0][0][4 * q + 1] += v[1]; acc[0][0][4 * q + 2] += v[2]; acc[0][0][4 * q + 3] += v[3];
+                }
+            }
+        }
+    }
+    float* ldsf = reinterpret_cast<float*>(lds_raw);
+    if (grp == 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
+    }
     __syncthreads();
-    gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid);
+    if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid);
 #ifdef AFM_TIMELINE
-    if (afm_timeline && tid == 0) {
+    if (afm_timeline && threadIdx.x == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -226,24 +279,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(const afm_linear_a
 #endif
 }
 
-template <int BM, int BN, int BKS, int NPROD>
+template <int BM, int BN, int BKS, int NPROD, int KG = 1>
 int launch_split(const afm_linear_args& a, hipStream_t s) {
     constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
-    constexpr int LDS_BYTES = 2 * STAGE > BM * (BN + 4) * 4 ? 2 * STAGE : BM * (BN + 4) * 4;
+    constexpr int LDS_BYTES = KG * 2 * STAGE > BM * (BN + 4) * 4 ? KG * 2 * STAGE : BM * (BN + 4) * 4;
     static const int attr = []() {
-        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16<BM, BN, BKS, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }();
     if (attr != 0) return attr;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    AfmProf prof(BM == 128 ? AFM_PROF_GEMM_SPLIT128 : AFM_PROF_GEMM_SPLIT64, 2.0 * a.M * a.N * a.K, s);
-    hipLaunchKernelGGL((gemm_f32_split_bf16<BM, BN, BKS, NPROD>), dim3(nbm * nbn), dim3(256), LDS_BYTES, s, a, nbm, nbn);
+    AfmProf prof(BM == 128 ? AFM_PROF_GEMM_SPLIT128 : (KG > 1 ? AFM_PROF_GEMM_SPLIT64_KG : AFM_PROF_GEMM_SPLIT64), 2.0 * a.M * a.N * a.K, s);
+    hipLaunchKernelGGL((gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG>), dim3(nbm * nbn), dim3(256 * KG), LDS_BYTES, s, a, nbm, nbn);
     AFM_CHECK_LAUNCH();
     return 0;
 }
 
 template <int NPROD>
 int dispatch_split(const afm_linear_args& a, hipStream_t s) {
-    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 0 = heuristic
+    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 7 = 64x64 split-K, 0 = heuristic
+    // Small launches (every 64x64 tile resident at once, at most two per CU): the launch is bound by the serial K chain of one MFMA
+    // tile, so the K segments of a tile go to separate 256-thread groups of one workgroup (bit-identical, see the kernel's header).
+    // Measured (profiles/r02_kernel_sweep_splitk.txt, us, sequential -> split): M = 1304: out_proj 20.0 -> 16.6, ffn2 (K = 1024, four groups)
+    // 32.7 -> 24.9, in_proj 30.4 -> 27.7; M = 326: 18.9 -> 15.4, 30.8 -> 22.4; M = 2608: out_proj (328 tiles) 26.0 -> 23.9 but ffn2 45.0 -> 47.5
+    // (four groups = 147 KB of LDS = one workgroup per CU, 328 tiles are 1.3 rounds) -> two groups up to 512 tiles, three / four up to 256.
+    {
+        const int64_t tiles64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        const int nseg = a.K / KSEG;
+        const bool splittable = (a.K % KSEG) == 0 && nseg >= 2 && nseg <= 4;
+        if (splittable && (tile == 7 || (tile == 0 && tiles64 <= (nseg == 2 ? 512 : 256)))) {
+            if (nseg == 2) return launch_split<64, 64, 16, NPROD, 2>(a, s);
+            if (nseg == 3) return launch_split<64, 64, 16, NPROD, 3>(a, s);
+            return launch_split<64, 64, 16, NPROD, 4>(a, s);
+        }
+        if (tile == 7) return AFM_E_UNSUPPORTED;
+    }
     // 128x128 amortises the split best (each thread splits 16 floats per 36 MFMAs of its wave) but holds 2 workgroups per CU = 512
     // resident tiles, so it only pays when its last resident round is nearly full; otherwise 64x64 tiles fill the chip better.
     // Measured (profiles/r02_kernel_sweep.txt, x9, us): N=1536 M=10432 (984 tiles, 96 % full) 161 vs 174 for 64x64; M=5216 (492, 96 %) 80 vs 86;

@@ -79,14 +79,16 @@ def test_linear_split_dispatch_is_independent_of_m():
 
 @pytest.mark.parametrize("M,N,K", [(1304, 512, 512), (1304, 512, 1024), (784, 263, 512), (2608, 512, 512), (10432, 512, 512), (97, 96, 64)])
 def test_linear_tile_shapes_are_bit_identical(M, N, K):
-    """Strong scaling runs B = 4 per GPU (M = 1304 rows): afm_linear then picks 32x32 / 32x64 workgroup tiles so the launch still fills
-    256 CUs.  Every tile shape of one arithmetic sums an output element in the same order, so the choice (which depends on M) must not
+    """Strong scaling runs B = 4 per GPU (M = 1304 rows): afm_linear then picks other workgroup shapes than at B = 32 (native kernel: 32x32 /
+    32x64 tiles; bf16-split kernel: 64x64 tiles whose 256-deep K segments run on separate wave groups of one workgroup).  Every shape of one
+    arithmetic adds the same numbers in the same order (K segments summed left to right), so the choice (which depends on M) must not
     change a single bit - the sharding / sub-batch invariance of the loop rests on it."""
     x = synth.gaussian("tile_x", (M, K)).to(dev()); w = (synth.gaussian("tile_w", (N, K)) / math.sqrt(K)).to(dev())
     b = synth.gaussian("tile_b", (N,)).to(dev()); res = synth.gaussian("tile_r", (M, N)).to(dev())
     saved, saved_tune = ops.get_gemm_split(), ops.set_gemm_tune(0)
     try:
-        for products, tiles in ((0, (0, 1, 2, 3, 4, 5)), (9, (0, 3, 5)), (6, (0, 3, 5))):
+        kg = (7,) if K % 256 == 0 and 2 <= K // 256 <= 4 else ()       # split-K form: the K segments of a tile on separate wave groups
+        for products, tiles in ((0, (0, 1, 2, 3, 4, 5)), (9, (0, 3, 5) + kg), (6, (0, 3, 5) + kg)):
             ops.set_gemm_split(products, 0)
             outs = []
             for tile in tiles:
