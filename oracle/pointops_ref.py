@@ -16,6 +16,18 @@ call sites (models/scene_models/pointops.py:10-45):
 Rules we add (and the HIP kernels implement bit-exactly):
   d2 = (dx*dx + dy*dy) + dz*dz evaluated in float32 WITHOUT fma contraction;
   FPS ties -> lowest index; kNN order -> lexicographic (d2, index).
+
+Why the tie rule cannot change a result.  Upstream's FPS kernel is the usual PointNet++ one: every thread scans a
+strided subset of the points and a shared-memory tree keeps `v2 > v1 ? i2 : i1`, so among EXACTLY equal running
+distances it prefers the lowest THREAD (point 1024, owned by thread 0, would beat point 1, owned by thread 1, once
+n > the block size) while this restatement prefers the lowest INDEX.  An exact tie of `tmp` between two points needs
+them to be at identical distances from every point sampled so far; with float32 coordinates of a real (or the synthetic,
+tie-free) scan that happens only for DUPLICATED points - identical xyz (prepare/generate_contact_data.py:418-423 can emit
+them).  Duplicates carry identical coordinates and, being the same scene point, identical features, so whichever of
+them is picked, the sampled coordinate, the gathered features and everything computed from them are identical; only the
+integer index stored in `idx` may differ, and nothing downstream of TransitionDown reads it as anything but a gather
+address (pointtransformer.py:61-68).  Same argument for kNN: equal-distance neighbours are duplicates of each other.
+tests/test_gpu_points.py::test_fps_ties_pick_lowest_index pins OUR rule on duplicated points.
 """
 from __future__ import annotations
 
