@@ -18,7 +18,7 @@ from . import autograd as AG
 from . import ffi, ops
 from .base import Model
 from ._cache import HeldKey
-from .cmdm import TimestepEmbedder, _param_version
+from .cmdm import TimestepEmbedder, _FlatParamsMixin, _param_version
 from .text import TextEncoderMixin, lang_feat_dim_type
 
 
@@ -225,7 +225,7 @@ def _dist_rank() -> int:
 
 
 @Model.register()
-class CDM(TextEncoderMixin, nn.Module):
+class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
     def __init__(self, cfg, *args, **kwargs):
         super().__init__()
         self.device = kwargs["device"] if "device" in kwargs else "cpu"

@@ -80,7 +80,40 @@ COND_SWITCHES = ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase")
 
 
 def _param_version(module: nn.Module) -> int:
-    return sum(p._version for p in module.parameters()) + sum(b._version for b in module.buffers())
+    """Changes whenever a parameter / buffer of `module` is written in place (optimiser step, load_state_dict, synth.fill_module_) - the key of
+    the weight packs and of the step-invariant caches.  The tensors are collected ONCE (the recursive `parameters()` walk costs 0.5 ms on the
+    282 tensors of the CMDM and ran three times per sampling call: most of a short loop's fixed cost); `_FlatParamsMixin` drops the list when
+    the tensors themselves can have been replaced (`.to()` / `.cuda()` / `load_state_dict`)."""
+    flat = module.__dict__.get("_afm_flat")
+    if flat is None:
+        flat = list(module.parameters()) + list(module.buffers())
+        module.__dict__["_afm_flat"] = flat
+    v = len(flat)
+    for t in flat:
+        v += t._version
+    return v
+
+
+class _FlatParamsMixin:
+    """Invalidates the cached tensor lists of `_param_version` (on this module and every submodule) when tensors may be replaced."""
+
+    def _drop_flat_params(self):
+        for m in self.modules():
+            m.__dict__.pop("_afm_flat", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_flat_params()
+        if "_pack" in self.__dict__:
+            self._pack = None                       # device pointers of the C-ABI weight pack are stale after .to() / .cuda()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._drop_flat_params()
+        if "_pack" in self.__dict__:
+            self._pack = None
+        return out
 
 
 def _dist_rank() -> int:
@@ -89,7 +122,7 @@ def _dist_rank() -> int:
 
 
 @Model.register()
-class CMDM(TextEncoderMixin, nn.Module):
+class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
     """`Model.get('CMDM')(cfg.model, device=...)` - see module docstring."""
 
     def __init__(self, cfg, *args, **kwargs):

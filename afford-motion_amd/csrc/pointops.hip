@@ -266,8 +266,7 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
         }                                                                                                                           \
         hipLaunchKernelGGL((fps_kernel<P, MT>), dim3(B), dim3(T), in_lds ? lds : 0, s, xyz, n, m, idx_out, in_lds);                  \
     } while (0)
-    if (T <= 128 && ppt > 32 && ppt <= 64) AFM_FPS(64, 128);
-    else if (T <= 512 && ppt > 16 && ppt <= 32) AFM_FPS(32, 512);
+    if (T <= 512 && ppt > 16 && ppt <= 32) AFM_FPS(32, 512);
     else if (ppt <= 1) AFM_FPS(1, 1024);
     else if (ppt <= 2) AFM_FPS(2, 1024);
     else if (ppt <= 4) AFM_FPS(4, 1024);

@@ -177,6 +177,7 @@ def main():
         return {k: v[i0:i0 + cnt].contiguous().to(dev) for k, v in full.items()}
 
     i0, B, total = shard(args.scaling)
+    assert B >= 1, f"--batch {args.batch} leaves rank {rank} of {world} without a sample"
     kw = batch_kwargs(total, i0, B)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
