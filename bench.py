@@ -58,11 +58,22 @@ def pmc_traffic(kernel: str):
             tr = json.load(f)
     except (OSError, ValueError):
         return None
-    want = kernel.replace(" ", "").rstrip(">")
-    for name, v in tr.get("kernels", {}).items():        # rocprof names carry every template argument: match on the prefix
-        if name.replace(" ", "").startswith(want):
-            return dict(v, kernel=name, source=tr.get("source"))
-    return None
+    want = kernel.replace(" ", "").replace(",split-K", "").rstrip(">")
+    split_k = "split-K" in kernel
+    # rocprof names carry every template argument: match on the prefix; the bf16-split kernel's last argument is the number of K groups per
+    # workgroup (1 = the large-launch form, > 1 = the split-K small-launch form) - keep the two apart, then take the most launched
+    cands = []
+    for name, v in tr.get("kernels", {}).items():
+        n = name.replace(" ", "")
+        if not n.startswith(want):
+            continue
+        if "split_bf16" in n and (n.endswith(",1>") == split_k):
+            continue
+        cands.append((v.get("launches", 0), name, v))
+    if not cands:
+        return None
+    _, name, v = max(cands, key=lambda c: c[0])
+    return dict(v, kernel=name, source=tr.get("source"))
 
 
 def build(dev, steps_cfg: str):
