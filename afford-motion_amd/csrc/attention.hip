@@ -22,6 +22,19 @@
 
 namespace {
 
+#ifdef AFM_TIMELINE          // tools/mha_timeline.hip only: per-workgroup phase cycle totals of wave 0; never compiled into the library
+struct AfmMhaRec { unsigned long long t0, t1, c0, c1, s_c, soft_c, pv_c, sync_c; unsigned hw_id, xcc_id; };
+__device__ AfmMhaRec* afm_mha_timeline = nullptr;
+__device__ __forceinline__ unsigned long long afm_cyc() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define TL(...) __VA_ARGS__
+#else
+#define TL(...)
+#endif
+
 constexpr int DH = 64;
 constexpr int KB = 32;           // keys per block
 constexpr int LDKK = 68;         // padded K row (floats)
@@ -39,6 +52,8 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
     // Tq queries (rows of qp_, stride ldq) attend over T keys / values (rows of kp_ / vp_, stride ldkv): self-attention passes the
     // packed in_proj output three times (q | k | v, ld = 3D, Tq == T), cross-attention a [B,Tq,D] query and a packed [B,T,2D] memory.
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    TL(const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(); const unsigned long long tl_c0 = afm_cyc();
+       unsigned long long tl_s = 0, tl_soft = 0, tl_pv = 0, tl_sync = 0;)
     float* Ks = smem;                               // [2][KB][LDKK]
     float* Vs = smem + 2 * KB * LDKK;               // [2][KB][DH]
     float* madd = Vs + 2 * KB * DH;                 // [nkb*KB] additive mask (0 / -inf)
@@ -123,6 +138,7 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
 
         for (int kb = 0; kb < nkb; ++kb) {
             const int buf = kb & 1;
+            TL(const unsigned long long tl_a = afm_cyc();)
             if (kb + 1 < nkb) load_block(kb + 1);
             if (active && blk_valid[kb]) {
                 // ---- S^T = K Q^T  (32 MFMA steps over the 64 head dims)
@@ -139,6 +155,7 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
                     s = mfma32(kv.w, q[4 * i + 3], s);
                 }
                 // ---- mask + online softmax; reg r <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
+                TL(asm volatile("" : "+v"(s)); const unsigned long long tl_b = afm_cyc(); tl_s += tl_b - tl_a;)
                 float mx = NEG_INF;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] *= dk(row_ix, col0 + (r & 3) + 8 * (r >> 2));
                 }
+                TL(asm volatile("" : "+v"(s)); const unsigned long long tl_c = afm_cyc(); tl_soft += tl_c - tl_b;)
                 const float* vp = Vs + buf * KB * DH + r32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -176,9 +194,12 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
                     o0 = mfma32(v0, s[r], o0);
                     o1 = mfma32(v1, s[r], o1);
                 }
+                TL(asm volatile("" : "+v"(o0), "+v"(o1)); const unsigned long long tl_d = afm_cyc(); tl_pv += tl_d - tl_c;)
             }
+            TL(const unsigned long long tl_e = afm_cyc();)
             if (kb + 1 < nkb) store_block(buf ^ 1);
             __syncthreads();
+            TL(tl_sync += afm_cyc() - tl_e;)
         }
 
         if (active) {
@@ -197,6 +218,12 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
             }
         }
     }
+    TL(if (afm_mha_timeline && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        afm_mha_timeline[blockIdx.x] = AfmMhaRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), tl_c0, afm_cyc(), tl_s, tl_soft, tl_pv, tl_sync, hw, xcc};
+    })
 }
 
 // group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 8 / 12; 0 = choose from the launch size; < 0 = one workgroup per
