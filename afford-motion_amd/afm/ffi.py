@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libafm_hip
 _lib = None
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
-ARITH_DEFAULT, ARITH_F32, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
+ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE = 0x1
 ABI_VERSION = 3

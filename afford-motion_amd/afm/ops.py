@@ -70,7 +70,7 @@ def _initial_split():
     import os
     p = os.environ.get("AFM_GEMM_SPLIT")
     products = int(p) if p is not None else 9
-    if products not in (0, 6, 9):
+    if products not in (0, 1, 6, 9):
         products = 0
     n = os.environ.get("AFM_GEMM_SPLIT_MIN_N")
     return products, max(0, int(n)) if n is not None else 0
@@ -85,15 +85,15 @@ def gemm_arith() -> Tuple[int, int]:
     products, min_n = _gemm_split
     if products == 0:
         return ffi.ARITH_F32, 0
-    return (ffi.ARITH_BF16X9 if products == 9 else ffi.ARITH_BF16X6), min_n
+    return {9: ffi.ARITH_BF16X9, 6: ffi.ARITH_BF16X6, 1: ffi.ARITH_BF16X1}[products], min_n
 
 
 def set_gemm_split(products: int, min_n: Optional[int] = None):
     """Arithmetic of `linear`'s GEMMs: 9 = exact three-way bf16 operand split on the bf16 matrix pipe with all nine cross products
     (default, every eligible GEMM: K >= 128, K % 16 == 0, aligned), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N threshold.
     Returns the previous setting in the same form (products, or (products, min_n) when ``min_n`` was given)."""
-    if int(products) not in (0, 6, 9):
-        raise ffi.AfmError(f"set_gemm_split: products must be 0, 6 or 9 (got {products})")
+    if int(products) not in (0, 1, 6, 9):
+        raise ffi.AfmError(f"set_gemm_split: products must be 0, 6 or 9 (or 1: plain bf16, informational only) (got {products})")
     if min_n is not None and int(min_n) < 0:
         raise ffi.AfmError(f"set_gemm_split: min_n must be >= 0 (got {min_n})")
     prev = tuple(_gemm_split)

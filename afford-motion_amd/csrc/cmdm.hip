@@ -188,8 +188,8 @@ int validate(const afm_cmdm_weights* w, int B, int L) {
     if (w->d <= 0 || (w->d & 3) || w->heads <= 0 || w->d % w->heads || w->ff <= 0 || (w->ff & 3)) return AFM_E_BADARG;
     if (w->n_layers <= 0 || w->n_layers > AFM_MAX_LAYERS || w->n_cond < 0 || w->motion_dim <= 0) return AFM_E_BADARG;
     if (w->d / w->heads != 64) return AFM_E_UNSUPPORTED;
-    if (w->gemm_arith != AFM_ARITH_DEFAULT && w->gemm_arith != AFM_ARITH_F32 && w->gemm_arith != AFM_ARITH_BF16X6 && w->gemm_arith != AFM_ARITH_BF16X9)
-        return AFM_E_BADARG;
+    if (w->gemm_arith != AFM_ARITH_DEFAULT && w->gemm_arith != AFM_ARITH_F32 && w->gemm_arith != AFM_ARITH_BF16X6 && w->gemm_arith != AFM_ARITH_BF16X9 &&
+        w->gemm_arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
     if (w->gemm_arith_min_n < 0 || w->attn_group_waves < 0) return AFM_E_BADARG;
     if (!w->motion_adapter_w || !w->motion_layer_w || !w->time_table || !w->pos_table) return AFM_E_BADARG;
     return 0;

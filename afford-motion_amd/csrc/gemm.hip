@@ -403,7 +403,8 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
-    if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9) return AFM_E_BADARG;
+    if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9 &&
+        a.arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
     if (a.arith_min_n < 0) return AFM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&

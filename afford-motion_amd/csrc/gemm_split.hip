@@ -15,8 +15,8 @@
 // Kernel: 256 threads = 2x2 waves, wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, K consumed BK at a time.
 //   global f32 -> registers (next K-tile, issued before the MFMAs of the current one) -> split in VALU, interleaved with
 //   the MFMA stream -> three bf16 planes in LDS ([row][BK] bf16, rows padded to 48 B: the 16 rows of each ds_read_b128 lane group
-//   {0-3,12-15,20-27} / {4-11,16-19,28-31} hit 16 distinct 16-byte slots; stores go even rows / odd rows per 8-lane group, also
-//   conflict-free: SQ_LDS_BANK_CONFLICT = 0) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
+//   {0-3,12-15,20-27} / {4-11,16-19,28-31} hit 16 distinct 16-byte slots; the 8-byte stores of a 16-lane group cover four rows of
+//   equal parity, also conflict-free) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
 //   One barrier per K-tile (double-buffered LDS), shared epilogue of gemm.hip.
 #include <type_traits>
 #include "common.h"
@@ -26,7 +26,8 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // first-class 16-byte value (HIP's uint4 struct copies can pin arrays in scratch)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));     // first-class 16-byte value (HIP's uint4 struct copies can pin arrays in scratch)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -64,15 +65,15 @@ constexpr int KSEG = 256;
 
 template <int BM, int BN, int BKS, int NPROD, int KG = 1>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
+    static_assert(BKS == 16, "one K16 MFMA step per K-tile");
     constexpr int TM = BM / 64, TN = BN / 64;
     static_assert(KG == 1 || (BM == 64 && BN == 64), "the split-K form exists for 64x64 tiles");
-    constexpr int CPR = BKS / 8;                      // 8-float chunks per row of a K-tile
     constexpr int ROWB = BKS * 2 + 16;                // LDS row bytes (bf16 + pad)
     constexpr int ROWS = BM + BN;                     // A rows then W rows
     constexpr int PLANE = ROWS * ROWB;
     constexpr int STAGE = 3 * PLANE;
-    constexpr int NI = ROWS * CPR / 256;              // (row, chunk) items per thread
-    static_assert(ROWS * CPR % 256 == 0, "tile does not divide over 256 threads");
+    constexpr int NA = BM / 64, NW = BN / 64;         // (row, 4 consecutive k) items of A / of W per thread and K-tile
+    constexpr int NI = NA + NW;
     constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // K segment of this 256-thread group
@@ -92,19 +93,20 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
 
+    // Staging items are (row, quarter) = 4 floats: the four lanes of a row fetch its 64 contiguous bytes of the K-tile with ONE
+    // load instruction (16 cache lines per wave-instruction; an 8-float item needs two instructions of 32 lines each:
+    // TCP_TOTAL_CACHE_ACCESSES 11.7 M -> 6.0 M per out_proj launch, 2-3 % faster), and every thread carries the same mix of A and W
+    // work.  16 consecutive lanes (the unit ds_write_b64 is serviced in) take the four quarters of four rows of equal parity inside a
+    // block of 8 rows: with rows 48 B apart those are four disjoint 32-byte windows of the 128-byte bank row.
     const RowMap amap{p.a_grp, p.a_stride, p.a_off};
     const float* src[NI];
     int dst[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        // item -> (row, chunk): inside every block of 8 rows, an 8-lane group (the unit ds_write_b128 is serviced in) takes the four
-        // even rows and the next group the four odd rows, so its eight 16-byte stores fall on eight different slots of the 128-byte
-        // bank window (with row stride 48 B, rows r and r + 3 would meet); lanes 2k, 2k+1 still read one row's 64 contiguous bytes
-        const int it = tid + 256 * i, blk = it >> 4, j = it & 15;
-        const int row = CPR == 2 ? blk * 8 + 2 * ((j & 7) >> 1) + (j >> 3) : it / CPR, ch = CPR == 2 ? (j & 1) : it % CPR;
-        src[i] = (row < BM ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
-                           : p.W + (int64_t)min(bn * BN + row - BM, p.N - 1) * p.ldw) + ch * 8 + grp * KSEG;
-        dst[i] = row * ROWB + ch * 16;
+        const int it = tid + 256 * (i < NA ? i : i - NA), q = it & 3, v = it >> 2, row = (v & ~7) + ((v & 3) << 1) + ((v >> 2) & 1);
+        src[i] = (i < NA ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
+                         : p.W + (int64_t)min(bn * BN + row, p.N - 1) * p.ldw) + q * 4 + grp * KSEG;
+        dst[i] = ((i < NA ? 0 : BM) + row) * ROWB + q * 8;
     }
 
     f32x16 acc[TM][TN];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     // Two register sets, always indexed with compile-time constants: at the top of K-tile kt the set (kt & 1) is free (its
     // tile went to LDS during kt - 1) and receives tile kt + 2; the other set holds tile kt + 1 (loaded one full K-tile
     // ago) and is split into the other LDS stage between the MFMAs of tile kt.
-    float4 g[2][NI][2];
+    f32x4 g[2][NI];
     const int nk = KG > 1 ? KSEG / BKS : p.K / BKS;
     constexpr int SEGT = KSEG / BKS;                  // K-tiles per segment
     f32x16 tot[TM][TN];                               // sum of the finished segments (KG == 1 with K > KSEG only)
@@ -127,10 +129,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         constexpr int S = decltype(SETC)::value;
         const int k = min(kt, nk - 1) * BKS;          // past the end: re-load the last tile (never consumed)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            g[S][i][0] = *reinterpret_cast<const float4*>(src[i] + k);
-            g[S][i][1] = *reinterpret_cast<const float4*>(src[i] + k + 4);
-        }
+        for (int i = 0; i < NI; ++i) g[S][i] = *reinterpret_cast<const f32x4*>(src[i] + k);
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
@@ -138,22 +137,20 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     load(Set1{}, 1);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        uint4 q1, q2, q3;
-        split2(g[0][i][0].x, g[0][i][0].y, q1.x, q2.x, q3.x);
-        split2(g[0][i][0].z, g[0][i][0].w, q1.y, q2.y, q3.y);
-        split2(g[0][i][1].x, g[0][i][1].y, q1.z, q2.z, q3.z);
-        split2(g[0][i][1].z, g[0][i][1].w, q1.w, q2.w, q3.w);
+        uint32_t a1, a2, a3, b1, b2, b3;
+        split2(g[0][i][0], g[0][i][1], a1, a2, a3);
+        split2(g[0][i][2], g[0][i][3], b1, b2, b3);
         unsigned char* d = lds + dst[i];
-        *reinterpret_cast<uint4*>(d) = q1;
-        *reinterpret_cast<uint4*>(d + PLANE) = q2;
-        *reinterpret_cast<uint4*>(d + 2 * PLANE) = q3;
+        *reinterpret_cast<u32x2*>(d) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{a2, b2};
+        *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{a3, b3};
     }
     __syncthreads();
 
     const int a_off = (wm * (BM / 2) + r32) * ROWB + hh * 16;
     const int w_off = (BM + wn * (BN / 2) + r32) * ROWB + hh * 16;
-    constexpr int NMFMA = (BKS / 16) * NPROD * TM * TN;      // MFMAs per wave per K-tile
-    constexpr int NPIECE = NI * 4 * 3;                        // split pieces per thread per K-tile (pair of floats x residual level)
+    constexpr int NMFMA = NPROD * TM * TN;                    // MFMAs per wave per K-tile
+    constexpr int NPIECE = NI * 2 * 3;                        // split pieces per thread per K-tile (pair of floats x residual level)
 
     // One K-tile.  The instruction order is written out and pinned with sched_barrier fences (hipcc otherwise hoists all
     // MFMAs in front of the split and chains the nine MFMAs of one accumulator back to back): after every MFMA a piece of
@@ -163,54 +160,49 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         load(CURC, kt + 2);
         const unsigned char* base = lds + cur * STAGE;
         unsigned char* wbase = lds + (cur ^ 1) * STAGE;
-        float r0[NI * 4], r1[NI * 4];
-        uint32_t sp[NI * 4][3];
+        float r0[NI * 2], r1[NI * 2];
+        uint32_t sp[NI * 2][3];
         int piece = 0, m = 0;
         auto do_piece = [&](int t) {
-            const int u = t / 3, lvl = t % 3, i = u / 4, c = u % 4;
+            const int u = t / 3, lvl = t % 3, i = u / 2, c = u % 2;
             if (lvl == 0) {
-                const float4 v = g[cur ^ 1][i][c >> 1];
-                r0[u] = (c & 1) ? v.z : v.x;
-                r1[u] = (c & 1) ? v.w : v.y;
+                r0[u] = g[cur ^ 1][i][2 * c];
+                r1[u] = g[cur ^ 1][i][2 * c + 1];
             }
             const uint32_t pk = cvt_pk_bf16(r0[u], r1[u]);
             sp[u][lvl] = pk;
             if (lvl < 2) {
                 r0[u] -= __uint_as_float(pk << 16);
                 r1[u] -= __uint_as_float(pk & 0xffff0000u);
-            } else if (c == 3) {
+            } else if (c == 1) {
                 unsigned char* d = wbase + dst[i];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    *reinterpret_cast<uint4*>(d + pl * PLANE) = make_uint4(sp[4 * i][pl], sp[4 * i + 1][pl], sp[4 * i + 2][pl], sp[4 * i + 3][pl]);
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * PLANE) = u32x2{sp[2 * i][pl], sp[2 * i + 1][pl]};
             }
         };
+        uint4 af[TM][3], bf[TN][3];
 #pragma unroll
-        for (int s = 0; s < BKS / 16; ++s) {
-            uint4 af[TM][3], bf[TN][3];
+        for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int i = 0; i < TM; ++i) af[i][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + a_off + i * 32 * ROWB);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + a_off + i * 32 * ROWB + s * 32);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + w_off + j * 32 * ROWB + s * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 9 - NPROD; q < 9; ++q)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        acc[tm][tn] = mfma_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn]);
-                        ++m;
-#pragma unroll
-                        for (int t = 0; t < NPIECE; ++t)
-                            if (t >= piece && t < (m * NPIECE) / NMFMA) do_piece(t);
-                        piece = (m * NPIECE) / NMFMA;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+            for (int j = 0; j < TN; ++j) bf[j][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + w_off + j * 32 * ROWB);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 9 - NPROD; q < 9; ++q)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = mfma_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn]);
+                    ++m;
+#pragma unroll
+                    for (int t = 0; t < NPIECE; ++t)
+                        if (t >= piece && t < (m * NPIECE) / NMFMA) do_piece(t);
+                    piece = (m * NPIECE) / NMFMA;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         if (KG == 1 && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {        // segment finished, more to come: bank it, restart from zero
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -337,6 +329,7 @@ int afm_linear_split_mode(const afm_linear_args& a) {
         case AFM_ARITH_DEFAULT: mode = 9; min_n = 0; break;
         case AFM_ARITH_BF16X9: mode = 9; min_n = a.arith_min_n; break;
         case AFM_ARITH_BF16X6: mode = 6; min_n = a.arith_min_n; break;
+        case AFM_ARITH_BF16X1: mode = 1; min_n = a.arith_min_n; break;
         default: return 0;
     }
     const bool ok = (a.K % 16 == 0) && a.K >= 128 && a.N >= min_n && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
@@ -345,5 +338,6 @@ int afm_linear_split_mode(const afm_linear_args& a) {
 }
 
 int afm_linear_split(const afm_linear_args& a, int mode, hipStream_t s) {
+    if (mode == 1) return dispatch_split<1>(a, s);        // informational: plain bf16 x bf16 (top terms only), NOT f32 arithmetic
     return mode == 9 ? dispatch_split<9>(a, s) : dispatch_split<6>(a, s);
 }

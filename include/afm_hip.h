@@ -94,6 +94,9 @@ typedef struct {
      *                      with f32 accumulation: the same exact products as the f32 MFMA in a different summation order
      *                      (measured error vs float64 <= the native kernel's, tools/kernel_sweep.cpp);
      *   AFM_ARITH_BF16X6   as X9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3).
+     *   AFM_ARITH_BF16X1   INFORMATIONAL, not f32 arithmetic: only the product of the two leading bf16 terms (what a plain bf16 x bf16 GEMM with f32
+     *                      accumulation computes; relative error ~2^-9 per product).  Exists to MEASURE what bf16 would cost in accuracy
+     *                      (tests/test_gpu_cmdm.py::test_bf16_one_product_drift...); never selected by the library.
      * The kernel choice is a function of (arith, arith_min_n, N, K, alignment) - never of M - and every tile shape of one
      * arithmetic sums a given output element in the same order, so a batch and its shards compute identical bits. */
     int32_t arith; int32_t arith_min_n;
@@ -103,6 +106,7 @@ typedef struct {
 
 #define AFM_ARITH_DEFAULT 0
 #define AFM_ARITH_F32     1
+#define AFM_ARITH_BF16X1  3
 #define AFM_ARITH_BF16X6  6
 #define AFM_ARITH_BF16X9  9
 

@@ -364,6 +364,38 @@ def test_1000_step_drift_vs_oracle():
     report("100-step prefix vs oracle (valid frames)", snaps[100].cpu()[valid], want[100][valid], 1e-3)
 
 
+def test_bf16_one_product_drift_is_measured_and_fails_the_f32_bar():
+    """VERDICT r1 #9 (informational): AFM_ARITH_BF16X1 keeps only the product of the leading bf16 terms - what a plain bf16 GEMM with
+    f32 accumulation computes.  Same 1000-step chain, same noise, against the default exact-split arithmetic (itself ~4e-6 from the
+    oracle, test above): the drift after 10 / 100 / 1000 steps is printed, and it must EXCEED the 1e-3 parity tolerance - the reason the
+    library never selects it."""
+    from afm import ops
+    cfg = cmdm_cfg(num_points=8192, steps=1000)
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    B, L = 2, 196
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("d1k_cont", (B, 128, 256)).to(dev()),
+              x_mask=synth.frame_mask(B, L, seed=12).to(dev()))
+    saved = ops.get_gemm_split()
+    chains = {}
+    try:
+        for products in (9, 1):
+            ops.set_gemm_split(products, 0)
+            snaps = {10: None, 100: None}
+            snaps[1000] = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=5, snapshots=snaps)
+            chains[products] = snaps
+    finally:
+        ops.set_gemm_split(*saved)
+    valid = ~kw["x_mask"]
+    drift = {k: (chains[1][k] - chains[9][k])[valid].abs().max().item() for k in (10, 100, 1000)}
+    for k, d in drift.items():
+        print(f"[bf16x1] after {k:4d} executed steps: max|bf16 one-product - default| = {d:.3e} "
+              f"(max|x| = {chains[9][k][valid].abs().max().item():.2f})")
+    assert all(torch.isfinite(chains[1][k]).all() for k in chains[1])
+    assert drift[1000] > 1e-3, "a plain-bf16 GEMM inside the f32 tolerance would be worth shipping; it is not"
+
+
 def test_small_batch_loop_is_bit_identical_to_the_large_batch():
     """Strong scaling gives each GPU 4 (or 1) of the job's samples: the GEMM tile shapes and attention groupings chosen for the small
     launch differ from the B = 32 launch's, the bits must not (T = 326, full-size layers, Philox noise keyed by global sample)."""

@@ -29,6 +29,28 @@ def test_linear_shapes(M, N, K):
     report(f"linear {M}x{N}x{K}", got, want, 2e-4)
 
 
+def test_linear_bf16_one_product_is_bf16_accurate_only():
+    """AFM_ARITH_BF16X1 (informational): the leading-term product alone carries bf16's 2^-9 relative rounding per operand - three orders
+    of magnitude above the f32 kernels' error, and identical across tile shapes like every other arithmetic."""
+    M, N, K = 5216, 512, 512
+    x = synth.gaussian("b1_x", (M, K)); w = synth.gaussian("b1_w", (N, K)) / math.sqrt(K)
+    ref = F.linear(x.double(), w.double())
+    scale = x.double().abs() @ w.double().abs().t() + 1e-30
+    saved, prev = ops.get_gemm_split(), 0
+    try:
+        ops.set_gemm_split(1, 0)
+        got = ops.linear(x.to(dev()), w.to(dev()), None)
+        prev = ops.set_gemm_tune(7 << ffi.TUNE_TILE_SHIFT)
+        got_k = ops.linear(x.to(dev()), w.to(dev()), None)
+    finally:
+        ops.set_gemm_tune(prev)
+        ops.set_gemm_split(*saved)
+    err = ((got.double().cpu() - ref).abs() / scale).max().item()
+    print(f"bf16 one-product {M}x{N}x{K}: max err / sum|a||w| = {err:.2e}")
+    assert 1e-5 < err < 1e-2
+    assert torch.equal(got, got_k)
+
+
 @pytest.mark.parametrize("products", [9, 6])
 @pytest.mark.parametrize("M,N,K", [(10432, 512, 1024), (9000, 1500, 256), (1000, 1536, 512), (5216, 512, 512), (777, 263, 512), (640, 96, 144)])
 def test_linear_split_bf16_mode(products, M, N, K):
