@@ -130,6 +130,31 @@ static void mha_sweep(const std::vector<int>& batches) {
     }
 }
 
+// one x9 GEMM launched `reps` times (profiling target for rocprofv3 --pmc): kernel_sweep one M N K tile flags reps
+static int one_gemm(int argc, char** argv) {
+    if (argc < 8) { fprintf(stderr, "usage: kernel_sweep one M N K tile flags reps\n"); return 1; }
+    const int M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]), tile = atoi(argv[5]), flags = atoi(argv[6]), reps = atoi(argv[7]);
+    std::mt19937 rng(3);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> A((size_t)M * K), W((size_t)N * K);
+    for (auto& v : A) v = nd(rng);
+    for (auto& v : W) v = nd(rng) * 0.05f;
+    float *dA, *dW, *dC;
+    CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+    CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+    afm_linear_args a;
+    memset(&a, 0, sizeof a);
+    a.A = dA; a.lda = K; a.W = dW; a.ldw = K; a.C = dC; a.ldc = N; a.M = M; a.N = N; a.K = K; a.arith = AFM_ARITH_BF16X9;
+    a.tune = (tile << AFM_TUNE_TILE_SHIFT) | flags;
+    for (int i = 0; i < reps; ++i)
+        if (int rc = afm_linear(&a, st)) { fprintf(stderr, "rc=%d\n", rc); return 3; }
+    CK(hipStreamSynchronize(st));
+    const double us = time_us([&] { afm_linear(&a, st); });
+    printf("M=%d N=%d K=%d tile=%d flags=%d: %.1f us %.1f TF\n", M, N, K, tile, flags, us, 2.0 * M * N * K / (us * 1e-6) / 1e12);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string what = argc > 1 ? argv[1] : "all";
     std::vector<int> batches = {32, 16, 8, 4, 1};
@@ -141,6 +166,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    if (what == "one") return one_gemm(argc, argv);
     if (what == "gemm" || what == "all") gemm_sweep(batches);
     if (what == "mha" || what == "all") mha_sweep(batches);
     return 0;
