@@ -289,10 +289,11 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             self.afm_native_loop = None         # other archs sample step by step
         self.sub_batches = int(os.environ.get("AFM_CDM_SUBBATCH", "1"))     # >1 costs more host time per step than it hides (measured)
         self._streams = []
+        self.no_fold = bool(os.environ.get("AFM_CDM_NO_FOLD"))      # measurement knob: the layer-by-layer sampling form
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
-        ver = _param_version(self)
+        ver = (_param_version(self), self.training, self.no_fold)
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
@@ -341,6 +342,21 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         q0, u, cu = self._latent_tokens(w, 1, table)
         keep += [table, q0, u, cu]
         w.time_q0, w.time_u, w.time_cu = q0.data_ptr(), u.data_ptr(), cu.data_ptr()
+        if not self.training and not self.no_fold and self.contact_dim <= 8 and cm.feat_dim > self.contact_dim and cm.dkv % 64 == 0:
+            # eval: weight products of the folded sampling form (afm_cdm_weights.fold_*; float64 products, rounded once).  Only the
+            # contact columns of the encoder input change between steps, and encoder_adapter -> decoder_adapter as well as
+            # linear2 (+ residual) -> contact_layer are linear chains (cdm.py:176-186,509-510).
+            cd = self.contact_dim
+            we, wd = cm.encoder_adapter.weight.detach().double(), cm.decoder_adapter.weight.detach().double()
+            fc2, cl = cm.decoder_cross_attn[1].module[3], self.contact_layer
+            wc = cl.weight.detach().double()
+            xu = we[:, :cd].t().contiguous()                                       # [cd, dkv]
+            xv = (wd @ we[:, :cd]).t().contiguous()                                # [cd, dkv]
+            bo = cm.decoder_cross_attn[0].module.attention.o_proj.bias.detach().double()
+            folds = dict(fold_xu=xu, fold_xv=xv, fold_w2=wc @ fc2.weight.detach().double(), fold_q=wc @ xv.t(),
+                         fold_c0=wc @ (fc2.bias.detach().double() + bo) + cl.bias.detach().double())
+            for name, t in folds.items():
+                setattr(w, name, P(t.float().contiguous()))
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()

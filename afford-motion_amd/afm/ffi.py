@@ -20,7 +20,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE = 0x1
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LAYERS = 16
 
 c_f32p = C.c_void_p
@@ -46,6 +46,8 @@ class LinearArgs(C.Structure):
         ("drop_p", C.c_float), ("drop_seed", u64), ("drop_id", C.c_uint32), ("drop_after", i32),
         # arithmetic of the product + bit-neutral tuning (ABI v3: fields instead of a process-wide switch)
         ("arith", i32), ("arith_min_n", i32), ("tune", i32),
+        # fused row-dot epilogue (ABI v4)
+        ("rowdot_w", c_f32p), ("rowdot_out", c_f32p), ("rowdot_n", i32),
     ]
 
 
@@ -93,6 +95,8 @@ class CdmWeights(C.Structure):
         ("dec_q_norm", Ln), ("dec_kv_norm", Ln), ("dec_attn", MhaW), ("dec_mlp", MlpW),
         ("contact_layer", Lin),
         ("gemm_arith", i32), ("gemm_arith_min_n", i32),
+        # weight products of the folded sampling form (ABI v4; all five or none)
+        ("fold_xu", c_f32p), ("fold_xv", c_f32p), ("fold_w2", c_f32p), ("fold_q", c_f32p), ("fold_c0", c_f32p),
     ]
 
 

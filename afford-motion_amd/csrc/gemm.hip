@@ -399,7 +399,13 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     const afm_linear_args& a = *args;
     if (a.M == 0) return 0;                                   // empty batch: nothing to do (pointers may be null)
     if (!a.A || !a.W || a.M < 0 || a.N <= 0 || a.K <= 0) return AFM_E_BADARG;
-    if (!a.C && !a.ddpm_out) return AFM_E_BADARG;
+    if (!a.C && !a.ddpm_out && !a.rowdot_out) return AFM_E_BADARG;
+    if (a.rowdot_w || a.rowdot_out) {            // row-dot epilogue: the 16-byte-row form of the shared epilogue, plain forward inputs only
+        const uintptr_t ptrs = (uintptr_t)a.C | (uintptr_t)a.residual | (uintptr_t)a.bias | (uintptr_t)a.scale | (uintptr_t)a.rowdot_w;
+        if (!a.rowdot_w || !a.rowdot_out || a.rowdot_n <= 0 || a.rowdot_n > 8 || (a.N & 3) || (a.ldc & 3) || (a.ldr & 3) || (ptrs & 15) ||
+            a.ddpm_out || a.rowtab || a.preact || a.dact_z || a.drop_p > 0.0f)
+            return AFM_E_BADARG;
+    }
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
@@ -423,6 +429,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
         const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64), t3264 = (int64_t)((a.M + 31) / 32) * ((a.N + 63) / 64);
         tile = t64 >= 512 ? 3 : (t3264 >= 512 ? 2 : 1);
     }
+    if (a.rowdot_w && tile == 1) tile = 2;          // a row-dot group is 64 columns of ONE tile
     switch (tile) {
         case 1: return launch_dma<1, 1, 1, 1>(a, AFM_PROF_GEMM32_DMA, s);
         case 2: return launch_dma<1, 2, 1, 1>(a, AFM_PROF_GEMM32x64_DMA, s);

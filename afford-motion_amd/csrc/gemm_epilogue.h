@@ -38,7 +38,45 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
                            ((uintptr_t)p.preact) | ((uintptr_t)p.dact_z)) & 15) == 0;
     const bool drop = p.drop_p > 0.0f;
     const DropKey dk(drop ? p.drop_p : 0.0f, p.drop_seed, p.drop_id);
-    if (vec_out) {
+    if (vec_out && p.rowdot_w) {
+        // row-dot form: every 64-column group of a row is owned by 16 consecutive lanes (4 columns each); all lanes stay in the loop
+        // (out-of-range ones contribute zeros) so that the xor-butterfly below is a full-wave operation
+        static_assert((BM * (BN / 4)) % NT == 0, "row-dot epilogue: every lane makes the same number of trips");
+        const int ngrp = (p.N + 63) / 64;
+        // a thread's column quad is the same on every trip (NT is a multiple of BN / 4): its slices of the R vectors live in registers
+        float4 rw[8];
+        {
+            const int gc = col0 + (tid % (BN / 4)) * 4;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                rw[r] = (r < p.rowdot_n && gc < p.N) ? *reinterpret_cast<const float4*>(p.rowdot_w + (int64_t)r * p.N + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int e = tid; (BN / 4) % 16 == 0 && e < BM * (BN / 4); e += NT) {      // 32-column tiles are never dispatched with a row-dot
+            const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
+            const int grow = bm * BM + row, gcol = col0 + cq;
+            const bool valid = grow < p.M && gcol < p.N;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int64_t orow = 0;
+            if (valid) {
+                v = *reinterpret_cast<const float4*>(lds + row * LDC + cq);
+                orow = cmap(grow);
+                if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + gcol); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+                if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+                if (p.residual) { const float4 t = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                if (p.act_post) { v.x = apply_act(v.x, p.act_post); v.y = apply_act(v.y, p.act_post); v.z = apply_act(v.z, p.act_post); v.w = apply_act(v.w, p.act_post); }
+                if (p.C) *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < p.rowdot_n) {                       // wave-uniform
+                    float d = (v.x * rw[r].x + v.y * rw[r].y) + (v.z * rw[r].z + v.w * rw[r].w);      // v == 0 on out-of-range lanes
+                    d += lane_xor<1>(d); d += lane_xor<2>(d); d += lane_xor<4>(d); d += lane_xor<8>(d);      // DPP inside the row of 16 lanes
+                    if (valid && (cq & 63) == 0) p.rowdot_out[(orow * ngrp + gcol / 64) * p.rowdot_n + r] = d;
+                }
+            }
+        }
+    } else if (vec_out) {
         for (int e = tid; e < BM * (BN / 4); e += NT) {
             const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
             const int grow = bm * BM + row, gcol = col0 + cq;

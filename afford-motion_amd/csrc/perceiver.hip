@@ -25,6 +25,8 @@ namespace {
 constexpr int NSPLIT = 16;          // workgroups per sample in enc_reduce (x4 waves = 64 partials per sample)
 constexpr int NPART = NSPLIT * 4;
 constexpr int MAXD = 512;           // dq upper bound for the latent kernels' LDS vectors
+// per-sample record written by latent_post: G [njh][256] | P [njh][256] | cb [njh] | WP [8][njh] (contact_layer.w . P, folded form)
+#define DEC_LAT_STRIDE(njh) (2 * (njh) * 256 + (njh) + 8 * (njh))
 
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
@@ -123,12 +125,15 @@ __global__ __launch_bounds__(1024) void latent_token_kernel(const afm_cdm_weight
 
 // ---------------------------------------------------------------- enc_reduce
 // grid (NSPLIT, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NQ = 16 folded queries.
-template <int NQ>
+// FOLD (the step-invariant form, see cdm_forward_impl): `enc_kv` holds only the step-invariant part of the adapter output and the
+// row of point n is enc_kv[n] + sum_j xt[n, j] * xu[j] (cd <= 8 contact channels, xu [cd, 256] = columns of the adapter weight).
+template <int NQ, bool FOLD>
 __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
                                                          const float* __restrict__ cu_text, const float* __restrict__ u_time,
                                                          const float* __restrict__ cu_time, const int64_t* __restrict__ t, int n_t,
                                                          int N, float* __restrict__ pm, float* __restrict__ pl,
-                                                         float* __restrict__ pacc) {
+                                                         float* __restrict__ pacc, const float* __restrict__ xt,
+                                                         const float* __restrict__ xu, int cd) {
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0 = lane * 4;
     int64_t ti = t[b];
@@ -151,8 +156,19 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
     // the per-point (alpha, p) of all 16 queries are then broadcast with v_readlane
     const int own = multi_owned_index<NQ>(lane);
     float m_own = -INFINITY, l_own = 0.f, c_own = cval(own);
+    float4 xw[FOLD ? 8 : 1];
+    if (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xw[j] = j < cd ? *reinterpret_cast<const float4*>(xu + j * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int n = n0 + wave; n < n1; n += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + n) * 256 + c0);
+        float4 x = *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + n) * 256 + c0);
+        if (FOLD) {
+            const float xl = lane < cd ? xt[((int64_t)b * N + n) * cd + lane] : 0.f;      // the point's contact row: one load, lanes 0..cd-1
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cd) { const float sj = lane_bcast(xl, j); x.x += sj * xw[j].x; x.y += sj * xw[j].y; x.z += sj * xw[j].z; x.w += sj * xw[j].w; }
+        }
         const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
         const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
         const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
@@ -288,9 +304,10 @@ __global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights
     __syncthreads();
     const float scd = 1.0f / sqrtf((float)hdd);
     const int njh = 2 * Hd;
-    float* G = dec_lat + (int64_t)b * (2 * njh * dkv + njh);
+    float* G = dec_lat + (int64_t)b * DEC_LAT_STRIDE(njh);
     float* P = G + njh * dkv;
     float* cb = P + njh * dkv;
+    float* WP = cb + njh;
     for (int e = threadIdx.x; e < njh * dkv; e += blockDim.x) {
         const int jh = e / dkv, c = e % dkv, j = jh / Hd, h = jh % Hd;
         float a = 0.f, pp = 0.f;
@@ -307,18 +324,35 @@ __global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights
         for (int r = 0; r < hdd; ++r) a += w.dec_attn.q.b[h * hdd + r] * t2[j * MAXD + h * hdd + r];
         cb[jh] = a * scd;
     }
+    if (w.fold_xu && w.contact_dim <= 8) {           // folded form: WP[r, jh] = contact_layer.w[r] . P[jh]  (one wave per dot product)
+        __syncthreads();                             // P was written by this workgroup just above
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int e = wave; e < w.contact_dim * njh; e += nw) {
+            const int r = e / njh, jh = e % njh;
+            float a = 0.f;
+            for (int k = lane; k < dkv; k += 64) a += w.contact_layer.w[(int64_t)r * dkv + k] * P[jh * dkv + k];
+            a = wave_sum(a);
+            if (lane == 0) WP[r * njh + jh] = a;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- dec_attend
 // grid (chunks, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NJH = 2 keys x 8 heads.
-template <int HD>      // HD must be 8 (NJH = 16 scores per point)
+// FOLD: dec_q0 holds the step-invariant part of the decoder query, the row of point n is dec_q0[n] + sum_j xt[n, j] * xv[j].  The
+// residual stream h1 = attention output + query is not stored: the (linear) tail of the network needs contact_layer.w[r] . h1[n],
+// whose attention part is sum_jh a[n, jh] * WP[r, jh] with WP = contact_layer.w . P precomputed per sample by latent_post - sixteen
+// scalars per point instead of a 256-wide dot (written to s1[n, r]); the query part is linear in step-invariant data and x_t and is
+// added by cdm_output_kernel.
+template <int HD, bool FOLD>      // HD must be 8 (NJH = 16 scores per point)
 __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat,
                                                          afm_ln qn, const float* __restrict__ bo, afm_ln mlpn, int N,
-                                                         float* __restrict__ h1, float* __restrict__ z) {
+                                                         float* __restrict__ h1, float* __restrict__ z, const float* __restrict__ xt,
+                                                         const float* __restrict__ xv, int cd, float* __restrict__ s1) {
     constexpr int NJH = 2 * HD;
     __shared__ __attribute__((aligned(16))) float GP[2 * NJH * 256 + NJH];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane * 4;
-    const float* src = dec_lat + (int64_t)b * (2 * NJH * 256 + NJH);
+    const float* src = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
     for (int i = threadIdx.x; i < 2 * NJH * 256 + NJH; i += blockDim.x) GP[i] = src[i];
     const float4 g1 = *reinterpret_cast<const float4*>(qn.g + c0), b1 = *reinterpret_cast<const float4*>(qn.b + c0);
     const float4 g2 = *reinterpret_cast<const float4*>(mlpn.g + c0), b2 = *reinterpret_cast<const float4*>(mlpn.b + c0);
@@ -332,6 +366,16 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
     // PP points per wave iteration: the folded key / value rows (G, P: 32 x ds_read_b128 per point) are read from LDS once
     // and used for PP points - the kernel is LDS-issue bound, not HBM bound
     constexpr int PP = 2;
+    float4 xw[FOLD ? 8 : 1];
+    float wp[FOLD ? 8 : 1];               // WP[r, jh] of the score this lane owns (one of its four owner lanes contributes)
+    if (FOLD) {
+        const int jh = multi_owned_index<NJH>(lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xw[j] = j < cd ? *reinterpret_cast<const float4*>(xv + j * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wp[j] = (j < cd && (lane & 3) == 0) ? src[2 * NJH * 256 + NJH + j * NJH + jh] : 0.f;
+        }
+    }
     for (int nb = n0 + wave * PP; nb < n1; nb += 4 * PP) {
         float4 x[PP];
         float y[PP][4], sc[PP][NJH];
@@ -339,8 +383,15 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             ok[u] = nb + u < n1;
-            const int64_t row = ((int64_t)b * N + min(nb + u, n1 - 1)) * 256 + c0;
+            const int64_t pt = (int64_t)b * N + min(nb + u, n1 - 1);
+            const int64_t row = pt * 256 + c0;
             x[u] = *reinterpret_cast<const float4*>(dec_q0 + row);
+            if (FOLD) {
+                const float xl = lane < cd ? xt[pt * cd + lane] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < cd) { const float sj = lane_bcast(xl, j); x[u].x += sj * xw[j].x; x[u].y += sj * xw[j].y; x[u].z += sj * xw[j].z; x[u].w += sj * xw[j].w; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
@@ -365,6 +416,16 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
             const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
             w_own[u] = e_own / (e_own + e_oth);
             o[u][0] = ob.x; o[u][1] = ob.y; o[u][2] = ob.z; o[u][3] = ob.w;
+            if (FOLD) {
+                float dj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dj[j] = w_own[u] * wp[j];
+                const float tot = wave_reduce_multi<8>(dj, lane);
+                if ((lane & 7) == 0 && ok[u]) {
+                    const int j = multi_owned_index<8>(lane);
+                    if (j < cd) s1[((int64_t)b * N + nb + u) * cd + j] = tot;
+                }
+            }
         }
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
@@ -380,7 +441,7 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
             if (!ok[u]) continue;
             const int64_t row = ((int64_t)b * N + nb + u) * 256 + c0;
             const float r0 = o[u][0] + x[u].x, r1 = o[u][1] + x[u].y, r2 = o[u][2] + x[u].z, r3 = o[u][3] + x[u].w;   // Residual adds the raw query
-            *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
+            if (!FOLD) *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
             const float mean = wave_sum((r0 + r1) + (r2 + r3)) * (1.0f / 256.0f);
             const float d0 = r0 - mean, d1 = r1 - mean, d2 = r2 - mean, d3 = r3 - mean;
             const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
@@ -391,7 +452,7 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 }
 
 struct CdmWs {
-    float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat;
+    float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
     int64_t bytes;
 };
 
@@ -404,7 +465,10 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     s.enc_kv = take(M * w.dkv * 4); s.bufB = take(M * w.dkv * 4); s.h1 = take(M * w.dkv * 4); s.z = take(M * w.dkv * 4);
     s.pm = take((int64_t)B * NPART * nih * 4); s.pl = take((int64_t)B * NPART * nih * 4);
     s.pacc = take((int64_t)B * NPART * nih * w.dkv * 4);
-    s.dec_lat = take((int64_t)B * (2 * njh * w.dkv + njh) * 4);
+    s.dec_lat = take((int64_t)B * DEC_LAT_STRIDE(njh) * 4);
+    s.s1 = take(M * 8 * 4);                                  // folded path: contact_layer . h1 per point (<= 8 channels)
+    s.rdot = take(M * (w.dkv / 64) * 8 * 4);                 // folded path: row-dot partials of the fc1 GEMM
+    s.qe = take(M * 8 * 4);                                  // folded path: contact_layer . (step-invariant part of the decoder query)
     s.bytes = off;
     return s;
 }
@@ -441,10 +505,112 @@ extern "C" int afm_cdm_latent_tokens(const afm_cdm_weights* wp, int32_t which, c
     return 0;
 }
 
+namespace {
+
+// out[n, j] = (((p0 + p1) + p2) + p3) + s1[n, j] + (E[n, j] + q[j] . x_t[n]) + c0[j] from the row-dot partials of the fc1 GEMM, optional DDPM
+// update IN PLACE: one thread per point reads the point's whole contact row before it writes any of it (every output channel needs
+// all input channels of the row through q)
+__global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict__ rdot, int ngrp, const float* __restrict__ s1,
+                                                         const float* __restrict__ qe, const float* __restrict__ fq,
+                                                         const float* __restrict__ c0, int cd, int64_t rows, int rows_per_sample,
+                                                         float* __restrict__ x0_out, const float* xt, const float* __restrict__ noise,
+                                                         float* x_next, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                         const float* __restrict__ sigma) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        float xr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xr[k] = k < cd ? xt[r * cd + k] : 0.f;
+        const int b = (int)(r / rows_per_sample);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= cd) break;
+            const int64_t i = r * cd + j;
+            float v = rdot[(r * ngrp) * cd + j];                                   // w2 . GELU(linear1 z), 64 columns per partial
+            for (int g = 1; g < ngrp; ++g) v += rdot[(r * ngrp + g) * cd + j];
+            float q = qe[i];                                                        // contact_layer.w . decoder query = invariant part + x_t part
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < cd) q += xr[k] * fq[j * cd + k];
+            v = ((v + s1[i]) + q) + c0[j];                                          // + attention part of contact_layer.w . h1 + constants
+            if (x0_out) x0_out[i] = v;
+            if (x_next) x_next[i] = (c1[b] * v + c2[b] * xr[j]) + sigma[b] * noise[i];
+        }
+    }
+}
+
+inline bool cdm_folded(const afm_cdm_weights& w) {
+    return w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
+}
+
+// the step-invariant parts of the two adapters: C = encoder_adapter(input with x = 0) -> ws.enc_kv, D = decoder_adapter(C) -> ws.bufB
+int cdm_prepare_invariants(const afm_cdm_weights& w, const float* feat, int B, int N, const CdmWs& ws, hipStream_t s) {
+    const int M = B * N, dkv = w.dkv, cd = w.contact_dim;
+    afm_linear_args a = {};
+    a.A = feat + cd; a.lda = w.feat_dim; a.W = w.encoder_adapter.w + cd; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
+    a.M = M; a.N = dkv; a.K = w.feat_dim - cd; a.bias = w.encoder_adapter.b;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    AFM_TRY(afm_linear(&a, s));
+    a = {};
+    a.A = ws.enc_kv; a.lda = dkv; a.W = w.decoder_adapter.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
+    a.M = M; a.N = dkv; a.K = dkv; a.bias = w.decoder_adapter.b;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    AFM_TRY(afm_linear(&a, s));
+    a = {};                                  // E = contact_layer.w . D: the step-invariant part of what the output layer sees of the query
+    a.A = ws.bufB; a.lda = dkv; a.W = w.contact_layer.w; a.ldw = dkv; a.C = ws.qe; a.ldc = cd;
+    a.M = M; a.N = cd; a.K = dkv;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    return afm_linear(&a, s);
+}
+
+// one denoiser evaluation in the folded form (see afm_cdm_weights.fold_*); `prepared`: ws.enc_kv / ws.bufB already hold C / D
+int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float* x_t, const int64_t* t, const float* text_q0,
+                       const float* text_u, const float* text_cu, float* x0_out, const afm_ddpm_args* ddpm, int B, int N, const CdmWs& ws,
+                       bool prepared, hipStream_t s) {
+    const int M = B * N, dkv = w.dkv, cd = w.contact_dim;
+    if (!prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        hipLaunchKernelGGL((enc_reduce_kernel<16, true>), dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
+                           w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.fold_xu, cd);
+        AFM_CHECK_LAUNCH();
+    }
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
+        AFM_CHECK_LAUNCH();
+    }
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        int chunks = (N + 255) / 256;
+        if (chunks > 64) chunks = 64;
+        hipLaunchKernelGGL((dec_attend_kernel<8, true>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b,
+                           w.dec_mlp.norm, N, (float*)nullptr, ws.z, x_t, w.fold_xv, cd, ws.s1);
+        AFM_CHECK_LAUNCH();
+    }
+    afm_linear_args a = {};                 // GELU(linear1 z) . w2 per 64-column group; the hidden activations are never stored
+    a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
+    a.rowdot_w = w.fold_w2; a.rowdot_out = ws.rdot; a.rowdot_n = cd;
+    a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    AFM_TRY(afm_linear(&a, s));
+    {
+        AfmProf prof(AFM_PROF_CDM, 0.0, s);
+        int64_t g = ((int64_t)M + 255) / 256; if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, dkv / 64, ws.s1, ws.qe, w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
+                           ddpm ? ddpm->noise : nullptr, ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr,
+                           ddpm ? ddpm->sigma : nullptr);
+        AFM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+}  // namespace
+
 static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
                             const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
                             const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
-                            void* side_stream, void* stream) {
+                            void* side_stream, void* stream, bool prepared = false) {
     AFM_TRY(validate(wp, B, N));
     if (!feat || !t || !text_q0 || !text_u || !text_cu || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
     if (!wp->time_q0 || !wp->time_u || !wp->time_cu) return AFM_E_BADARG;
@@ -455,6 +621,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     const CdmWs ws = carve(w, B, N, workspace);
     if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
     const int M = B * N, dkv = w.dkv;
+    if (cdm_folded(w) && x_t) return cdm_forward_folded(w, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, ws, prepared, s);
 
     afm_linear_args a = {};
     a.A = feat; a.lda = w.feat_dim; a.W = w.encoder_adapter.w; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
@@ -468,8 +635,8 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        hipLaunchKernelGGL(enc_reduce_kernel<16>, dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
-                           w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc);
+        hipLaunchKernelGGL((enc_reduce_kernel<16, false>), dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
+                           w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, (const float*)nullptr, (const float*)nullptr, 0);
         AFM_CHECK_LAUNCH();
     }
     if (side) {           // fork AFTER enc_reduce (a full-chip kernel): the GEMM shares the chip with latent_post only
@@ -508,8 +675,8 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
         int chunks = (N + 255) / 256;
         if (chunks > 64) chunks = 64;
-        hipLaunchKernelGGL(dec_attend_kernel<8>, dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b,
-                           w.dec_mlp.norm, N, ws.h1, ws.z);
+        hipLaunchKernelGGL((dec_attend_kernel<8, false>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b,
+                           w.dec_mlp.norm, N, ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
         AFM_CHECK_LAUNCH();
     }
     a = {};
@@ -646,6 +813,15 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
     }
     const int64_t per = (int64_t)N * cd;
     int rc = 0;
+    // folded form: the step-invariant parts of the two adapters are computed once for the whole range of steps and x_t is read where
+    // it is needed - no per-step rewrite of the input block, no adapter GEMMs inside the loop
+    const bool folded = cdm_folded(*w);
+    if (folded) {
+        for (int s = 0; s < nsub && rc == 0; ++s) {
+            if (count[s] == 0) continue;
+            rc = cdm_prepare_invariants(*w, feat + (int64_t)start[s] * N * fd, count[s], N, carve(*w, count[s], N, wsp[s]), mainst[s]);
+        }
+    }
     for (int j = 0; j < n_steps && rc == 0; ++j) {
         for (int s = 0; s < nsub && rc == 0; ++s) {
             if (count[s] == 0) continue;
@@ -653,7 +829,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             float* fs = feat + (int64_t)start[s] * N * fd;
             const int64_t rows = (int64_t)count[s] * N;
             int64_t gx = (rows * cd + 255) / 256; if (gx > 2048) gx = 2048;
-            hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)gx), dim3(256), 0, mainst[s], xs, fs, rows, cd, fd);
+            if (!folded) hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)gx), dim3(256), 0, mainst[s], xs, fs, rows, cd, fd);
             afm_ddpm_args dd = {};
             if (step_noise) dd.noise = step_noise + ((int64_t)j * B + start[s]) * per;
             else {
@@ -666,7 +842,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = first_step + j;
             rc = cdm_forward_impl(w, fs, xs, t_all + (int64_t)j * B + start[s], text_q0 + (int64_t)start[s] * dq,
                                   text_u + (int64_t)start[s] * He * dkv, text_cu + (int64_t)start[s] * He, nullptr, &dd, count[s], N, wsp[s], wsb[s],
-                                  sidest[s], mainst[s]);
+                                  sidest[s], mainst[s], folded);
         }
     }
     if (nsub > 1) {

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 3
+#define AFM_ABI_VERSION 4
 
 #define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
 #define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
@@ -102,6 +102,12 @@ typedef struct {
     int32_t arith; int32_t arith_min_n;
     /* performance-only knobs for experiments (bit-neutral; 0 = the library's heuristics): AFM_TUNE_* bits */
     int32_t tune;
+    /* ---- fused row-dot epilogue (ABI v4; NULL = off): for a linear layer that is followed by a NARROW linear one (the CDM's
+     * contact_layer, contact_dim <= 8 outputs) the wide output never has to exist: with R = rowdot_n vectors rowdot_w [R, N] the kernel
+     * writes rowdot_out[row, g, r] = sum over the 64-column group g of C[row, col] * rowdot_w[r, col]  ([M, ceil(N / 64), R], rows
+     * through the c_* remap) in a fixed summation order that does not depend on the tile shape; the consumer adds the groups left to
+     * right.  C may be NULL.  Needs N % 4 == 0 and 16-byte aligned side inputs. */
+    const float* rowdot_w; float* rowdot_out; int32_t rowdot_n;
 } afm_linear_args;
 
 #define AFM_ARITH_DEFAULT 0
@@ -491,6 +497,21 @@ typedef struct {
     afm_ln dec_q_norm, dec_kv_norm; afm_mha_w dec_attn; afm_mlp_w dec_mlp;          /* decoder_cross_attn.{0,1}.module */
     afm_lin contact_layer;     /* [contact_dim, dkv]                                               */
     int32_t gemm_arith, gemm_arith_min_n;   /* ABI v3: afm_linear_args.arith / arith_min_n of the dense per-point layers */
+    /* ABI v4 (all five or none; the host builds them in eval mode when contact_dim <= 8 < ... and feat_dim > contact_dim): weight
+     * products that let the sampling form skip everything that is linear in step-invariant data.  Only the contact_dim leading
+     * columns of the encoder input (the noisy contact map x_t) change between the steps of a loop and no nonlinearity separates
+     * encoder_adapter from decoder_adapter, nor linear2 (+ residual) from contact_layer (cdm.py:176-186,509-510):
+     *   enc_kv[n] = C[n] + sum_j x_t[n,j] xu[j],  C = encoder_adapter(input with x = 0)      computed once per loop,
+     *   dec_q0[n] = D[n] + sum_j x_t[n,j] xv[j],  D = decoder_adapter(C)                     computed once per loop,
+     *   out[n]    = w2 . GELU(linear1 z[n]) + contact_layer.w . h1[n] + c0                   (linear2 and h1 never materialise;
+     *               contact_layer.w . h1 = sum_jh a[n,jh] (contact_layer.w . P[jh]) + contact_layer.w . dec_q0[n] + const, the last
+     *               again split into an invariant part E[n] and q . x_t[n]).
+     * Same function as the layer-by-layer form up to f32 re-association (tests: 2e-4 abs against the reference goldens). */
+    const float* fold_xu;      /* [contact_dim, dkv]  encoder_adapter.w[:, j]                                 */
+    const float* fold_xv;      /* [contact_dim, dkv]  decoder_adapter.w @ encoder_adapter.w[:, j]             */
+    const float* fold_w2;      /* [contact_dim, dkv]  contact_layer.w @ dec_mlp.fc2.w                         */
+    const float* fold_q;       /* [contact_dim, contact_dim]  contact_layer.w @ fold_xv^T                     */
+    const float* fold_c0;      /* [contact_dim]  contact_layer.w @ (dec_mlp.fc2.b + dec_attn.o.b) + contact_layer.b */
 } afm_cdm_weights;
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);

@@ -174,8 +174,14 @@ def config4(quick):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="config2 | config3 | config0 | config4: run one configuration")
     a = ap.parse_args()
     ffi.load()
+    if a.only:
+        r = globals()[a.only](a.quick)
+        for line in (r if isinstance(r, list) else [r]):
+            print(json.dumps(line), flush=True)
+        return
     results = []
     for fn in (config4, config2, config3, config0):        # the long two-stage run first, on a fresh allocator state
         r = fn(a.quick)
