@@ -290,6 +290,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.sub_batches = int(os.environ.get("AFM_CDM_SUBBATCH", "1"))     # >1 costs more host time per step than it hides (measured)
         self._streams = []
         self.no_fold = bool(os.environ.get("AFM_CDM_NO_FOLD"))      # measurement knob: the layer-by-layer sampling form
+        self.serial_latent = bool(os.environ.get("AFM_CDM_SERIAL_LATENT"))   # measurement knob: latent chain as one workgroup per sample
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
@@ -297,6 +298,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
+            w.flags = ffi.CDM_SERIAL_LATENT if self.serial_latent else 0
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -360,6 +362,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
+        w.flags = ffi.CDM_SERIAL_LATENT if self.serial_latent else 0
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):

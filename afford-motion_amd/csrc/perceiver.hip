@@ -337,6 +337,237 @@ __global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights
     }
 }
 
+// ---------------------------------------------------------------- latent chain, batched over the samples
+// latent_post above walks ~16 dependent matrix-vector stages inside ONE workgroup per sample: every workgroup streams every weight
+// matrix (1 MB each at dq = 512) through one CU, ~33 us per stage with 224 of 256 CUs idle.  The same chain as a sequence of small
+// launches over all 2 B latent tokens at once: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
+// workgroups per stage (every weight row is read once per token block, by one workgroup), ~5 us per launch.
+//   toklin_kernel: 64 tokens x 8 outputs per workgroup.  The (optionally LayerNorm-ed) input rows are staged in LDS ([64][K + 4] f32,
+//   conflict-free 16-byte row reads); lane = token, wave = output pair; the weight rows are wave-uniform and come through scalar loads.
+constexpr int TL_TOK = 64, TL_OB = 8;
+struct TokLin {
+    const float* X; int ldx;                 // input rows: token tok at X + tok * ldx (+ head offset)
+    int head_out, x_head_stride;             // head_out > 0: outputs [h * head_out, (h + 1) * head_out) read X + h * x_head_stride (per-head inputs)
+    const float* W[3]; const float* b[3];    // up to three stacked weight matrices [ncol, K] (q | k | v), ncol outputs each
+    int ncol;
+    afm_ln ln; int use_ln;                   // LayerNorm (eps 1e-5) of the input rows
+    int act;                                 // AFM_ACT_*
+    const float* R; int ldr;                 // residual rows or NULL (may be Y: every element is read and written by the same lane)
+    float* Y; int ldy;
+    int ntok, N, K;
+    int kshift;                              // K == 1 << kshift (row / column of a staging item by shifts; an integer division costs ~40 VALU)
+};
+
+__global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
+    extern __shared__ __attribute__((aligned(16))) float tl_x[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB, ldsx = p.K + 4;
+    const float* xbase = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0);
+    // All global loads of the workgroup are issued before anything waits: its TL_OB weight rows (<= 4 float4 per thread) and the
+    // 64 input rows (<= 32 float4 per thread) - one memory round trip per launch instead of one per batch.
+    float* tl_w = tl_x + TL_TOK * ldsx;
+    const int kq = p.K >> 2, qs = p.kshift - 2;                  // float4 per row
+    const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a workgroup lie in one weight part (ncol % TL_OB == 0)
+    float4 wv[4], xv[32];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = (threadIdx.x + u * 256) * 4;
+        const int r = idx >> p.kshift, c = idx & (p.K - 1), o = o0 + r;
+        const int part = o < p.N ? part0 : 0, oc = o < p.N ? oc0 + r : 0;
+        wv[u] = idx < TL_OB * p.K ? *reinterpret_cast<const float4*>(p.W[part] + (int64_t)oc * p.K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int idx = threadIdx.x + u * 256, tk = idx >> qs, c = (idx & (kq - 1)) * 4, tok = tb + tk;
+        xv[u] = (idx < TL_TOK * kq && tok < p.ntok) ? *reinterpret_cast<const float4*>(xbase + (int64_t)tok * p.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = (threadIdx.x + u * 256) * 4;
+        if (idx < TL_OB * p.K) *reinterpret_cast<float4*>(tl_w + idx) = wv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int idx = threadIdx.x + u * 256, tk = idx >> qs, c = (idx & (kq - 1)) * 4;
+        if (idx < TL_TOK * kq) *reinterpret_cast<float4*>(tl_x + tk * ldsx + c) = xv[u];
+    }
+    __syncthreads();
+    if (p.use_ln) {
+        // LayerNorm in place: 16 lanes per row (four rows per wave and pass), reductions inside the row of 16 lanes (DPP)
+        const int sub = lane >> 4, l16 = lane & 15;
+        for (int tk = wave * 4 + sub; tk < TL_TOK; tk += 16) {
+            float* row = tl_x + tk * ldsx;
+            float4 v[8];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = (i * 16 + l16) * 4;
+                v[i] = c < p.K ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+            sum += lane_xor<1>(sum); sum += lane_xor<2>(sum); sum += lane_xor<4>(sum); sum += lane_xor<8>(sum);
+            const float mean = sum / (float)p.K;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = (i * 16 + l16) * 4;
+                if (c < p.K) { const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean; sq += (a * a + b * b) + (cc * cc + d * d); }
+            }
+            sq += lane_xor<1>(sq); sq += lane_xor<2>(sq); sq += lane_xor<4>(sq); sq += lane_xor<8>(sq);
+            const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = (i * 16 + l16) * 4;
+                if (c < p.K) {
+                    const float4 g = *reinterpret_cast<const float4*>(p.ln.g + c), bb = *reinterpret_cast<const float4*>(p.ln.b + c);
+                    *reinterpret_cast<float4*>(row + c) = make_float4((v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
+                                                                      (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    constexpr int OW = TL_OB / 4;                                // outputs per wave
+    float acc[OW];
+    int oidx[OW];
+#pragma unroll
+    for (int j = 0; j < OW; ++j) {
+        const int o = o0 + wave * OW + j;                        // wave-uniform
+        oidx[j] = o;
+        acc[j] = (o < p.N && p.b[part0]) ? p.b[part0][oc0 + wave * OW + j] : 0.f;
+    }
+    const float* xr = tl_x + lane * ldsx;
+    const float* wr = tl_w + wave * OW * p.K;
+#pragma unroll 8
+    for (int k = 0; k < p.K; k += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(xr + k);
+#pragma unroll
+        for (int j = 0; j < OW; ++j) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + j * p.K + k);       // same address in every lane: LDS broadcast
+            acc[j] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+        }
+    }
+    const int tok = tb + lane;
+    if (tok < p.ntok) {
+#pragma unroll
+        for (int j = 0; j < OW; ++j) {
+            if (oidx[j] >= p.N) continue;
+            float v = acc[j];
+            if (p.act) v = apply_act(v, p.act);
+            if (p.R) v += p.R[(int64_t)tok * p.ldr + oidx[j]];
+            p.Y[(int64_t)tok * p.ldy + oidx[j]] = v;
+        }
+    }
+}
+
+// combine the per-wave partials of enc_reduce into s [ntok][He][dkv] (token = 2 b + i, i = 0 text latent, 1 time latent) and set the
+// latent state x0 [ntok][dq].  grid (B, 2 He), block dkv = 256.
+__global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                          const float* __restrict__ pacc, int nih, int dkv, const float* __restrict__ q0_text,
+                                                          const float* __restrict__ q0_time, const int64_t* __restrict__ t, int n_t, int dq,
+                                                          float* __restrict__ sbuf, float* __restrict__ x0) {
+    __shared__ float wq[NPART];
+    const int b = blockIdx.x, ih = blockIdx.y;
+    if (threadIdx.x < 64) {                                       // wave 0: NPART = 64 partial (max, sum) pairs
+        const int pi = threadIdx.x;
+        const float mm = pi < NPART ? pm[((int64_t)b * NPART + pi) * nih + ih] : -INFINITY;
+        float M = mm;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+        const float ww = (mm == -INFINITY) ? 0.f : __expf(mm - M);
+        const float L = wave_sum(pi < NPART ? pl[((int64_t)b * NPART + pi) * nih + ih] * ww : 0.f);
+        if (pi < NPART) wq[pi] = ww * (1.0f / L);
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < dkv) {
+        float a = 0.f;
+        for (int pi = 0; pi < NPART; ++pi) a += wq[pi] * pacc[(((int64_t)b * NPART + pi) * nih + ih) * dkv + c];
+        const int He = nih / 2, i = ih / He, h = ih % He;
+        sbuf[(((int64_t)b * 2 + i) * He + h) * dkv + c] = a;
+    }
+    if (ih < 2) {                                                 // latent token i = ih of this sample
+        int64_t ti = t[b];
+        ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
+        const float* src = ih == 0 ? q0_text + (int64_t)b * dq : q0_time + ti * dq;
+        for (int k = threadIdx.x; k < dq; k += blockDim.x) x0[((int64_t)b * 2 + ih) * dq + k] = src[k];
+    }
+}
+
+// self-attention of the two latent tokens of a sample (modules.py:544-648): qkv [ntok][3 dq] -> out [ntok][dq].  grid B, block 256.
+__global__ __launch_bounds__(256) void lat_selfattn_kernel(const float* __restrict__ qkv, int dq, int He, float* __restrict__ out) {
+    __shared__ float sc[64], aw[64];
+    const int b = blockIdx.x, hd = dq / He;
+    const float* q = qkv + (int64_t)b * 2 * 3 * dq;               // token rows 2 b, 2 b + 1: [q | k | v]
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (threadIdx.x < He * 4) {                                   // (h, i, j) scores
+        const int h = threadIdx.x >> 2, i = (threadIdx.x >> 1) & 1, j = threadIdx.x & 1;
+        float a = 0.f;
+        for (int r = 0; r < hd; ++r) a += (q[i * 3 * dq + h * hd + r] * scale) * q[j * 3 * dq + dq + h * hd + r];
+        sc[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < He * 2) {                                   // softmax over the 2 keys
+        const int base = threadIdx.x * 2;
+        const float a0 = sc[base], a1 = sc[base + 1], mx = fmaxf(a0, a1);
+        const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
+        aw[base] = e0 * inv; aw[base + 1] = e1 * inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * dq; e += blockDim.x) {
+        const int i = e / dq, c = e % dq, h = c / hd;
+        out[((int64_t)b * 2 + i) * dq + c] = aw[(h * 2 + i) * 2 + 0] * q[2 * dq + c] + aw[(h * 2 + i) * 2 + 1] * q[3 * dq + 2 * dq + c];
+    }
+}
+
+// decoder keys / values of the two latents folded through W_q / W_o of the decoder attention (+ contact_layer for the folded form):
+// kv [ntok][2 dkv] (k | v) -> dec_lat record of the sample.  grid (B, Hd), block dkv = 256: workgroup (b, h) owns jh = h and Hd + h.
+__global__ __launch_bounds__(256) void lat_decfold_kernel(const afm_cdm_weights w, const float* __restrict__ kv, float* __restrict__ dec_lat) {
+    __shared__ float red[4][16];
+    const int b = blockIdx.x, h = blockIdx.y, c = threadIdx.x, dkv = w.dkv, Hd = w.dec_heads, hdd = dkv / Hd, njh = 2 * Hd;
+    const float scd = 1.0f / sqrtf((float)hdd);
+    float* G = dec_lat + (int64_t)b * DEC_LAT_STRIDE(njh);
+    float* P = G + njh * dkv;
+    float* cb = P + njh * dkv;
+    float* WP = cb + njh;
+    float pj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* kd = kv + ((int64_t)b * 2 + j) * 2 * dkv + h * hdd;
+        const float* vd = kd + dkv;
+        float a = 0.f, pp = 0.f;
+        for (int r = 0; r < hdd; ++r) {
+            a += w.dec_attn.q.w[(int64_t)(h * hdd + r) * dkv + c] * kd[r];
+            pp += w.dec_attn.o.w[(int64_t)c * dkv + h * hdd + r] * vd[r];
+        }
+        const int jh = j * Hd + h;
+        G[jh * dkv + c] = a * scd;
+        P[jh * dkv + c] = pp;
+        pj[j] = pp;
+        if (c == 0) {
+            float cbv = 0.f;
+            for (int r = 0; r < hdd; ++r) cbv += w.dec_attn.q.b[h * hdd + r] * kd[r];
+            cb[jh] = cbv * scd;
+        }
+    }
+    if (w.fold_xu && w.contact_dim <= 8) {                        // WP[r, jh] = contact_layer.w[r] . P[jh]
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int r = 0; r < w.contact_dim; ++r) {
+            const float wc = w.contact_layer.w[(int64_t)r * dkv + c];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float s = wave_sum(wc * pj[j]);
+                if (lane == 0) red[wave][r * 2 + j] = s;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < w.contact_dim * 2) {
+            const int r = threadIdx.x >> 1, j = threadIdx.x & 1;
+            WP[r * njh + j * Hd + h] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- dec_attend
 // grid (chunks, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NJH = 2 keys x 8 heads.
 // FOLD: dec_q0 holds the step-invariant part of the decoder query, the row of point n is dec_q0[n] + sum_j xt[n, j] * xv[j].  The
@@ -453,6 +684,7 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 
 struct CdmWs {
     float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
+    float *lat_s, *lat_x, *lat_t1, *lat_t2, *lat_qkv, *lat_kv;     // batched latent chain: [2B] token rows
     int64_t bytes;
 };
 
@@ -469,6 +701,9 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     s.s1 = take(M * 8 * 4);                                  // folded path: contact_layer . h1 per point (<= 8 channels)
     s.rdot = take(M * (w.dkv / 64) * 8 * 4);                 // folded path: row-dot partials of the fc1 GEMM
     s.qe = take(M * 8 * 4);                                  // folded path: contact_layer . (step-invariant part of the decoder query)
+    const int64_t ntok = 2 * (int64_t)B;
+    s.lat_s = take(ntok * w.enc_heads * w.dkv * 4); s.lat_x = take(ntok * w.dq * 4); s.lat_t1 = take(ntok * w.dq * 4);
+    s.lat_t2 = take(ntok * w.dq * 4); s.lat_qkv = take(ntok * 3 * w.dq * 4); s.lat_kv = take(ntok * 2 * w.dkv * 4);
     s.bytes = off;
     return s;
 }
@@ -508,34 +743,117 @@ extern "C" int afm_cdm_latent_tokens(const afm_cdm_weights* wp, int32_t which, c
 namespace {
 
 // out[n, j] = (((p0 + p1) + p2) + p3) + s1[n, j] + (E[n, j] + q[j] . x_t[n]) + c0[j] from the row-dot partials of the fc1 GEMM, optional DDPM
-// update IN PLACE: one thread per point reads the point's whole contact row before it writes any of it (every output channel needs
-// all input channels of the row through q)
+// update IN PLACE.  Every output channel needs the point's whole contact row (through q), so a block owns WHOLE rows (256 / cd of
+// them per trip, one thread per element) and all its reads of x_t happen before a barrier, its writes after.
 __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict__ rdot, int ngrp, const float* __restrict__ s1,
                                                          const float* __restrict__ qe, const float* __restrict__ fq,
                                                          const float* __restrict__ c0, int cd, int64_t rows, int rows_per_sample,
                                                          float* __restrict__ x0_out, const float* xt, const float* __restrict__ noise,
                                                          float* x_next, const float* __restrict__ c1, const float* __restrict__ c2,
                                                          const float* __restrict__ sigma) {
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
-        float xr[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xr[k] = k < cd ? xt[r * cd + k] : 0.f;
-        const int b = (int)(r / rows_per_sample);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j >= cd) break;
-            const int64_t i = r * cd + j;
-            float v = rdot[(r * ngrp) * cd + j];                                   // w2 . GELU(linear1 z), 64 columns per partial
+    const int rpb = 256 / cd;                                     // rows per block and trip
+    const int lr = threadIdx.x / cd, j = threadIdx.x - lr * cd;
+    const bool act = lr < rpb;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < rows; r0 += (int64_t)gridDim.x * rpb) {      // uniform trip count per block
+        const int64_t r = r0 + lr;
+        const bool ok = act && r < rows;
+        const int64_t i = r * cd + j;
+        float v = 0.f, xj = 0.f;
+        if (ok) {
+            v = rdot[(r * ngrp) * cd + j];                                         // w2 . GELU(linear1 z), 64 columns per partial
             for (int g = 1; g < ngrp; ++g) v += rdot[(r * ngrp + g) * cd + j];
             float q = qe[i];                                                        // contact_layer.w . decoder query = invariant part + x_t part
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < cd) q += xr[k] * fq[j * cd + k];
+            for (int k = 0; k < cd; ++k) {
+                const float xk = xt[r * cd + k];
+                q += xk * fq[j * cd + k];
+                if (k == j) xj = xk;
+            }
             v = ((v + s1[i]) + q) + c0[j];                                          // + attention part of contact_layer.w . h1 + constants
+        }
+        __syncthreads();                                                            // every read of this block's rows of x_t is done
+        if (ok) {
             if (x0_out) x0_out[i] = v;
-            if (x_next) x_next[i] = (c1[b] * v + c2[b] * xr[j]) + sigma[b] * noise[i];
+            if (x_next) {
+                const int b = (int)(r / rows_per_sample);
+                x_next[i] = (c1[b] * v + c2[b] * xj) + sigma[b] * noise[i];
+            }
         }
     }
+}
+
+int launch_toklin(const TokLin& p, hipStream_t s) {
+    const size_t lds = ((size_t)TL_TOK * (p.K + 4) + (size_t)TL_OB * p.K) * sizeof(float);
+    static const int attr = (int)hipFuncSetAttribute((const void*)toklin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (TL_TOK * (MAXD + 4) + TL_OB * MAXD) * (int)sizeof(float));
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL(toklin_kernel, dim3((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK), dim3(256), lds, s, p);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// enc_reduce partials -> dec_lat records, as 17 small launches over all 2 B latent tokens (see toklin_kernel)
+int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s) {
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
+    hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
+                       ws.lat_s, ws.lat_x);
+    AFM_CHECK_LAUNCH();
+    auto lin = [&](const float* X, int ldx, int K, const afm_lin& l, int N, float* Y, int ldy) {
+        TokLin p = {};
+        p.X = X; p.ldx = ldx; p.W[0] = l.w; p.b[0] = l.b; p.ncol = N; p.Y = Y; p.ldy = ldy; p.ntok = ntok; p.N = N; p.K = K;
+        p.kshift = 31 - __builtin_clz((unsigned)K);
+        return p;
+    };
+    auto mlp = [&](const afm_mlp_w& m) {          // x <- x + fc2(GELU(fc1(LN(x))))
+        TokLin p = lin(ws.lat_x, dq, dq, m.fc1, dq, ws.lat_t2, dq);
+        p.ln = m.norm; p.use_ln = 1; p.act = AFM_ACT_GELU;
+        AFM_TRY(launch_toklin(p, s));
+        p = lin(ws.lat_t2, dq, dq, m.fc2, dq, ws.lat_x, dq);
+        p.R = ws.lat_x; p.ldr = dq;
+        return launch_toklin(p, s);
+    };
+    {   // attention output of the encoder cross-attention: o[tok, h hd + r] = W_v[h hd + r] . s[tok, h] + b_v, then o_proj + residual, MLP
+        TokLin p = lin(ws.lat_s, He * dkv, dkv, w.enc_attn.v, dq, ws.lat_t1, dq);
+        p.head_out = dq / He; p.x_head_stride = dkv;
+        AFM_TRY(launch_toklin(p, s));
+        p = lin(ws.lat_t1, dq, dq, w.enc_attn.o, dq, ws.lat_x, dq);
+        p.R = ws.lat_x; p.ldr = dq;
+        AFM_TRY(launch_toklin(p, s));
+        AFM_TRY(mlp(w.enc_mlp));
+    }
+    for (int li = 0; li < w.n_self; ++li) {        // self-attention block on the two latents of every sample (modules.py:544-648)
+        TokLin p = lin(ws.lat_x, dq, dq, w.self_attn[li].q, 3 * dq, ws.lat_qkv, 3 * dq);
+        p.W[1] = w.self_attn[li].k.w; p.b[1] = w.self_attn[li].k.b; p.W[2] = w.self_attn[li].v.w; p.b[2] = w.self_attn[li].v.b; p.ncol = dq;
+        p.ln = w.self_norm[li]; p.use_ln = 1;
+        AFM_TRY(launch_toklin(p, s));
+        hipLaunchKernelGGL(lat_selfattn_kernel, dim3(B), dim3(256), 0, s, ws.lat_qkv, dq, He, ws.lat_t1);
+        AFM_CHECK_LAUNCH();
+        p = lin(ws.lat_t1, dq, dq, w.self_attn[li].o, dq, ws.lat_x, dq);
+        p.R = ws.lat_x; p.ldr = dq;
+        AFM_TRY(launch_toklin(p, s));
+        AFM_TRY(mlp(w.self_mlp[li]));
+    }
+    {   // decoder keys / values of the two latents, folded through W_q / W_o of the decoder attention
+        TokLin p = lin(ws.lat_x, dq, dq, w.dec_attn.k, 2 * dkv, ws.lat_kv, 2 * dkv);
+        p.W[1] = w.dec_attn.v.w; p.b[1] = w.dec_attn.v.b; p.ncol = dkv;
+        p.ln = w.dec_kv_norm; p.use_ln = 1;
+        AFM_TRY(launch_toklin(p, s));
+        hipLaunchKernelGGL(lat_decfold_kernel, dim3(B, w.dec_heads), dim3(256), 0, s, w, ws.lat_kv, ws.dec_lat);
+        AFM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// serial form (one workgroup per sample, measurement knob AFM_CDM_SERIAL_LATENT) or the batched chain
+int cdm_latents(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s) {
+    const bool pow2 = (w.dq & (w.dq - 1)) == 0 && (w.dkv & (w.dkv - 1)) == 0;
+    if (!(w.flags & AFM_CDM_SERIAL_LATENT) && pow2 && w.dq >= 64 && w.dq <= MAXD && (w.dq / w.enc_heads) % TL_OB == 0) return cdm_latent_chain(w, text_q0, t, ws, B, s);
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    const size_t lds = (size_t)(16 * w.dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
+    AFM_CHECK_LAUNCH();
+    return 0;
 }
 
 inline bool cdm_folded(const afm_cdm_weights& w) {
@@ -574,13 +892,7 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
                            w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.fold_xu, cd);
         AFM_CHECK_LAUNCH();
     }
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
-        AFM_CHECK_LAUNCH();
-    }
+    AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
         int chunks = (N + 255) / 256;
@@ -596,7 +908,8 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
     AFM_TRY(afm_linear(&a, s));
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        int64_t g = ((int64_t)M + 255) / 256; if (g > 4096) g = 4096;
+        const int rpb = 256 / cd;
+        int64_t g = ((int64_t)M + rpb - 1) / rpb; if (g > 8192) g = 8192;
         hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, dkv / 64, ws.s1, ws.qe, w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
                            ddpm ? ddpm->noise : nullptr, ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr,
                            ddpm ? ddpm->sigma : nullptr);
@@ -644,13 +957,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
             hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
         (void)hipEventRecord(ev_fork, s);
     }
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        const size_t lds = (size_t)(16 * dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
-        AFM_CHECK_LAUNCH();
-    }
+    AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
     if (side) {           // enqueued after latent_post so that its 32 workgroups get their CUs first
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         afm_linear_args d = {};

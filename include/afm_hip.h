@@ -510,9 +510,12 @@ typedef struct {
     const float* fold_xu;      /* [contact_dim, dkv]  encoder_adapter.w[:, j]                                 */
     const float* fold_xv;      /* [contact_dim, dkv]  decoder_adapter.w @ encoder_adapter.w[:, j]             */
     const float* fold_w2;      /* [contact_dim, dkv]  contact_layer.w @ dec_mlp.fc2.w                         */
+    int32_t flags;             /* AFM_CDM_* bits (ABI v4)                                                       */
     const float* fold_q;       /* [contact_dim, contact_dim]  contact_layer.w @ fold_xv^T                     */
     const float* fold_c0;      /* [contact_dim]  contact_layer.w @ (dec_mlp.fc2.b + dec_attn.o.b) + contact_layer.b */
 } afm_cdm_weights;
+
+#define AFM_CDM_SERIAL_LATENT 0x1      /* measurement: the latent chain as one workgroup per sample (latent_post_kernel) instead of batched stages */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
 
