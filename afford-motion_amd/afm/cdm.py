@@ -349,16 +349,18 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             # contact columns of the encoder input change between steps, and encoder_adapter -> decoder_adapter as well as
             # linear2 (+ residual) -> contact_layer are linear chains (cdm.py:176-186,509-510).
             cd = self.contact_dim
-            we, wd = cm.encoder_adapter.weight.detach().double(), cm.decoder_adapter.weight.detach().double()
+            f64 = lambda t: t.detach().double().cpu()        # a few 256 x 256 products: on the host, exactly reproducible
+            we, wd = f64(cm.encoder_adapter.weight), f64(cm.decoder_adapter.weight)
             fc2, cl = cm.decoder_cross_attn[1].module[3], self.contact_layer
-            wc = cl.weight.detach().double()
+            wc = f64(cl.weight)
             xu = we[:, :cd].t().contiguous()                                       # [cd, dkv]
             xv = (wd @ we[:, :cd]).t().contiguous()                                # [cd, dkv]
-            bo = cm.decoder_cross_attn[0].module.attention.o_proj.bias.detach().double()
-            folds = dict(fold_xu=xu, fold_xv=xv, fold_w2=wc @ fc2.weight.detach().double(), fold_q=wc @ xv.t(),
-                         fold_c0=wc @ (fc2.bias.detach().double() + bo) + cl.bias.detach().double())
+            bo = f64(cm.decoder_cross_attn[0].module.attention.o_proj.bias)
+            folds = dict(fold_xu=xu, fold_xv=xv, fold_w2=wc @ f64(fc2.weight), fold_q=wc @ xv.t(),
+                         fold_c0=wc @ (f64(fc2.bias) + bo) + f64(cl.bias))
+            dev = cl.weight.device
             for name, t in folds.items():
-                setattr(w, name, P(t.float().contiguous()))
+                setattr(w, name, P(t.float().contiguous().to(dev)))
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()

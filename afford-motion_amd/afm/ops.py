@@ -20,11 +20,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            act_post: int = ffi.ACT_NONE,
            scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            rowtab: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           rows: Optional[int] = None, a_map: Optional[RowMap] = None, c_map: Optional[RowMap] = None) -> torch.Tensor:
+           rows: Optional[int] = None, a_map: Optional[RowMap] = None, c_map: Optional[RowMap] = None,
+           rowdot_w: Optional[torch.Tensor] = None, rowdot_out: Optional[torch.Tensor] = None, store: bool = True) -> torch.Tensor:
     """``act_post(act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)])`` on f32 MFMA.
 
     x [..., K] (or a 2-D row pool when ``a_map`` gathers rows), weight [N, K] as in nn.Linear.
-    With ``out`` given (2-D row pool [R, N]) and ``c_map``, rows are scattered into it."""
+    With ``out`` given (2-D row pool [R, N]) and ``c_map``, rows are scattered into it.
+    ``rowdot_w`` [R, N] + ``rowdot_out`` [rows, ceil(N / 64), R]: the fused row-dot epilogue (afm_linear_args.rowdot_*): per 64-column
+    group, the dot of the output row with each of the R vectors; ``store=False`` then skips writing the output itself."""
     lib = ffi.load()
     ffi.require_gpu(x, weight)
     x = ffi.f32c(x)
@@ -58,6 +61,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         a.a_grp, a.a_stride, a.a_off = a_map
     if c_map:
         a.c_grp, a.c_stride, a.c_off = c_map
+    if rowdot_w is not None:
+        rowdot_w = ffi.f32c(rowdot_w)
+        assert rowdot_w.shape[1] == N and rowdot_out is not None and rowdot_out.is_contiguous() and rowdot_out.dtype == torch.float32
+        keep += [rowdot_w, rowdot_out]
+        a.rowdot_w, a.rowdot_out, a.rowdot_n = rowdot_w.data_ptr(), rowdot_out.data_ptr(), rowdot_w.shape[0]
+        if not store:
+            a.C = None
     fill_arith(a)
     ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
     return out

@@ -29,6 +29,52 @@ def test_linear_shapes(M, N, K):
     report(f"linear {M}x{N}x{K}", got, want, 2e-4)
 
 
+@pytest.mark.parametrize("M,N,K,R", [(5000, 256, 256, 6), (777, 320, 512, 8), (1304, 512, 512, 1), (200, 256, 96, 3)])
+def test_linear_rowdot_epilogue(M, N, K, R):
+    """ABI v4 row-dot epilogue (the CDM's linear2 + contact_layer collapse): rowdot_out[m, g, r] = sum over the 64-column group g of
+    GELU(x W^T + b)[m, col] * w[r, col].  Checked against the stored output in float64, required to be bit-identical across tile shapes
+    and arithmetics' tile choices (the summation order inside a group is fixed), and usable without storing the output at all."""
+    x = synth.gaussian("rd_x", (M, K)); w = synth.gaussian("rd_w", (N, K)) / math.sqrt(K); b = synth.gaussian("rd_b", (N,))
+    rw = synth.gaussian("rd_rw", (R, N))
+    xd, wd, bd, rwd = x.to(dev()), w.to(dev()), b.to(dev()), rw.to(dev())
+    ngrp = (N + 63) // 64
+    outs = {}
+    for tile in (0, 3, 5):
+        prev = ops.set_gemm_tune(tile << ffi.TUNE_TILE_SHIFT)
+        try:
+            rd = torch.full((M, ngrp, R), float("nan"), device=dev())
+            c = ops.linear(xd, wd, bd, act=ffi.ACT_GELU, rowdot_w=rwd, rowdot_out=rd)
+            rd2 = torch.full((M, ngrp, R), float("nan"), device=dev())
+            junk = torch.full((M, N), 7.0, device=dev())
+            ops.linear(xd, wd, bd, act=ffi.ACT_GELU, rowdot_w=rwd, rowdot_out=rd2, out=junk, store=False)
+        finally:
+            ops.set_gemm_tune(prev)
+        assert torch.equal(rd, rd2) and bool((junk == 7.0).all())          # store=False leaves the output buffer alone
+        outs[tile] = (c, rd)
+    c0, rd0 = outs[0]
+    assert torch.equal(c0, ops.linear(xd, wd, bd, act=ffi.ACT_GELU))
+    for tile in (3, 5):
+        assert torch.equal(outs[tile][1], rd0), f"tile {tile}: row-dot partials depend on the tile shape"
+    cpad = torch.zeros(M, ngrp * 64, dtype=torch.float64); cpad[:, :N] = c0.double().cpu()
+    wpad = torch.zeros(R, ngrp * 64, dtype=torch.float64); wpad[:, :N] = rw.double()
+    want = torch.einsum("mgc,rgc->mgr", cpad.view(M, ngrp, 64), wpad.view(R, ngrp, 64))
+    scale = torch.einsum("mgc,rgc->mgr", cpad.view(M, ngrp, 64).abs(), wpad.view(R, ngrp, 64).abs()) + 1e-30
+    err = ((rd0.double().cpu() - want).abs() / scale).max().item()
+    print(f"row-dot {M}x{N}x{K} R={R}: max err / sum|c||w| = {err:.2e}")
+    assert err < 5e-7
+    saved = ops.get_gemm_split()                                               # native f32 MFMA kernels share the epilogue
+    try:
+        ops.set_gemm_split(0, 0)
+        rdn = torch.empty((M, ngrp, R), device=dev())
+        cn = ops.linear(xd, wd, bd, act=ffi.ACT_GELU, rowdot_w=rwd, rowdot_out=rdn)
+    finally:
+        ops.set_gemm_split(*saved)
+    wantn = torch.einsum("mgc,rgc->mgr", torch.nn.functional.pad(cn.double().cpu(), (0, ngrp * 64 - N)).view(M, ngrp, 64), wpad.view(R, ngrp, 64))
+    assert ((rdn.double().cpu() - wantn).abs() / scale).max().item() < 5e-7
+    with pytest.raises(ffi.AfmError):                                          # N % 4 != 0: the row-dot form needs 16-byte rows
+        ops.linear(xd, wd[:N - 1].contiguous(), None, rowdot_w=rwd[:, :N - 1].contiguous(), rowdot_out=rd)
+
+
 def test_linear_bf16_one_product_is_bf16_accurate_only():
     """AFM_ARITH_BF16X1 (informational): the leading-term product alone carries bf16's 2^-9 relative rounding per operand - three orders
     of magnitude above the f32 kernels' error, and identical across tile shapes like every other arithmetic."""

@@ -4,8 +4,8 @@ out = sys.argv[1]
 
 
 def short(n):
-    n = n.replace("void (anonymous namespace)::", "").split("(")[0]
-    return n
+    n = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")     # non-template kernels carry no "void"
+    return n.split("(")[0]
 
 
 print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
