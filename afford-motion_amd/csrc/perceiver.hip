@@ -395,6 +395,13 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     if (p.use_ln) {
         // LayerNorm in place: 16 lanes per row (four rows per wave and pass), reductions inside the row of 16 lanes (DPP)
         const int sub = lane >> 4, l16 = lane & 15;
+        float4 lg[8], lb[8];                                     // this lane's slices of gamma / beta: loaded once, not once per row
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = (i * 16 + l16) * 4;
+            lg[i] = c < p.K ? *reinterpret_cast<const float4*>(p.ln.g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            lb[i] = c < p.K ? *reinterpret_cast<const float4*>(p.ln.b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         for (int tk = wave * 4 + sub; tk < TL_TOK; tk += 16) {
             float* row = tl_x + tk * ldsx;
             float4 v[8];
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
             for (int i = 0; i < 8; ++i) {
                 const int c = (i * 16 + l16) * 4;
                 if (c < p.K) {
-                    const float4 g = *reinterpret_cast<const float4*>(p.ln.g + c), bb = *reinterpret_cast<const float4*>(p.ln.b + c);
+                    const float4 g = lg[i], bb = lb[i];
                     *reinterpret_cast<float4*>(row + c) = make_float4((v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
                                                                       (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w);
                 }
