@@ -22,6 +22,8 @@ extern "C" int afm_linear(const afm_linear_args*, void*);
 
 namespace {
 
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int NSPLIT = 16;          // workgroups per sample in enc_reduce (x4 waves = 64 partials per sample)
 constexpr int NPART = NSPLIT * 4;
 constexpr int MAXD = 512;           // dq upper bound for the latent kernels' LDS vectors
@@ -141,12 +143,14 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
     // folded query q < NQ/2: text latent of this sample; q >= NQ/2: time latent of timestep t[b]
     auto uptr = [&](int q) { return q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256; };
     auto cval = [&](int q) { return q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]; };
-    float uq[NQ][4], acc[NQ][4], m[NQ], l[NQ];
+    // packed f32 pairs (v_pk_mul / v_pk_fma: two lanes' worth of IEEE f32 per instruction): channels (c0, c0 + 1) and (c0 + 2, c0 + 3)
+    pf32x2 uqa[NQ], uqb[NQ], acca[NQ], accb[NQ];
+    float m[NQ], l[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(uptr(q) + c0);
-        uq[q][0] = v.x; uq[q][1] = v.y; uq[q][2] = v.z; uq[q][3] = v.w;
-        acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+        uqa[q] = pf32x2{v.x, v.y}; uqb[q] = pf32x2{v.z, v.w};
+        acca[q] = pf32x2{0.f, 0.f}; accb[q] = pf32x2{0.f, 0.f};
         m[q] = -INFINITY; l[q] = 0.f;
     }
     const float4 g = *reinterpret_cast<const float4*>(kvn.g + c0), be = *reinterpret_cast<const float4*>(kvn.b + c0);
@@ -161,10 +165,20 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j) xw[j] = j < cd ? *reinterpret_cast<const float4*>(xu + j * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // The loop is a dependent chain load -> ~350 VALU -> next load with two waves per SIMD: the next point's row (and contact row) is
+    // fetched before the current one is processed, otherwise every point pays a full HBM round trip (measured 1.07 TB/s without).
+    auto load_row = [&](int n) { return *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + min(n, n1 - 1)) * 256 + c0); };
+    // (every lane loads - clamped column - so that the load is not under a lane-dependent branch: hipcc cannot count a load that may
+    // or may not have been issued and would wait for the PREFETCHED row instead of the current one)
+    auto load_xl = [&](int n) { return FOLD ? xt[((int64_t)b * N + min(n, n1 - 1)) * cd + min(lane, cd - 1)] : 0.f; };
+    float4 x_next = load_row(n0 + wave);
+    float xl_next = load_xl(n0 + wave);
     for (int n = n0 + wave; n < n1; n += 4) {
-        float4 x = *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + n) * 256 + c0);
+        float4 x = x_next;
+        const float xl = xl_next;                                                          // the point's contact row: one load, lanes 0..cd-1
+        x_next = load_row(n + 4);
+        xl_next = load_xl(n + 4);
         if (FOLD) {
-            const float xl = lane < cd ? xt[((int64_t)b * N + n) * cd + lane] : 0.f;      // the point's contact row: one load, lanes 0..cd-1
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (j < cd) { const float sj = lane_bcast(xl, j); x.x += sj * xw[j].x; x.y += sj * xw[j].y; x.z += sj * xw[j].z; x.w += sj * xw[j].w; }
@@ -173,19 +187,34 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
         const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
         const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
         const float y0 = d0 * rstd * g.x + be.x, y1 = d1 * rstd * g.y + be.y, y2 = d2 * rstd * g.z + be.z, y3 = d3 * rstd * g.w + be.w;
+        const pf32x2 ya = {y0, y1}, yb = {y2, y3};
         float d[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) d[q] = (y0 * uq[q][0] + y1 * uq[q][1]) + (y2 * uq[q][2] + y3 * uq[q][3]);
+        for (int q = 0; q < NQ; ++q) {
+            const pf32x2 tq = yb * uqb[q] + ya * uqa[q];
+            d[q] = tq[0] + tq[1];
+        }
         const float sown = wave_reduce_multi<NQ>(d, lane) + c_own;
         const float mn = fmaxf(m_own, sown);
         const float alpha = __expf(m_own - mn), pw = __expf(sown - mn);
         l_own = l_own * alpha + pw;
         m_own = mn;
+        // the running maxima settle after the first few hundred points: when no query's maximum moved (alpha == 1 in every lane, a
+        // wave-uniform test) the rescale of the 16 x 4 accumulators is skipped - multiplying by 1.0f would change nothing
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float aq = lane_bcast(alpha, multi_owner_lane<NQ>(q)), pq = lane_bcast(pw, multi_owner_lane<NQ>(q));
-            acc[q][0] = acc[q][0] * aq + pq * y0; acc[q][1] = acc[q][1] * aq + pq * y1;
-            acc[q][2] = acc[q][2] * aq + pq * y2; acc[q][3] = acc[q][3] * aq + pq * y3;
+            for (int q = 0; q < NQ; ++q) {
+                const float pq = lane_bcast(pw, multi_owner_lane<NQ>(q));
+                const pf32x2 p2 = {pq, pq};
+                acca[q] = ya * p2 + acca[q]; accb[q] = yb * p2 + accb[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float aq = lane_bcast(alpha, multi_owner_lane<NQ>(q)), pq = lane_bcast(pw, multi_owner_lane<NQ>(q));
+                const pf32x2 a2 = {aq, aq}, p2 = {pq, pq};
+                acca[q] = ya * p2 + acca[q] * a2; accb[q] = yb * p2 + accb[q] * a2;
+            }
         }
     }
 #pragma unroll
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (lane == 0) { pm[base + q] = m[q]; pl[base + q] = l[q]; }
-        *reinterpret_cast<float4*>(pacc + (base + q) * 256 + c0) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+        *reinterpret_cast<float4*>(pacc + (base + q) * 256 + c0) = make_float4(acca[q][0], acca[q][1], accb[q][0], accb[q][1]);
     }
 }
 
@@ -614,18 +643,32 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
             wp[j] = (j < cd && (lane & 3) == 0) ? src[2 * NJH * 256 + NJH + j * NJH + jh] : 0.f;
         }
     }
+    // next pair of rows (and contact rows) in flight while the current pair is processed: without the prefetch every trip pays a full
+    // memory round trip with two waves per SIMD to hide it
+    float4 xn[PP];
+    float xln[PP];
+    auto fetch = [&](int nb_) {
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int64_t pt = (int64_t)b * N + min(nb_ + u, n1 - 1);
+            xn[u] = *reinterpret_cast<const float4*>(dec_q0 + pt * 256 + c0);
+            xln[u] = FOLD ? xt[pt * cd + min(lane, cd - 1)] : 0.f;          // every lane loads (clamped column): no lane-dependent branch around a counted load
+        }
+    };
+    fetch(n0 + wave * PP);
     for (int nb = n0 + wave * PP; nb < n1; nb += 4 * PP) {
         float4 x[PP];
+        float xlc[PP];
         float y[PP][4], sc[PP][NJH];
         bool ok[PP];
 #pragma unroll
+        for (int u = 0; u < PP; ++u) { x[u] = xn[u]; xlc[u] = xln[u]; }
+        fetch(nb + 4 * PP);
+#pragma unroll
         for (int u = 0; u < PP; ++u) {
             ok[u] = nb + u < n1;
-            const int64_t pt = (int64_t)b * N + min(nb + u, n1 - 1);
-            const int64_t row = pt * 256 + c0;
-            x[u] = *reinterpret_cast<const float4*>(dec_q0 + row);
             if (FOLD) {
-                const float xl = lane < cd ? xt[pt * cd + lane] : 0.f;
+                const float xl = xlc[u];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (j < cd) { const float sj = lane_bcast(xl, j); x[u].x += sj * xw[j].x; x[u].y += sj * xw[j].y; x[u].z += sj * xw[j].z; x[u].w += sj * xw[j].w; }
@@ -638,13 +681,18 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
             const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
             y[u][0] = d0 * rstd * g1.x + b1.x; y[u][1] = d1 * rstd * g1.y + b1.y; y[u][2] = d2 * rstd * g1.z + b1.z; y[u][3] = d3 * rstd * g1.w + b1.w;
         }
+        pf32x2 ya[PP], yb[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) { ya[u] = pf32x2{y[u][0], y[u][1]}; yb[u] = pf32x2{y[u][2], y[u][3]}; }
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
             const float4 gv = *reinterpret_cast<const float4*>(G + jh * 256 + c0);
+            const pf32x2 ga = {gv.x, gv.y}, gb = {gv.z, gv.w};
 #pragma unroll
-            for (int u = 0; u < PP; ++u) sc[u][jh] = (y[u][0] * gv.x + y[u][1] * gv.y) + (y[u][2] * gv.z + y[u][3] * gv.w);
+            for (int u = 0; u < PP; ++u) { const pf32x2 tq = yb[u] * gb + ya[u] * ga; sc[u][jh] = tq[0] + tq[1]; }      // packed f32 pairs
         }
-        float w_own[PP], o[PP][4];
+        float w_own[PP];
+        pf32x2 oa[PP], ob2[PP];
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             // lane owns score jh = j*HD + h (j <-> lane bit 5); its softmax partner (other key, same head) is lane ^ 32
@@ -653,7 +701,7 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
             const float mx = fmaxf(s_own, s_oth);
             const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
             w_own[u] = e_own / (e_own + e_oth);
-            o[u][0] = ob.x; o[u][1] = ob.y; o[u][2] = ob.z; o[u][3] = ob.w;
+            oa[u] = pf32x2{ob.x, ob.y}; ob2[u] = pf32x2{ob.z, ob.w};
             if (FOLD) {
                 float dj[8];
 #pragma unroll
@@ -668,17 +716,19 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 #pragma unroll
         for (int jh = 0; jh < NJH; ++jh) {
             const float4 pv = *reinterpret_cast<const float4*>(P + jh * 256 + c0);
+            const pf32x2 pa = {pv.x, pv.y}, pb = {pv.z, pv.w};
 #pragma unroll
             for (int u = 0; u < PP; ++u) {
                 const float wj = lane_bcast(w_own[u], multi_owner_lane<NJH>(jh));
-                o[u][0] += wj * pv.x; o[u][1] += wj * pv.y; o[u][2] += wj * pv.z; o[u][3] += wj * pv.w;
+                const pf32x2 w2 = {wj, wj};
+                oa[u] = pa * w2 + oa[u]; ob2[u] = pb * w2 + ob2[u];
             }
         }
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             if (!ok[u]) continue;
             const int64_t row = ((int64_t)b * N + nb + u) * 256 + c0;
-            const float r0 = o[u][0] + x[u].x, r1 = o[u][1] + x[u].y, r2 = o[u][2] + x[u].z, r3 = o[u][3] + x[u].w;   // Residual adds the raw query
+            const float r0 = oa[u][0] + x[u].x, r1 = oa[u][1] + x[u].y, r2 = ob2[u][0] + x[u].z, r3 = ob2[u][1] + x[u].w;   // Residual adds the raw query
             if (!FOLD) *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
             const float mean = wave_sum((r0 + r1) + (r2 + r3)) * (1.0f / 256.0f);
             const float d0 = r0 - mean, d1 = r1 - mean, d2 = r2 - mean, d3 = r3 - mean;
