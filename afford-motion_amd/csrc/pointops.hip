@@ -140,10 +140,22 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
         buf[take ? cnt : BUF][tid] = make_float2(d, __int_as_float(id));
         cnt += take ? 1 : 0;
     };
+    // tile fill through registers, one tile ahead: all of a thread's loads are in flight before the first store (a load -> store loop
+    // waits a full memory round trip per element), and the next tile's loads are issued before the current tile is scanned
+    constexpr int NF = 3 * KNN_TILE / 256;
+    float stage[NF];
+    auto fetch = [&](int t0_) {
+        const int lim = (min(KNN_TILE, n - t0_)) * 3;
+#pragma unroll
+        for (int u = 0; u < NF; ++u) { const int f = tid + u * 256; stage[u] = (t0_ < n && f < lim) ? P[(int64_t)t0_ * 3 + f] : 0.f; }
+    };
+    fetch(0);
     for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
         const int tc = min(KNN_TILE, n - t0);
-        for (int f = tid; f < tc * 3; f += blockDim.x) tile[f] = P[(int64_t)t0 * 3 + f];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) { const int f = tid + u * 256; if (f < tc * 3) tile[f] = stage[u]; }
         __syncthreads();
+        fetch(t0 + KNN_TILE);
         int i = 0;
         for (; i + 4 <= tc; i += 4) {
             const float4 c0 = *reinterpret_cast<const float4*>(tile + 3 * i), c1 = *reinterpret_cast<const float4*>(tile + 3 * i + 4),
