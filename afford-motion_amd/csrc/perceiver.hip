@@ -620,7 +620,21 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float GP[2 * NJH * 256 + NJH];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane * 4;
     const float* src = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
-    for (int i = threadIdx.x; i < 2 * NJH * 256 + NJH; i += blockDim.x) GP[i] = src[i];
+    {   // folded keys / values of the sample -> LDS: 16-byte loads, all of a thread's loads in flight before its first store (an element-wise
+        // load -> store loop is 32 dependent memory round trips per thread: ~30 us of prologue per workgroup, measured)
+        constexpr int NV4 = (2 * NJH * 256 + NJH) / 4;            // 2052 float4 (records are 16-byte aligned and a multiple of 4 floats apart)
+        float4 gv[(NV4 + 255) / 256];
+#pragma unroll
+        for (int u = 0; u < (NV4 + 255) / 256; ++u) {
+            const int i4 = threadIdx.x + u * 256;
+            gv[u] = i4 < NV4 ? reinterpret_cast<const float4*>(src)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < (NV4 + 255) / 256; ++u) {
+            const int i4 = threadIdx.x + u * 256;
+            if (i4 < NV4) reinterpret_cast<float4*>(GP)[i4] = gv[u];
+        }
+    }
     const float4 g1 = *reinterpret_cast<const float4*>(qn.g + c0), b1 = *reinterpret_cast<const float4*>(qn.b + c0);
     const float4 g2 = *reinterpret_cast<const float4*>(mlpn.g + c0), b2 = *reinterpret_cast<const float4*>(mlpn.b + c0);
     const float4 ob = *reinterpret_cast<const float4*>(bo + c0);

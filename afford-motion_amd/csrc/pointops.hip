@@ -47,7 +47,13 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz
         tmp[s >> 1][s & 1] = 1e10f;
     }
     if (xyz_in_lds) {
-        for (int i = tid; i < 3 * n; i += T) pts[i] = P[i];
+        for (int i0 = tid; i0 < 3 * n; i0 += 8 * T) {                // eight loads in flight per thread (not a load -> store chain per element)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + u * T < 3 * n ? P[i0 + u * T] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * T < 3 * n) pts[i0 + u * T] = v[u];
+        }
         __syncthreads();
     }
     const float* C = xyz_in_lds ? pts : P;
