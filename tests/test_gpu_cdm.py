@@ -219,3 +219,23 @@ def test_folded_sampling_form_and_batched_latent_chain_match_the_layered_form(cd
         assert not cdm._weights().fold_xu, "training mode keeps the layer-by-layer form (weights change every step)"
     finally:
         cdm.eval()
+
+
+def test_batched_latent_chain_with_more_than_one_token_block(cdm):
+    """B = 40 samples are 80 latent tokens: two 64-token blocks per stage of the batched chain (the second one partly filled), and a
+    sub-batched loop whose parts are 1 / 2 / 37 samples wide; the one-workgroup-per-sample chain is the reference."""
+    B, N = 40, 128
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_pc_xyz=synth.scene_cloud(B, N, seed=9).to(dev()))
+    x = synth.gaussian("tb_x", (B, N, 6)).to(dev())
+    t = (torch.arange(B, device=dev()) * 12) % 500
+    try:
+        with torch.no_grad():
+            got = cdm(x, t, **kw)
+            cdm.serial_latent = True
+            want = cdm(x, t, **kw)
+    finally:
+        cdm.serial_latent = False
+    report("CDM forward B=40: batched chain vs serial chain", got, want.cpu(), 2e-5)
+    with torch.no_grad():
+        parts = torch.cat([cdm(x[a:b], t[a:b], **{k: v[a:b] for k, v in kw.items()}) for a, b in ((0, 1), (1, 3), (3, 40))])
+    assert torch.equal(parts, got), "a sample's result must not depend on which batch it is computed in"
