@@ -291,6 +291,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._streams = []
         self.no_fold = bool(os.environ.get("AFM_CDM_NO_FOLD"))      # measurement knob: the layer-by-layer sampling form
         self.serial_latent = bool(os.environ.get("AFM_CDM_SERIAL_LATENT"))   # measurement knob: latent chain as one workgroup per sample
+        self.valu_reduce = bool(os.environ.get("AFM_CDM_VALU_REDUCE"))       # measurement knob: enc_reduce on the VALU instead of MFMA
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
@@ -298,7 +299,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
-            w.flags = ffi.CDM_SERIAL_LATENT if self.serial_latent else 0
+            w.flags = (ffi.CDM_SERIAL_LATENT if self.serial_latent else 0) | (ffi.CDM_VALU_REDUCE if self.valu_reduce else 0)
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -364,7 +365,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
-        w.flags = ffi.CDM_SERIAL_LATENT if self.serial_latent else 0
+        w.flags = (ffi.CDM_SERIAL_LATENT if self.serial_latent else 0) | (ffi.CDM_VALU_REDUCE if self.valu_reduce else 0)
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):

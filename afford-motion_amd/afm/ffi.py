@@ -20,7 +20,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE = 0x1
-CDM_SERIAL_LATENT = 0x1
+CDM_SERIAL_LATENT, CDM_VALU_REDUCE = 0x1, 0x2
 ABI_VERSION = 4
 MAX_LAYERS = 16
 

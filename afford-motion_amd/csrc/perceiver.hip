@@ -228,6 +228,167 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- enc_reduce on the matrix pipe
+// The form above spends ~500 issue slots per point and wave on two contractions a matrix core does natively: the 16 scores of a
+// point (LN(e_n) . u_q over 256 channels) and the weighted row sums (sum_n p_nq LN(e_n)).  Here a wave takes 16 points at a time:
+//   layout A  lane (p = lane & 15, g = lane >> 4) holds channels {16 j + 4 g + e} of point p (16 float4 loads straight from memory);
+//   LayerNorm statistics on the VALU in layout A (64 values per lane + two cross-lane steps), y = (e - mean) * rstd WITHOUT the affine
+//             part: gamma is folded into the queries (u'_q = gamma * u_q), beta into the score constants and into the final sums;
+//   scores    S[p, q] = sum_c y[p, c] u'[q, c]: 64 x v_mfma_f32_16x16x4_f32, A = y and B = u' both in layout A (k = channel);
+//   softmax   online over the point tiles in the accumulator layout (lane (q, g) holds points 4 g + r): tile maximum / sum across g;
+//   sums      Acc[q, c] += sum_p P[p, q] y[p, c]: 64 MFMAs, A = P (the score accumulators as they are), B = y with the POINT as k:
+//             the one transposition of the tile, through a per-wave LDS tile [16][260] (conflict-free b128 writes, b32 reads).
+// The next tile's rows are fetched while the second product runs.  ~40 VALU + 8 MFMA per point instead of ~320 VALU + ~170 SALU.
+// Exact f32 products, f32 accumulation (v_mfma_f32_16x16x4_f32); a re-association of the same arithmetic (tests: 2e-5 vs the VALU form).
+constexpr int ERM_WAVES = 8, ERM_SPLIT = NPART / ERM_WAVES;       // workgroups per sample x waves = NPART partials, as in the VALU form
+constexpr int ERM_LDY = 260;
+constexpr int ERM_LDS_FLOATS = ERM_WAVES * 16 * ERM_LDY + 16 * ERM_LDY + 8 * 256 + 16 + ERM_WAVES * 16;
+
+// One workgroup of 8 waves per CU (158 KB of LDS: eight transposition tiles, the 16 folded queries u' = gamma * u_q shared by the
+// waves - they are all of one sample -, the contact columns of the adapter); registers: 64 (rows) + 64 (sums) per lane.
+template <bool FOLD>
+__global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
+                                                                           const float* __restrict__ cu_text, const float* __restrict__ u_time,
+                                                                           const float* __restrict__ cu_time, const int64_t* __restrict__ t, int n_t,
+                                                                           int N, float* __restrict__ pm, float* __restrict__ pl,
+                                                                           float* __restrict__ pacc, const float* __restrict__ xt,
+                                                                           const float* __restrict__ xu, int cd) {
+    constexpr int NQ = 16, LDY = ERM_LDY, NT = 64 * ERM_WAVES;
+    extern __shared__ __attribute__((aligned(16))) float er_sm[];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    float* ytile = er_sm + wave * 16 * LDY;                       // this wave's transposition tile
+    float* ups = er_sm + ERM_WAVES * 16 * LDY;                    // [16][LDY] u'_q = gamma * u_q
+    float* xus = ups + 16 * LDY;                                  // [8][256] contact columns of the adapter (FOLD)
+    float* ccs = xus + 8 * 256;                                   // [16] beta . u_q + c_q
+    float* tr = ccs + 16 + wave * 16;                             // 16 floats per wave: a 16-vector from lanes (q, .) to lanes (., g)
+    int64_t ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
+    // folded query q < 8: text latent of the sample, else the time latent of t[b]
+    auto uptr = [&](int q) { return q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256; };
+    for (int i = threadIdx.x; i < NQ * 64; i += NT) {              // (query, float4) items
+        const int q = i >> 6, c = (i & 63) * 4;
+        const float4 u = *reinterpret_cast<const float4*>(uptr(q) + c), gm = *reinterpret_cast<const float4*>(kvn.g + c);
+        *reinterpret_cast<float4*>(ups + q * LDY + c) = make_float4(u.x * gm.x, u.y * gm.y, u.z * gm.z, u.w * gm.w);
+    }
+    for (int q = wave; q < NQ; q += ERM_WAVES) {                  // one wave per dot product beta . u_q
+        const float4 u = *reinterpret_cast<const float4*>(uptr(q) + lane * 4), bt = *reinterpret_cast<const float4*>(kvn.b + lane * 4);
+        const float d = wave_sum((u.x * bt.x + u.y * bt.y) + (u.z * bt.z + u.w * bt.w));
+        if (lane == 0) ccs[q] = d + (q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]);
+    }
+    if (FOLD) {
+        for (int i = threadIdx.x; i < 8 * 256; i += NT) xus[i] = i < cd * 256 ? xu[i] : 0.f;
+    }
+    __syncthreads();
+    const float cconst = ccs[p16];
+
+    const int per = (N + ERM_SPLIT - 1) / ERM_SPLIT;
+    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    const int wper = ((per + ERM_WAVES - 1) / ERM_WAVES + 15) & ~15;      // points per wave, whole tiles
+    const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
+
+    f32x4 acc[16];                                                // Acc[q = 4 g + r][c = 16 t + p16]
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;                          // of query p16, replicated over g
+
+    float4 e[16];
+    float xrow[8];
+    auto fetch = [&](int nb) {                                     // rows of tile [nb, nb + 16): this lane's 64 channels of point nb + p16
+        const int64_t pt = (int64_t)b * N + min(nb + p16, n1 - 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e[j] = *reinterpret_cast<const float4*>(enc_kv + pt * 256 + 16 * j + 4 * g);
+        if (FOLD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xrow[j] = xt[pt * cd + min(j, cd - 1)];
+        }
+    };
+    if (w0 < w1) fetch(w0);
+    for (int nb = w0; nb < w1; nb += 16) {
+        if (FOLD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cd) {                                      // wave-uniform
+                    const float xj = xrow[j];
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const float4 w = *reinterpret_cast<const float4*>(xus + j * 256 + 16 * jj + 4 * g);
+                        e[jj].x += xj * w.x; e[jj].y += xj * w.y; e[jj].z += xj * w.z; e[jj].w += xj * w.w;
+                    }
+                }
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += (e[j].x + e[j].y) + (e[j].z + e[j].w);
+        sum += xor16(sum); sum += xor32(sum);
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            e[j].x -= mean; e[j].y -= mean; e[j].z -= mean; e[j].w -= mean;
+            sq += (e[j].x * e[j].x + e[j].y * e[j].y) + (e[j].z * e[j].z + e[j].w * e[j].w);
+        }
+        sq += xor16(sq); sq += xor32(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + 1e-5f);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sc1 = sc, sc2 = sc, sc3 = sc;      // four independent accumulation chains
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            e[j].x *= rstd; e[j].y *= rstd; e[j].z *= rstd; e[j].w *= rstd;
+            *reinterpret_cast<float4*>(ytile + p16 * LDY + 16 * j + 4 * g) = e[j];
+            const float4 u4 = *reinterpret_cast<const float4*>(ups + p16 * LDY + 16 * j + 4 * g);      // lane (q = p16, g): u'_q of the same channels
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(e[j].x, u4.x, sc, 0, 0, 0);
+            sc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e[j].y, u4.y, sc1, 0, 0, 0);
+            sc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e[j].z, u4.z, sc2, 0, 0, 0);
+            sc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(e[j].w, u4.w, sc3, 0, 0, 0);
+        }
+        sc = (sc + sc1) + (sc2 + sc3);
+        const int nvalid = w1 - nb;                                // points 4 g + r >= nvalid do not exist
+        if (nb + 16 < w1) fetch(nb + 16);                          // e[] is free: the next tile's rows fly under the second product
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = (4 * g + r < nvalid) ? sc[r] + cconst : -INFINITY;
+            mt = fmaxf(mt, sc[r]);
+        }
+        mt = fmaxf(mt, xor16(mt)); mt = fmaxf(mt, xor32(mt));
+        const float mn = fmaxf(m_run, mt);                         // finite: every processed tile has a valid point
+        const float alpha = __expf(m_run - mn);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = __expf(sc[r] - mn); ls += sc[r]; }
+        ls += xor16(ls); ls += xor32(ls);
+        l_run = l_run * alpha + ls;
+        m_run = mn;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {     // some query's maximum moved: rescale its sums (rows q = 4 g + r)
+            if (g == 0) tr[p16] = alpha;
+            const float a0 = tr[4 * g], a1 = tr[4 * g + 1], a2 = tr[4 * g + 2], a3 = tr[4 * g + 3];
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) { acc[tt][0] *= a0; acc[tt][1] *= a1; acc[tt][2] *= a2; acc[tt][3] *= a3; }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r], ytile[(4 * g + r) * LDY + 16 * tt + p16], acc[tt], 0, 0, 0);
+            if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS operand reads of four column tiles at a time in flight, not of all 16
+        }
+    }
+    // partial of this wave: true sums = gamma_c * Acc + beta_c * l_q
+    const int part = blockIdx.x * ERM_WAVES + wave;
+    const int64_t base = ((int64_t)b * NPART + part) * NQ;
+    if (g == 0) { pm[base + p16] = m_run; pl[base + p16] = l_run; tr[p16] = l_run; }
+    const float l0 = tr[4 * g], l1 = tr[4 * g + 1], l2 = tr[4 * g + 2], l3 = tr[4 * g + 3];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+        const int c = 16 * tt + p16;
+        const float gm = kvn.g[c], bt = kvn.b[c];
+        pacc[(base + 4 * g + 0) * 256 + c] = gm * acc[tt][0] + bt * l0;
+        pacc[(base + 4 * g + 1) * 256 + c] = gm * acc[tt][1] + bt * l1;
+        pacc[(base + 4 * g + 2) * 256 + c] = gm * acc[tt][2] + bt * l2;
+        pacc[(base + 4 * g + 3) * 256 + c] = gm * acc[tt][3] + bt * l3;
+    }
+}
+
 // ---------------------------------------------------------------- latent_post
 // grid B, block 1024.  Output dec_lat [B][ G(2*Hd*dkv) | P(2*Hd*dkv) | cb(2*Hd) ]
 __global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ q0_text,
@@ -852,6 +1013,33 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
     }
 }
 
+// enc_reduce: the matrix-pipe form, or the VALU form (measurement knob AFM_CDM_VALU_REDUCE)
+int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* text_u, const float* text_cu, const int64_t* t, int B, int N,
+                      const CdmWs& ws, const float* x_t, bool fold, hipStream_t s) {
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    const float* xu = fold ? w.fold_xu : nullptr;
+    const int cd = fold ? w.contact_dim : 0;
+    if (w.flags & AFM_CDM_VALU_REDUCE) {
+        if (fold) hipLaunchKernelGGL((enc_reduce_kernel<16, true>), dim3(NSPLIT, B), dim3(256), 0, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                     w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
+        else hipLaunchKernelGGL((enc_reduce_kernel<16, false>), dim3(NSPLIT, B), dim3(256), 0, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
+    } else {
+        constexpr int LDS = ERM_LDS_FLOATS * (int)sizeof(float);
+        static const int attr = []() {
+            int rc = (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            return rc ? rc : (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        }();
+        if (attr != 0) return attr;
+        if (fold) hipLaunchKernelGGL(enc_reduce_mfma_kernel<true>, dim3(ERM_SPLIT, B), dim3(64 * ERM_WAVES), LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                     w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
+        else hipLaunchKernelGGL(enc_reduce_mfma_kernel<false>, dim3(ERM_SPLIT, B), dim3(64 * ERM_WAVES), LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
+    }
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_toklin(const TokLin& p, hipStream_t s) {
     const size_t lds = ((size_t)TL_TOK * (p.K + 4) + (size_t)TL_OB * p.K) * sizeof(float);
     static const int attr = (int)hipFuncSetAttribute((const void*)toklin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -957,12 +1145,7 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
                        bool prepared, hipStream_t s) {
     const int M = B * N, dkv = w.dkv, cd = w.contact_dim;
     if (!prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        hipLaunchKernelGGL((enc_reduce_kernel<16, true>), dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
-                           w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.fold_xu, cd);
-        AFM_CHECK_LAUNCH();
-    }
+    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, true, s));
     AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
@@ -1017,12 +1200,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     // with a side stream the GEMM runs under the latent chain and the two join in front of dec_attend.
     hipStream_t side = (hipStream_t)side_stream;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        hipLaunchKernelGGL((enc_reduce_kernel<16, false>), dim3(NSPLIT, B), dim3(256), 0, s, ws.enc_kv, w.enc_kv_norm, text_u, text_cu, w.time_u,
-                           w.time_cu, t, w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, (const float*)nullptr, (const float*)nullptr, 0);
-        AFM_CHECK_LAUNCH();
-    }
+    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, nullptr, false, s));
     if (side) {           // fork AFTER enc_reduce (a full-chip kernel): the GEMM shares the chip with latent_post only
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();

@@ -515,6 +515,7 @@ typedef struct {
     const float* fold_c0;      /* [contact_dim]  contact_layer.w @ (dec_mlp.fc2.b + dec_attn.o.b) + contact_layer.b */
 } afm_cdm_weights;
 
+#define AFM_CDM_VALU_REDUCE   0x2      /* measurement: enc_reduce on the VALU (one wave per point) instead of the 16x16x4 MFMA form */
 #define AFM_CDM_SERIAL_LATENT 0x1      /* measurement: the latent chain as one workgroup per sample (latent_post_kernel) instead of batched stages */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
