@@ -914,6 +914,186 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- dec_attend on the matrix pipe
+// Same idea as enc_reduce_mfma_kernel, per tile of 16 points and wave, everything row-shaped stays in layout A (lane (p, g): channels
+// {16 j + 4 g + e} of point p):
+//   scores    S[p, jh] = sum_c yhat[p, c] G'[jh, c] with G' = gamma_q * G (LayerNorm's affine part folded into the keys and the score
+//             constants): 64 MFMAs, result in lanes (jh, g) for points 4 g + r; the two keys of a head are 8 lanes apart (one DPP step);
+//   output    O^T[c, p] = sum_jh P[jh, c] a[p, jh]: 64 MFMAs with the CHANNEL as the output row, so that the result lands in layout A
+//             (lane (p, g), channel 16 t + 4 g + r) next to the query row it is added to; the only transposition is the 16 x 16
+//             matrix of attention weights (1 KB per wave through LDS);
+//   folded    contact_layer.w . (attention output) = sum_jh a[p, jh] WP[r, jh]: 4 more MFMAs (the 8 output rows are the contact channels);
+//   residual + second LayerNorm + affine on the VALU in layout A, rows written with 16-byte stores.
+// G', P, the three channel vectors (b_o, gamma_mlp, beta_mlp) and the contact columns live in LDS once per workgroup (one sample).
+constexpr int DAM_LDG = 260;
+constexpr int DAM_LDS_FLOATS = 2 * 16 * DAM_LDG + 3 * 256 + 16 + 8 * 16 + 8 * 256 + 4 * 16 * 17;
+
+template <bool FOLD>
+__global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat, afm_ln qn,
+                                                                const float* __restrict__ bo, afm_ln mlpn, int N, float* __restrict__ h1,
+                                                                float* __restrict__ z, const float* __restrict__ xt,
+                                                                const float* __restrict__ xv, int cd, float* __restrict__ s1) {
+    constexpr int NJH = 16, LDG = DAM_LDG;
+    extern __shared__ __attribute__((aligned(16))) float da_sm[];
+    float* Gs = da_sm;                                            // [16][LDG]  gamma_q * G
+    float* Ps = Gs + 16 * LDG;                                    // [16][LDG]  P
+    float* vec3 = Ps + 16 * LDG;                                  // [3][256]   b_o, gamma_mlp, beta_mlp
+    float* gcs = vec3 + 3 * 256;                                  // [16]       beta_q . G[jh] + cb[jh]
+    float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P  (rows >= cd: 0)
+    float* xvs = WPs + 8 * 16;                                    // [8][256]   contact columns of the decoder query (FOLD)
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    float* aT = xvs + 8 * 256 + wave * 16 * 17;                   // [16 points][17] attention weights of the tile, transposed
+    const float* rec = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
+    for (int i = threadIdx.x; i < NJH * 64; i += 256) {            // (jh, float4) items
+        const int jh = i >> 6, c = (i & 63) * 4;
+        const float4 gv = *reinterpret_cast<const float4*>(rec + jh * 256 + c), pv = *reinterpret_cast<const float4*>(rec + NJH * 256 + jh * 256 + c),
+                     gm = *reinterpret_cast<const float4*>(qn.g + c);
+        *reinterpret_cast<float4*>(Gs + jh * LDG + c) = make_float4(gv.x * gm.x, gv.y * gm.y, gv.z * gm.z, gv.w * gm.w);
+        *reinterpret_cast<float4*>(Ps + jh * LDG + c) = pv;
+    }
+    for (int jh = wave; jh < NJH; jh += 4) {
+        const float4 gv = *reinterpret_cast<const float4*>(rec + jh * 256 + lane * 4), bt = *reinterpret_cast<const float4*>(qn.b + lane * 4);
+        const float d = wave_sum((gv.x * bt.x + gv.y * bt.y) + (gv.z * bt.z + gv.w * bt.w));
+        if (lane == 0) gcs[jh] = d + rec[2 * NJH * 256 + jh];
+    }
+    for (int i = threadIdx.x; i < 256; i += 256) { vec3[i] = bo[i]; vec3[256 + i] = mlpn.g[i]; vec3[512 + i] = mlpn.b[i]; }
+    if (threadIdx.x < 8 * 16) WPs[threadIdx.x] = (FOLD && (int)(threadIdx.x >> 4) < cd) ? rec[2 * NJH * 256 + NJH + threadIdx.x] : 0.f;
+    if (FOLD) {
+        for (int i = threadIdx.x; i < 8 * 256; i += 256) xvs[i] = i < cd * 256 ? xv[i] : 0.f;
+    }
+    __syncthreads();
+    const float gconst = gcs[p16];
+
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    const int wper = ((per + 3) / 4 + 15) & ~15;                  // points per wave, whole tiles
+    const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
+
+    float4 e[16];
+    float xrow[8];
+    auto fetch = [&](int nb) {                                     // 32-bit element offsets from the uniform bases (one address register per load)
+        const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
+        const unsigned ro = pti * 256u + 4u * (unsigned)g;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e[j] = *reinterpret_cast<const float4*>(dec_q0 + (ro + 16u * j));
+        if (FOLD) {
+            const unsigned xo = pti * (unsigned)cd;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xrow[j] = xt[xo + (unsigned)min(j, cd - 1)];
+        }
+    };
+    if (w0 < w1) fetch(w0);
+    for (int nb = w0; nb < w1; nb += 16) {
+        const int64_t pt = (int64_t)b * N + nb + p16;
+        const bool pvalid = nb + p16 < w1;
+        if (FOLD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j >= cd) break;                                // wave-uniform
+                const float xj = xrow[j];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const float4 w = *reinterpret_cast<const float4*>(xvs + j * 256 + 16 * jj + 4 * g);
+                    e[jj].x += xj * w.x; e[jj].y += xj * w.y; e[jj].z += xj * w.z; e[jj].w += xj * w.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);               // one contact column's LDS reads in flight at a time (registers)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // phase boundary: keeps the scheduler from overlapping phases (registers)
+        // LayerNorm statistics of the query row; scores against the folded keys (affine part inside G' / gconst)
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += (e[j].x + e[j].y) + (e[j].z + e[j].w);
+        sum += xor16(sum); sum += xor32(sum);
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float a0 = e[j].x - mean, a1 = e[j].y - mean, a2 = e[j].z - mean, a3 = e[j].w - mean;
+            sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        sq += xor16(sq); sq += xor32(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + 1e-5f);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sc1 = sc, sc2 = sc, sc3 = sc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 g4 = *reinterpret_cast<const float4*>(Gs + p16 * LDG + 16 * j + 4 * g);        // lane (jh = p16, g)
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].x - mean) * rstd, g4.x, sc, 0, 0, 0);
+            sc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].y - mean) * rstd, g4.y, sc1, 0, 0, 0);
+            sc2 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].z - mean) * rstd, g4.z, sc2, 0, 0, 0);
+            sc3 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].w - mean) * rstd, g4.w, sc3, 0, 0, 0);
+        }
+        sc = (sc + sc1) + (sc2 + sc3);
+        __builtin_amdgcn_sched_barrier(0);                         // phase boundary: keeps the scheduler from overlapping phases (registers)
+        // softmax over the two keys of a head (jh and jh ^ 8: eight lanes apart), then the weights transposed to (point, jh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s_own = sc[r] + gconst, s_oth = lane_xor<8>(s_own);
+            const float mx = fmaxf(s_own, s_oth);
+            const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
+            aT[(4 * g + r) * 17 + p16] = e_own / (e_own + e_oth);
+        }
+        float aB[4];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) aB[sI] = aT[p16 * 17 + 4 * g + sI];       // lane (p = p16, g): a[p, jh = 4 g + s]
+        f32x4 acc[16];
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+            acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ps[(4 * g + sI) * LDG + 16 * tt + p16], aB[sI], acc[tt], 0, 0, 0);
+            if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FOLD) {                                                // contact_layer.w . (attention output): rows = contact channels
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? WPs[p16 * 16 + 4 * g + sI] : 0.f, aB[sI], sa, 0, 0, 0);
+            if (pvalid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < cd) s1[pt * cd + 4 * g + r] = sa[r];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // phase boundary: keeps the scheduler from overlapping phases (registers)
+        // residual (adds the raw query row) in layout A, then e[] is free for the next tile's rows
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 ob = *reinterpret_cast<const float4*>(vec3 + 16 * j + 4 * g);
+            acc[j][0] = (acc[j][0] + ob.x) + e[j].x; acc[j][1] = (acc[j][1] + ob.y) + e[j].y;
+            acc[j][2] = (acc[j][2] + ob.z) + e[j].z; acc[j][3] = (acc[j][3] + ob.w) + e[j].w;
+            // (the residual stream is stored in the layered form only: h1 == NULL in the folded one.  The test stays a run-time one on
+            // purpose: with the store compiled out hipcc schedules this phase into 40 more live registers and spills)
+            if (pvalid && h1) *reinterpret_cast<float4*>(h1 + pt * 256 + 16 * j + 4 * g) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // phase boundary: keeps the scheduler from overlapping phases (registers)
+        if (nb + 16 < w1) fetch(nb + 16);
+        __builtin_amdgcn_sched_barrier(0);                         // phase boundary: keeps the scheduler from overlapping phases (registers)
+        float sum2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum2 += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+        sum2 += xor16(sum2); sum2 += xor32(sum2);
+        const float mean2 = sum2 * (1.0f / 256.0f);
+        float sq2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[j][0] -= mean2; acc[j][1] -= mean2; acc[j][2] -= mean2; acc[j][3] -= mean2;
+            sq2 += (acc[j][0] * acc[j][0] + acc[j][1] * acc[j][1]) + (acc[j][2] * acc[j][2] + acc[j][3] * acc[j][3]);
+        }
+        sq2 += xor16(sq2); sq2 += xor32(sq2);
+        const float rstd2 = 1.0f / sqrtf(sq2 * (1.0f / 256.0f) + 1e-5f);
+        if (pvalid) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 g2 = *reinterpret_cast<const float4*>(vec3 + 256 + 16 * j + 4 * g), b2 = *reinterpret_cast<const float4*>(vec3 + 512 + 16 * j + 4 * g);
+                *reinterpret_cast<float4*>(z + pt * 256 + 16 * j + 4 * g) =
+                    make_float4(acc[j][0] * rstd2 * g2.x + b2.x, acc[j][1] * rstd2 * g2.y + b2.y, acc[j][2] * rstd2 * g2.z + b2.z, acc[j][3] * rstd2 * g2.w + b2.w);
+            }
+        }
+    }
+}
+
 struct CdmWs {
     float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
     float *lat_s, *lat_x, *lat_t1, *lat_t2, *lat_qkv, *lat_kv;     // batched latent chain: [2B] token rows
@@ -1040,6 +1220,35 @@ int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* 
     return 0;
 }
 
+// dec_attend: the matrix-pipe form, or the VALU form (measurement knob AFM_CDM_VALU_REDUCE)
+int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, bool fold, hipStream_t s) {
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    const int cd = fold ? w.contact_dim : 0;
+    if (w.flags & AFM_CDM_VALU_REDUCE) {
+        int chunks = (N + 255) / 256;
+        if (chunks > 64) chunks = 64;
+        if (fold) hipLaunchKernelGGL((dec_attend_kernel<8, true>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                     (float*)nullptr, ws.z, x_t, w.fold_xv, cd, ws.s1);
+        else hipLaunchKernelGGL((dec_attend_kernel<8, false>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
+    } else {
+        constexpr int LDS = DAM_LDS_FLOATS * (int)sizeof(float);
+        static const int attr = []() {
+            int rc = (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            return rc ? rc : (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        }();
+        if (attr != 0) return attr;
+        int chunks = (N + 511) / 512;                              // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
+        if (chunks > 16) chunks = 16;
+        if (fold) hipLaunchKernelGGL(dec_attend_mfma_kernel<true>, dim3(chunks, B), dim3(256), LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                     (float*)nullptr, ws.z, x_t, w.fold_xv, cd, ws.s1);
+        else hipLaunchKernelGGL(dec_attend_mfma_kernel<false>, dim3(chunks, B), dim3(256), LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
+    }
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_toklin(const TokLin& p, hipStream_t s) {
     const size_t lds = ((size_t)TL_TOK * (p.K + 4) + (size_t)TL_OB * p.K) * sizeof(float);
     static const int attr = (int)hipFuncSetAttribute((const void*)toklin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1147,14 +1356,7 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
     if (!prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
     AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, true, s));
     AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        int chunks = (N + 255) / 256;
-        if (chunks > 64) chunks = 64;
-        hipLaunchKernelGGL((dec_attend_kernel<8, true>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b,
-                           w.dec_mlp.norm, N, (float*)nullptr, ws.z, x_t, w.fold_xv, cd, ws.s1);
-        AFM_CHECK_LAUNCH();
-    }
+    AFM_TRY(launch_dec_attend(w, B, N, ws, x_t, true, s));
     afm_linear_args a = {};                 // GELU(linear1 z) . w2 per 64-column group; the hidden activations are never stored
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
     a.rowdot_w = w.fold_w2; a.rowdot_out = ws.rdot; a.rowdot_n = cd;
@@ -1227,14 +1429,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
         a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));
     }
-    {
-        AfmProf prof(AFM_PROF_CDM, 0.0, s);
-        int chunks = (N + 255) / 256;
-        if (chunks > 64) chunks = 64;
-        hipLaunchKernelGGL((dec_attend_kernel<8, false>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b,
-                           w.dec_mlp.norm, N, ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
-        AFM_CHECK_LAUNCH();
-    }
+    AFM_TRY(launch_dec_attend(w, B, N, ws, nullptr, false, s));
     a = {};
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
