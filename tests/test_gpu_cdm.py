@@ -192,8 +192,8 @@ def test_folded_sampling_form_and_batched_latent_chain_match_the_layered_form(cd
     """Round 2: in eval mode the CDM samples in a FOLDED form (step-invariant parts of the two adapters hoisted out of the loop, linear2 +
     residual + contact_layer collapsed into row-dots in linear1's epilogue, h1 never stored) and runs its 2-latent chain as batched
     stages over all samples.  Both are re-associations of the same f32 arithmetic: against the layer-by-layer form / the one-workgroup-
-    per-sample chain (measurement knobs `no_fold`, `serial_latent`) a forward agrees to 2e-5 and an 8-step loop to 1e-4; the batched
-    chain must be bit-identical for every sub-batching of the loop (it only ever sees whole samples)."""
+    per-sample chain / the round-1 VALU per-point kernels (measurement knobs `no_fold`, `serial_latent`, `valu_reduce`; "layered" is the
+    complete round-1 path) a forward agrees to 2e-5 and an 8-step loop to 1e-4."""
     B, N = 5, 512
     kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_pc_xyz=synth.scene_cloud(B, N, seed=4).to(dev()))
     x = synth.gaussian("fold_x", (B, N, 6)).to(dev())
@@ -201,16 +201,17 @@ def test_folded_sampling_form_and_batched_latent_chain_match_the_layered_form(cd
     d8 = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="8"))
     res = {}
     try:
-        for tag, (nf, sl) in dict(default=(False, False), serial_latent=(False, True), layered=(True, True), layered_chain=(True, False)).items():
-            cdm.no_fold, cdm.serial_latent = nf, sl
+        for tag, (nf, sl, vr) in dict(default=(False, False, False), serial_latent=(False, True, False), layered=(True, True, True),
+                                      layered_chain=(True, False, False), valu_kernels=(False, False, True)).items():
+            cdm.no_fold, cdm.serial_latent, cdm.valu_reduce = nf, sl, vr      # vr: per-point kernels on the VALU instead of 16x16x4 MFMA
             with torch.no_grad():
                 f = cdm(x, t, **kw)
             res[tag] = (f, d8.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=5))
     finally:
-        cdm.no_fold = cdm.serial_latent = False
+        cdm.no_fold = cdm.serial_latent = cdm.valu_reduce = False
     w = cdm._weights()
     assert w.fold_xu and w.fold_w2 and w.fold_q, "eval-mode pack carries the folded weight products"
-    for tag in ("serial_latent", "layered", "layered_chain"):
+    for tag in ("serial_latent", "layered", "layered_chain", "valu_kernels"):
         report(f"CDM forward: default vs {tag}", res["default"][0], res[tag][0].cpu(), 2e-5)
         report(f"CDM 8-step loop: default vs {tag}", res["default"][1], res[tag][1].cpu(), 1e-4)
     assert not torch.equal(res["default"][0], res["layered"][0])              # the knobs really select other code
