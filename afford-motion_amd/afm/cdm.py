@@ -284,7 +284,10 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._ws = {}
         import os
         self.overlap_streams = os.environ.get("AFM_CDM_OVERLAP", "1") != "0"
-        self.loop_sub_batches = int(os.environ.get("AFM_CDM_LOOP_SUBBATCH", "1"))   # measured at B=32: 1: 2.19, 2: 2.41, 3: 2.22 ms/step
+        # sub-batches of the native loop on their own streams: 0 = automatic (two from B = 16 on: one sub-batch's 2-latent chain - 17 small
+        # dependent launches, a third of its step - runs under the other's full-chip kernels; measured at B = 32 with the round-2
+        # kernels: 1: 0.933, 2: 0.891, 3: 0.954, 4: 1.346 ms/step), AFM_CDM_LOOP_SUBBATCH overrides
+        self.loop_sub_batches = int(os.environ.get("AFM_CDM_LOOP_SUBBATCH", "0"))
         if self.arch != "Perceiver":
             self.afm_native_loop = None         # other archs sample step by step
         self.sub_batches = int(os.environ.get("AFM_CDM_SUBBATCH", "1"))     # >1 costs more host time per step than it hides (measured)
@@ -470,8 +473,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
     def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False):
         """Whole p_sample_loop of the ADM on the device (afm_cdm_sample_loop): x holds x_T on entry, returns the sample.  ``progress``
         slices the chain (afm_cdm_sample_loop_range) so a tqdm bar can advance, with bit-identical results.  The batch
-        can run as `loop_sub_batches` sub-batches on their own stream pairs (AFM_CDM_LOOP_SUBBATCH; default 1: the M = B*N GEMMs are
-        already efficient and the latent chain is hidden by the side stream, splitting only costs)."""
+        runs as `loop_sub_batches` sub-batches on their own stream pairs (two from B = 16 on, see __init__; bit-identical results)."""
         if self.arch != "Perceiver":
             raise NotImplementedError("the native loop covers the Perceiver arch")
         lib = ffi.load()
@@ -486,7 +488,8 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             tab = diffusion.tables(dev)
             n = diffusion.num_timesteps
             sched = torch.empty(lib.afm_cmdm_sched_scratch_bytes(n, B), dtype=torch.uint8, device=dev)
-            nsub = max(1, min(int(self.loop_sub_batches), B))
+            nsub = int(self.loop_sub_batches) or (2 if B >= 16 else 1)
+            nsub = max(1, min(nsub, B))
             need = 2 * nsub if nsub > 1 else (1 if self.overlap_streams else 0)
             while len(self._streams) < need:
                 self._streams.append(torch.cuda.Stream(device=dev))
