@@ -65,6 +65,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                         rc = rc or 1
                 continue
             keep.append(line)
+        if rc != 0 and os.path.exists(o):
+            os.remove(o)           # a rejected object must not satisfy the next (incremental) build
         return s, rc, "\n".join(keep)
 
     with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:

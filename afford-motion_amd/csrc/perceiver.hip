@@ -727,24 +727,48 @@ __global__ __launch_bounds__(256) void lat_decfold_kernel(const afm_cdm_weights 
     float* P = G + njh * dkv;
     float* cb = P + njh * dkv;
     float* WP = cb + njh;
+    // Both latents of the sample share the weight reads: W_q rows h*hdd .. (coalesced over c) and the 32-float run of W_o's row c
+    // (eight 16-byte loads per thread, issued together, instead of 2 x 32 dependent 4-byte loads at a 1 KB stride).
+    // The 4 x hdd key / value entries of this (sample, head) are staged in LDS and read back into VGPRs, NOT read with scalar loads.
+    // The scalar-load form of this kernel (operands of the packed-f32 products in SGPR pairs) was non-deterministic on MI355X whenever
+    // the other sub-batch stream had kernels in flight: in ~1/4 of 50-step loops single waves lost ONE product of the P sum in lanes
+    // 48..63 (always one with an odd-indexed SGPR operand).  Stale caches, instruction alignment and SGPR write-after-read were ruled
+    // out by experiment and two instruction-level replays did not reproduce it, so the mechanism is open; this form ran 80/80 loops
+    // bit-identical in the same harness (profiles/r02_decfold_nondeterminism.md, tests/test_gpu_cdm.py::test_two_sub_batch_loop_repeats).
+    __shared__ __attribute__((aligned(16))) float kvs[4][32];     // [k of latent 0 | k of latent 1 | v of latent 0 | v of latent 1][hdd <= 32]
+    if (c < 4 * hdd) {
+        const int a = c / hdd, r = c - a * hdd;
+        kvs[a][r] = kv[((int64_t)b * 2 + (a & 1)) * 2 * dkv + (a >> 1) * dkv + h * hdd + r];
+    }
+    __syncthreads();
     float pj[2];
+    {
+        const float *kd0 = kvs[0], *kd1 = kvs[1], *vd0 = kvs[2], *vd1 = kvs[3];
+        float4 ow[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float* kd = kv + ((int64_t)b * 2 + j) * 2 * dkv + h * hdd;
-        const float* vd = kd + dkv;
-        float a = 0.f, pp = 0.f;
+        for (int u = 0; u < 8; ++u) ow[u] = (4 * u < hdd) ? *reinterpret_cast<const float4*>(w.dec_attn.o.w + (int64_t)c * dkv + h * hdd + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float a0 = 0.f, a1 = 0.f, p0 = 0.f, p1 = 0.f;
+#pragma unroll 8
         for (int r = 0; r < hdd; ++r) {
-            a += w.dec_attn.q.w[(int64_t)(h * hdd + r) * dkv + c] * kd[r];
-            pp += w.dec_attn.o.w[(int64_t)c * dkv + h * hdd + r] * vd[r];
+            const float wq = w.dec_attn.q.w[(int64_t)(h * hdd + r) * dkv + c];
+            a0 += wq * kd0[r];
+            a1 += wq * kd1[r];
         }
-        const int jh = j * Hd + h;
-        G[jh * dkv + c] = a * scd;
-        P[jh * dkv + c] = pp;
-        pj[j] = pp;
-        if (c == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (4 * u < hdd) {
+                p0 += (ow[u].x * vd0[4 * u] + ow[u].y * vd0[4 * u + 1]) + (ow[u].z * vd0[4 * u + 2] + ow[u].w * vd0[4 * u + 3]);
+                p1 += (ow[u].x * vd1[4 * u] + ow[u].y * vd1[4 * u + 1]) + (ow[u].z * vd1[4 * u + 2] + ow[u].w * vd1[4 * u + 3]);
+            }
+        }
+        G[h * dkv + c] = a0 * scd; G[(Hd + h) * dkv + c] = a1 * scd;
+        P[h * dkv + c] = p0; P[(Hd + h) * dkv + c] = p1;
+        pj[0] = p0; pj[1] = p1;
+        if (c < 2) {
+            const float* kd = c == 0 ? kd0 : kd1;
             float cbv = 0.f;
             for (int r = 0; r < hdd; ++r) cbv += w.dec_attn.q.b[h * hdd + r] * kd[r];
-            cb[jh] = cbv * scd;
+            cb[c * Hd + h] = cbv * scd;
         }
     }
     if (w.fold_xu && w.contact_dim <= 8) {                        // WP[r, jh] = contact_layer.w[r] . P[jh]

@@ -188,6 +188,31 @@ def test_config4_full_size_properties():
             assert torch.equal(got, whole[name]), f"{name}: {shards} shards of {per} samples differ from the single batch of {K}"
 
 
+def test_two_sub_batch_loop_repeats():
+    """Round 2 regression (profiles/r02_decfold_nondeterminism.md): at configs[4]'s ADM size the native loop runs as two sub-batches on
+    their own streams.  A build of lat_decfold_kernel that was correct on one stream lost single products in single waves in ~1/4 of
+    50-step loops once the second stream was active - invisible to a single run-twice check.  Twelve loops with the two streams against
+    the single-stream result, bit for bit (the failing build passed this with probability ~0.03)."""
+    K, N = 32, 8192
+    adm = create_model(cdm_cfg(num_points=N), device=dev()); load_named_weights(adm); adm = adm.to(dev()).eval()
+    d = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="50"))
+    kw = dict(c_text_feat=synth.text_feature(1).repeat(K, 1).contiguous().to(dev()),
+              c_pc_xyz=synth.scene_cloud(1, N, seed=71).repeat(K, 1, 1).contiguous().to(dev()))
+
+    def run(nsub):
+        adm.loop_sub_batches = nsub
+        return d.p_sample_loop(adm, (K, N, 6), clip_denoised=False, model_kwargs=kw, seed=5).clone()
+
+    ref = run(1)
+    assert torch.isfinite(ref).all()
+    for r in range(12):
+        junk = torch.randn(64 << 20, device=dev()) if r % 2 else None      # vary allocator state and stream timing between the loops
+        out = run(0)
+        del junk
+        bad = (out != ref).flatten(1).any(1).nonzero().flatten().tolist()
+        assert not bad, f"loop {r}: samples {bad} differ from the single-stream result (max {(out - ref).abs().max().item():.2e})"
+
+
 def test_folded_sampling_form_and_batched_latent_chain_match_the_layered_form(cdm):
     """Round 2: in eval mode the CDM samples in a FOLDED form (step-invariant parts of the two adapters hoisted out of the loop, linear2 +
     residual + contact_layer collapsed into row-dots in linear1's epilogue, h1 never stored) and runs its 2-latent chain as batched

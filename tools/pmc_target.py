@@ -23,6 +23,9 @@ if which == "cdm":
     model, diff = create_model_and_diffusion(cfg, device=dev)
     synth.fill_module_(model)
     model = model.to(dev).eval()
+    # one sub-batch stream: per-kernel durations and counters of whole-batch launches, not of two half-batch launches overlapping each
+    # other (the product default from B = 16 on is two streams; steps/s is quoted on that)
+    model.loop_sub_batches = int(os.environ.get("AFM_PROFILE_SUBBATCH", "1"))
     kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev))
     for _ in range(2):
         diff.p_sample_loop(model, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=1)
