@@ -6,7 +6,7 @@ import torch
 
 from afm import synth
 from afm.config import to_config
-from afm.base import create_model_and_diffusion, create_gaussian_diffusion
+from afm.base import create_model, create_model_and_diffusion, create_gaussian_diffusion
 from conftest import golden
 from gpu_util import dev, load_named_weights, report
 
@@ -180,6 +180,30 @@ def test_sub_batch_streams_are_bit_identical(cmdm):
         outs.append(diff.p_sample_loop(model, (2, 16, 263), clip_denoised=False, model_kwargs=kw, seed=5).cpu())
     model.loop_streams, model.loop_streams_auto = 2, True
     assert torch.equal(outs[0], outs[1])
+
+
+def test_two_stream_loop_repeats_at_the_headline_shape():
+    """Round 2 (profiles/r02_decfold_nondeterminism.md): a kernel can be bit-exact on one stream and wrong once in a while when a second
+    stream's kernels share the chip - a single run-twice check passes most of the time.  The headline loop (B = 32, L = 196, N = 8192)
+    runs as two sub-batch streams: ten 100-step loops against the single-stream result, bit for bit."""
+    B, L, N = 32, 196, 8192
+    model = create_model(cmdm_cfg(num_points=N), device=dev()); load_named_weights(model); model = model.to(dev()).eval()
+    diff = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="100"))
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_pc_xyz=synth.scene_cloud(B, N, seed=3).to(dev()),
+              c_pc_contact=synth.contact_map(B, N).to(dev()), x_mask=synth.frame_mask(B, L, seed=2).to(dev()))
+
+    def run(streams):
+        model.loop_streams, model.loop_streams_auto = streams, False
+        return diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=9).clone()
+
+    ref = run(1)
+    assert torch.isfinite(ref).all()
+    for r in range(10):
+        junk = torch.randn(32 << 20, device=dev()) if r % 2 else None      # vary allocator state and stream timing between the loops
+        out = run(2)
+        del junk
+        bad = (out != ref).flatten(1).any(1).nonzero().flatten().tolist()
+        assert not bad, f"loop {r}: samples {bad} differ from the single-stream result (max {(out - ref).abs().max().item():.2e})"
 
 
 def test_config0_100_step_loop_vs_oracle():
