@@ -126,6 +126,17 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
     }
     return v;
 }
+// 32-bit maximum / minimum over the 64 lanes, wave-uniform result: four DPP steps inside the rows, the four row results through SGPRs
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, dpp_u32<0xB1>(v)); v = max(v, dpp_u32<0x4E>(v)); v = max(v, dpp_u32<0x141>(v)); v = max(v, dpp_u32<0x140>(v));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     v = row_max_u64(v);
     unsigned long long r = 0ull;

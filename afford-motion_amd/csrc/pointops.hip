@@ -20,6 +20,12 @@
 
 #ifdef AFM_PROBE
 int afm_probe_fps_threads = 0;
+__device__ unsigned long long afm_probe_fps_cyc[8];     // summed phase cycles of wave 0 of workgroup 0 (tools/points_probe.hip)
+#endif
+#ifdef AFM_PROBE_TIMELINE      // with -DAFM_PROBE: per-phase cycle stamps inside the FPS round (they lengthen the round by ~15 %)
+#define AFM_FPS_STAMP(k) do { if (probe_) { const unsigned long long t_ = __builtin_readcyclecounter(); cyc_[k] += t_ - last_; last_ = t_; } } while (0)
+#else
+#define AFM_FPS_STAMP(k) do { } while (0)
 #endif
 
 namespace {
@@ -30,23 +36,28 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // processed as packed f32 pairs (v_pk_add / v_pk_mul: same IEEE results, half the instructions), the per-thread arg-max is a
 // 32-bit (distance bits, slot) select - slots are visited in increasing point index, so a strict '>' keeps the lowest index on
 // ties - and the 64-bit (dist | ~index) key that the wave / workgroup reduction orders by is built once per thread per round.
-template <int PPT, int MAXT = 1024>
-__global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out, int xyz_in_lds) {
+template <int PPT, int MAXT, bool IN_LDS>
+__global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
     constexpr int NP = (PPT + 1) / 2;                 // packed pairs (PPT == 1: second half is a dead slot)
     __shared__ unsigned long long keys[2][16];
     extern __shared__ float pts[];                    // [3n] copy of the sample for the winner's coordinates (critical path)
     const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     const float* P = xyz + (int64_t)b * n * 3;
-    f32x2 px[NP], py[NP], pz[NP], tmp[NP];
-    bool ok[2 * NP];
+    f32x2 px[NP], py[NP], pz[NP];
+    // running minimum distance of every slot, kept as BITS: distances are sums of squares (>= +0, never NaN), so unsigned order is
+    // float order and v_min_u32 replaces fminf (no canonicalisation of the operands, the bits feed the arg-max directly).  A slot
+    // without a point starts at 0 and stays there: it can never beat the strict '>' below (what the per-slot validity select did).
+    unsigned tmpb[2 * NP];
+    bool ok0 = false;
 #pragma unroll
     for (int s = 0; s < 2 * NP; ++s) {
         const int i = s * T + tid;
-        ok[s] = (s < PPT) && (i < n);
-        px[s >> 1][s & 1] = ok[s] ? P[i * 3 + 0] : 0.f; py[s >> 1][s & 1] = ok[s] ? P[i * 3 + 1] : 0.f; pz[s >> 1][s & 1] = ok[s] ? P[i * 3 + 2] : 0.f;
-        tmp[s >> 1][s & 1] = 1e10f;
+        const bool ok = (s < PPT) && (i < n);
+        if (s == 0) ok0 = ok;
+        px[s >> 1][s & 1] = ok ? P[i * 3 + 0] : 0.f; py[s >> 1][s & 1] = ok ? P[i * 3 + 1] : 0.f; pz[s >> 1][s & 1] = ok ? P[i * 3 + 2] : 0.f;
+        tmpb[s] = ok ? __float_as_uint(1e10f) : 0u;
     }
-    if (xyz_in_lds) {
+    if (IN_LDS) {
         for (int i0 = tid; i0 < 3 * n; i0 += 8 * T) {                // eight loads in flight per thread (not a load -> store chain per element)
             float v[8];
 #pragma unroll
@@ -56,11 +67,20 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz
         }
         __syncthreads();
     }
-    const float* C = xyz_in_lds ? pts : P;
     int cur = 0;
     if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
+#ifdef AFM_PROBE_TIMELINE
+    const bool probe_ = blockIdx.x == 0 && wave == 0;
+    unsigned long long cyc_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
     for (int j = 1; j < m; ++j) {
-        const float cx = C[cur * 3 + 0], cy = C[cur * 3 + 1], cz = C[cur * 3 + 2];
+        AFM_FPS_STAMP(5);
+        // the winner's coordinates head the round's dependent chain: an explicit LDS read (ds_read), not a generic-pointer load
+        // (a run-time `in_lds ? pts : P` compiles to flat_load, which waits on both memory counters and takes the slow aperture path)
+        float cx, cy, cz;
+        if (IN_LDS) { cx = pts[cur * 3 + 0]; cy = pts[cur * 3 + 1]; cz = pts[cur * 3 + 2]; }
+        else { cx = P[cur * 3 + 0]; cy = P[cur * 3 + 1]; cz = P[cur * 3 + 2]; }
+        AFM_FPS_STAMP(0);                             // winner's coordinates arrived
         const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
         unsigned bd = 0u, bs = 0u;                    // best distance bits (distances are >= 0: bits order like values), its slot
 #pragma unroll
@@ -71,24 +91,51 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz
             for (int h = 0; h < 2; ++h) {
                 const int s = 2 * p2 + h;
                 if (s < PPT) {
-                    tmp[p2][h] = fminf(tmp[p2][h], d[h]);
-                    const unsigned db = ok[s] ? __float_as_uint(tmp[p2][h]) : 0u;
+                    const unsigned db = min(tmpb[s], __float_as_uint(d[h]));
+                    tmpb[s] = db;
                     const bool better = db > bd;
                     bd = better ? db : bd;
                     bs = better ? (unsigned)s : bs;
                 }
             }
         }
-        // slot 0 wins an all-zero tie, which is also the lowest index of this thread; invalid threads carry key 0
+        // slot 0 wins an all-zero tie, which is also the lowest index of this thread; invalid threads carry key 0.
+        // The key orders by (distance bits, lowest point index).  Wave level: a 32-bit maximum of the distances (DPP), then the lowest
+        // index among the lanes that hold it - one ballot and one v_readlane when a single lane does (the usual case), a second 32-bit
+        // reduction only on a tie.  (A 64-bit key carried through the DPP steps costs a v_cmp_u64 + two selects per step: 250 cycles
+        // of the ~2200-cycle round, profiles/r02_points_probe.txt.)
         const unsigned bi = bs * (unsigned)T + (unsigned)tid;
-        unsigned long long best = ok[0] ? (((unsigned long long)bd << 32) | (unsigned long long)(0xFFFFFFFFu - bi)) : 0ull;
-        best = wave_max_u64(best);                    // DPP + readlane: no LDS-crossbar shuffles on the round's critical path
+        AFM_FPS_STAMP(1);                             // per-thread scan
+        const unsigned wmax = wave_max_u32(ok0 ? bd : 0u);
+        const unsigned long long holders = __builtin_amdgcn_ballot_w64(ok0 && bd == wmax);
+        unsigned long long best = 0ull;
+        if (holders) {                                // wave-uniform
+            unsigned wbi;
+            if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)bi, __builtin_ctzll(holders));
+            else wbi = wave_min_u32((ok0 && bd == wmax) ? bi : 0xFFFFFFFFu);
+            best = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
+        }
+        AFM_FPS_STAMP(2);                             // wave arg-max
         if (lane == 0) keys[j & 1][wave] = best;
         __syncthreads();
-        const unsigned long long k = row_max_u64(keys[j & 1][((lane & 15) < nw) ? (lane & 15) : 0]);   // <= 16 waves: one DPP row
-        cur = __builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)));
+        AFM_FPS_STAMP(3);                             // LDS hop + barrier
+        // workgroup level, same scheme on the <= 16 wave keys (lane l of every row reads key l; one LDS round trip)
+        const bool has = (lane & 15) < nw;
+        const unsigned long long kw = keys[j & 1][has ? (lane & 15) : 0];
+        const unsigned khi = has ? (unsigned)(kw >> 32) : 0u, klo = has ? (unsigned)kw : 0u;       // lo = ~index: larger is the lower index
+        unsigned gm = khi;
+        gm = max(gm, dpp_u32<0xB1>(gm)); gm = max(gm, dpp_u32<0x4E>(gm)); gm = max(gm, dpp_u32<0x141>(gm)); gm = max(gm, dpp_u32<0x140>(gm));
+        const unsigned long long hold2 = __builtin_amdgcn_ballot_w64(has && lane < 16 && khi == gm);       // row 0 is enough: the rows are copies
+        unsigned wlo;
+        if ((hold2 & (hold2 - 1)) == 0) wlo = (unsigned)__builtin_amdgcn_readlane((int)klo, __builtin_ctzll(hold2 | (1ull << 63)));
+        else wlo = wave_max_u32((has && khi == gm) ? klo : 0u);
+        cur = __builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu - wlo));
+        AFM_FPS_STAMP(4);                             // cross-wave arg-max
         if (tid == 0) idx_out[(int64_t)b * m + j] = b * n + cur;
     }
+#ifdef AFM_PROBE_TIMELINE
+    if (probe_ && lane == 0) for (int k = 0; k < 6; ++k) afm_probe_fps_cyc[k] = cyc_[k];
+#endif
 }
 
 constexpr int KNN_TILE = 1024;
@@ -261,10 +308,10 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
     if (!xyz || !idx_out || B < 0 || n <= 0 || m < 0 || m > n) return AFM_E_BADARG;
     if (B == 0 || m == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // Threads per workgroup: a round is a dependent chain (per-thread scan -> wave arg-max -> LDS hop -> barrier -> broadcast), and the
-    // chain gets SHORTER with fewer, fatter threads: n = 8192 measured 1.18 / 1.06 / 1.00 / 1.65 us per round with 1024 / 512 / 256 / 128
-    // threads (8 / 16 / 32 / 64 points per thread; profiles/r02_points_probe.txt) - 4 waves = one per SIMD pay the cheapest barrier and
-    // cross-wave step while 32 independent distance chains per thread still fill the VALU.  Results do not depend on the split.
+    // Threads per workgroup: a round is a dependent chain (per-thread scan -> wave arg-max -> LDS hop -> barrier -> broadcast) on ONE
+    // compute unit per sample.  Its VALU work (n points x 8 instructions: ~1100 issue cycles of the ~2100-cycle round at n = 8192) is
+    // the same for every split, the reductions are not: 0.94 / 0.96 / 0.91 us per round with 1024 / 512 / 256 threads
+    // (profiles/r02_points_probe.txt).  Results do not depend on the split.
     int T = (((n + 31) / 32 + 63) / 64) * 64;
     if (T < 64) T = 64;
     if (T > 512) T = 512;
@@ -278,11 +325,15 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
     const int in_lds = lds <= 150 * 1024 ? 1 : 0;
 #define AFM_FPS(P, MT)                                                                                                              \
     do {                                                                                                                            \
-        if (in_lds && lds > 48 * 1024) {                                                                                            \
-            hipError_t e__ = hipFuncSetAttribute((const void*)fps_kernel<P, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
-            if (e__ != hipSuccess) return (int)e__;                                                                                 \
+        if (in_lds) {                                                                                                               \
+            if (lds > 48 * 1024) {                                                                                                  \
+                hipError_t e__ = hipFuncSetAttribute((const void*)fps_kernel<P, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+                if (e__ != hipSuccess) return (int)e__;                                                                             \
+            }                                                                                                                       \
+            hipLaunchKernelGGL((fps_kernel<P, MT, true>), dim3(B), dim3(T), lds, s, xyz, n, m, idx_out);                            \
+        } else {                                                                                                                    \
+            hipLaunchKernelGGL((fps_kernel<P, MT, false>), dim3(B), dim3(T), 0, s, xyz, n, m, idx_out);                             \
         }                                                                                                                           \
-        hipLaunchKernelGGL((fps_kernel<P, MT>), dim3(B), dim3(T), in_lds ? lds : 0, s, xyz, n, m, idx_out, in_lds);                  \
     } while (0)
     if (T <= 512 && ppt > 16 && ppt <= 32) AFM_FPS(32, 512);
     else if (ppt <= 1) AFM_FPS(1, 1024);

@@ -32,7 +32,7 @@ int main() {
     };
     std::vector<int> ref((size_t)B * 2048), got((size_t)B * 2048);
     for (int m : {2048, 1024}) {
-        for (int T : {0, 1024, 512, 256, 128}) {
+        for (int T : {0, 1024, 512, 256}) {
             afm_probe_fps_threads = T;
             const float ms = time([&] { int rc = afm_fps(dp, B, n, m, didx, st); if (rc) { printf("fps rc=%d\n", rc); } });
             CK(hipMemcpy(got.data(), didx, (size_t)B * m * 4, hipMemcpyDeviceToHost));
@@ -40,6 +40,19 @@ int main() {
             printf("fps  B=%d n=%d m=%d threads=%4d: %7.3f ms  %.3f us/round  %s\n", B, n, m, T, ms, 1e3 * ms / (m - 1), std::equal(got.begin(), got.begin() + (size_t)B * m, ref.begin()) ? "same indices" : "DIFFERENT");
         }
         afm_probe_fps_threads = 0;
+#ifdef AFM_PROBE_TIMELINE
+        {   // phase timeline of the default shape: summed cycles of wave 0 of workgroup 0 between the stamps (s_memtime: 100 MHz x ... no: shader clock)
+            int rc = afm_fps(dp, B, n, m, didx, st); (void)rc;
+            CK(hipStreamSynchronize(st));
+            unsigned long long cyc[8];
+            CK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(afm_probe_fps_cyc), sizeof(cyc)));
+            const char* nm[6] = {"coords (ds_read)", "scan", "wave arg-max", "LDS hop + barrier", "cross-wave arg-max", "loop overhead / store"};
+            double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)cyc[k];
+            printf("fps  phase timeline m=%d (counter ticks per round, wave 0 of workgroup 0; stamps cost ~5 x s_memtime):", m);
+            for (int k = 0; k < 6; ++k) printf("  %s %.0f", nm[k], (double)cyc[k] / (m - 1));
+            printf("  | total %.0f\n", tot / (m - 1));
+        }
+#endif
         CK(hipMemcpy(got.data(), didx, (size_t)B * m * 4, hipMemcpyDeviceToHost));
         afm_gather_rows(dp, didx, dq, (int64_t)B * m, 3, st);
         const float ms = time([&] { afm_knn(16, dp, dq, B, n, m, dk, dd, st); });
