@@ -33,6 +33,24 @@ def test_fps_ties_pick_lowest_index():
     assert torch.equal(got, want) and got.max() < 64
 
 
+@pytest.mark.parametrize("n,shift,m", [(8192, 70, 600), (2048, 33, 300), (512, 1, 256)])
+def test_fps_ties_across_lanes_and_waves(n, shift, m):
+    """Every point twice, the copies `shift` rows apart: the two holders of every maximum sit in different lanes and (n = 8192: 4 waves,
+    n = 2048: 1 wave of 32-point threads) different waves, so each round exercises the tie paths of the wave-level and of the workgroup-level
+    arg-max (ballot with more than one holder -> lowest index).  Bit-exact against the oracle."""
+    from oracle import pointops_ref as po
+    base = synth.scene_cloud(1, n // 2, seed=27).reshape(n // 2, 3)
+    p = torch.cat([base, base.roll(shift, 0)], 0).contiguous()
+    o, no = torch.tensor([n], dtype=torch.int32), torch.tensor([m], dtype=torch.int32)
+    want = po.furthest_sampling(p, o, no)
+    got = pointops.furthest_point_sampling(p.to(dev()), 1, n, m).cpu()
+    assert torch.equal(got, want), f"{(got != want).sum().item()} of {m} indices differ"
+    both = torch.cat([p, p.flip(0)], 0).contiguous()              # two samples in one launch, the second with the copies in reverse order
+    want2 = po.furthest_sampling(both, torch.tensor([n, 2 * n], dtype=torch.int32), torch.tensor([m, 2 * m], dtype=torch.int32))
+    got2 = pointops.furthest_point_sampling(both.to(dev()), 2, n, m).cpu()
+    assert torch.equal(got2, want2)
+
+
 @pytest.mark.parametrize("k,B,n,m", [(8, 2, 300, 300), (16, 2, 2048, 512), (16, 2, 8192, 2048), (8, 1, 8192, 8192), (3, 2, 128, 512), (16, 1, 16, 16)])
 def test_knn_bit_exact(k, B, n, m):
     from oracle import pointops_ref as po
