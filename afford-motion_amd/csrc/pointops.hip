@@ -20,6 +20,7 @@
 
 #ifdef AFM_PROBE
 int afm_probe_fps_threads = 0;
+int afm_probe_fps_prune = -1;                           // 0: plain fps_kernel even where the pruned one applies; 256 / 512 / 1024: its threads
 __device__ unsigned long long afm_probe_fps_cyc[8];     // summed phase cycles of wave 0 of workgroup 0 (tools/points_probe.hip)
 #endif
 #ifdef AFM_PROBE_TIMELINE      // with -DAFM_PROBE: per-phase cycle stamps inside the FPS round (they lengthen the round by ~15 %)
@@ -136,6 +137,159 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(const float* __restrict__ xyz
 #ifdef AFM_PROBE_TIMELINE
     if (probe_ && lane == 0) for (int k = 0; k < 6; ++k) afm_probe_fps_cyc[k] = cyc_[k];
 #endif
+}
+
+// ---------------------------------------------------------------- FPS with an exact pruning of the per-round scan
+// The plain kernel above updates the running minimum of ALL n points every round: ~1100 of its ~2100 cycles per round, on the one compute
+// unit a sample occupies.  Most of those updates are no-ops: a point's minimum only changes if the new sample is closer than its current
+// minimum.  Here the points of a sample are sorted along a Morton curve once (bitonic sort of (key, index) in LDS, ~20 us) and a thread owns
+// PPT CONSECUTIVE sorted points - a compact cell with a bounding box - and a wave 64 neighbouring cells.  Per round a thread evaluates the
+// squared distance from the new sample to its box with the SAME float operations and association as the point distances
+// (ex = max(lo - c, c - hi, 0) per axis, (ex^2 + ey^2) + ez^2): rounding is monotonic, so this is a lower bound of every COMPUTED distance
+// of the cell, and if it is not below the cell's current maximum no minimum can change - the wave skips the cell's update when none of its 64
+// cells needs one (16 % of the waves scan per round at n = 8192, m = 2048).  The kept state (running minima, per-cell maximum and its lowest
+// ORIGINAL index) is exactly what the plain kernel would hold, so the sampled indices are identical, ties included (lowest original index).
+__device__ __forceinline__ unsigned morton_part10(unsigned x) {
+    x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+
+template <int PPT, int T>
+__global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
+    constexpr int CAP = T * PPT, NP = PPT / 2;
+    static_assert(PPT % 2 == 0 && PPT <= 32 && T % 64 == 0 && T <= 1024, "cell sizes");
+    __shared__ unsigned long long keys[2][16];
+    __shared__ float bb[6][16];
+    extern __shared__ float pts[];                    // first the sort arrays (2 x CAP words), then the [3n] copy of the sample
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nw = T / 64;
+    const float* P = xyz + (int64_t)b * n * 3;
+    // ---- bounding box of the sample (for the Morton quantisation only: any permutation gives the same samples)
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += T) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = P[i * 3 + a]; lo3[a] = fminf(lo3[a], v); hi3[a] = fmaxf(hi3[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], o)); hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], o)); }
+        if (lane == 0) { bb[a][wave] = lo3[a]; bb[3 + a][wave] = hi3[a]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = bb[a][0], h = bb[3 + a][0];
+        for (int w2 = 1; w2 < nw; ++w2) { l = fminf(l, bb[a][w2]); h = fmaxf(h, bb[3 + a][w2]); }
+        lo3[a] = l; hi3[a] = 1023.0f / fmaxf(h - l, 1e-12f);          // hi3 now holds the quantisation scale
+    }
+    // ---- Morton keys and the bitonic sort of (key, original index); entries beyond n sort to the end
+    unsigned* kk = reinterpret_cast<unsigned*>(pts);
+    unsigned* vv = kk + CAP;
+    for (int i = tid; i < CAP; i += T) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n) {
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float f = (P[i * 3 + a] - lo3[a]) * hi3[a]; q[a] = (unsigned)min(1023, max(0, (int)f)); }
+            key = morton_part10(q[0]) | (morton_part10(q[1]) << 1) | (morton_part10(q[2]) << 2);
+        }
+        kk[i] = key; vv[i] = i < n ? (unsigned)i : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CAP; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < CAP; i += T) {
+                const int x = i ^ jj;
+                if (x > i) {
+                    const unsigned ka = kk[i], kb = kk[x];
+                    if ((ka > kb) == ((i & k) == 0)) { kk[i] = kb; kk[x] = ka; const unsigned va = vv[i]; vv[i] = vv[x]; vv[x] = va; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- this thread's cell: PPT consecutive sorted points, their original indices, the cell's box
+    unsigned oi[PPT];
+    f32x2 px[NP], py[NP], pz[NP];
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool cell_ok = false;
+#pragma unroll
+    for (int s2 = 0; s2 < PPT; ++s2) {
+        oi[s2] = vv[tid * PPT + s2];
+        const bool ok = oi[s2] != 0xFFFFFFFFu;
+        cell_ok = cell_ok || ok;
+        const float x = ok ? P[oi[s2] * 3 + 0] : 0.f, y = ok ? P[oi[s2] * 3 + 1] : 0.f, z = ok ? P[oi[s2] * 3 + 2] : 0.f;
+        px[s2 >> 1][s2 & 1] = x; py[s2 >> 1][s2 & 1] = y; pz[s2 >> 1][s2 & 1] = z;
+        if (ok) { clo[0] = fminf(clo[0], x); chi[0] = fmaxf(chi[0], x); clo[1] = fminf(clo[1], y); chi[1] = fmaxf(chi[1], y); clo[2] = fminf(clo[2], z); chi[2] = fmaxf(chi[2], z); }
+    }
+    __syncthreads();                                  // the sort arrays are dead: the same LDS becomes the copy of the sample
+    for (int i0 = tid; i0 < 3 * n; i0 += 8 * T) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + u * T < 3 * n ? P[i0 + u * T] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * T < 3 * n) pts[i0 + u * T] = v[u];
+    }
+    __syncthreads();
+    // running minima as bits (see fps_kernel); an empty slot holds 0 and the index 0xFFFFFFFF: it can never win
+    unsigned tmpb[PPT];
+#pragma unroll
+    for (int s2 = 0; s2 < PPT; ++s2) tmpb[s2] = oi[s2] != 0xFFFFFFFFu ? __float_as_uint(1e10f) : 0u;
+    unsigned bd = 0u, boi = 0xFFFFFFFFu;              // the cell's maximum and the lowest original index that holds it
+    auto cell_argmax = [&]() {                        // two passes: the maximum (v_max3), then the lowest original index that holds it (v_min3)
+        bd = 0u;
+#pragma unroll
+        for (int s2 = 0; s2 < PPT; s2 += 2) bd = max(bd, max(tmpb[s2], tmpb[s2 + 1]));
+        boi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s2 = 0; s2 < PPT; s2 += 2)
+            boi = min(boi, min(tmpb[s2] == bd ? oi[s2] : 0xFFFFFFFFu, tmpb[s2 + 1] == bd ? oi[s2 + 1] : 0xFFFFFFFFu));
+    };
+    cell_argmax();
+    int cur = 0;
+    if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
+    for (int j = 1; j < m; ++j) {
+        const float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
+        // lower bound of every computed distance of the cell (same operations, same association as below)
+        const float ex = fmaxf(fmaxf(clo[0] - cx, cx - chi[0]), 0.f), ey = fmaxf(fmaxf(clo[1] - cy, cy - chi[1]), 0.f), ez = fmaxf(fmaxf(clo[2] - cz, cz - chi[2]), 0.f);
+        const float lb = (ex * ex + ey * ey) + ez * ez;
+        const bool need = cell_ok && __float_as_uint(lb) < bd;
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {          // wave-uniform: some cell of the wave can change
+            const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) {
+                const f32x2 dx = px[p2] - cx2, dy = py[p2] - cy2, dz = pz[p2] - cz2;
+                const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                tmpb[2 * p2] = min(tmpb[2 * p2], __float_as_uint(d[0]));
+                tmpb[2 * p2 + 1] = min(tmpb[2 * p2 + 1], __float_as_uint(d[1]));
+            }
+            cell_argmax();
+        }
+        // (distance bits, lowest original index): wave level, then the 16 wave keys - as in fps_kernel
+        const unsigned wmax = wave_max_u32(cell_ok ? bd : 0u);
+        const unsigned long long holders = __builtin_amdgcn_ballot_w64(cell_ok && bd == wmax);
+        unsigned long long best = 0ull;
+        if (holders) {
+            unsigned wbi;
+            if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)boi, __builtin_ctzll(holders));
+            else wbi = wave_min_u32((cell_ok && bd == wmax) ? boi : 0xFFFFFFFFu);
+            best = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
+        }
+        if (lane == 0) keys[j & 1][wave] = best;
+        __syncthreads();
+        const bool has = (lane & 15) < nw;
+        const unsigned long long kw = keys[j & 1][has ? (lane & 15) : 0];
+        const unsigned khi = has ? (unsigned)(kw >> 32) : 0u, klo = has ? (unsigned)kw : 0u;
+        unsigned gm = khi;
+        gm = max(gm, dpp_u32<0xB1>(gm)); gm = max(gm, dpp_u32<0x4E>(gm)); gm = max(gm, dpp_u32<0x141>(gm)); gm = max(gm, dpp_u32<0x140>(gm));
+        const unsigned long long hold2 = __builtin_amdgcn_ballot_w64(has && lane < 16 && khi == gm);
+        unsigned wlo;
+        if ((hold2 & (hold2 - 1)) == 0) wlo = (unsigned)__builtin_amdgcn_readlane((int)klo, __builtin_ctzll(hold2 | (1ull << 63)));
+        else wlo = wave_max_u32((has && khi == gm) ? klo : 0u);
+        cur = __builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu - wlo));
+        if (tid == 0) idx_out[(int64_t)b * m + j] = b * n + cur;
+    }
 }
 
 constexpr int KNN_TILE = 1024;
@@ -308,6 +462,41 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
     if (!xyz || !idx_out || B < 0 || n <= 0 || m < 0 || m > n) return AFM_E_BADARG;
     if (B == 0 || m == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    {   // exact pruning of the scan (fps_pruned_kernel): PT threads, np2 / PT Morton-consecutive points per thread
+        int np2 = 2048;
+        while (np2 < n) np2 <<= 1;
+        bool prune = n >= 1536 && np2 <= 8192 && m >= 32;
+        int PT = 1024;
+#ifdef AFM_PROBE
+        if (afm_probe_fps_prune == 0) prune = false;
+        if (afm_probe_fps_prune > 0) PT = afm_probe_fps_prune;
+#endif
+        if (prune) {
+            AfmProf prof(AFM_PROF_FPS, (double)B * (m - 1) * n, s);
+            const size_t lds = (size_t)max(3 * n, 2 * np2) * sizeof(float);
+#define AFM_FPS_PRUNED(P, PT_)                                                                                                          \
+    do {                                                                                                                            \
+        if (lds > 48 * 1024) {                                                                                                      \
+            hipError_t e__ = hipFuncSetAttribute((const void*)fps_pruned_kernel<P, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            if (e__ != hipSuccess) return (int)e__;                                                                                 \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((fps_pruned_kernel<P, PT_>), dim3(B), dim3(PT_), lds, s, xyz, n, m, idx_out);                            \
+    } while (0)
+#define AFM_FPS_PRUNED_T(PT_)                                                                                                           \
+    do {                                                                                                                            \
+        if (np2 == 2048) AFM_FPS_PRUNED(2048 / PT_, PT_);                                                                           \
+        else if (np2 == 4096) AFM_FPS_PRUNED(4096 / PT_, PT_);                                                                      \
+        else AFM_FPS_PRUNED(8192 / PT_, PT_);                                                                                       \
+    } while (0)
+            if (PT == 256) AFM_FPS_PRUNED_T(256);
+            else if (PT == 512) AFM_FPS_PRUNED_T(512);
+            else AFM_FPS_PRUNED_T(1024);
+#undef AFM_FPS_PRUNED_T
+#undef AFM_FPS_PRUNED
+            AFM_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     // Threads per workgroup: a round is a dependent chain (per-thread scan -> wave arg-max -> LDS hop -> barrier -> broadcast) on ONE
     // compute unit per sample.  Its VALU work (n points x 8 instructions: ~1100 issue cycles of the ~2100-cycle round at n = 8192) is
     // the same for every split, the reductions are not: 0.94 / 0.96 / 0.91 us per round with 1024 / 512 / 256 threads

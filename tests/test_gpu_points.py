@@ -11,7 +11,8 @@ from gpu_util import dev, load_named_weights, report
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,n,m", [(2, 200, 50), (3, 512, 128), (2, 2048, 512), (2, 8192, 2048), (1, 8192, 1024), (2, 100, 100), (1, 64, 1)])
+@pytest.mark.parametrize("B,n,m", [(2, 200, 50), (3, 512, 128), (2, 2048, 512), (2, 8192, 2048), (1, 8192, 1024), (2, 100, 100), (1, 64, 1),
+                                   (2, 3000, 700), (1, 1536, 100), (3, 5000, 1250), (1, 8192, 8192), (2, 2049, 40), (1, 4096, 31)])
 def test_fps_bit_exact(B, n, m):
     from oracle import pointops_ref as po
     p = synth.scene_cloud(B, n, seed=21).reshape(B * n, 3)

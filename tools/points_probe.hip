@@ -32,14 +32,26 @@ int main() {
     };
     std::vector<int> ref((size_t)B * 2048), got((size_t)B * 2048);
     for (int m : {2048, 1024}) {
+        {   // exact pruning of the scan (fps_pruned_kernel, the default at this size) against the plain kernel below
+            afm_probe_fps_threads = 0;
+            for (int PT : {1024, 512, 256}) {
+                afm_probe_fps_prune = PT;
+                const float ms = time([&] { int rc = afm_fps(dp, B, n, m, didx, st); if (rc) { printf("fps rc=%d\n", rc); } });
+                CK(hipMemcpy(got.data(), didx, (size_t)B * m * 4, hipMemcpyDeviceToHost));
+                if (PT == 1024) ref = got;
+                printf("fps  B=%d n=%d m=%d pruned scan, %4d threads: %7.3f ms  %.3f us/round  %s\n", B, n, m, PT, ms, 1e3 * ms / (m - 1),
+                       std::equal(got.begin(), got.begin() + (size_t)B * m, ref.begin()) ? "same indices" : "DIFFERENT");
+            }
+            afm_probe_fps_prune = 0;
+        }
         for (int T : {0, 1024, 512, 256}) {
             afm_probe_fps_threads = T;
             const float ms = time([&] { int rc = afm_fps(dp, B, n, m, didx, st); if (rc) { printf("fps rc=%d\n", rc); } });
             CK(hipMemcpy(got.data(), didx, (size_t)B * m * 4, hipMemcpyDeviceToHost));
-            if (T == 0) ref = got;
             printf("fps  B=%d n=%d m=%d threads=%4d: %7.3f ms  %.3f us/round  %s\n", B, n, m, T, ms, 1e3 * ms / (m - 1), std::equal(got.begin(), got.begin() + (size_t)B * m, ref.begin()) ? "same indices" : "DIFFERENT");
         }
         afm_probe_fps_threads = 0;
+        afm_probe_fps_prune = -1;
 #ifdef AFM_PROBE_TIMELINE
         {   // phase timeline of the default shape: summed cycles of wave 0 of workgroup 0 between the stamps (s_memtime: 100 MHz x ... no: shader clock)
             int rc = afm_fps(dp, B, n, m, didx, st); (void)rc;
