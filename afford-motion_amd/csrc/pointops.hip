@@ -248,6 +248,7 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
     };
     cell_argmax();
     int cur = 0;
+    unsigned long long best = 0ull;                   // this wave's key, kept across the rounds in which the wave skips
     if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
     for (int j = 1; j < m; ++j) {
         const float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
         const float ex = fmaxf(fmaxf(clo[0] - cx, cx - chi[0]), 0.f), ey = fmaxf(fmaxf(clo[1] - cy, cy - chi[1]), 0.f), ez = fmaxf(fmaxf(clo[2] - cz, cz - chi[2]), 0.f);
         const float lb = (ex * ex + ey * ey) + ez * ez;
         const bool need = cell_ok && __float_as_uint(lb) < bd;
-        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {          // wave-uniform: some cell of the wave can change
+        const bool scan = __builtin_amdgcn_ballot_w64(need) != 0ull;
+        if (scan) {                                               // wave-uniform: some cell of the wave can change
             const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
 #pragma unroll
             for (int p2 = 0; p2 < NP; ++p2) {
@@ -266,15 +268,18 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
             }
             cell_argmax();
         }
-        // (distance bits, lowest original index): wave level, then the 16 wave keys - as in fps_kernel
-        const unsigned wmax = wave_max_u32(cell_ok ? bd : 0u);
-        const unsigned long long holders = __builtin_amdgcn_ballot_w64(cell_ok && bd == wmax);
-        unsigned long long best = 0ull;
-        if (holders) {
-            unsigned wbi;
-            if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)boi, __builtin_ctzll(holders));
-            else wbi = wave_min_u32((cell_ok && bd == wmax) ? boi : 0xFFFFFFFFu);
-            best = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
+        // (distance bits, lowest original index): wave level, then the 16 wave keys - as in fps_kernel.  A wave that skipped the update holds
+        // the cells it held the round before: its key is unchanged and only re-published (the key buffers alternate)
+        if (scan || j == 1) {
+            const unsigned wmax = wave_max_u32(cell_ok ? bd : 0u);
+            const unsigned long long holders = __builtin_amdgcn_ballot_w64(cell_ok && bd == wmax);
+            best = 0ull;
+            if (holders) {
+                unsigned wbi;
+                if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)boi, __builtin_ctzll(holders));
+                else wbi = wave_min_u32((cell_ok && bd == wmax) ? boi : 0xFFFFFFFFu);
+                best = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
+            }
         }
         if (lane == 0) keys[j & 1][wave] = best;
         __syncthreads();
