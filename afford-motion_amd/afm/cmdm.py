@@ -209,7 +209,14 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         w.d, w.heads, w.ff, w.n_layers = self.latent_dim, self.num_heads, layers[0].linear1.out_features, len(layers)
         w.motion_dim = self.motion_dim
         w.n_cond = 1 + self.contact_encoder.num_groups
-        w.motion_adapter_w, w.motion_adapter_b = P(self.motion_adapter.weight), P(self.motion_adapter.bias)
+        # K = motion_dim = 263 ('h3d') is not a multiple of 16: the weight is zero-padded once per weight version to K = 272 and the loop
+        # keeps a padded copy of x_t, so the adapter runs on the bf16-split GEMM like every other layer (padding adds exact zeros)
+        kpad = -(-self.motion_dim // 16) * 16
+        w.motion_adapter_kpad = kpad if (kpad != self.motion_dim and kpad >= 128) else 0
+        maw = self.motion_adapter.weight.detach()
+        if w.motion_adapter_kpad:
+            maw = torch.nn.functional.pad(maw, (0, kpad - self.motion_dim))
+        w.motion_adapter_w, w.motion_adapter_b = P(maw), P(self.motion_adapter.bias)
         w.motion_layer_w, w.motion_layer_b = P(self.motion_layer.weight), P(self.motion_layer.bias)
         w.time_table, w.n_timesteps = P(self.timestep_embedder.table()), self.timestep_embedder.pe.shape[0]
         w.pos_table = P(self.positional_encoder.pe[:, 0, :])

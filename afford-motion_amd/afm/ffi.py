@@ -21,7 +21,7 @@ ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6,
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE = 0x1
 CDM_SERIAL_LATENT, CDM_VALU_REDUCE = 0x1, 0x2
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 16
 
 c_f32p = C.c_void_p
@@ -119,6 +119,7 @@ class CmdmWeights(C.Structure):
         ("time_table", c_f32p), ("n_timesteps", i32), ("pos_table", c_f32p),
         ("layer", EncoderLayerWeights * MAX_LAYERS),
         ("gemm_arith", i32), ("gemm_arith_min_n", i32), ("attn_group_waves", i32), ("flags", i32),
+        ("motion_adapter_kpad", i32),
     ]
 
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 import concurrent.futures as cf
 import glob
 import os
+import re
 import subprocess
 import sys
 
@@ -22,6 +23,93 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.j
          "-Wall", "-Wno-unused-function", "-Werror=pass-failed",          # a failed `#pragma unroll` demotes register arrays to scratch
          "-Rpass-analysis=kernel-resource-usage"]
 MAX_SCRATCH_BYTES = 32       # per lane; anything larger means an accumulator array left the register file
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+# ---- ISA scan (profiles/r02_decfold_nondeterminism.md, profiles/r03_isa_scan.md).  One build of lat_decfold_kernel lost single
+# products in single quarter-waves whenever a second stream had kernels in flight.  Its code differed from every other kernel of the
+# library in ONE instruction shape: a packed-f32 VALU op (v_pk_mul/fma/add_f32) reading the HIGH half of an SGPR pair that a scalar
+# register-to-register copy (`s_mov_b32 s_pair, s_other`: the re-pack of scalar-LOADED data) wrote within a few instructions of it.
+# The mechanism is open, so the shape itself is fenced: an object containing it is rejected.  (Pairs set from literals - the GELU
+# constants of the GEMM epilogues - and pairs used as broadcast low halves are everywhere in the library and have never misbehaved.)
+_PK = re.compile(r"^\s*(v_pk_(?:mul|fma|add)_f32)\s+(.*?)(?://.*)?$")
+_INS = re.compile(r"^\s*([a-z_0-9]+)\s+(.*?)(?://.*)?$")
+_MOD = re.compile(r"\s+(?:op_sel|op_sel_hi|neg_lo|neg_hi|clamp)\b.*$")
+ISA_SCAN_WINDOW = 8
+
+
+def _sregs(tok):
+    m = re.match(r"^s\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"^s(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def scan_disassembly(text, window=ISA_SCAN_WINDOW):
+    """-> [(function, packed instruction, scalar copy)] for every fenced instruction pair in an llvm-objdump -d listing."""
+    hits, fn, body = [], "?", []
+
+    def flush():
+        for i, (op, rest) in enumerate(body):
+            if not _PK.match(op + " " + rest):
+                continue
+            sel = {k: None for k in ("op_sel", "op_sel_hi")}
+            for k in sel:
+                mm = re.search(k + r":\[([0-9,]+)\]", rest)
+                if mm:
+                    sel[k] = [int(x) for x in mm.group(1).split(",")]
+            srcs = re.split(r",\s*", _MOD.sub("", rest.strip()))[1:]
+            hi_pairs = []
+            for si, tok in enumerate(srcs):
+                if not re.match(r"^s\[\d+:\d+\]$", tok):
+                    continue
+                lo_sel = sel["op_sel"][si] if sel["op_sel"] else 0            # which half feeds the low lane
+                hi_sel = sel["op_sel_hi"][si] if sel["op_sel_hi"] else 1      # which half feeds the high lane (default: the high half)
+                if lo_sel or hi_sel:
+                    hi_pairs.append(max(_sregs(tok)))                         # the pair's high register is read
+            if not hi_pairs:
+                continue
+            for j in range(max(0, i - window), min(len(body), i + window + 1)):
+                o2, r2 = body[j]
+                if o2 != "s_mov_b32":
+                    continue
+                ops2 = re.split(r",\s*", r2.strip())
+                if len(ops2) == 2 and _sregs(ops2[0]) & set(hi_pairs) and _sregs(ops2[1]):     # SGPR -> SGPR copy into a read high half
+                    hits.append((fn, op + " " + rest.strip(), o2 + " " + r2.strip()))
+    for line in text.splitlines():
+        m0 = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m0:
+            flush()
+            body, fn = [], m0.group(1)
+            continue
+        m = _INS.match(line)
+        if m:
+            body.append(m.groups())
+    flush()
+    return hits
+
+
+def scan_object(obj):
+    """Disassemble the gfx950 code object embedded in a hipcc -c object and scan it; -> list of hits (empty = clean)."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="afm_isa_")
+    try:
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", os.path.basename(local)], cwd=tmp, capture_output=True, text=True)
+        cos = [f for f in os.listdir(tmp) if "gfx950" in f]
+        if not cos:                                      # host-only translation unit (profile.hip)
+            return []
+        hits = []
+        for co in cos:
+            r = subprocess.run([OBJDUMP, "-d", co], cwd=tmp, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"llvm-objdump failed on {obj}: {r.stderr[:400]}")
+            hits += scan_disassembly(r.stdout)
+        return hits
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _stale(target, deps):
@@ -65,6 +153,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
                         rc = rc or 1
                 continue
             keep.append(line)
+        if rc == 0:
+            for fn, pk, mv in scan_object(o):
+                keep.append(f"error: fenced instruction shape in {fn}: `{pk}` next to `{mv}` (see ISA scan in build_hip.py)")
+                rc = 1
         if rc != 0 and os.path.exists(o):
             os.remove(o)           # a rejected object must not satisfy the next (incremental) build
         return s, rc, "\n".join(keep)

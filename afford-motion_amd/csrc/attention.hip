@@ -18,6 +18,7 @@
 #include <atomic>
 #include "common.h"
 #include "profile.h"
+#include "bf16split.h"
 #include <math.h>
 
 namespace {
@@ -39,6 +40,7 @@ constexpr int DH = 64;
 constexpr int KB = 32;           // keys per block
 constexpr int LDKK = 68;         // padded K row (floats)
 constexpr int MAX_WAVES = 12;      // 3 waves per SIMD -> 168 VGPRs each, no spills
+constexpr int AFM_MHA_DEFAULT_GROUP = 4;      // waves per workgroup of the inference kernel when the caller does not choose
 
 // TRAIN: also writes lse[b,h,q] = log-sum-exp of the scaled, masked logits (saved for afm_mha_bwd) and applies
 // attention-probability dropout to the P used in P V (the softmax normaliser uses the undropped P, as in torch).
@@ -226,8 +228,249 @@ __global__ __launch_bounds__(NWC ? 64 * NWC : (NST == 4 ? 512 : 64 * MAX_WAVES))
     })
 }
 
-// group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 8 / 12; 0 = choose from the launch size; < 0 = one workgroup per
-// (sample, head) that walks all query blocks (long-query cross-attention, training).
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Inference attention on the bf16 matrix pipe with f32 results (round 3).  gfx950's f32 MFMA runs at 1/16 of its bf16 MFMA, so -
+// exactly as in gemm_split.hip - every f32 operand is split into three bf16 terms (8 + 8 + 8 significant bits, exact) and the nine
+// exact cross products accumulate in f32 inside v_mfma_f32_32x32x16_bf16: 9 x 32 = 288 matrix-pipe cycles per (32 x 32 x 16) block
+// product instead of 8 x 64 = 512 on v_mfma_f32_32x32x2_f32, the same f32 products in another summation order.
+//   Q   split once per wave (registers: three planes x four K16 steps);
+//   K/V split once per WORKGROUP while a 32-key block is staged (the waves of a group share the planes through LDS):
+//       K planes  [32 keys][64 dims] bf16, rows padded to 144 B (conflict-free ds_read_b128 lane groups, 64-bank rule);
+//       V planes  TRANSPOSED [64 dims][32 key slots] bf16, rows padded to 80 B - the bf16 MFMA wants eight consecutive k per lane, and
+//                 for O^T = V^T P^T the k index is the key.  A staging thread owns 4 keys x 4 dims: its four bf16 of one dim are
+//                 one 8-byte store (16 lanes = 8 key quads x 2 dim-quad parities: 16 distinct 8-byte slots of the 32 write banks);
+//   P   split in registers right after the softmax: the S^T accumulator layout (lane = query, 16 keys) IS the B operand of the second
+//       product once the key <-> k-slot map is chosen accordingly: slot 16 t + 8 hh + e <-> key 16 t + 8 (e >> 2) + 4 hh + (e & 3),
+//       i.e. key bits 2 and 3 swapped - the V planes are written in that slot order.
+// Everything else (swapped products, online softmax, exact -inf masking, skipped fully-masked blocks, grid = (sample, head, query
+// group), double-buffered stage with one barrier per block) is the f32 kernel's.  A query row's arithmetic does not depend on the
+// grouping (bit-identical results for every NW).
+constexpr int KROWB = 144, VROWB = 80;                 // plane row bytes
+constexpr int KPLANE = KB * KROWB, VPLANE = DH * VROWB;
+constexpr int KVSTAGE = 3 * KPLANE + 3 * VPLANE;       // 29184 bytes per stage
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW == 12 ? 3 : 1)) void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
+                                                                const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
+                                                                float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk) {
+    constexpr int NT = 64 * NW;
+    constexpr int NIT = (256 + NT - 1) / NT;            // staging items per thread (256 items per block: 128 of K, 128 of V)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* kv = smem_raw;                       // [2][KVSTAGE]
+    float* madd = reinterpret_cast<float*>(smem_raw + 2 * KVSTAGE);                 // [nkb * KB] additive mask (0 / -inf)
+    int* blk_valid = reinterpret_cast<int*>(madd + ((T + KB - 1) / KB) * KB);       // [nkb]
+
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bh = bid / nchunk, chunk = bid % nchunk;
+    const int b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int D = H * DH;
+    const int nkb = (T + KB - 1) / KB, nqb = (Tq + 31) / 32;
+    const float* qbase = qp_ + (int64_t)b * Tq * ldq + h * DH;
+    const float* kbase = kp_ + (int64_t)b * T * ldkv + h * DH;
+    const float* vbase = vp_ + (int64_t)b * T * ldkv + h * DH;
+    const float NEG_INF = -INFINITY;
+
+    for (int i = tid; i < nkb; i += NT) blk_valid[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nkb * KB; i += NT) {
+        const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
+        madd[i] = ok ? 0.0f : NEG_INF;
+        if (ok) blk_valid[i / KB] = 1;              // benign race: every writer stores 1
+    }
+
+    // Staging items (all loads unconditional, rows past the last key clamped to key T-1: those keys carry an additive -inf):
+    //   item i < 128  (K): float4 c4 = i & 15 of keys (i >> 4) + 8 q, q = 0..3  -> per load instruction 4 key rows x 256 contiguous bytes
+    //   item 128 + i  (V): keys 4 kq .. 4 kq + 3 (kq = i & 7) x dims 4 c .. 4 c + 3 (c = ((i >> 3) & 1) + 2 (i >> 4))
+    f32x4 st[NIT][4];
+    auto load_block = [&](int kb) {
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) {
+            const int item = tid + n * NT;
+            if (NT * NIT > 256 && item >= 256) continue;
+            if (item < 128) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int key = min(kb * KB + (item >> 4) + 8 * q, T - 1);
+                    st[n][q] = *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * ldkv + (item & 15) * 4);
+                }
+            } else {
+                const int i = item - 128, kq = i & 7, c = ((i >> 3) & 1) + 2 * (i >> 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int key = min(kb * KB + 4 * kq + q, T - 1);
+                    st[n][q] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * ldkv + c * 4);
+                }
+            }
+        }
+    };
+    auto store_block = [&](int buf) {
+        unsigned char* base = kv + buf * KVSTAGE;
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) {
+            const int item = tid + n * NT;
+            if (NT * NIT > 256 && item >= 256) continue;
+            if (item < 128) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t a1, a2, a3, b1, b2, b3;
+                    split2(st[n][q][0], st[n][q][1], a1, a2, a3);
+                    split2(st[n][q][2], st[n][q][3], b1, b2, b3);
+                    unsigned char* d = base + ((item >> 4) + 8 * q) * KROWB + (item & 15) * 8;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{a1, b1};
+                    *reinterpret_cast<u32x2*>(d + KPLANE) = u32x2{a2, b2};
+                    *reinterpret_cast<u32x2*>(d + 2 * KPLANE) = u32x2{a3, b3};
+                }
+            } else {
+                const int i = item - 128, kq = i & 7, c = ((i >> 3) & 1) + 2 * (i >> 4);
+                const int sq = (kq & 4) | ((kq & 1) << 1) | ((kq >> 1) & 1);        // key bits 2 <-> 3 swapped: slot quad of key quad kq
+                unsigned char* d0 = base + 3 * KPLANE + (4 * c) * VROWB + sq * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                                       // dim 4 c + j: its four keys are one 8-byte store per plane
+                    uint32_t a1, a2, a3, b1, b2, b3;
+                    split2(st[n][0][j], st[n][1][j], a1, a2, a3);
+                    split2(st[n][2][j], st[n][3][j], b1, b2, b3);
+                    unsigned char* d = d0 + j * VROWB;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{a1, b1};
+                    *reinterpret_cast<u32x2*>(d + VPLANE) = u32x2{a2, b2};
+                    *reinterpret_cast<u32x2*>(d + 2 * VPLANE) = u32x2{a3, b3};
+                }
+            }
+        }
+    };
+
+    for (int q0 = chunk * NW; q0 < nqb; q0 += NW * nchunk) {
+        const int qb = q0 + wave;
+        const bool active = qb < nqb;
+        // Q planes: query row (clamped), K16 step s covers head dims 16 s + 8 hh .. + 7, pre-scaled (1 / sqrt(64) is a power of two)
+        u32x4 qpl[4][3];
+        {
+            const int qrow = min(qb * 32 + r32, Tq - 1);
+            const float* qp = qbase + (int64_t)(active ? qrow : 0) * ldq + hh * 8;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * s), v1 = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4);
+                uint32_t w1[4], w2[4], w3[4];
+                split2(v0[0] * scale, v0[1] * scale, w1[0], w2[0], w3[0]);
+                split2(v0[2] * scale, v0[3] * scale, w1[1], w2[1], w3[1]);
+                split2(v1[0] * scale, v1[1] * scale, w1[2], w2[2], w3[2]);
+                split2(v1[2] * scale, v1[3] * scale, w1[3], w2[3], w3[3]);
+                qpl[s][0] = u32x4{w1[0], w1[1], w1[2], w1[3]};
+                qpl[s][1] = u32x4{w2[0], w2[1], w2[2], w2[3]};
+                qpl[s][2] = u32x4{w3[0], w3[1], w3[2], w3[3]};
+            }
+        }
+        float m_run = NEG_INF, l_run = 0.0f;
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+        __syncthreads();                 // previous pass done with LDS; madd / blk_valid visible
+        load_block(0);
+        store_block(0);
+        __syncthreads();
+
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < nkb) load_block(kb + 1);
+            if (active && blk_valid[kb]) {
+                const unsigned char* kpl = kv + buf * KVSTAGE + r32 * KROWB + hh * 16;
+                const unsigned char* vpl = kv + buf * KVSTAGE + 3 * KPLANE + r32 * VROWB + hh * 16;
+                // ---- S^T = K Q^T: A = K block (row = key), B = Q^T (column = query), 4 K16 steps x 9 products
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int st_ = 0; st_ < 4; ++st_) {
+                    u32x4 ak[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ak[pl] = *reinterpret_cast<const u32x4*>(kpl + pl * KPLANE + st_ * 32);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) s = mfma_bf16(ak[AFM_PA[q]], qpl[st_][AFM_PB[q]], s);
+                }
+                // ---- mask + online softmax; reg r <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
+                float mx = NEG_INF;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ma = *reinterpret_cast<const float4*>(madd + kb * KB + 8 * g + 4 * hh);
+                    s[4 * g + 0] += ma.x; s[4 * g + 1] += ma.y; s[4 * g + 2] += ma.z; s[4 * g + 3] += ma.w;
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
+                }
+                mx = fmaxf(mx, xor32(mx));
+                const float m_new = fmaxf(m_run, mx);
+                const float m_safe = (m_new == NEG_INF) ? 0.0f : m_new;
+                const float alpha = __expf(m_run - m_safe);
+                float rs = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = __expf(s[r] - m_safe);
+                    rs += s[r];
+                }
+                rs += xor32(rs);
+                l_run = l_run * alpha + rs;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                // ---- O^T += V^T P^T: K16 step t takes the P registers 8 t .. 8 t + 7 of this lane (k-slot 8 hh + e <-> register 8 t + e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    uint32_t w1[4], w2[4], w3[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) split2(s[8 * t + 2 * i], s[8 * t + 2 * i + 1], w1[i], w2[i], w3[i]);
+                    const u32x4 pp[3] = {u32x4{w1[0], w1[1], w1[2], w1[3]}, u32x4{w2[0], w2[1], w2[2], w2[3]}, u32x4{w3[0], w3[1], w3[2], w3[3]}};
+                    u32x4 av0[3], av1[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        av0[pl] = *reinterpret_cast<const u32x4*>(vpl + pl * VPLANE + t * 32);
+                        av1[pl] = *reinterpret_cast<const u32x4*>(vpl + pl * VPLANE + 32 * VROWB + t * 32);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        o0 = mfma_bf16(av0[AFM_PA[q]], pp[AFM_PB[q]], o0);
+                        o1 = mfma_bf16(av1[AFM_PA[q]], pp[AFM_PB[q]], o1);
+                    }
+                }
+            }
+            if (kb + 1 < nkb) store_block(buf ^ 1);
+            __syncthreads();
+        }
+
+        if (active) {
+            const int qrow = qb * 32 + r32;
+            if (qrow < Tq) {
+                const float inv = 1.0f / l_run;
+                float* op = out + ((int64_t)b * Tq + qrow) * D + h * DH + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<float4*>(op + 8 * g) =
+                        make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                    *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                        make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+                }
+            }
+        }
+    }
+}
+
+// group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 6 / 8 / 12; 0 = the library's choice; < 0 = one workgroup per
+// (sample, head) that walks all query blocks (long-query cross-attention, training).  Inference runs the bf16-split kernel, training
+// (lse output, attention dropout) the f32-MFMA kernel.
+template <int NW>
+int launch_split_mha(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, int B, int Tq, int T, int H,
+                     float scale, int nchunk, size_t lds, hipStream_t s) {
+    static const int attr = (int)hipFuncSetAttribute((const void*)mha_fwd_split_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL((mha_fwd_split_kernel<NW>), dim3(B * H * nchunk), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, nchunk);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, float* lse, int32_t B,
                    int32_t Tq, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, int group_waves,
                    void* stream) {
@@ -235,50 +478,53 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     if (B == 0) return 0;                                     // empty batch (pointers may be null)
     if (!q || !k || !v || !out || B < 0 || T <= 0 || Tq <= 0 || H <= 0) return AFM_E_BADARG;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return AFM_E_BADARG;
+    if ((ldq & 3) || (ldkv & 3)) return AFM_E_BADARG;
     if (train && (!lse || drop_p < 0.0f || drop_p >= 1.0f)) return AFM_E_BADARG;
     const int nqb = (Tq + 31) / 32, nkb = (T + 31) / 32;
-    int nw, nchunk = 1;
-    if (group_waves < 0) {
-        nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
-    } else {
-        if (group_waves != 0 && group_waves != 1 && group_waves != 2 && group_waves != 4 && group_waves != 8 && group_waves != 12) return AFM_E_BADARG;
-        nw = group_waves;
-        // 4-wave groups everywhere (profiles/r02_kernel_sweep.txt, T = 326, us for 12 / 8 / 4 / 2 / 1 waves per group): B = 32: 93 / 119 / 94 / 128 / 150,
-        // B = 16: 85 / 62 / 63 / 69 / 98, B = 4: 79 / 57 / 36 / 41 / 49, B = 1: 78 / 56 / 36 / 40 / 48 - the four waves share every K / V
-        // tile they stage (smaller groups re-stage it per wave), and three groups fit one CU (larger ones leave SIMDs unevenly loaded)
-        if (nw == 0) nw = 4;
-        if (nw > nqb) nw = nqb >= 8 ? nqb : (nqb >= 4 ? 4 : (nqb >= 2 ? 2 : 1));      // never more waves than query blocks
-        nchunk = (nqb + nw - 1) / nw;
-    }
-    const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nkb * KB) * sizeof(float) + (size_t)nkb * sizeof(int);
-    if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~30000 keys
-    if (lds > 64 * 1024) {                                     // long memories (cross-attention over N = 8192 points): opt in once
-        static std::atomic<bool> attr_set{false};      // idempotent attribute: a race only repeats the call
-        if (!attr_set.load(std::memory_order_acquire)) {
-            const void* fns[8] = {(const void*)mha_fwd_kernel<2, false, 0>, (const void*)mha_fwd_kernel<4, false, 0>, (const void*)mha_fwd_kernel<2, true, 0>,
-                                  (const void*)mha_fwd_kernel<4, true, 0>, (const void*)mha_fwd_kernel<8, false, 2>, (const void*)mha_fwd_kernel<16, false, 1>,
-                                  (const void*)mha_fwd_kernel<2, false, 8>, (const void*)mha_fwd_kernel<4, false, 4>};
-            for (int i = 0; i < 8; ++i) {
-                hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return (int)e;
-            }
-            attr_set.store(true, std::memory_order_release);
-        }
-    }
     const float scale = 1.0f / sqrtf((float)dh);
     hipStream_t s = (hipStream_t)stream;
+    if (train) {
+        const int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
+        const size_t lds = (size_t)(2 * KB * LDKK + 2 * KB * DH + nkb * KB) * sizeof(float) + (size_t)nkb * sizeof(int);
+        if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;
+        if (lds > 64 * 1024) {
+            static std::atomic<bool> attr_set{false};      // idempotent attribute: a race only repeats the call
+            if (!attr_set.load(std::memory_order_acquire)) {
+                const void* fns[2] = {(const void*)mha_fwd_kernel<2, true, 0>, (const void*)mha_fwd_kernel<4, true, 0>};
+                for (int i = 0; i < 2; ++i) {
+                    hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return (int)e;
+                }
+                attr_set.store(true, std::memory_order_release);
+            }
+        }
+        AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
+        if (nw >= 8) hipLaunchKernelGGL((mha_fwd_kernel<2, true, 0>), dim3(B * H), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id, 1);
+        else hipLaunchKernelGGL((mha_fwd_kernel<4, true, 0>), dim3(B * H), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id, 1);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
+    int nw, nchunk = 1;
+    if (group_waves < 0) {
+        nw = nqb <= 4 ? 4 : (nqb <= 6 ? 6 : (nqb <= 8 ? 8 : 12));
+    } else {
+        if (group_waves != 0 && group_waves != 1 && group_waves != 2 && group_waves != 4 && group_waves != 6 && group_waves != 8 && group_waves != 12)
+            return AFM_E_BADARG;
+        nw = group_waves ? group_waves : AFM_MHA_DEFAULT_GROUP;
+        if (nw > nqb) nw = nqb >= 12 ? 12 : (nqb >= 8 ? 8 : (nqb >= 6 ? 6 : (nqb >= 4 ? 4 : (nqb >= 2 ? 2 : 1))));      // never more waves than query blocks
+        nchunk = (nqb + nw - 1) / nw;
+    }
+    const size_t lds = (size_t)2 * KVSTAGE + (size_t)nkb * KB * sizeof(float) + (size_t)nkb * sizeof(int);
+    if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~25000 keys
     AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
-#define AFM_MHA(NST, TR, NWC) hipLaunchKernelGGL((mha_fwd_kernel<NST, TR, NWC>), dim3(B * H * nchunk), dim3(nw * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, lse, drop_p, drop_seed, drop_id, nchunk)
-    if (train) { if (nw >= 8) AFM_MHA(2, true, 0); else AFM_MHA(4, true, 0); }
-    else if (nw == 8) AFM_MHA(2, false, 8);
-    else if (nw > 8) AFM_MHA(2, false, 0);
-    else if (nw == 4) AFM_MHA(4, false, 4);
-    else if (nw > 4) AFM_MHA(4, false, 0);
-    else if (nw == 2) AFM_MHA(8, false, 2);
-    else AFM_MHA(16, false, 1);
-#undef AFM_MHA
-    AFM_CHECK_LAUNCH();
-    return 0;
+    switch (nw) {
+        case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+        case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+        case 4: return launch_split_mha<4>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+        case 6: return launch_split_mha<6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+        case 8: return launch_split_mha<8>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+        default: return launch_split_mha<12>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+    }
 }
 
 }  // namespace

@@ -23,7 +23,7 @@ namespace {
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 struct Workspace {
-    float *seq0, *y, *x1, *tmp, *qkv, *qkv0, *att, *hid, *noise;
+    float *seq0, *y, *x1, *tmp, *qkv, *qkv0, *att, *hid, *noise, *xpad;
     uint8_t* keymask;
     int64_t bytes;
 };
@@ -44,17 +44,28 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.hid = (float*)take(M * (int64_t)w.ff * 4);
     ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
     ws.keymask = (uint8_t*)take(M);
+    ws.xpad = w.motion_adapter_kpad > 0 ? (float*)take((int64_t)B * L * w.motion_adapter_kpad * 4) : nullptr;      // x_t with rows padded to the GEMM's K
     ws.bytes = off;
     return ws;
 }
 
-// grid (B, 1 + n_cond): token 0 = time_table[t] + pos[0]; tokens 1..n_cond = cond copy; also key mask.
+// grid (B, 1 + n_cond): token 0 = time_table[t] + pos[0]; tokens 1..n_cond = cond copy; also key mask.  With xpad != NULL the
+// blocks of a sample also copy its x_t rows into rows of kpad floats (zero padded): the motion adapter's K = 263 is not a multiple
+// of 16, its padded copy is (the A operand of the bf16-split GEMM needs 16-byte rows and whole K16 steps).
 __global__ __launch_bounds__(128) void prologue_kernel(float* __restrict__ seq0, const float* __restrict__ time_table,
                                                        const float* __restrict__ pos_table, const int64_t* __restrict__ t,
                                                        const float* __restrict__ cond, const uint8_t* __restrict__ frame_mask,
                                                        uint8_t* __restrict__ keymask, int T, int L, int n_cond, int d,
-                                                       int n_timesteps, int copy_cond) {
+                                                       int n_timesteps, int copy_cond, const float* __restrict__ x_t,
+                                                       float* __restrict__ xpad, int md, int kpad) {
     const int b = blockIdx.x, tok = blockIdx.y;
+    if (xpad) {
+        for (int l = tok; l < L; l += gridDim.y) {
+            const float* src = x_t + ((int64_t)b * L + l) * md;
+            float* dstp = xpad + ((int64_t)b * L + l) * kpad;
+            for (int c = threadIdx.x; c < kpad; c += blockDim.x) dstp[c] = c < md ? src[c] : 0.0f;
+        }
+    }
     float* dst = seq0 + ((int64_t)b * T + tok) * d;
     if (tok == 0) {
         int64_t ti = t[b];
@@ -103,13 +114,14 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
     uint8_t* keymask = frame_mask ? ws.keymask : nullptr;
 
     hipLaunchKernelGGL(prologue_kernel, dim3(B, 1 + w.n_cond), dim3(128), 0, s, ws.seq0, w.time_table, w.pos_table, t, cond,
-                       frame_mask, keymask, T, L, w.n_cond, d, w.n_timesteps, copy_cond ? 1 : 0);
+                       frame_mask, keymask, T, L, w.n_cond, d, w.n_timesteps, copy_cond ? 1 : 0, x_t, ws.xpad, w.motion_dim, w.motion_adapter_kpad);
     AFM_CHECK_LAUNCH();
 
     {   // motion_adapter (cmdm.py:159) scattered to token rows 1+n_cond.., + positional encoding (cmdm.py:162)
         afm_linear_args a = {};
-        a.A = x_t; a.lda = w.motion_dim; a.W = w.motion_adapter_w; a.ldw = w.motion_dim;
-        a.C = ws.seq0; a.ldc = d; a.M = B * L; a.N = d; a.K = w.motion_dim;
+        const int kp = w.motion_adapter_kpad;           // > 0: motion_adapter_w is [d, kp] (zero-padded columns) and the A rows are ws.xpad
+        a.A = kp ? ws.xpad : x_t; a.lda = kp ? kp : w.motion_dim; a.W = w.motion_adapter_w; a.ldw = a.lda;
+        a.C = ws.seq0; a.ldc = d; a.M = B * L; a.N = d; a.K = (int)a.lda;
         a.bias = w.motion_adapter_b;
         a.rowtab = w.pos_table + (int64_t)(1 + w.n_cond) * d; a.rowtab_period = L;
         a.c_grp = L; a.c_stride = T; a.c_off = 1 + w.n_cond;
@@ -191,6 +203,7 @@ int validate(const afm_cmdm_weights* w, int B, int L) {
     if (w->gemm_arith != AFM_ARITH_DEFAULT && w->gemm_arith != AFM_ARITH_F32 && w->gemm_arith != AFM_ARITH_BF16X6 && w->gemm_arith != AFM_ARITH_BF16X9 &&
         w->gemm_arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
     if (w->gemm_arith_min_n < 0 || w->attn_group_waves < 0) return AFM_E_BADARG;
+    if (w->motion_adapter_kpad != 0 && (w->motion_adapter_kpad < w->motion_dim || (w->motion_adapter_kpad & 3))) return AFM_E_BADARG;
     if (!w->motion_adapter_w || !w->motion_layer_w || !w->time_table || !w->pos_table) return AFM_E_BADARG;
     return 0;
 }

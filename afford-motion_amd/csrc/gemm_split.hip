@@ -22,39 +22,9 @@
 #include "common.h"
 #include "profile.h"
 #include "gemm_epilogue.h"
+#include "bf16split.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));     // first-class 16-byte value (HIP's uint4 struct copies can pin arrays in scratch)
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// v_cvt_pk_bf16_f32 (round to nearest even); a builtin conversion, not inline asm, so the machine scheduler can place it
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-// two f32 -> three packed bf16 pairs; every residual subtraction is exact (|x - bf16(x)| <= half a bf16 ulp of x)
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    p1 = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
-    p2 = cvt_pk_bf16(r0, r1);
-    r0 -= __uint_as_float(p2 << 16);
-    r1 -= __uint_as_float(p2 & 0xffff0000u);
-    p3 = cvt_pk_bf16(r0, r1);
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// product order: small terms first inside every K16 step
-__device__ constexpr int PA[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0};
-__device__ constexpr int PB[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
 
 // K is summed in SEGMENTS of KSEG = 256: every segment accumulates from zero and the segment sums are added left to right,
 // ((s0 + s1) + s2) + s3.  With KG == 1 a workgroup walks all segments itself (a second accumulator set, one add per segment: free);
@@ -195,7 +165,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = mfma_bf16(af[tm][PA[q]], bf[tn][PB[q]], acc[tm][tn]);
+                    acc[tm][tn] = mfma_bf16(af[tm][AFM_PA[q]], bf[tn][AFM_PB[q]], acc[tm][tn]);
                     ++m;
 #pragma unroll
                     for (int t = 0; t < NPIECE; ++t)

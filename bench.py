@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-gemm", action="store_true", help="skip the informational passes with the other GEMM arithmetic settings")
     ap.add_argument("--streams", type=int, default=None, help="sub-batch HIP streams of the native loop (default: model default)")
+    ap.add_argument("--attn-group", type=int, default=None, help="waves per attention workgroup (bit-neutral tuning; default: library choice)")
     args = ap.parse_args()
 
     from afm import dist as adist, ffi, synth
@@ -170,6 +171,8 @@ def main():
     model, diff_k, cfg = build(dev, str(K))
     if args.streams is not None:
         model.loop_streams, model.loop_streams_auto = args.streams, False
+    if args.attn_group is not None:
+        model.attn_group_waves = args.attn_group
     from afm.base import create_gaussian_diffusion
     cfg.diffusion.timestep_respacing = str(max(W, 1))
     diff_w = create_gaussian_diffusion(cfg)

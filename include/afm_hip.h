@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 4
+#define AFM_ABI_VERSION 5
 
 #define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
 #define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
@@ -399,6 +399,9 @@ typedef struct {
     int32_t gemm_arith, gemm_arith_min_n;
     int32_t attn_group_waves;              /* afm_mha_fwd_grouped's group_waves (0 = auto)                              */
     int32_t flags;                         /* AFM_CMDM_* bits                                                           */
+    /* ABI v5: 0, or the row length (a multiple of 4, >= motion_dim) motion_adapter_w is zero-padded to: [d, kpad].  The loop then keeps a
+     * padded copy of x_t in its workspace so that the adapter (K = 263 for 'h3d') runs with K = 272 on the bf16-split GEMM. */
+    int32_t motion_adapter_kpad;
 } afm_cmdm_weights;
 
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */

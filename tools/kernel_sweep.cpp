@@ -113,7 +113,7 @@ static void mha_sweep(const std::vector<int>& batches) {
         CK(hipMemcpy(dm, mask.data(), mask.size(), hipMemcpyHostToDevice));
         for (int masked = 0; masked < 2; ++masked) {
             bool have_ref = false;
-            for (int g : {12, 8, 4, 2, 1, 0}) {
+            for (int g : {12, 8, 6, 4, 2, 1, 0}) {
                 CK(hipMemsetAsync(dout, 0xFF, no * 4, st));
                 int rc = afm_mha_fwd_grouped(dq, masked ? dm : nullptr, dout, B, T, H, dh, g, st);
                 if (rc) { printf("B=%-2d mha group=%d rc=%d\n", B, g, rc); continue; }
