@@ -22,7 +22,8 @@ OBJ = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-Werror=pass-failed",          # a failed `#pragma unroll` demotes register arrays to scratch
          "-Rpass-analysis=kernel-resource-usage"]
-MAX_SCRATCH_BYTES = 32       # per lane; anything larger means an accumulator array left the register file
+MAX_SCRATCH_BYTES = 64       # per lane; anything larger means an accumulator array left the register file (the 168-register attention
+                             # variants park a few pointers - 44 B - in scratch outside their main loop: checked in the ISA, round 3)
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 # ---- ISA scan (profiles/r02_decfold_nondeterminism.md, profiles/r03_isa_scan.md).  One build of lat_decfold_kernel lost single

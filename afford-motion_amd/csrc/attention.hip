@@ -254,9 +254,12 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW == 12 ? 3 : 1)) void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
                                                                 const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
                                                                 float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk) {
+    // `scale` = log2(e) / sqrt(dh): the logits are kept in base-2 units, so the softmax is exp2(s - m) = one v_exp_f32 per element
     constexpr int NT = 64 * NW;
     constexpr int NIT = (256 + NT - 1) / NT;            // staging items per thread (256 items per block: 128 of K, 128 of V)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TL(const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(); const unsigned long long tl_c0 = afm_cyc();
+       unsigned long long tl_s = 0, tl_soft = 0, tl_pv = 0, tl_sync = 0;)
     unsigned char* kv = smem_raw;                       // [2][KVSTAGE]
     float* madd = reinterpret_cast<float*>(smem_raw + 2 * KVSTAGE);                 // [nkb * KB] additive mask (0 / -inf)
     int* blk_valid = reinterpret_cast<int*>(madd + ((T + KB - 1) / KB) * KB);       // [nkb]
@@ -277,12 +280,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
     const float* vbase = vp_ + (int64_t)b * T * ldkv + h * DH;
     const float NEG_INF = -INFINITY;
 
+    // blk_valid[kb]: bit 0 = the block has a valid key, bit 1 = it has a masked key (blocks without bit 0 are skipped, blocks without bit 1
+    // skip the mask addition); both written with atomic ORs by whichever threads see such a key
     for (int i = tid; i < nkb; i += NT) blk_valid[i] = 0;
     __syncthreads();
     for (int i = tid; i < nkb * KB; i += NT) {
         const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
         madd[i] = ok ? 0.0f : NEG_INF;
-        if (ok) blk_valid[i / KB] = 1;              // benign race: every writer stores 1
+        atomicOr(&blk_valid[i / KB], ok ? 1 : 2);
     }
 
     // Staging items (all loads unconditional, rows past the last key clamped to key T-1: those keys carry an additive -inf):
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
     for (int q0 = chunk * NW; q0 < nqb; q0 += NW * nchunk) {
         const int qb = q0 + wave;
         const bool active = qb < nqb;
+        if (NW <= 4) load_block(0);      // in flight under the Q loads and the Q split (the 168-register variants cannot afford the live range)
         // Q planes: query row (clamped), K16 step s covers head dims 16 s + 8 hh .. + 7, pre-scaled (1 / sqrt(64) is a power of two)
         u32x4 qpl[4][3];
         {
@@ -372,14 +378,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 
         __syncthreads();                 // previous pass done with LDS; madd / blk_valid visible
-        load_block(0);
+        if (NW > 4) load_block(0);
         store_block(0);
         __syncthreads();
 
         for (int kb = 0; kb < nkb; ++kb) {
             const int buf = kb & 1;
+            TL(const unsigned long long tl_a = afm_cyc();)
             if (kb + 1 < nkb) load_block(kb + 1);
-            if (active && blk_valid[kb]) {
+            const int bflag = blk_valid[kb];
+            if (active && (bflag & 1)) {
                 const unsigned char* kpl = kv + buf * KVSTAGE + r32 * KROWB + hh * 16;
                 const unsigned char* vpl = kv + buf * KVSTAGE + 3 * KPLANE + r32 * VROWB + hh * 16;
                 // ---- S^T = K Q^T: A = K block (row = key), B = Q^T (column = query), 4 K16 steps x 9 products
@@ -395,21 +403,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
                     for (int q = 0; q < 9; ++q) s = mfma_bf16(ak[AFM_PA[q]], qpl[st_][AFM_PB[q]], s);
                 }
                 // ---- mask + online softmax; reg r <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
+                TL(asm volatile("" : "+v"(s)); const unsigned long long tl_b = afm_cyc(); tl_s += tl_b - tl_a;)
                 float mx = NEG_INF;
+                if (bflag & 2) {                 // wave-uniform: only blocks with a masked key pay the addition
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 ma = *reinterpret_cast<const float4*>(madd + kb * KB + 8 * g + 4 * hh);
-                    s[4 * g + 0] += ma.x; s[4 * g + 1] += ma.y; s[4 * g + 2] += ma.z; s[4 * g + 3] += ma.w;
-                    mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 ma = *reinterpret_cast<const float4*>(madd + kb * KB + 8 * g + 4 * hh);
+                        s[4 * g + 0] += ma.x; s[4 * g + 1] += ma.y; s[4 * g + 2] += ma.z; s[4 * g + 3] += ma.w;
+                    }
                 }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
                 mx = fmaxf(mx, xor32(mx));
                 const float m_new = fmaxf(m_run, mx);
                 const float m_safe = (m_new == NEG_INF) ? 0.0f : m_new;
-                const float alpha = __expf(m_run - m_safe);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
                 float rs = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] = __expf(s[r] - m_safe);
+                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_safe);
                     rs += s[r];
                 }
                 rs += xor32(rs);
@@ -417,6 +429,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
                 m_run = m_new;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                TL(asm volatile("" : "+v"(s)); const unsigned long long tl_c = afm_cyc(); tl_soft += tl_c - tl_b;)
                 // ---- O^T += V^T P^T: K16 step t takes the P registers 8 t .. 8 t + 7 of this lane (k-slot 8 hh + e <-> register 8 t + e)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -436,9 +449,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
                         o1 = mfma_bf16(av1[AFM_PA[q]], pp[AFM_PB[q]], o1);
                     }
                 }
+                TL(asm volatile("" : "+v"(o0), "+v"(o1)); const unsigned long long tl_d = afm_cyc(); tl_pv += tl_d - tl_c;)
             }
+            TL(const unsigned long long tl_e = afm_cyc();)
             if (kb + 1 < nkb) store_block(buf ^ 1);
             __syncthreads();
+            TL(tl_sync += afm_cyc() - tl_e;)
         }
 
         if (active) {
@@ -456,6 +472,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
             }
         }
     }
+    TL(if (afm_mha_timeline && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        afm_mha_timeline[blockIdx.x] = AfmMhaRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), tl_c0, afm_cyc(), tl_s, tl_soft, tl_pv, tl_sync, hw, xcc};
+    })
 }
 
 // group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 6 / 8 / 12; 0 = the library's choice; < 0 = one workgroup per
@@ -482,6 +504,7 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     if (train && (!lse || drop_p < 0.0f || drop_p >= 1.0f)) return AFM_E_BADARG;
     const int nqb = (Tq + 31) / 32, nkb = (T + 31) / 32;
     const float scale = 1.0f / sqrtf((float)dh);
+    const float scale2 = 1.4426950408889634f * scale;         // log2(e) / sqrt(dh): the inference kernel's logits are in base-2 units
     hipStream_t s = (hipStream_t)stream;
     if (train) {
         const int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
@@ -510,20 +533,22 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     } else {
         if (group_waves != 0 && group_waves != 1 && group_waves != 2 && group_waves != 4 && group_waves != 6 && group_waves != 8 && group_waves != 12)
             return AFM_E_BADARG;
-        nw = group_waves ? group_waves : AFM_MHA_DEFAULT_GROUP;
-        if (nw > nqb) nw = nqb >= 12 ? 12 : (nqb >= 8 ? 8 : (nqb >= 6 ? 6 : (nqb >= 4 ? 4 : (nqb >= 2 ? 2 : 1))));      // never more waves than query blocks
+        // one 12-wave workgroup per (sample, head) when those alone fill the chip (every K / V block is split and staged once, three waves per
+        // SIMD: profiles/r03_mha_timeline.txt), 4-wave groups (three workgroups per (sample, head)) for small launches.  Bit-identical either way.
+        nw = group_waves ? group_waves : ((int64_t)B * H >= 128 ? 12 : AFM_MHA_DEFAULT_GROUP);
+        if (nw > nqb) nw = nqb > 8 ? 12 : (nqb > 6 ? 8 : (nqb > 4 ? 6 : (nqb > 2 ? 4 : nqb)));      // the smallest group that covers the query blocks
         nchunk = (nqb + nw - 1) / nw;
     }
     const size_t lds = (size_t)2 * KVSTAGE + (size_t)nkb * KB * sizeof(float) + (size_t)nkb * sizeof(int);
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~25000 keys
     AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
     switch (nw) {
-        case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
-        case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
-        case 4: return launch_split_mha<4>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
-        case 6: return launch_split_mha<6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
-        case 8: return launch_split_mha<8>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
-        default: return launch_split_mha<12>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale, nchunk, lds, s);
+        case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
+        case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
+        case 4: return launch_split_mha<4>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
+        case 6: return launch_split_mha<6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
+        case 8: return launch_split_mha<8>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
+        default: return launch_split_mha<12>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
     }
 }
 

@@ -213,6 +213,16 @@ def test_two_sub_batch_loop_repeats():
         assert not bad, f"loop {r}: samples {bad} differ from the single-stream result (max {(out - ref).abs().max().item():.2e})"
 
 
+def test_two_stream_loop_soak():
+    """Round 3: the soak harness of profiles/r02_decfold_nondeterminism.md inside the suite - 50 two-stream 50-step loops of
+    the ADM at configs[4]'s size against the single-stream result, bit for bit (the failing round-2 build differed in ~1/4 of such loops)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from loop_determinism_probe import probe_cdm
+    bad = probe_cdm(50, dev())
+    assert not bad, f"{len(bad)} of 50 two-stream loops differ from the single-stream result: {bad[:4]}"
+
+
 def test_folded_sampling_form_and_batched_latent_chain_match_the_layered_form(cdm):
     """Round 2: in eval mode the CDM samples in a FOLDED form (step-invariant parts of the two adapters hoisted out of the loop, linear2 +
     residual + contact_layer collapsed into row-dots in linear1's epilogue, h1 never stored) and runs its 2-latent chain as batched

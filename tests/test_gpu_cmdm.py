@@ -440,3 +440,13 @@ def test_small_batch_loop_is_bit_identical_to_the_large_batch():
                 break
         got = torch.cat(parts)
         assert torch.equal(got, whole[: got.shape[0]]), f"shards of {nb} samples differ from the batch of {B}"
+
+
+def test_two_stream_loop_soak():
+    """Round 3: 50 two-stream 100-step loops of the headline CMDM shape (B = 32, L = 196, N = 8192) against the
+    single-stream result, bit for bit - the harness that caught round 2's lat_decfold defect (profiles/r02_decfold_nondeterminism.md)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from loop_determinism_probe import probe_cmdm
+    bad = probe_cmdm(50, dev())
+    assert not bad, f"{len(bad)} of 50 two-stream loops differ from the single-stream result: {bad[:4]}"

@@ -210,6 +210,43 @@ def test_gemm_arithmetic_switches_are_host_state():
         assert ffi.load().afm_version() == ffi.ABI_VERSION == 5
 
 
+def _build_hip_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("afm_build_hip", os.path.join(ROOT, "afford-motion_amd", "build_hip.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_isa_scan_flags_the_known_bad_kernel_form(tmp_path):
+    """Round 3: the build rejects the instruction shape of round 2's lat_decfold defect - a packed-f32 VALU op reading the
+    HIGH half of an SGPR pair that an `s_mov_b32 s, s` re-pack of scalar-loaded data wrote next to it (profiles/r02_decfold_nondeterminism.md).
+    The failing kernel form is kept as tools/probes/decfold_scalar_form.hip: compiled for gfx950 here (no GPU needed) it must be flagged,
+    and every object of the shipped library must be clean."""
+    import glob
+    import shutil
+    import subprocess
+    bh = _build_hip_module()
+    # unit level: the disassembly parser on a hand-written listing (hi half read + SGPR->SGPR copy = hit; literal move or low-half broadcast = clean)
+    bad = "0000000000001000 <k>:\n\ts_mov_b32 s31, s40   // 0\n\tv_pk_mul_f32 v[36:37], v[30:31], s[30:31] op_sel:[1,0] op_sel_hi:[0,1] // 1\n"
+    lit = "0000000000001000 <k>:\n\ts_mov_b32 s35, 0.5   // 0\n\tv_pk_mul_f32 v[24:25], v[24:25], s[34:35] // 1\n"
+    low = "0000000000001000 <k>:\n\ts_mov_b32 s13, s40   // 0\n\tv_pk_fma_f32 v[0:1], s[12:13], v[2:3], v[0:1] op_sel_hi:[0,1,1] // 1\n"
+    assert len(bh.scan_disassembly(bad)) == 1 and bh.scan_disassembly(lit) == [] and bh.scan_disassembly(low) == []
+    if shutil.which("hipcc") is None or not os.path.exists(bh.OBJDUMP):
+        pytest.skip("hipcc / llvm-objdump not available")
+    obj = str(tmp_path / "decfold_bad.o")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(ROOT, "tools", "probes", "decfold_scalar_form.hip"), "-o", obj],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    hits = bh.scan_object(obj)
+    assert hits and all(h[0] == "decfold_scalar_form" for h in hits), hits[:3]
+    objs = glob.glob(os.path.join(ROOT, "afford-motion_amd", "build", "*.o"))
+    if not objs:
+        pytest.skip("library objects not built")
+    for o in objs:
+        assert bh.scan_object(o) == [], f"{os.path.basename(o)} contains the fenced instruction shape"
+
+
 def test_progress_slices_cover_the_chain():
     """`progress=True` (test.py:94-101) runs the native loop as chained slices: contiguous, complete, ~50 of them."""
     assert ffi.progress_slices(1000, False) == [(0, 1000)]
