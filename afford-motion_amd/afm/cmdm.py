@@ -185,6 +185,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._side_streams: List[torch.cuda.Stream] = []
         self.attn_group_waves = 0  # afm_mha_fwd_grouped workgroup shape (0 = library heuristic; results do not depend on it)
         self.no_l0_cache = bool(os.environ.get("AFM_CMDM_NO_L0_CACHE"))      # measurement knob (host state, passed in the pack)
+        self.fused_layernorm = False       # norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; measured slower on MI355X, profiles/r03_ln_fusion.md)
         self._pack = None          # (version, CmdmWeights, keep-alive tensors)
         self._cond_cache = None    # (key, cond_tokens)
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -233,7 +234,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         """Per-call settings of the pack: the host's GEMM arithmetic (afm.ops.set_gemm_split) and bit-neutral tuning fields."""
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
         w.attn_group_waves = int(self.attn_group_waves)
-        w.flags = ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0
+        w.flags = (ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0) | (ffi.CMDM_FUSED_LN if self.fused_layernorm else 0)
         return w
 
     def _workspace(self, w: ffi.CmdmWeights, B: int, L: int, device) -> torch.Tensor:

@@ -19,7 +19,7 @@ _lib = None
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
-CMDM_NO_L0_CACHE = 0x1
+CMDM_NO_L0_CACHE, CMDM_FUSED_LN = 0x1, 0x2
 CDM_SERIAL_LATENT, CDM_VALU_REDUCE = 0x1, 0x2
 ABI_VERSION = 5
 MAX_LAYERS = 16
@@ -49,6 +49,8 @@ class LinearArgs(C.Structure):
         ("arith", i32), ("arith_min_n", i32), ("tune", i32),
         # fused row-dot epilogue (ABI v4)
         ("rowdot_w", c_f32p), ("rowdot_out", c_f32p), ("rowdot_n", i32),
+        # fused LayerNorm of the output rows (ABI v5)
+        ("ln_gamma", c_f32p), ("ln_beta", c_f32p), ("ln_out", c_f32p), ("ldo", i64), ("ln_eps", C.c_float), ("ln_counters", C.c_void_p),
     ]
 
 

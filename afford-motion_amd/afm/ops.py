@@ -21,13 +21,18 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            rowtab: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            rows: Optional[int] = None, a_map: Optional[RowMap] = None, c_map: Optional[RowMap] = None,
-           rowdot_w: Optional[torch.Tensor] = None, rowdot_out: Optional[torch.Tensor] = None, store: bool = True) -> torch.Tensor:
+           rowdot_w: Optional[torch.Tensor] = None, rowdot_out: Optional[torch.Tensor] = None, store: bool = True,
+           ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, ln_out: Optional[torch.Tensor] = None,
+           ln_counters: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``act_post(act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)])`` on f32 MFMA.
 
     x [..., K] (or a 2-D row pool when ``a_map`` gathers rows), weight [N, K] as in nn.Linear.
     With ``out`` given (2-D row pool [R, N]) and ``c_map``, rows are scattered into it.
     ``rowdot_w`` [R, N] + ``rowdot_out`` [rows, ceil(N / 64), R]: the fused row-dot epilogue (afm_linear_args.rowdot_*): per 64-column
-    group, the dot of the output row with each of the R vectors; ``store=False`` then skips writing the output itself."""
+    group, the dot of the output row with each of the R vectors; ``store=False`` then skips writing the output itself.
+    ``ln`` = (gamma, beta, eps) + ``ln_out`` (same row layout as the output): the fused LayerNorm of the output rows (afm_linear_args.ln_*,
+    the workgroup finishing the last column tile of a row block normalises it); ``ln_counters`` = zeroed int32 scratch of >= ceil(M / 32)
+    words (allocated here when omitted).  Returns the (pre-LayerNorm) output; the normalised rows are in ``ln_out``."""
     lib = ffi.load()
     ffi.require_gpu(x, weight)
     x = ffi.f32c(x)
@@ -63,11 +68,23 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         a.c_grp, a.c_stride, a.c_off = c_map
     if rowdot_w is not None:
         rowdot_w = ffi.f32c(rowdot_w)
-        assert rowdot_w.shape[1] == N and rowdot_out is not None and rowdot_out.is_contiguous() and rowdot_out.dtype == torch.float32
+        R = rowdot_w.shape[0]
+        assert rowdot_w.shape[1] == N and 1 <= R <= 8, rowdot_w.shape
+        assert rowdot_out is not None and rowdot_out.is_contiguous() and rowdot_out.dtype == torch.float32 and rowdot_out.device == x.device
+        assert rowdot_out.numel() >= M * ((N + 63) // 64) * R, (rowdot_out.shape, M, N, R)      # [rows, ceil(N / 64), R]: an undersized buffer is written out of bounds
         keep += [rowdot_w, rowdot_out]
         a.rowdot_w, a.rowdot_out, a.rowdot_n = rowdot_w.data_ptr(), rowdot_out.data_ptr(), rowdot_w.shape[0]
         if not store:
             a.C = None
+    if ln is not None:
+        g, b, eps = ln
+        g, b = ffi.f32c(g), ffi.f32c(b)
+        assert ln_out is not None and ln_out.dtype == torch.float32 and ln_out.is_contiguous() and ln_out.shape[-1] == N and g.numel() == N and b.numel() == N
+        if ln_counters is None:
+            ln_counters = torch.zeros((M + 31) // 32, dtype=torch.int32, device=x.device)
+        assert ln_counters.dtype == torch.int32 and ln_counters.numel() >= (M + 31) // 32
+        keep += [g, b, ln_out, ln_counters]
+        a.ln_gamma, a.ln_beta, a.ln_out, a.ldo, a.ln_eps, a.ln_counters = g.data_ptr(), b.data_ptr(), ln_out.data_ptr(), N, float(eps), ln_counters.data_ptr()
     fill_arith(a)
     ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
     return out

@@ -25,6 +25,7 @@ inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 struct Workspace {
     float *seq0, *y, *x1, *tmp, *qkv, *qkv0, *att, *hid, *noise, *xpad;
     uint8_t* keymask;
+    uint32_t* lncnt;          // tickets of the fused LayerNorm (one word per 32 output rows; zero between launches)
     int64_t bytes;
 };
 
@@ -44,6 +45,7 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.hid = (float*)take(M * (int64_t)w.ff * 4);
     ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
     ws.keymask = (uint8_t*)take(M);
+    ws.lncnt = (uint32_t*)take(((M + 31) / 32) * 4);
     ws.xpad = w.motion_adapter_kpad > 0 ? (float*)take((int64_t)B * L * w.motion_adapter_kpad * 4) : nullptr;      // x_t with rows padded to the GEMM's K
     ws.bytes = off;
     return ws;
@@ -159,8 +161,14 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.A = ws.att; a.lda = d; a.W = lw.out_proj_w; a.ldw = d; a.C = ws.tmp; a.ldc = d;
         a.M = rows; a.N = d; a.K = d; a.bias = lw.out_proj_b; a.residual = X; a.ldr = d;
         a.a_grp = g; a.a_stride = gs; a.a_off = go; a.c_grp = g; a.c_stride = gs; a.c_off = go;
+        // norm1 / norm2 CAN run inside the GEMM that produces their input (afm_linear_args.ln_*: the workgroup finishing the last column
+        // tile of a block of rows normalises it; bit-identical).  Measured SLOWER than the separate launch on MI355X (B = 32: +20 us per
+        // GEMM launch against 10.7 us per LayerNorm launch; B = 4: 0.679 vs 0.628 ms/step; profiles/r03_ln_fusion.md): every tile's
+        // workgroup has to drain its write-through stores and wait for its ticket before it can retire.  Opt-in: AFM_CMDM_FUSED_LN.
+        const bool fuse_ln = (w.flags & AFM_CMDM_FUSED_LN) != 0;
+        if (fuse_ln) { a.ln_gamma = lw.norm1_w; a.ln_beta = lw.norm1_b; a.ln_out = ws.x1; a.ldo = d; a.ln_eps = 1e-5f; a.ln_counters = ws.lncnt; }
         AFM_TRY(run_linear(w, a, s));
-        AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, rows, d, 1e-5f, g, gs, go, s));
+        if (!fuse_ln) AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, rows, d, 1e-5f, g, gs, go, s));
         a = {};
         a.A = ws.x1; a.lda = d; a.W = lw.lin1_w; a.ldw = d; a.C = ws.hid; a.ldc = w.ff;
         a.M = rows; a.N = w.ff; a.K = d; a.bias = lw.lin1_b; a.act = AFM_ACT_GELU;
@@ -170,8 +178,9 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.A = ws.hid; a.lda = w.ff; a.W = lw.lin2_w; a.ldw = w.ff; a.C = ws.tmp; a.ldc = d;
         a.M = rows; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.x1; a.ldr = d;
         a.c_grp = g; a.c_stride = gs; a.c_off = go;
+        if (fuse_ln) { a.ln_gamma = lw.norm2_w; a.ln_beta = lw.norm2_b; a.ln_out = ws.y; a.ldo = d; a.ln_eps = 1e-5f; a.ln_counters = ws.lncnt; }
         AFM_TRY(run_linear(w, a, s));
-        AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm2_w, lw.norm2_b, ws.y, rows, d, 1e-5f, g, gs, go, s));
+        if (!fuse_ln) AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm2_w, lw.norm2_b, ws.y, rows, d, 1e-5f, g, gs, go, s));
         X = ws.y;
     }
 
@@ -227,6 +236,7 @@ extern "C" int afm_cmdm_forward(const afm_cmdm_weights* w, const float* x_t, con
     if (B == 0) return 0;
     const Workspace ws = carve(*w, B, L, workspace);
     if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
+    if (hipMemsetAsync(ws.lncnt, 0, (size_t)(((int64_t)B * (1 + w->n_cond + L) + 31) / 32) * 4, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     return forward_impl(*w, x_t, t, cond_tokens, frame_mask, x0_out, ddpm, B, L, ws, true, (hipStream_t)stream);
 }
 
@@ -302,7 +312,8 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
     }
 
     const int T = 1 + w->n_cond + L;
-    (void)T;
+    for (int s = 0; s < nsub; ++s)        // ticket words of the fused LayerNorm: zero once, every launch leaves them zero
+        if (count[s] > 0 && hipMemsetAsync(ws[s].lncnt, 0, (size_t)(((int64_t)count[s] * T + 31) / 32) * 4, st[s]) != hipSuccess) return (int)hipGetLastError();
     const int64_t row = (int64_t)L * w->motion_dim;
     int rc = 0;
     for (int j = 0; j < n_steps && rc == 0; ++j) {

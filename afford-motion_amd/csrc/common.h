@@ -150,6 +150,48 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return r;
 }
 
+// LayerNorm of one row by one wave (dim % 4 == 0, dim <= 256 * MAXV): the row lives in registers, lane l holds the float4 at columns
+// (64 i + l) * 4.  Shared by layernorm_kernel and the fused "last arriver" LayerNorm of the GEMM epilogues: no fp contraction, so that
+// both contexts compile to the same operations (the fused and the two-launch forms are bit-identical).
+template <int MAXV>
+__device__ __forceinline__ void layernorm_row(const float* __restrict__ xp, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float* __restrict__ yp, int dim, float eps, int lane) {
+#pragma clang fp contract(off)
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (c < dim) ? *reinterpret_cast<const float4*>(xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < dim) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < dim) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 bb = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+            *reinterpret_cast<float4*>(yp + c) = o;
+        }
+    }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -14,41 +14,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     if (grp) row = (row / grp) * stride + off + row % grp;          // logical row -> strided token row
-    const float* xp = x + row * dim;
-    float4 v[MAXV];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        v[i] = (c < dim) ? *reinterpret_cast<const float4*>(xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    const float mean = wave_sum(sum) / (float)dim;
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < dim) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            sq += (a * a + b * b) + (cc * cc + d * d);
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
-    float* yp = y + row * dim;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < dim) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 bb = *reinterpret_cast<const float4*>(beta + c);
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * g.x + bb.x;
-            o.y = (v[i].y - mean) * rstd * g.y + bb.y;
-            o.z = (v[i].z - mean) * rstd * g.z + bb.z;
-            o.w = (v[i].w - mean) * rstd * g.w + bb.w;
-            *reinterpret_cast<float4*>(yp + c) = o;
-        }
-    }
+    layernorm_row<MAXV>(x + row * dim, gamma, beta, y + row * dim, dim, eps, lane);
 }
 
 // any dim (not a multiple of 4, e.g. the 646-wide input LayerNorm of the CDM 'MLP' arch, cdm.py:18-23): wave per row,

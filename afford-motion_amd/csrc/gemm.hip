@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
     __syncthreads();
 
     gemm_epilogue<BM, BN>(p, lds, bm, bn, tid);
+    gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(lds));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
                 lds[(wm * TM * 32 + tm * 32 + mfma_row(r, lane)) * LDC + wn * TN * 32 + tn * 32 + r32] = acc[tm][tn][r];
     __syncthreads();
     gemm_epilogue<BM, BN, NT>(p, lds, bm, bn, tid);
+    gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(lds));
 #ifdef AFM_TIMELINE
     if (afm_timeline && tid == 0) {
         unsigned hw, xcc;
@@ -409,6 +411,12 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
+    if (a.ln_out) {                               // fused LayerNorm of the output rows (ABI v5)
+        const uintptr_t lp = (uintptr_t)a.C | (uintptr_t)a.ln_out | (uintptr_t)a.ln_gamma | (uintptr_t)a.ln_beta;
+        if (!a.C || !a.ln_gamma || !a.ln_beta || !a.ln_counters || (a.N & 3) || (a.ldc & 3) || (a.ldo & 3) || (lp & 15) || a.N > 1024 ||
+            a.ln_out == a.C || a.ln_out == a.A || a.ln_out == a.residual || a.ddpm_out || a.rowdot_w)
+            return AFM_E_BADARG;
+    }
     if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9 &&
         a.arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
     if (a.arith_min_n < 0) return AFM_E_BADARG;

@@ -13,6 +13,14 @@ struct RowMap {
     }
 };
 
+// 16-byte WRITE-THROUGH store (sc1): the tile of a fused-LayerNorm launch is read back by another workgroup, possibly on another XCD
+// (private L2s).  Written through, it needs no release fence (cdna_hip_programming.md section 6 Guideline 16, recipe R1: a per-tile
+// `buffer_wbl2` release cost 45 us per launch here).  The trailing s_nop keeps the data registers intact until the store has read them.
+__device__ __forceinline__ void store_f4_sc1(float* ptr, const float4& v) {
+    const f32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(d) : "memory");
+}
+
 // epilogue math for one output element (compact: instantiated once, looped over, never unrolled 64x)
 __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int grow, int64_t orow, int gcol) {
     if (p.scale) v *= p.scale[gcol];
@@ -94,7 +102,8 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             if (p.rowtab) { const float4 t = *reinterpret_cast<const float4*>(p.rowtab + (int64_t)(grow % p.rowtab_period) * p.N + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             if (p.act_post) { v.x = apply_act(v.x, p.act_post); v.y = apply_act(v.y, p.act_post); v.z = apply_act(v.z, p.act_post); v.w = apply_act(v.w, p.act_post); }
             if (drop && p.drop_after) { const uint32_t ro = (uint32_t)orow, co = (uint32_t)gcol; v.x *= dk(ro, co); v.y *= dk(ro, co + 1); v.z *= dk(ro, co + 2); v.w *= dk(ro, co + 3); }
-            *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
+            if (p.ln_out) store_f4_sc1(p.C + orow * p.ldc + gcol, v);           // uniform: published to the row block's last arriver
+            else *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
         }
     } else {
         for (int e = tid; e < BM * BN; e += NT) {
@@ -103,13 +112,50 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             if (grow >= p.M || gcol >= p.N) continue;
             const int64_t orow = cmap(grow);
             const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol);
-            if (p.C) p.C[orow * p.ldc + gcol] = v;
+            if (p.C && p.ln_out) __hip_atomic_store(p.C + orow * p.ldc + gcol, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1), scalar form
+            else if (p.C) p.C[orow * p.ldc + gcol] = v;
             if (p.ddpm_out) {
                 const int b = grow / p.rows_per_sample;
                 const int64_t ix = orow * p.ldx + gcol;
                 p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
             }
         }
+    }
+}
+
+// Fused LayerNorm of the output rows ("last arriver", afm_linear_args.ln_*): called by EVERY thread of the workgroup after its tile's
+// epilogue.  The tile is published with the placement-independent hand-off of cdna_hip_programming.md section 6 Guideline 16 (R1 with a
+// ticket counter): the tile was stored write-through (sc1), every storing wave drains its stores, ONE lane takes a ticket on the row
+// block's counter (relaxed, agent scope); the workgroup that draws the last ticket does ONE agent-scope acquire and then normalises the
+// block's rows with plain loads - one wave per row, the arithmetic of layernorm_kernel.  `flag` is a word of the kernel's (now idle)
+// LDS staging area.
+template <int BM>
+__device__ __forceinline__ void gemm_ln_tail(const afm_linear_args& p, int bm, int nbn, int* flag) {
+    if (!p.ln_out) return;                                           // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave: its write-through stores have landed
+    __syncthreads();                                                 // (also: every read of the staging area is done)
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(p.ln_counters + bm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (unsigned)(nbn - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.ln_counters + bm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < BM; r += nw) {
+        const int grow = bm * BM + r;
+        if (grow >= p.M) break;
+        const int64_t orow = cmap(grow);
+        const float* xp = p.C + orow * p.ldc;
+        float* yp = p.ln_out + orow * p.ldo;
+        if (p.N <= 256) layernorm_row<1>(xp, p.ln_gamma, p.ln_beta, yp, p.N, p.ln_eps, lane);
+        else if (p.N <= 512) layernorm_row<2>(xp, p.ln_gamma, p.ln_beta, yp, p.N, p.ln_eps, lane);
+        else layernorm_row<4>(xp, p.ln_gamma, p.ln_beta, yp, p.N, p.ln_eps, lane);
     }
 }
 

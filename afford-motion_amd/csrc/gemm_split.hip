@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     }
     __syncthreads();
     if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid);
+    gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(ldsf));
 #ifdef AFM_TIMELINE
     if (afm_timeline && threadIdx.x == 0) {
         unsigned hw, xcc;

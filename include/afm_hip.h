@@ -108,6 +108,14 @@ typedef struct {
      * through the c_* remap) in a fixed summation order that does not depend on the tile shape; the consumer adds the groups left to
      * right.  C may be NULL.  Needs N % 4 == 0 and 16-byte aligned side inputs. */
     const float* rowdot_w; float* rowdot_out; int32_t rowdot_n;
+    /* ---- fused LayerNorm of the output rows (ABI v5; ln_out NULL = off): out_proj / linear2 of a post-LN encoder layer are followed by
+     * nn.LayerNorm over the whole output row (cmdm.py:66-77), which no column tile owns.  With ln_out set, the workgroup that finishes the
+     * LAST column tile of a block of output rows ("last arriver": one agent-scope release per tile, one ticket per tile on ln_counters, one
+     * agent-scope acquire by the last) reads those rows of C back and writes ln_out[row] = LayerNorm(C[row]) * ln_gamma + ln_beta with
+     * the arithmetic of afm_layernorm (bit-identical to the two-launch form).  ln_out rows follow the c_* remap, row stride ldo.
+     * ln_counters: >= ceil(M / 32) device words, ZERO on entry, zero again on exit.  Needs C, N % 4 == 0, N <= 1024, 16-byte rows; ln_out
+     * must not alias C, A or residual. */
+    const float* ln_gamma; const float* ln_beta; float* ln_out; int64_t ldo; float ln_eps; uint32_t* ln_counters;
 } afm_linear_args;
 
 #define AFM_ARITH_DEFAULT 0
@@ -405,6 +413,7 @@ typedef struct {
 } afm_cmdm_weights;
 
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
+#define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */
 
 /* bytes of workspace afm_cmdm_forward needs for (B, L). */
 int64_t afm_cmdm_workspace_bytes(const afm_cmdm_weights* w, int32_t B, int32_t L);

@@ -450,3 +450,27 @@ def test_two_stream_loop_soak():
     from loop_determinism_probe import probe_cmdm
     bad = probe_cmdm(50, dev())
     assert not bad, f"{len(bad)} of 50 two-stream loops differ from the single-stream result: {bad[:4]}"
+
+
+def test_fused_layernorm_loop_is_bit_identical_to_separate_launches():
+    """Round 3: norm1 / norm2 can run inside the out_proj / linear2 GEMMs (last-arriver LayerNorm, `model.fused_layernorm`; opt-in: it
+    measured slower than the separate launches).  Same arithmetic as the separate launch: a sampling loop must not change by a bit, on
+    one stream and on two, at a large and at a small batch."""
+    cfg = cmdm_cfg(num_points=8192, steps=1000, respacing="12")
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    for B, L in ((16, 196), (3, 60)):
+        kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("fl_cont", (B, 128, 256)).to(dev()),
+                  x_mask=synth.frame_mask(B, L, seed=5).to(dev()))
+        outs = {}
+        for fused in (True, False):
+            for streams in (1, 2):
+                model.fused_layernorm = fused
+                model.loop_streams, model.loop_streams_auto = streams, False
+                outs[(fused, streams)] = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=33).clone()
+        model.fused_layernorm = False
+        ref = outs[(False, 1)]
+        assert torch.isfinite(ref).all()
+        for key, o in outs.items():
+            assert torch.equal(o, ref), f"B={B}: fused={key[0]} streams={key[1]} differs by {(o - ref).abs().max().item():.3e}"

@@ -75,6 +75,54 @@ def test_linear_rowdot_epilogue(M, N, K, R):
         ops.linear(xd, wd[:N - 1].contiguous(), None, rowdot_w=rwd[:, :N - 1].contiguous(), rowdot_out=rd)
 
 
+@pytest.mark.parametrize("M,N,K", [(10432, 512, 512), (1304, 512, 1024), (777, 256, 256), (6272, 512, 512), (100, 1024, 128), (33, 64, 96)])
+def test_linear_fused_layernorm_is_bit_identical_to_two_launches(M, N, K):
+    """ABI v5: LayerNorm of the output rows inside the GEMM (the workgroup finishing the last column tile of a row block normalises it,
+    agent-scope release / ticket / acquire).  Must equal afm_layernorm of the stored output bit for bit, for every arithmetic and tile
+    shape, through a row remap, on ragged M, and repeatedly (the ticket words return to zero after every launch)."""
+    x = synth.gaussian("fln_x", (M, K)); w = synth.gaussian("fln_w", (N, K)) / math.sqrt(K); b = synth.gaussian("fln_b", (N,))
+    res = synth.gaussian("fln_r", (M, N)); g = synth.gaussian("fln_g", (N,)) * 0.2 + 1.0; be = synth.gaussian("fln_be", (N,)) * 0.1
+    xd, wd, bd, rd, gd, bed = (t.to(dev()) for t in (x, w, b, res, g, be))
+    cnt = torch.zeros((M + 31) // 32, dtype=torch.int32, device=dev())
+    saved = ops.get_gemm_split()
+    try:
+        for products in (9, 0):
+            ops.set_gemm_split(products, 0)
+            for tile in ((0, 3, 5, 7) if products else (0, 1, 2, 3, 5)):
+                prev = ops.set_gemm_tune(tile << ffi.TUNE_TILE_SHIFT)
+                try:
+                    try:
+                        plain = ops.linear(xd, wd, bd, residual=rd)
+                    except ffi.AfmError:
+                        continue                                    # this (tile, shape) combination does not exist (split-K needs K % 256 == 0)
+                    want = ops.layernorm(plain, gd, bed, 1e-5)
+                    for rep in range(3):
+                        ln_out = torch.full((M, N), float("nan"), device=dev())
+                        got_c = ops.linear(xd, wd, bd, residual=rd, ln=(gd, bed, 1e-5), ln_out=ln_out, ln_counters=cnt)
+                        assert torch.equal(got_c, plain), (products, tile, rep)
+                        assert torch.equal(ln_out, want), f"arith x{products} tile {tile} rep {rep}: max diff {(ln_out - want).abs().max().item():.3e}, nan {int(torch.isnan(ln_out).sum())}"
+                        assert int(cnt.abs().sum()) == 0
+                finally:
+                    ops.set_gemm_tune(prev)
+    finally:
+        ops.set_gemm_split(*saved)
+    ref = F.layer_norm(F.linear(x.double(), w.double(), b.double()) + res.double(), (N,), g.double(), be.double(), 1e-5).float()
+    report(f"fused linear+LN {M}x{N}x{K}", ln_out, ref, 2e-4)
+
+
+def test_linear_fused_layernorm_through_a_row_map():
+    """The last encoder layer runs out_proj / FFN on the motion rows only: output rows (and their LayerNorm) are scattered by the c_* remap."""
+    B, L, T, N, K = 5, 50, 83, 512, 512
+    x = synth.gaussian("flm_x", (B * L, K)).to(dev()); w = (synth.gaussian("flm_w", (N, K)) / math.sqrt(K)).to(dev())
+    g = (synth.gaussian("flm_g", (N,)) * 0.2 + 1.0).to(dev()); be = (synth.gaussian("flm_be", (N,)) * 0.1).to(dev())
+    out = torch.zeros(B * T, N, device=dev()); ln_out = torch.zeros(B * T, N, device=dev())
+    ops.linear(x, w, None, out=out, c_map=(L, T, T - L), rows=B * L, ln=(g, be, 1e-5), ln_out=ln_out)
+    want_c = ops.linear(x, w, None)
+    want = ops.layernorm(want_c, g, be, 1e-5)
+    assert torch.equal(out.view(B, T, N)[:, T - L:], want_c.view(B, L, N)) and torch.equal(ln_out.view(B, T, N)[:, T - L:], want.view(B, L, N))
+    assert float(ln_out.view(B, T, N)[:, :T - L].abs().sum()) == 0.0          # rows outside the map are untouched
+
+
 def test_linear_bf16_one_product_is_bf16_accurate_only():
     """AFM_ARITH_BF16X1 (informational): the leading-term product alone carries bf16's 2^-9 relative rounding per operand - three orders
     of magnitude above the f32 kernels' error, and identical across tile shapes like every other arithmetic."""
