@@ -282,19 +282,17 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._pack = None
         self._text_cache = None
         self._ws = {}
-        import os
-        self.overlap_streams = os.environ.get("AFM_CDM_OVERLAP", "1") != "0"
-        # sub-batches of the native loop on their own streams: 0 = automatic (two from B = 16 on: one sub-batch's 2-latent chain - 17 small
-        # dependent launches, a third of its step - runs under the other's full-chip kernels; measured at B = 32 with the round-2
-        # kernels: 1: 0.933, 2: 0.891, 3: 0.954, 4: 1.346 ms/step), AFM_CDM_LOOP_SUBBATCH overrides
-        self.loop_sub_batches = int(os.environ.get("AFM_CDM_LOOP_SUBBATCH", "0"))
+        # Host-side tuning attributes (plain attributes: set them on the instance; nothing is read from the environment).
+        self.overlap_streams = True     # layer-by-layer form: decoder-adapter GEMM on a side stream under the latent chain
+        # sub-batches of the native loop on their own streams (bit-identical results): 0 = automatic (two from B = 16 on: one sub-batch's
+        # 2-latent chain - 15 small dependent launches - runs under the other's full-chip kernels)
+        self.loop_sub_batches = 0
         if self.arch != "Perceiver":
             self.afm_native_loop = None         # other archs sample step by step
-        self.sub_batches = int(os.environ.get("AFM_CDM_SUBBATCH", "1"))     # >1 costs more host time per step than it hides (measured)
+        self.sub_batches = 1                    # per-call sub-batches of forward(): >1 costs more host time per step than it hides (measured)
         self._streams = []
-        self.no_fold = bool(os.environ.get("AFM_CDM_NO_FOLD"))      # measurement knob: the layer-by-layer sampling form
-        self.serial_latent = bool(os.environ.get("AFM_CDM_SERIAL_LATENT"))   # measurement knob: latent chain as one workgroup per sample
-        self.valu_reduce = bool(os.environ.get("AFM_CDM_VALU_REDUCE"))       # measurement knob: enc_reduce on the VALU instead of MFMA
+        self.no_fold = False            # measurement: the layer-by-layer sampling form (what training-mode forward also runs)
+        self.no_gen = False             # measurement: round 2's folded form (step-invariant adapter parts materialised) instead of generated rows
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
@@ -302,7 +300,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
-            w.flags = (ffi.CDM_SERIAL_LATENT if self.serial_latent else 0) | (ffi.CDM_VALU_REDUCE if self.valu_reduce else 0)
+            w.flags = ffi.CDM_NO_GEN if self.no_gen else 0
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -362,13 +360,21 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             bo = f64(cm.decoder_cross_attn[0].module.attention.o_proj.bias)
             folds = dict(fold_xu=xu, fold_xv=xv, fold_w2=wc @ f64(fc2.weight), fold_q=wc @ xv.t(),
                          fold_c0=wc @ (f64(fc2.bias) + bo) + f64(cl.bias))
+            if cm.feat_dim + 1 <= 12:
+                # generator tables (afm_cdm_weights.gen_*): both adapters as maps of the K = feat_dim + 1 inputs [x_t | features | 1]
+                F_, be, bd = cm.feat_dim, f64(cm.encoder_adapter.bias), f64(cm.decoder_adapter.bias)
+                gen_enc = torch.zeros(12, cm.dkv, dtype=torch.float64)
+                gen_enc[:F_] = we.t(); gen_enc[F_] = be
+                gen_dec = torch.zeros(12, cm.dkv, dtype=torch.float64)
+                gen_dec[:F_] = (wd @ we).t(); gen_dec[F_] = wd @ be + bd
+                folds.update(gen_enc=gen_enc, gen_dec=gen_dec, gen_qe=wc @ gen_dec.t())
             dev = cl.weight.device
             for name, t in folds.items():
                 setattr(w, name, P(t.float().contiguous().to(dev)))
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
-        w.flags = (ffi.CDM_SERIAL_LATENT if self.serial_latent else 0) | (ffi.CDM_VALU_REDUCE if self.valu_reduce else 0)
+        w.flags = ffi.CDM_NO_GEN if self.no_gen else 0
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):
@@ -470,10 +476,11 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         return out
 
     # ------------------------------------------------------------------ native sampling loop
-    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False):
+    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False, snapshots=None):
         """Whole p_sample_loop of the ADM on the device (afm_cdm_sample_loop): x holds x_T on entry, returns the sample.  ``progress``
         slices the chain (afm_cdm_sample_loop_range) so a tqdm bar can advance, with bit-identical results.  The batch
-        runs as `loop_sub_batches` sub-batches on their own stream pairs (two from B = 16 on, see __init__; bit-identical results)."""
+        runs as `loop_sub_batches` sub-batches on their own stream pairs (see __init__; bit-identical results).  ``snapshots`` =
+        {executed step count: None} is filled with clones of x after those steps, as in CMDM.afm_native_loop."""
         if self.arch != "Perceiver":
             raise NotImplementedError("the native loop covers the Perceiver arch")
         lib = ffi.load()
@@ -514,7 +521,17 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                     tab.coef1[lo:].data_ptr(), tab.coef2[lo:].data_ptr(), tab.sigma[lo:].data_ptr(), cnt, j0, seed & (2**64 - 1),
                     sample_index0, B, N, sched.data_ptr(), ws.data_ptr(), ws.numel(), nsub, handles, stream), "afm_cdm_sample_loop_range")
 
-            ffi.run_slices(ffi.progress_slices(n, progress), enqueue, progress, dev)
+            slices = ffi.progress_slices(n, progress)
+            if snapshots is not None:
+                slices = ffi.cut_slices(slices, sorted(k for k in snapshots if 0 < k < n))
+
+                def enqueue_snap(j0, j1, _inner=enqueue):
+                    _inner(j0, j1)
+                    if j1 in snapshots:
+                        snapshots[j1] = x.clone()
+                ffi.run_slices(slices, enqueue_snap, progress, dev)
+            else:
+                ffi.run_slices(slices, enqueue, progress, dev)
             self._last_loop_scratch = (sched, step_noise, feat, tq0, tu, tcu)
         return x
 

@@ -20,7 +20,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE, CMDM_FUSED_LN = 0x1, 0x2
-CDM_SERIAL_LATENT, CDM_VALU_REDUCE = 0x1, 0x2
+CDM_NO_GEN = 0x2
 ABI_VERSION = 5
 MAX_LAYERS = 16
 
@@ -100,6 +100,8 @@ class CdmWeights(C.Structure):
         ("gemm_arith", i32), ("gemm_arith_min_n", i32),
         # weight products of the folded sampling form (ABI v4; all five or none)
         ("fold_xu", c_f32p), ("fold_xv", c_f32p), ("fold_w2", c_f32p), ("flags", i32), ("fold_q", c_f32p), ("fold_c0", c_f32p),
+        # generator tables of the two adapters (ABI v5; all three or none)
+        ("gen_enc", c_f32p), ("gen_dec", c_f32p), ("gen_qe", c_f32p),
     ]
 
 

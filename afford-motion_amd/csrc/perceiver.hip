@@ -77,20 +77,6 @@ __device__ void ln2(const float* in, float* out, afm_ln p, int dim, int stride) 
     }
 }
 
-// x <- x + fc2(GELU(fc1(LN(x))))  on 2 tokens (modules.py:651-661 + Residual :222-231); tmp1/tmp2 are [2][dim] scratch
-__device__ void mlp_residual2(float* x, float* tmp1, float* tmp2, const afm_mlp_w& m, int dim) {
-    ln2(x, tmp1, m.norm, dim, MAXD);
-    __syncthreads();
-    matvec2(m.fc1.w, m.fc1.b, tmp1, tmp2, dim, dim, MAXD, MAXD);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x) { float* p = tmp2 + (i / dim) * MAXD + (i % dim); *p = gelu_erf(*p); }
-    __syncthreads();
-    matvec2(m.fc2.w, m.fc2.b, tmp2, tmp1, dim, dim, MAXD, MAXD);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * dim; i += blockDim.x) { const int o = (i / dim) * MAXD + (i % dim); x[o] += tmp1[o]; }
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------- latent_token
 // One latent token per workgroup (grid = number of tokens, block 1024): adapter -> enc_q0 row, LN_q, q_proj, dp_scale,
 // and the folded queries u[h][c] = sum_r W_k[h*hd + r][c] q[h*hd + r], cu[h] = q_h . b_k[h].
@@ -125,109 +111,6 @@ __global__ __launch_bounds__(1024) void latent_token_kernel(const afm_cdm_weight
     }
 }
 
-// ---------------------------------------------------------------- enc_reduce
-// grid (NSPLIT, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NQ = 16 folded queries.
-// FOLD (the step-invariant form, see cdm_forward_impl): `enc_kv` holds only the step-invariant part of the adapter output and the
-// row of point n is enc_kv[n] + sum_j xt[n, j] * xu[j] (cd <= 8 contact channels, xu [cd, 256] = columns of the adapter weight).
-template <int NQ, bool FOLD>
-__global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
-                                                         const float* __restrict__ cu_text, const float* __restrict__ u_time,
-                                                         const float* __restrict__ cu_time, const int64_t* __restrict__ t, int n_t,
-                                                         int N, float* __restrict__ pm, float* __restrict__ pl,
-                                                         float* __restrict__ pacc, const float* __restrict__ xt,
-                                                         const float* __restrict__ xu, int cd) {
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = lane * 4;
-    int64_t ti = t[b];
-    ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
-    // folded query q < NQ/2: text latent of this sample; q >= NQ/2: time latent of timestep t[b]
-    auto uptr = [&](int q) { return q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256; };
-    auto cval = [&](int q) { return q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]; };
-    // packed f32 pairs (v_pk_mul / v_pk_fma: two lanes' worth of IEEE f32 per instruction): channels (c0, c0 + 1) and (c0 + 2, c0 + 3)
-    pf32x2 uqa[NQ], uqb[NQ], acca[NQ], accb[NQ];
-    float m[NQ], l[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(uptr(q) + c0);
-        uqa[q] = pf32x2{v.x, v.y}; uqb[q] = pf32x2{v.z, v.w};
-        acca[q] = pf32x2{0.f, 0.f}; accb[q] = pf32x2{0.f, 0.f};
-        m[q] = -INFINITY; l[q] = 0.f;
-    }
-    const float4 g = *reinterpret_cast<const float4*>(kvn.g + c0), be = *reinterpret_cast<const float4*>(kvn.b + c0);
-    const int per = (N + NSPLIT - 1) / NSPLIT;
-    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
-    // each lane OWNS one folded query (index multi_owned_index<16>(lane)) for the online-softmax state;
-    // the per-point (alpha, p) of all 16 queries are then broadcast with v_readlane
-    const int own = multi_owned_index<NQ>(lane);
-    float m_own = -INFINITY, l_own = 0.f, c_own = cval(own);
-    float4 xw[FOLD ? 8 : 1];
-    if (FOLD) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xw[j] = j < cd ? *reinterpret_cast<const float4*>(xu + j * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // The loop is a dependent chain load -> ~350 VALU -> next load with two waves per SIMD: the next point's row (and contact row) is
-    // fetched before the current one is processed, otherwise every point pays a full HBM round trip (measured 1.07 TB/s without).
-    auto load_row = [&](int n) { return *reinterpret_cast<const float4*>(enc_kv + ((int64_t)b * N + min(n, n1 - 1)) * 256 + c0); };
-    // (every lane loads - clamped column - so that the load is not under a lane-dependent branch: hipcc cannot count a load that may
-    // or may not have been issued and would wait for the PREFETCHED row instead of the current one)
-    auto load_xl = [&](int n) { return FOLD ? xt[((int64_t)b * N + min(n, n1 - 1)) * cd + min(lane, cd - 1)] : 0.f; };
-    float4 x_next = load_row(n0 + wave);
-    float xl_next = load_xl(n0 + wave);
-    for (int n = n0 + wave; n < n1; n += 4) {
-        float4 x = x_next;
-        const float xl = xl_next;                                                          // the point's contact row: one load, lanes 0..cd-1
-        x_next = load_row(n + 4);
-        xl_next = load_xl(n + 4);
-        if (FOLD) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < cd) { const float sj = lane_bcast(xl, j); x.x += sj * xw[j].x; x.y += sj * xw[j].y; x.z += sj * xw[j].z; x.w += sj * xw[j].w; }
-        }
-        const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
-        const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
-        const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
-        const float y0 = d0 * rstd * g.x + be.x, y1 = d1 * rstd * g.y + be.y, y2 = d2 * rstd * g.z + be.z, y3 = d3 * rstd * g.w + be.w;
-        const pf32x2 ya = {y0, y1}, yb = {y2, y3};
-        float d[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const pf32x2 tq = yb * uqb[q] + ya * uqa[q];
-            d[q] = tq[0] + tq[1];
-        }
-        const float sown = wave_reduce_multi<NQ>(d, lane) + c_own;
-        const float mn = fmaxf(m_own, sown);
-        const float alpha = __expf(m_own - mn), pw = __expf(sown - mn);
-        l_own = l_own * alpha + pw;
-        m_own = mn;
-        // the running maxima settle after the first few hundred points: when no query's maximum moved (alpha == 1 in every lane, a
-        // wave-uniform test) the rescale of the 16 x 4 accumulators is skipped - multiplying by 1.0f would change nothing
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float pq = lane_bcast(pw, multi_owner_lane<NQ>(q));
-                const pf32x2 p2 = {pq, pq};
-                acca[q] = ya * p2 + acca[q]; accb[q] = yb * p2 + accb[q];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float aq = lane_bcast(alpha, multi_owner_lane<NQ>(q)), pq = lane_bcast(pw, multi_owner_lane<NQ>(q));
-                const pf32x2 a2 = {aq, aq}, p2 = {pq, pq};
-                acca[q] = ya * p2 + acca[q] * a2; accb[q] = yb * p2 + accb[q] * a2;
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { m[q] = lane_bcast(m_own, multi_owner_lane<NQ>(q)); l[q] = lane_bcast(l_own, multi_owner_lane<NQ>(q)); }
-    const int part = blockIdx.x * 4 + wave;
-    const int64_t base = ((int64_t)b * NPART + part) * NQ;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (lane == 0) { pm[base + q] = m[q]; pl[base + q] = l[q]; }
-        *reinterpret_cast<float4*>(pacc + (base + q) * 256 + c0) = make_float4(acca[q][0], acca[q][1], accb[q][0], accb[q][1]);
-    }
-}
-
 // ---------------------------------------------------------------- enc_reduce on the matrix pipe
 // The form above spends ~500 issue slots per point and wave on two contractions a matrix core does natively: the 16 scores of a
 // point (LN(e_n) . u_q over 256 channels) and the weighted row sums (sum_n p_nq LN(e_n)).  Here a wave takes 16 points at a time:
@@ -242,24 +125,32 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(const float* __restrict
 // Exact f32 products, f32 accumulation (v_mfma_f32_16x16x4_f32); a re-association of the same arithmetic (tests: 2e-5 vs the VALU form).
 constexpr int ERM_WAVES = 8, ERM_SPLIT = NPART / ERM_WAVES;       // workgroups per sample x waves = NPART partials, as in the VALU form
 constexpr int ERM_LDY = 260;
-constexpr int ERM_LDS_FLOATS = ERM_WAVES * 16 * ERM_LDY + 16 * ERM_LDY + 8 * 256 + 16 + ERM_WAVES * 16;
+constexpr int ERM_LDS_FLOATS = ERM_WAVES * 16 * ERM_LDY + 16 * ERM_LDY + 12 * 256 + 16 + ERM_WAVES * 16;
 
 // One workgroup of 8 waves per CU (158 KB of LDS: eight transposition tiles, the 16 folded queries u' = gamma * u_q shared by the
 // waves - they are all of one sample -, the contact columns of the adapter); registers: 64 (rows) + 64 (sums) per lane.
-template <bool FOLD>
+// MODE 0: rows read from `enc_kv`; MODE 1 (FOLD): rows = enc_kv[n] + sum_j x_t[n, j] xu[j] (step-invariant part materialised once per
+// loop); MODE 2 (GEN, round 3): rows are never materialised - the adapter is a K <= 12 linear map of [x_t | features | 1], so a tile's
+// rows are GENERATED on the matrix pipe straight into layout A: D[i][j] = sum_k G[k][16 jj + i] in[j][k] with the channel as the output
+// row (lane (p, g) receives channels 16 jj + 4 g + r of point p: exactly e[jj]), 3 K4 steps x 16 column tiles = 48 MFMAs per 16 points
+// instead of 1 KB of HBM reads per point.  The table G[k][c] (weight column k, bias as the row of the constant input 1, zero rows up to
+// 12) is the A operand, read from LDS in operand order; the B operand is three input values per lane.
+constexpr int GEN_K = 12;
+template <int MODE>
 __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
                                                                            const float* __restrict__ cu_text, const float* __restrict__ u_time,
                                                                            const float* __restrict__ cu_time, const int64_t* __restrict__ t, int n_t,
                                                                            int N, float* __restrict__ pm, float* __restrict__ pl,
                                                                            float* __restrict__ pacc, const float* __restrict__ xt,
-                                                                           const float* __restrict__ xu, int cd) {
+                                                                           const float* __restrict__ xu, int cd, const float* __restrict__ feat, int fd) {
+    constexpr bool FOLD = MODE == 1, GEN = MODE == 2;
     constexpr int NQ = 16, LDY = ERM_LDY, NT = 64 * ERM_WAVES;
     extern __shared__ __attribute__((aligned(16))) float er_sm[];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* ytile = er_sm + wave * 16 * LDY;                       // this wave's transposition tile
     float* ups = er_sm + ERM_WAVES * 16 * LDY;                    // [16][LDY] u'_q = gamma * u_q
-    float* xus = ups + 16 * LDY;                                  // [8][256] contact columns of the adapter (FOLD)
-    float* ccs = xus + 8 * 256;                                   // [16] beta . u_q + c_q
+    float* xus = ups + 16 * LDY;                                  // FOLD: [8][256] contact columns of the adapter; GEN: [3][16][64] generator table in operand order
+    float* ccs = xus + 12 * 256;                                  // [16] beta . u_q + c_q
     float* tr = ccs + 16 + wave * 16;                             // 16 floats per wave: a 16-vector from lanes (q, .) to lanes (., g)
     int64_t ti = t[b];
     ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
@@ -278,6 +169,12 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
     if (FOLD) {
         for (int i = threadIdx.x; i < 8 * 256; i += NT) xus[i] = i < cd * 256 ? xu[i] : 0.f;
     }
+    if (GEN) {            // xus[(ks * 16 + jj) * 64 + lane] = G[k = 4 ks + (lane >> 4)][c = 16 jj + (lane & 15)]  (xu = the [GEN_K][256] table)
+        for (int i = threadIdx.x; i < GEN_K * 256; i += NT) {
+            const int l = i & 63, jj = (i >> 6) & 15, ks = i >> 10;
+            xus[i] = xu[(4 * ks + (l >> 4)) * 256 + 16 * jj + (l & 15)];
+        }
+    }
     __syncthreads();
     const float cconst = ccs[p16];
 
@@ -293,8 +190,18 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
 
     float4 e[16];
     float xrow[8];
+    float xin[3];                                                  // GEN: inputs k = 4 ks + g of point p16 (the B operand of the generating product)
     auto fetch = [&](int nb) {                                     // rows of tile [nb, nb + 16): this lane's 64 channels of point nb + p16
         const int64_t pt = (int64_t)b * N + min(nb + p16, n1 - 1);
+        if (GEN) {                                                 // in[k]: k < cd from x_t, k < fd from the feature row, k == fd the constant 1, 0 beyond
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int k = 4 * ks + g;
+                const float vx = xt[pt * cd + min(k, cd - 1)], vf = feat[pt * fd + min(k, fd - 1)];        // unconditional, clamped
+                xin[ks] = k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = *reinterpret_cast<const float4*>(enc_kv + pt * 256 + 16 * j + 4 * g);
         if (FOLD) {
@@ -304,6 +211,15 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
     };
     if (w0 < w1) fetch(w0);
     for (int nb = w0; nb < w1; nb += 16) {
+        if (GEN) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(xus[(ks * 16 + jj) * 64 + lane], xin[ks], d, 0, 0, 0);
+                e[jj] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
         if (FOLD) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -343,7 +259,7 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
         }
         sc = (sc + sc1) + (sc2 + sc3);
         const int nvalid = w1 - nb;                                // points 4 g + r >= nvalid do not exist
-        if (nb + 16 < w1) fetch(nb + 16);                          // e[] is free: the next tile's rows fly under the second product
+        if (nb + 16 < w1) fetch(nb + 16);                          // e[] is free: the next tile's rows (GEN: inputs) fly under the second product
         float mt = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -389,148 +305,9 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
     }
 }
 
-// ---------------------------------------------------------------- latent_post
-// grid B, block 1024.  Output dec_lat [B][ G(2*Hd*dkv) | P(2*Hd*dkv) | cb(2*Hd) ]
-__global__ __launch_bounds__(1024) void latent_post_kernel(const afm_cdm_weights w, const float* __restrict__ q0_text,
-                                                          const float* __restrict__ q0_time, const int64_t* __restrict__ t,
-                                                          const float* __restrict__ pm, const float* __restrict__ pl,
-                                                          const float* __restrict__ pacc, float* __restrict__ dec_lat) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, dq = w.dq, dkv = w.dkv, He = w.enc_heads, Hd = w.dec_heads;
-    const int nih = 2 * He, hd = dq / He, hdd = dkv / Hd;
-    float* s = sm;                          // [nih][dkv]
-    float* x = s + nih * dkv;               // [2][MAXD] latent state
-    float* t1 = x + 2 * MAXD;               // scratch vectors [2][MAXD] each
-    float* t2 = t1 + 2 * MAXD;
-    float* t3 = t2 + 2 * MAXD;
-    float* t4 = t3 + 2 * MAXD;
-    float* wq = t4 + 2 * MAXD;              // [nih][NPART] combine weights, later small scratch
-    // ---- combine the per-wave partials of enc_reduce
-    for (int e = threadIdx.x; e < nih; e += blockDim.x) {
-        float M = -INFINITY;
-        for (int p = 0; p < NPART; ++p) M = fmaxf(M, pm[((int64_t)b * NPART + p) * nih + e]);
-        float L = 0.f;
-        for (int p = 0; p < NPART; ++p) {
-            const float mm = pm[((int64_t)b * NPART + p) * nih + e];
-            const float ww = (mm == -INFINITY) ? 0.f : __expf(mm - M);
-            wq[e * NPART + p] = ww;
-            L += pl[((int64_t)b * NPART + p) * nih + e] * ww;
-        }
-        const float inv = 1.0f / L;
-        for (int p = 0; p < NPART; ++p) wq[e * NPART + p] *= inv;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < nih * dkv; e += blockDim.x) {
-        const int ih = e / dkv, c = e % dkv;
-        float a = 0.f;
-        for (int p = 0; p < NPART; ++p) a += wq[ih * NPART + p] * pacc[(((int64_t)b * NPART + p) * nih + ih) * dkv + c];
-        s[e] = a;
-    }
-    {
-        int64_t ti = t[b];
-        ti = ti < 0 ? 0 : (ti >= w.n_timesteps ? w.n_timesteps - 1 : ti);
-        for (int i = threadIdx.x; i < dq; i += blockDim.x) { x[i] = q0_text[(int64_t)b * dq + i]; x[MAXD + i] = q0_time[ti * dq + i]; }
-    }
-    __syncthreads();
-    {   // ---- attention output o[i][h*hd + r] = W_v[h*hd+r] . s[i,h] + b_v   -> t1
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int o = wave; o < dq; o += nw) {
-            const int h = o / hd;
-            float a0 = 0.f, a1 = 0.f;
-            for (int k = lane; k < dkv; k += 64) {
-                const float wv = w.enc_attn.v.w[(int64_t)o * dkv + k];
-                a0 += wv * s[(0 * He + h) * dkv + k];
-                a1 += wv * s[(1 * He + h) * dkv + k];
-            }
-            a0 = wave_sum(a0); a1 = wave_sum(a1);
-            if (lane == 0) { t1[o] = a0 + w.enc_attn.v.b[o]; t1[MAXD + o] = a1 + w.enc_attn.v.b[o]; }
-        }
-    }
-    __syncthreads();
-    matvec2(w.enc_attn.o.w, w.enc_attn.o.b, t1, t2, dq, dq, MAXD, MAXD);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) { const int o = (i / dq) * MAXD + (i % dq); x[o] += t2[o]; }
-    __syncthreads();
-    mlp_residual2(x, t1, t2, w.enc_mlp, dq);
-    // ---- self-attention block on the two latents (modules.py:544-648)
-    const float sc = 1.0f / sqrtf((float)hd);
-    for (int li = 0; li < w.n_self; ++li) {
-        ln2(x, t1, w.self_norm[li], dq, MAXD);
-        __syncthreads();
-        matvec2(w.self_attn[li].q.w, w.self_attn[li].q.b, t1, t2, dq, dq, MAXD, MAXD);
-        matvec2(w.self_attn[li].k.w, w.self_attn[li].k.b, t1, t3, dq, dq, MAXD, MAXD);
-        matvec2(w.self_attn[li].v.w, w.self_attn[li].v.b, t1, t4, dq, dq, MAXD, MAXD);
-        __syncthreads();
-        if (threadIdx.x < He * 4) {                      // (h, i, j) scores
-            const int h = threadIdx.x >> 2, i = (threadIdx.x >> 1) & 1, j = threadIdx.x & 1;
-            float a = 0.f;
-            for (int r = 0; r < hd; ++r) a += (t2[i * MAXD + h * hd + r] * sc) * t3[j * MAXD + h * hd + r];
-            wq[threadIdx.x] = a;
-        }
-        __syncthreads();
-        if (threadIdx.x < He * 2) {                      // softmax over the 2 keys
-            const int base = threadIdx.x * 2;
-            const float a0 = wq[base], a1 = wq[base + 1], mx = fmaxf(a0, a1);
-            const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
-            wq[64 + base] = e0 * inv; wq[64 + base + 1] = e1 * inv;
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < 2 * dq; e += blockDim.x) {
-            const int i = e / dq, c = e % dq, h = c / hd;
-            t1[i * MAXD + c] = wq[64 + (h * 2 + i) * 2 + 0] * t4[c] + wq[64 + (h * 2 + i) * 2 + 1] * t4[MAXD + c];
-        }
-        __syncthreads();
-        matvec2(w.self_attn[li].o.w, w.self_attn[li].o.b, t1, t2, dq, dq, MAXD, MAXD);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * dq; i += blockDim.x) { const int o = (i / dq) * MAXD + (i % dq); x[o] += t2[o]; }
-        __syncthreads();
-        mlp_residual2(x, t1, t2, w.self_mlp[li], dq);
-    }
-    // ---- decoder keys / values from the two latents, folded through W_q / W_o of the decoder attention
-    ln2(x, t1, w.dec_kv_norm, dq, MAXD);
-    __syncthreads();
-    matvec2(w.dec_attn.k.w, w.dec_attn.k.b, t1, t2, dkv, dq, MAXD, MAXD);      // kd [2][dkv]
-    matvec2(w.dec_attn.v.w, w.dec_attn.v.b, t1, t3, dkv, dq, MAXD, MAXD);      // vd [2][dkv]
-    __syncthreads();
-    const float scd = 1.0f / sqrtf((float)hdd);
-    const int njh = 2 * Hd;
-    float* G = dec_lat + (int64_t)b * DEC_LAT_STRIDE(njh);
-    float* P = G + njh * dkv;
-    float* cb = P + njh * dkv;
-    float* WP = cb + njh;
-    for (int e = threadIdx.x; e < njh * dkv; e += blockDim.x) {
-        const int jh = e / dkv, c = e % dkv, j = jh / Hd, h = jh % Hd;
-        float a = 0.f, pp = 0.f;
-        for (int r = 0; r < hdd; ++r) {
-            a += w.dec_attn.q.w[(int64_t)(h * hdd + r) * dkv + c] * t2[j * MAXD + h * hdd + r];
-            pp += w.dec_attn.o.w[(int64_t)c * dkv + h * hdd + r] * t3[j * MAXD + h * hdd + r];
-        }
-        G[e] = a * scd;
-        P[e] = pp;
-    }
-    for (int jh = threadIdx.x; jh < njh; jh += blockDim.x) {
-        const int j = jh / Hd, h = jh % Hd;
-        float a = 0.f;
-        for (int r = 0; r < hdd; ++r) a += w.dec_attn.q.b[h * hdd + r] * t2[j * MAXD + h * hdd + r];
-        cb[jh] = a * scd;
-    }
-    if (w.fold_xu && w.contact_dim <= 8) {           // folded form: WP[r, jh] = contact_layer.w[r] . P[jh]  (one wave per dot product)
-        __syncthreads();                             // P was written by this workgroup just above
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int e = wave; e < w.contact_dim * njh; e += nw) {
-            const int r = e / njh, jh = e % njh;
-            float a = 0.f;
-            for (int k = lane; k < dkv; k += 64) a += w.contact_layer.w[(int64_t)r * dkv + k] * P[jh * dkv + k];
-            a = wave_sum(a);
-            if (lane == 0) WP[r * njh + jh] = a;
-        }
-    }
-}
-
 // ---------------------------------------------------------------- latent chain, batched over the samples
-// latent_post above walks ~16 dependent matrix-vector stages inside ONE workgroup per sample: every workgroup streams every weight
-// matrix (1 MB each at dq = 512) through one CU, ~33 us per stage with 224 of 256 CUs idle.  The same chain as a sequence of small
-// launches over all 2 B latent tokens at once: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
+// The 2-latent chain (cross-attention output, o_proj, MLP, self-attention blocks, decoder K / V folding) is ~16 dependent
+// matrix-vector stages per sample.  It runs batched over all 2 B latent tokens as a sequence of small launches: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
 // workgroups per stage (every weight row is read once per token block, by one workgroup), ~5 us per launch.
 //   toklin_kernel: 64 tokens x 8 outputs per workgroup.  The (optionally LayerNorm-ed) input rows are staged in LDS ([64][K + 4] f32,
 //   conflict-free 16-byte row reads); lane = token, wave = output pair; the weight rows are wave-uniform and come through scalar loads.
@@ -789,155 +566,6 @@ __global__ __launch_bounds__(256) void lat_decfold_kernel(const afm_cdm_weights 
     }
 }
 
-// ---------------------------------------------------------------- dec_attend
-// grid (chunks, B), block 256: one wave per point, 4 channels per lane (dkv == 256), NJH = 2 keys x 8 heads.
-// FOLD: dec_q0 holds the step-invariant part of the decoder query, the row of point n is dec_q0[n] + sum_j xt[n, j] * xv[j].  The
-// residual stream h1 = attention output + query is not stored: the (linear) tail of the network needs contact_layer.w[r] . h1[n],
-// whose attention part is sum_jh a[n, jh] * WP[r, jh] with WP = contact_layer.w . P precomputed per sample by latent_post - sixteen
-// scalars per point instead of a 256-wide dot (written to s1[n, r]); the query part is linear in step-invariant data and x_t and is
-// added by cdm_output_kernel.
-template <int HD, bool FOLD>      // HD must be 8 (NJH = 16 scores per point)
-__global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat,
-                                                         afm_ln qn, const float* __restrict__ bo, afm_ln mlpn, int N,
-                                                         float* __restrict__ h1, float* __restrict__ z, const float* __restrict__ xt,
-                                                         const float* __restrict__ xv, int cd, float* __restrict__ s1) {
-    constexpr int NJH = 2 * HD;
-    __shared__ __attribute__((aligned(16))) float GP[2 * NJH * 256 + NJH];
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c0 = lane * 4;
-    const float* src = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
-    {   // folded keys / values of the sample -> LDS: 16-byte loads, all of a thread's loads in flight before its first store (an element-wise
-        // load -> store loop is 32 dependent memory round trips per thread: ~30 us of prologue per workgroup, measured)
-        constexpr int NV4 = (2 * NJH * 256 + NJH) / 4;            // 2052 float4 (records are 16-byte aligned and a multiple of 4 floats apart)
-        float4 gv[(NV4 + 255) / 256];
-#pragma unroll
-        for (int u = 0; u < (NV4 + 255) / 256; ++u) {
-            const int i4 = threadIdx.x + u * 256;
-            gv[u] = i4 < NV4 ? reinterpret_cast<const float4*>(src)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < (NV4 + 255) / 256; ++u) {
-            const int i4 = threadIdx.x + u * 256;
-            if (i4 < NV4) reinterpret_cast<float4*>(GP)[i4] = gv[u];
-        }
-    }
-    const float4 g1 = *reinterpret_cast<const float4*>(qn.g + c0), b1 = *reinterpret_cast<const float4*>(qn.b + c0);
-    const float4 g2 = *reinterpret_cast<const float4*>(mlpn.g + c0), b2 = *reinterpret_cast<const float4*>(mlpn.b + c0);
-    const float4 ob = *reinterpret_cast<const float4*>(bo + c0);
-    __syncthreads();
-    const float* G = GP;
-    const float* P = GP + NJH * 256;
-    const float* cb = P + NJH * 256;
-    const int per = (N + gridDim.x - 1) / gridDim.x;
-    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
-    // PP points per wave iteration: the folded key / value rows (G, P: 32 x ds_read_b128 per point) are read from LDS once
-    // and used for PP points - the kernel is LDS-issue bound, not HBM bound
-    constexpr int PP = 2;
-    float4 xw[FOLD ? 8 : 1];
-    float wp[FOLD ? 8 : 1];               // WP[r, jh] of the score this lane owns (one of its four owner lanes contributes)
-    if (FOLD) {
-        const int jh = multi_owned_index<NJH>(lane);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            xw[j] = j < cd ? *reinterpret_cast<const float4*>(xv + j * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wp[j] = (j < cd && (lane & 3) == 0) ? src[2 * NJH * 256 + NJH + j * NJH + jh] : 0.f;
-        }
-    }
-    // next pair of rows (and contact rows) in flight while the current pair is processed: without the prefetch every trip pays a full
-    // memory round trip with two waves per SIMD to hide it
-    float4 xn[PP];
-    float xln[PP];
-    auto fetch = [&](int nb_) {
-#pragma unroll
-        for (int u = 0; u < PP; ++u) {
-            const int64_t pt = (int64_t)b * N + min(nb_ + u, n1 - 1);
-            xn[u] = *reinterpret_cast<const float4*>(dec_q0 + pt * 256 + c0);
-            xln[u] = FOLD ? xt[pt * cd + min(lane, cd - 1)] : 0.f;          // every lane loads (clamped column): no lane-dependent branch around a counted load
-        }
-    };
-    fetch(n0 + wave * PP);
-    for (int nb = n0 + wave * PP; nb < n1; nb += 4 * PP) {
-        float4 x[PP];
-        float xlc[PP];
-        float y[PP][4], sc[PP][NJH];
-        bool ok[PP];
-#pragma unroll
-        for (int u = 0; u < PP; ++u) { x[u] = xn[u]; xlc[u] = xln[u]; }
-        fetch(nb + 4 * PP);
-#pragma unroll
-        for (int u = 0; u < PP; ++u) {
-            ok[u] = nb + u < n1;
-            if (FOLD) {
-                const float xl = xlc[u];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < cd) { const float sj = lane_bcast(xl, j); x[u].x += sj * xw[j].x; x[u].y += sj * xw[j].y; x[u].z += sj * xw[j].z; x[u].w += sj * xw[j].w; }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PP; ++u) {
-            const float mean = wave_sum((x[u].x + x[u].y) + (x[u].z + x[u].w)) * (1.0f / 256.0f);
-            const float d0 = x[u].x - mean, d1 = x[u].y - mean, d2 = x[u].z - mean, d3 = x[u].w - mean;
-            const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
-            y[u][0] = d0 * rstd * g1.x + b1.x; y[u][1] = d1 * rstd * g1.y + b1.y; y[u][2] = d2 * rstd * g1.z + b1.z; y[u][3] = d3 * rstd * g1.w + b1.w;
-        }
-        pf32x2 ya[PP], yb[PP];
-#pragma unroll
-        for (int u = 0; u < PP; ++u) { ya[u] = pf32x2{y[u][0], y[u][1]}; yb[u] = pf32x2{y[u][2], y[u][3]}; }
-#pragma unroll
-        for (int jh = 0; jh < NJH; ++jh) {
-            const float4 gv = *reinterpret_cast<const float4*>(G + jh * 256 + c0);
-            const pf32x2 ga = {gv.x, gv.y}, gb = {gv.z, gv.w};
-#pragma unroll
-            for (int u = 0; u < PP; ++u) { const pf32x2 tq = yb[u] * gb + ya[u] * ga; sc[u][jh] = tq[0] + tq[1]; }      // packed f32 pairs
-        }
-        float w_own[PP];
-        pf32x2 oa[PP], ob2[PP];
-#pragma unroll
-        for (int u = 0; u < PP; ++u) {
-            // lane owns score jh = j*HD + h (j <-> lane bit 5); its softmax partner (other key, same head) is lane ^ 32
-            const float s_own = wave_reduce_multi<NJH>(sc[u], lane) + cb[multi_owned_index<NJH>(lane)];
-            const float s_oth = xor32(s_own);
-            const float mx = fmaxf(s_own, s_oth);
-            const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
-            w_own[u] = e_own / (e_own + e_oth);
-            oa[u] = pf32x2{ob.x, ob.y}; ob2[u] = pf32x2{ob.z, ob.w};
-            if (FOLD) {
-                float dj[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dj[j] = w_own[u] * wp[j];
-                const float tot = wave_reduce_multi<8>(dj, lane);
-                if ((lane & 7) == 0 && ok[u]) {
-                    const int j = multi_owned_index<8>(lane);
-                    if (j < cd) s1[((int64_t)b * N + nb + u) * cd + j] = tot;
-                }
-            }
-        }
-#pragma unroll
-        for (int jh = 0; jh < NJH; ++jh) {
-            const float4 pv = *reinterpret_cast<const float4*>(P + jh * 256 + c0);
-            const pf32x2 pa = {pv.x, pv.y}, pb = {pv.z, pv.w};
-#pragma unroll
-            for (int u = 0; u < PP; ++u) {
-                const float wj = lane_bcast(w_own[u], multi_owner_lane<NJH>(jh));
-                const pf32x2 w2 = {wj, wj};
-                oa[u] = pa * w2 + oa[u]; ob2[u] = pb * w2 + ob2[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PP; ++u) {
-            if (!ok[u]) continue;
-            const int64_t row = ((int64_t)b * N + nb + u) * 256 + c0;
-            const float r0 = oa[u][0] + x[u].x, r1 = oa[u][1] + x[u].y, r2 = ob2[u][0] + x[u].z, r3 = ob2[u][1] + x[u].w;   // Residual adds the raw query
-            if (!FOLD) *reinterpret_cast<float4*>(h1 + row) = make_float4(r0, r1, r2, r3);
-            const float mean = wave_sum((r0 + r1) + (r2 + r3)) * (1.0f / 256.0f);
-            const float d0 = r0 - mean, d1 = r1 - mean, d2 = r2 - mean, d3 = r3 - mean;
-            const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f) + 1e-5f);
-            *reinterpret_cast<float4*>(z + row) =
-                make_float4(d0 * rstd * g2.x + b2.x, d1 * rstd * g2.y + b2.y, d2 * rstd * g2.z + b2.z, d3 * rstd * g2.w + b2.w);
-        }
-    }
-}
-
 // ---------------------------------------------------------------- dec_attend on the matrix pipe
 // Same idea as enc_reduce_mfma_kernel, per tile of 16 points and wave, everything row-shaped stays in layout A (lane (p, g): channels
 // {16 j + 4 g + e} of point p):
@@ -950,13 +578,17 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 //   residual + second LayerNorm + affine on the VALU in layout A, rows written with 16-byte stores.
 // G', P, the three channel vectors (b_o, gamma_mlp, beta_mlp) and the contact columns live in LDS once per workgroup (one sample).
 constexpr int DAM_LDG = 260;
-constexpr int DAM_LDS_FLOATS = 2 * 16 * DAM_LDG + 3 * 256 + 16 + 8 * 16 + 8 * 256 + 4 * 16 * 17;
+constexpr int DAM_LDS_FLOATS = 2 * 16 * DAM_LDG + 3 * 256 + 16 + 8 * 16 + 12 * 256 + 4 * 16 * 17;
 
-template <bool FOLD>
+// MODE 0 / 1 / 2 as in enc_reduce_mfma_kernel: query rows from memory / + the contact columns (FOLD) / generated on the matrix pipe from
+// [x_t | features | 1] and the [GEN_K][256] table xv = (decoder_adapter o encoder_adapter) (GEN: the decoder query is never materialised).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat, afm_ln qn,
                                                                 const float* __restrict__ bo, afm_ln mlpn, int N, float* __restrict__ h1,
                                                                 float* __restrict__ z, const float* __restrict__ xt,
-                                                                const float* __restrict__ xv, int cd, float* __restrict__ s1) {
+                                                                const float* __restrict__ xv, int cd, float* __restrict__ s1,
+                                                                const float* __restrict__ feat, int fd) {
+    constexpr bool FOLD = MODE == 1 || MODE == 2, GEN = MODE == 2;      // FOLD also covers what both share: h1 is not stored, s1 is
     constexpr int NJH = 16, LDG = DAM_LDG;
     extern __shared__ __attribute__((aligned(16))) float da_sm[];
     float* Gs = da_sm;                                            // [16][LDG]  gamma_q * G
@@ -964,9 +596,9 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     float* vec3 = Ps + 16 * LDG;                                  // [3][256]   b_o, gamma_mlp, beta_mlp
     float* gcs = vec3 + 3 * 256;                                  // [16]       beta_q . G[jh] + cb[jh]
     float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P  (rows >= cd: 0)
-    float* xvs = WPs + 8 * 16;                                    // [8][256]   contact columns of the decoder query (FOLD)
+    float* xvs = WPs + 8 * 16;                                    // FOLD: [8][256] contact columns of the decoder query; GEN: [3][16][64] generator table in operand order
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
-    float* aT = xvs + 8 * 256 + wave * 16 * 17;                   // [16 points][17] attention weights of the tile, transposed
+    float* aT = xvs + 12 * 256 + wave * 16 * 17;                  // [16 points][17] attention weights of the tile, transposed
     const float* rec = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
     for (int i = threadIdx.x; i < NJH * 64; i += 256) {            // (jh, float4) items
         const int jh = i >> 6, c = (i & 63) * 4;
@@ -982,8 +614,14 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     }
     for (int i = threadIdx.x; i < 256; i += 256) { vec3[i] = bo[i]; vec3[256 + i] = mlpn.g[i]; vec3[512 + i] = mlpn.b[i]; }
     if (threadIdx.x < 8 * 16) WPs[threadIdx.x] = (FOLD && (int)(threadIdx.x >> 4) < cd) ? rec[2 * NJH * 256 + NJH + threadIdx.x] : 0.f;
-    if (FOLD) {
+    if (FOLD && !GEN) {
         for (int i = threadIdx.x; i < 8 * 256; i += 256) xvs[i] = i < cd * 256 ? xv[i] : 0.f;
+    }
+    if (GEN) {
+        for (int i = threadIdx.x; i < GEN_K * 256; i += 256) {
+            const int l = i & 63, jj = (i >> 6) & 15, ks = i >> 10;
+            xvs[i] = xv[(4 * ks + (l >> 4)) * 256 + 16 * jj + (l & 15)];
+        }
     }
     __syncthreads();
     const float gconst = gcs[p16];
@@ -995,8 +633,18 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
 
     float4 e[16];
     float xrow[8];
+    float xin[3];
     auto fetch = [&](int nb) {                                     // 32-bit element offsets from the uniform bases (one address register per load)
         const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
+        if (GEN) {
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int k = 4 * ks + g;
+                const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
+                xin[ks] = k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
+            }
+            return;
+        }
         const unsigned ro = pti * 256u + 4u * (unsigned)g;
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = *reinterpret_cast<const float4*>(dec_q0 + (ro + 16u * j));
@@ -1010,7 +658,16 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     for (int nb = w0; nb < w1; nb += 16) {
         const int64_t pt = (int64_t)b * N + nb + p16;
         const bool pvalid = nb + p16 < w1;
-        if (FOLD) {
+        if (GEN) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(xvs[(ks * 16 + jj) * 64 + lane], xin[ks], d, 0, 0, 0);
+                e[jj] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+        if (FOLD && !GEN) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j >= cd) break;                                // wave-uniform

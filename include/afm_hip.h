@@ -525,10 +525,17 @@ typedef struct {
     int32_t flags;             /* AFM_CDM_* bits (ABI v4)                                                       */
     const float* fold_q;       /* [contact_dim, contact_dim]  contact_layer.w @ fold_xv^T                     */
     const float* fold_c0;      /* [contact_dim]  contact_layer.w @ (dec_mlp.fc2.b + dec_attn.o.b) + contact_layer.b */
+    /* ABI v5 (all three or none; built by the host next to fold_* when feat_dim + 1 <= 12, i.e. the H3D variant's 9 input channels):
+     * GENERATOR tables.  Both adapters are linear maps of the K = feat_dim + 1 <= 12 inputs [x_t | point features, xyz | 1], so neither
+     * enc_kv nor dec_q0 is ever materialised: the per-point kernels generate a tile's rows on the matrix pipe from the point's inputs
+     * (16x16x4 f32 MFMA, the channel as the output row), and the output layer takes its query part straight from the inputs.
+     *   gen_enc [12, dkv]          row k < feat_dim: encoder_adapter.w[:, k]; row feat_dim: encoder_adapter.b; zero rows after
+     *   gen_dec [12, dkv]          row k: (decoder_adapter.w @ encoder_adapter.w)[:, k]; row feat_dim: decoder_adapter.w @ enc.b + dec.b
+     *   gen_qe  [contact_dim, 12]  contact_layer.w @ gen_dec^T */
+    const float* gen_enc; const float* gen_dec; const float* gen_qe;
 } afm_cdm_weights;
 
-#define AFM_CDM_VALU_REDUCE   0x2      /* measurement: enc_reduce on the VALU (one wave per point) instead of the 16x16x4 MFMA form */
-#define AFM_CDM_SERIAL_LATENT 0x1      /* measurement: the latent chain as one workgroup per sample (latent_post_kernel) instead of batched stages */
+#define AFM_CDM_NO_GEN         0x2     /* measurement: rows of the per-point kernels from the materialised step-invariant tensors (round 2's folded form) */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
 
