@@ -309,9 +309,13 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
 // The 2-latent chain (cross-attention output, o_proj, MLP, self-attention blocks, decoder K / V folding) is ~16 dependent
 // matrix-vector stages per sample.  It runs batched over all 2 B latent tokens as a sequence of small launches: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
 // workgroups per stage (every weight row is read once per token block, by one workgroup), ~5 us per launch.
-//   toklin_kernel: 64 tokens x 8 outputs per workgroup.  The (optionally LayerNorm-ed) input rows are staged in LDS ([64][K + 4] f32,
-//   conflict-free 16-byte row reads); lane = token, wave = output pair; the weight rows are wave-uniform and come through scalar loads.
-constexpr int TL_TOK = 64, TL_OB = 8;
+//   toklin_kernel: 64 tokens x 16 outputs per workgroup.  The (optionally LayerNorm-ed) input rows are staged in LDS ([64][K + 4] f32);
+//   the product runs on the matrix pipe (round 3; phase timeline of the VALU form - lane = token, 8 outputs, weight rows in LDS - and
+//   of the first matrix form in profiles/r03_cdm_chain.md): wave w owns tokens 16 w .. 16 w + 15, a 16 x 16 output tile = K / 4
+//   v_mfma_f32_16x16x4_f32 with A = the staged rows (ds_read_b128: four k per lane) and B = the weight rows, which every lane fetches
+//   for itself in operand order at kernel ENTRY (K / 16 float4 per lane: in flight under the staging and the LayerNorm; fetched
+//   inside the product loop they cost 8.5 us per launch).
+constexpr int TL_TOK = 64, TL_OB = 16;
 struct TokLin {
     const float* X; int ldx;                 // input rows: token tok at X + tok * ldx (+ head offset)
     int head_out, x_head_stride;             // head_out > 0: outputs [h * head_out, (h + 1) * head_out) read X + h * x_head_stride (per-head inputs)
@@ -321,37 +325,29 @@ struct TokLin {
     int act;                                 // AFM_ACT_*
     const float* R; int ldr;                 // residual rows or NULL (may be Y: every element is read and written by the same lane)
     float* Y; int ldy;
-    int ntok, N, K;
+    int ntok, N, K;                          // K: a power of two, 128 <= K <= MAXD
     int kshift;                              // K == 1 << kshift (row / column of a staging item by shifts; an integer division costs ~40 VALU)
 };
 
 __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     extern __shared__ __attribute__((aligned(16))) float tl_x[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB, ldsx = p.K + 4;
     const float* xbase = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0);
-    // All global loads of the workgroup are issued before anything waits: its TL_OB weight rows (<= 4 float4 per thread) and the
-    // 64 input rows (<= 32 float4 per thread) - one memory round trip per launch instead of one per batch.
-    float* tl_w = tl_x + TL_TOK * ldsx;
     const int kq = p.K >> 2, qs = p.kshift - 2;                  // float4 per row
     const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a workgroup lie in one weight part (ncol % TL_OB == 0)
-    float4 wv[4], xv[32];
+    // ---- every global load of the workgroup is issued before anything waits: this lane's B operands (weight row o0 + p16, k = 16 u + 4 g ..)
+    // and the 64 input rows (<= 32 float4 per thread)
+    const bool ovalid = o0 + p16 < p.N;
+    const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g;
+    const int nk16 = p.K >> 4;
+    float4 wreg[MAXD / 16], xv[32];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int idx = (threadIdx.x + u * 256) * 4;
-        const int r = idx >> p.kshift, c = idx & (p.K - 1), o = o0 + r;
-        const int part = o < p.N ? part0 : 0, oc = o < p.N ? oc0 + r : 0;
-        wv[u] = idx < TL_OB * p.K ? *reinterpret_cast<const float4*>(p.W[part] + (int64_t)oc * p.K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int u = 0; u < MAXD / 16; ++u) wreg[u] = u < nk16 ? *reinterpret_cast<const float4*>(wrow + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
         const int idx = threadIdx.x + u * 256, tk = idx >> qs, c = (idx & (kq - 1)) * 4, tok = tb + tk;
         xv[u] = (idx < TL_TOK * kq && tok < p.ntok) ? *reinterpret_cast<const float4*>(xbase + (int64_t)tok * p.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int idx = (threadIdx.x + u * 256) * 4;
-        if (idx < TL_OB * p.K) *reinterpret_cast<float4*>(tl_w + idx) = wv[u];
     }
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -360,7 +356,8 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     }
     __syncthreads();
     if (p.use_ln) {
-        // LayerNorm in place: 16 lanes per row (four rows per wave and pass), reductions inside the row of 16 lanes (DPP)
+        // LayerNorm in place: 16 lanes per row (four rows per wave and pass, the four passes unrolled so that their LDS round trips and
+        // reductions overlap), reductions inside the row of 16 lanes (DPP)
         const int sub = lane >> 4, l16 = lane & 15;
         float4 lg[8], lb[8];                                     // this lane's slices of gamma / beta: loaded once, not once per row
 #pragma unroll
@@ -369,7 +366,9 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
             lg[i] = c < p.K ? *reinterpret_cast<const float4*>(p.ln.g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             lb[i] = c < p.K ? *reinterpret_cast<const float4*>(p.ln.b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int tk = wave * 4 + sub; tk < TL_TOK; tk += 16) {
+#pragma unroll
+        for (int pass = 0; pass < TL_TOK / 16; ++pass) {
+            const int tk = wave * 4 + sub + 16 * pass;
             float* row = tl_x + tk * ldsx;
             float4 v[8];
             float sum = 0.f;
@@ -393,43 +392,38 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
             for (int i = 0; i < 8; ++i) {
                 const int c = (i * 16 + l16) * 4;
                 if (c < p.K) {
-                    const float4 g = lg[i], bb = lb[i];
-                    *reinterpret_cast<float4*>(row + c) = make_float4((v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
-                                                                      (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w);
+                    const float4 gg = lg[i], bb = lb[i];
+                    *reinterpret_cast<float4*>(row + c) = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                                                                      (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
                 }
             }
         }
         __syncthreads();
     }
-    constexpr int OW = TL_OB / 4;                                // outputs per wave
-    float acc[OW];
-    int oidx[OW];
+    // ---- the product on the matrix pipe: D[i = token][j = output] += X[i][k] W[j][k], four k per lane and step (lane (l & 15, l >> 4)
+    // supplies k = 16 u + 4 (l >> 4) + e to MFMA e of step u on both operands); two accumulators halve the dependent chain
+    const float* xrow = tl_x + (wave * 16 + p16) * ldsx + 4 * g;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-    for (int j = 0; j < OW; ++j) {
-        const int o = o0 + wave * OW + j;                        // wave-uniform
-        oidx[j] = o;
-        acc[j] = (o < p.N && p.b[part0]) ? p.b[part0][oc0 + wave * OW + j] : 0.f;
-    }
-    const float* xr = tl_x + lane * ldsx;
-    const float* wr = tl_w + wave * OW * p.K;
-#pragma unroll 8
-    for (int k = 0; k < p.K; k += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(xr + k);
-#pragma unroll
-        for (int j = 0; j < OW; ++j) {
-            const float4 w = *reinterpret_cast<const float4*>(wr + j * p.K + k);       // same address in every lane: LDS broadcast
-            acc[j] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+    for (int u = 0; u < MAXD / 16; ++u) {
+        if (u < nk16) {                                          // uniform
+            const float4 xq = *reinterpret_cast<const float4*>(xrow + 16 * u);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.x, wreg[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.y, wreg[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.z, wreg[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.w, wreg[u].w, acc1, 0, 0, 0);
         }
     }
-    const int tok = tb + lane;
-    if (tok < p.ntok) {
+    if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the wave's tile)
+        const float bias = p.b[part0] ? p.b[part0][oc0 + p16] : 0.f;
 #pragma unroll
-        for (int j = 0; j < OW; ++j) {
-            if (oidx[j] >= p.N) continue;
-            float v = acc[j];
+        for (int r = 0; r < 4; ++r) {
+            const int tok = tb + wave * 16 + 4 * g + r;
+            if (tok >= p.ntok) continue;
+            float v = (acc0[r] + acc1[r]) + bias;
             if (p.act) v = apply_act(v, p.act);
-            if (p.R) v += p.R[(int64_t)tok * p.ldr + oidx[j]];
-            p.Y[(int64_t)tok * p.ldy + oidx[j]] = v;
+            if (p.R) v += p.R[(int64_t)tok * p.ldr + o0 + p16];
+            p.Y[(int64_t)tok * p.ldy + o0 + p16] = v;
         }
     }
 }
