@@ -800,6 +800,8 @@ int validate(const afm_cdm_weights* w, int B, int N) {
     if (w->dkv != 256 || w->dq <= 0 || w->dq > MAXD || (w->dq & 3) || w->text_dim > MAXD || w->time_dim > MAXD) return AFM_E_UNSUPPORTED;
     if (w->enc_heads != 8 || w->dec_heads != 8 || w->n_self < 0 || w->n_self > 4) return AFM_E_UNSUPPORTED;
     if (w->feat_dim <= 0 || w->contact_dim <= 0 || w->n_timesteps <= 0) return AFM_E_BADARG;
+    // the batched latent chain: 64-token x 16-output work items, rows staged with shifts (widths are powers of two >= 128)
+    if ((w->dq & (w->dq - 1)) != 0 || w->dq < 128 || (w->dq / w->enc_heads) % TL_OB != 0) return AFM_E_UNSUPPORTED;
     return 0;
 }
 
@@ -832,12 +834,14 @@ namespace {
 // out[n, j] = (((p0 + p1) + p2) + p3) + s1[n, j] + (E[n, j] + q[j] . x_t[n]) + c0[j] from the row-dot partials of the fc1 GEMM, optional DDPM
 // update IN PLACE.  Every output channel needs the point's whole contact row (through q), so a block owns WHOLE rows (256 / cd of
 // them per trip, one thread per element) and all its reads of x_t happen before a barrier, its writes after.
+// GEN form (feat != NULL): nothing of the decoder query is materialised, its part of the output is fq [cd][GEN_K] . [x_t | features | 1]
+// (fq = contact_layer.w folded through the generator table of the query); qe is unused.
 __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict__ rdot, int ngrp, const float* __restrict__ s1,
                                                          const float* __restrict__ qe, const float* __restrict__ fq,
                                                          const float* __restrict__ c0, int cd, int64_t rows, int rows_per_sample,
                                                          float* __restrict__ x0_out, const float* xt, const float* __restrict__ noise,
                                                          float* x_next, const float* __restrict__ c1, const float* __restrict__ c2,
-                                                         const float* __restrict__ sigma) {
+                                                         const float* __restrict__ sigma, const float* __restrict__ feat, int fd) {
     const int rpb = 256 / cd;                                     // rows per block and trip
     const int lr = threadIdx.x / cd, j = threadIdx.x - lr * cd;
     const bool act = lr < rpb;
@@ -849,11 +853,22 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
         if (ok) {
             v = rdot[(r * ngrp) * cd + j];                                         // w2 . GELU(linear1 z), 64 columns per partial
             for (int g = 1; g < ngrp; ++g) v += rdot[(r * ngrp + g) * cd + j];
-            float q = qe[i];                                                        // contact_layer.w . decoder query = invariant part + x_t part
-            for (int k = 0; k < cd; ++k) {
-                const float xk = xt[r * cd + k];
-                q += xk * fq[j * cd + k];
-                if (k == j) xj = xk;
+            float q;                                                                // contact_layer.w . decoder query = invariant part + x_t part
+            if (feat) {
+                q = fq[j * GEN_K + fd];                                             // the constant input 1 (bias row of the generator)
+                for (int k = 0; k < cd; ++k) {
+                    const float xk = xt[r * cd + k];
+                    q += xk * fq[j * GEN_K + k];
+                    if (k == j) xj = xk;
+                }
+                for (int k = cd; k < fd; ++k) q += feat[r * fd + k] * fq[j * GEN_K + k];
+            } else {
+                q = qe[i];
+                for (int k = 0; k < cd; ++k) {
+                    const float xk = xt[r * cd + k];
+                    q += xk * fq[j * cd + k];
+                    if (k == j) xj = xk;
+                }
             }
             v = ((v + s1[i]) + q) + c0[j];                                          // + attention part of contact_layer.w . h1 + constants
         }
@@ -868,73 +883,62 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
     }
 }
 
-// enc_reduce: the matrix-pipe form, or the VALU form (measurement knob AFM_CDM_VALU_REDUCE)
+// per-point kernels: mode 0 = rows from memory (layer-by-layer form), 1 = FOLD (step-invariant part materialised once per loop + contact
+// columns), 2 = GEN (rows generated on the matrix pipe from [x_t | features | 1]; nothing materialised)
 int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* text_u, const float* text_cu, const int64_t* t, int B, int N,
-                      const CdmWs& ws, const float* x_t, bool fold, hipStream_t s) {
+                      const CdmWs& ws, const float* x_t, const float* feat, int mode, hipStream_t s) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
-    const float* xu = fold ? w.fold_xu : nullptr;
-    const int cd = fold ? w.contact_dim : 0;
-    if (w.flags & AFM_CDM_VALU_REDUCE) {
-        if (fold) hipLaunchKernelGGL((enc_reduce_kernel<16, true>), dim3(NSPLIT, B), dim3(256), 0, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                                     w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
-        else hipLaunchKernelGGL((enc_reduce_kernel<16, false>), dim3(NSPLIT, B), dim3(256), 0, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                                w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
-    } else {
-        constexpr int LDS = ERM_LDS_FLOATS * (int)sizeof(float);
-        static const int attr = []() {
-            int rc = (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            return rc ? rc : (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        }();
-        if (attr != 0) return attr;
-        if (fold) hipLaunchKernelGGL(enc_reduce_mfma_kernel<true>, dim3(ERM_SPLIT, B), dim3(64 * ERM_WAVES), LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                                     w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
-        else hipLaunchKernelGGL(enc_reduce_mfma_kernel<false>, dim3(ERM_SPLIT, B), dim3(64 * ERM_WAVES), LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                                w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, xu, cd);
-    }
+    constexpr int LDS = ERM_LDS_FLOATS * (int)sizeof(float);
+    static const int attr = []() {
+        int rc = (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (!rc) rc = (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        return rc ? rc : (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    }();
+    if (attr != 0) return attr;
+    const dim3 grid(ERM_SPLIT, B), block(64 * ERM_WAVES);
+    if (mode == 2) hipLaunchKernelGGL(enc_reduce_mfma_kernel<2>, grid, block, LDS, s, (const float*)nullptr, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                      w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.gen_enc, w.contact_dim, feat, w.feat_dim);
+    else if (mode == 1) hipLaunchKernelGGL(enc_reduce_mfma_kernel<1>, grid, block, LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                           w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.fold_xu, w.contact_dim, (const float*)nullptr, 0);
+    else hipLaunchKernelGGL(enc_reduce_mfma_kernel<0>, grid, block, LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                            w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }
 
-// dec_attend: the matrix-pipe form, or the VALU form (measurement knob AFM_CDM_VALU_REDUCE)
-int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, bool fold, hipStream_t s) {
+int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, int mode, hipStream_t s) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
-    const int cd = fold ? w.contact_dim : 0;
-    if (w.flags & AFM_CDM_VALU_REDUCE) {
-        int chunks = (N + 255) / 256;
-        if (chunks > 64) chunks = 64;
-        if (fold) hipLaunchKernelGGL((dec_attend_kernel<8, true>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                                     (float*)nullptr, ws.z, x_t, w.fold_xv, cd, ws.s1);
-        else hipLaunchKernelGGL((dec_attend_kernel<8, false>), dim3(chunks, B), dim3(256), 0, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                                ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
-    } else {
-        constexpr int LDS = DAM_LDS_FLOATS * (int)sizeof(float);
-        static const int attr = []() {
-            int rc = (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            return rc ? rc : (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        }();
-        if (attr != 0) return attr;
-        int chunks = (N + 511) / 512;                              // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
-        if (chunks > 16) chunks = 16;
-        if (fold) hipLaunchKernelGGL(dec_attend_mfma_kernel<true>, dim3(chunks, B), dim3(256), LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                                     (float*)nullptr, ws.z, x_t, w.fold_xv, cd, ws.s1);
-        else hipLaunchKernelGGL(dec_attend_mfma_kernel<false>, dim3(chunks, B), dim3(256), LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                                ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
-    }
+    constexpr int LDS = DAM_LDS_FLOATS * (int)sizeof(float);
+    static const int attr = []() {
+        int rc = (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (!rc) rc = (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        return rc ? rc : (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    }();
+    if (attr != 0) return attr;
+    int chunks = (N + 511) / 512;                                  // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
+    if (chunks > 16) chunks = 16;
+    const dim3 grid(chunks, B), block(256);
+    if (mode == 2) hipLaunchKernelGGL(dec_attend_mfma_kernel<2>, grid, block, LDS, s, (const float*)nullptr, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                      (float*)nullptr, ws.z, x_t, w.gen_dec, w.contact_dim, ws.s1, feat, w.feat_dim);
+    else if (mode == 1) hipLaunchKernelGGL(dec_attend_mfma_kernel<1>, grid, block, LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                           (float*)nullptr, ws.z, x_t, w.fold_xv, w.contact_dim, ws.s1, (const float*)nullptr, 0);
+    else hipLaunchKernelGGL(dec_attend_mfma_kernel<0>, grid, block, LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                            ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_toklin(const TokLin& p, hipStream_t s) {
-    const size_t lds = ((size_t)TL_TOK * (p.K + 4) + (size_t)TL_OB * p.K) * sizeof(float);
+    const size_t lds = (size_t)TL_TOK * (p.K + 4) * sizeof(float);
     static const int attr = (int)hipFuncSetAttribute((const void*)toklin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (TL_TOK * (MAXD + 4) + TL_OB * MAXD) * (int)sizeof(float));
+                                                     TL_TOK * (MAXD + 4) * (int)sizeof(float));
     if (attr != 0) return attr;
     hipLaunchKernelGGL(toklin_kernel, dim3((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK), dim3(256), lds, s, p);
     AFM_CHECK_LAUNCH();
     return 0;
 }
 
-// enc_reduce partials -> dec_lat records, as 17 small launches over all 2 B latent tokens (see toklin_kernel)
+// enc_reduce partials -> dec_lat records, as 17 small launches over all 2 B latent tokens (see toklin_kernel; 14-18 us each, ~2 us apart)
 int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
@@ -987,21 +991,18 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
     return 0;
 }
 
-// serial form (one workgroup per sample, measurement knob AFM_CDM_SERIAL_LATENT) or the batched chain
 int cdm_latents(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s) {
-    const bool pow2 = (w.dq & (w.dq - 1)) == 0 && (w.dkv & (w.dkv - 1)) == 0;
-    if (!(w.flags & AFM_CDM_SERIAL_LATENT) && pow2 && w.dq >= 64 && w.dq <= MAXD && (w.dq / w.enc_heads) % TL_OB == 0) return cdm_latent_chain(w, text_q0, t, ws, B, s);
-    AfmProf prof(AFM_PROF_CDM, 0.0, s);
-    const size_t lds = (size_t)(16 * w.dkv + 10 * MAXD + 16 * NPART + 128) * sizeof(float);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)latent_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(latent_post_kernel, dim3(B), dim3(1024), lds, s, w, text_q0, w.time_q0, t, ws.pm, ws.pl, ws.pacc, ws.dec_lat);
-    AFM_CHECK_LAUNCH();
-    return 0;
+    return cdm_latent_chain(w, text_q0, t, ws, B, s);
 }
 
-inline bool cdm_folded(const afm_cdm_weights& w) {
-    return w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
+// sampling form of the per-point kernels: 2 = GEN (generator tables present, feat_dim + 1 <= GEN_K), 1 = FOLD, 0 = layer by layer
+inline int cdm_mode(const afm_cdm_weights& w) {
+    const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
+    if (!folded) return 0;
+    const bool gen = w.gen_enc && w.gen_dec && w.gen_qe && w.feat_dim + 1 <= GEN_K && !(w.flags & AFM_CDM_NO_GEN);
+    return gen ? 2 : 1;
 }
+inline bool cdm_folded(const afm_cdm_weights& w) { return cdm_mode(w) != 0; }
 
 // the step-invariant parts of the two adapters: C = encoder_adapter(input with x = 0) -> ws.enc_kv, D = decoder_adapter(C) -> ws.bufB
 int cdm_prepare_invariants(const afm_cdm_weights& w, const float* feat, int B, int N, const CdmWs& ws, hipStream_t s) {
@@ -1023,15 +1024,15 @@ int cdm_prepare_invariants(const afm_cdm_weights& w, const float* feat, int B, i
     return afm_linear(&a, s);
 }
 
-// one denoiser evaluation in the folded form (see afm_cdm_weights.fold_*); `prepared`: ws.enc_kv / ws.bufB already hold C / D
+// one denoiser evaluation in the folded (mode 1) or generated (mode 2) form; `prepared` (mode 1): ws.enc_kv / ws.bufB already hold C / D
 int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float* x_t, const int64_t* t, const float* text_q0,
                        const float* text_u, const float* text_cu, float* x0_out, const afm_ddpm_args* ddpm, int B, int N, const CdmWs& ws,
                        bool prepared, hipStream_t s) {
-    const int M = B * N, dkv = w.dkv, cd = w.contact_dim;
-    if (!prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
-    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, true, s));
+    const int M = B * N, dkv = w.dkv, cd = w.contact_dim, mode = cdm_mode(w);
+    if (mode == 1 && !prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
+    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, feat, mode, s));
     AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
-    AFM_TRY(launch_dec_attend(w, B, N, ws, x_t, true, s));
+    AFM_TRY(launch_dec_attend(w, B, N, ws, x_t, feat, mode, s));
     afm_linear_args a = {};                 // GELU(linear1 z) . w2 per 64-column group; the hidden activations are never stored
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
     a.rowdot_w = w.fold_w2; a.rowdot_out = ws.rdot; a.rowdot_n = cd;
@@ -1041,9 +1042,10 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
         const int rpb = 256 / cd;
         int64_t g = ((int64_t)M + rpb - 1) / rpb; if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, dkv / 64, ws.s1, ws.qe, w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
+        hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, dkv / 64, ws.s1, mode == 2 ? (const float*)nullptr : ws.qe,
+                           mode == 2 ? w.gen_qe : w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
                            ddpm ? ddpm->noise : nullptr, ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr,
-                           ddpm ? ddpm->sigma : nullptr);
+                           ddpm ? ddpm->sigma : nullptr, mode == 2 ? feat : (const float*)nullptr, w.feat_dim);
         AFM_CHECK_LAUNCH();
     }
     return 0;
@@ -1077,7 +1079,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     // with a side stream the GEMM runs under the latent chain and the two join in front of dec_attend.
     hipStream_t side = (hipStream_t)side_stream;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, nullptr, false, s));
+    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, nullptr, nullptr, 0, s));
     if (side) {           // fork AFTER enc_reduce (a full-chip kernel): the GEMM shares the chip with latent_post only
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
@@ -1104,7 +1106,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
         a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));
     }
-    AFM_TRY(launch_dec_attend(w, B, N, ws, nullptr, false, s));
+    AFM_TRY(launch_dec_attend(w, B, N, ws, nullptr, nullptr, 0, s));
     a = {};
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.C = ws.bufB; a.ldc = dkv;
     a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
@@ -1242,7 +1244,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
     // folded form: the step-invariant parts of the two adapters are computed once for the whole range of steps and x_t is read where
     // it is needed - no per-step rewrite of the input block, no adapter GEMMs inside the loop
     const bool folded = cdm_folded(*w);
-    if (folded) {
+    if (cdm_mode(*w) == 1) {                   // (the generated form has nothing to prepare)
         for (int s = 0; s < nsub && rc == 0; ++s) {
             if (count[s] == 0) continue;
             rc = cdm_prepare_invariants(*w, feat + (int64_t)start[s] * N * fd, count[s], N, carve(*w, count[s], N, wsp[s]), mainst[s]);
