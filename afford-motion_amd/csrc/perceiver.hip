@@ -309,13 +309,14 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
 // The 2-latent chain (cross-attention output, o_proj, MLP, self-attention blocks, decoder K / V folding) is ~16 dependent
 // matrix-vector stages per sample.  It runs batched over all 2 B latent tokens as a sequence of small launches: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
 // workgroups per stage (every weight row is read once per token block, by one workgroup), ~5 us per launch.
-//   toklin_kernel: 64 tokens x 16 outputs per workgroup.  The (optionally LayerNorm-ed) input rows are staged in LDS ([64][K + 4] f32);
-//   the product runs on the matrix pipe (round 3; phase timeline of the VALU form - lane = token, 8 outputs, weight rows in LDS - and
-//   of the first matrix form in profiles/r03_cdm_chain.md): wave w owns tokens 16 w .. 16 w + 15, a 16 x 16 output tile = K / 4
-//   v_mfma_f32_16x16x4_f32 with A = the staged rows (ds_read_b128: four k per lane) and B = the weight rows, which every lane fetches
-//   for itself in operand order at kernel ENTRY (K / 16 float4 per lane: in flight under the staging and the LayerNorm; fetched
-//   inside the product loop they cost 8.5 us per launch).
-constexpr int TL_TOK = 64, TL_OB = 16;
+//   toklin_kernel: ONE WAVE per 16 tokens x 16 outputs, everything in registers, no LDS, no barrier (round 3; the phase timelines of the
+//   earlier forms - VALU with LDS-staged rows and weights: 15 us per work item; matrix pipe with LDS-staged rows: staging 4-8 us,
+//   LayerNorm 4 us, product 3-8 us - are in profiles/r03_cdm_chain.md).  The 16 x 16 output tile is K / 4 v_mfma_f32_16x16x4_f32; both
+//   operands want "row (l & 15), four consecutive k at 16 u + 4 (l >> 4)" per lane, which is how a lane reads its 16-byte pieces of an
+//   input row and of a weight row straight from global memory: K / 16 float4 each, all issued at kernel entry.  A token's row is then
+//   spread over the four lanes (l & 15) + 16 g, so the LayerNorm statistics are a per-lane sum plus two cross-lane steps and the
+//   normalisation happens in registers.
+constexpr int TL_TOK = 16, TL_OB = 16;
 struct TokLin {
     const float* X; int ldx;                 // input rows: token tok at X + tok * ldx (+ head offset)
     int head_out, x_head_stride;             // head_out > 0: outputs [h * head_out, (h + 1) * head_out) read X + h * x_head_stride (per-head inputs)
@@ -325,107 +326,84 @@ struct TokLin {
     int act;                                 // AFM_ACT_*
     const float* R; int ldr;                 // residual rows or NULL (may be Y: every element is read and written by the same lane)
     float* Y; int ldy;
-    int ntok, N, K;                          // K: a power of two, 128 <= K <= MAXD
-    int kshift;                              // K == 1 << kshift (row / column of a staging item by shifts; an integer division costs ~40 VALU)
+    int ntok, N, K;                          // K % 16 == 0, K <= MAXD
 };
 
-__global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
-    extern __shared__ __attribute__((aligned(16))) float tl_x[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
-    const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB, ldsx = p.K + 4;
-    const float* xbase = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0);
-    const int kq = p.K >> 2, qs = p.kshift - 2;                  // float4 per row
-    const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a workgroup lie in one weight part (ncol % TL_OB == 0)
-    // ---- every global load of the workgroup is issued before anything waits: this lane's B operands (weight row o0 + p16, k = 16 u + 4 g ..)
-    // and the 64 input rows (<= 32 float4 per thread)
+#ifdef AFM_TOKLIN_TIMELINE      // tools/probes/toklin_timeline.py only (a debug build of this file); never compiled into the library
+__device__ unsigned long long afm_tk_tl[16 * 8];      // [launch slot][stamp]
+__device__ int afm_tk_slot = 0;
+#define TKTL(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { afm_tk_tl[(afm_tk_slot & 15) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 4) afm_tk_slot = afm_tk_slot + 1; } } while (0)
+#else
+#define TKTL(i)
+#endif
+
+__global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
+    TKTL(0);
+    const int lane = threadIdx.x, p16 = lane & 15, g = lane >> 4;
+    const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB;
+    const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a wave lie in one weight part (ncol % TL_OB == 0)
     const bool ovalid = o0 + p16 < p.N;
-    const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g;
     const int nk16 = p.K >> 4;
-    float4 wreg[MAXD / 16], xv[32];
+    // A operand: token tb + p16 (clamped: rows past the end are computed and dropped); B operand: weight row o0 + p16
+    const float* xrow = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0) + (int64_t)min(tb + p16, p.ntok - 1) * p.ldx + 4 * g;
+    const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g;
+    float4 xr[MAXD / 16], wr[MAXD / 16];
 #pragma unroll
-    for (int u = 0; u < MAXD / 16; ++u) wreg[u] = u < nk16 ? *reinterpret_cast<const float4*>(wrow + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const int idx = threadIdx.x + u * 256, tk = idx >> qs, c = (idx & (kq - 1)) * 4, tok = tb + tk;
-        xv[u] = (idx < TL_TOK * kq && tok < p.ntok) ? *reinterpret_cast<const float4*>(xbase + (int64_t)tok * p.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < MAXD / 16; ++u) {
+        xr[u] = u < nk16 ? *reinterpret_cast<const float4*>(xrow + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wr[u] = u < nk16 ? *reinterpret_cast<const float4*>(wrow + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    TKTL(1);
+    if (p.use_ln) {                                              // uniform.  Statistics over the row's four lanes (same p16, g = 0..3), two passes
+        float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const int idx = threadIdx.x + u * 256, tk = idx >> qs, c = (idx & (kq - 1)) * 4;
-        if (idx < TL_TOK * kq) *reinterpret_cast<float4*>(tl_x + tk * ldsx + c) = xv[u];
-    }
-    __syncthreads();
-    if (p.use_ln) {
-        // LayerNorm in place: 16 lanes per row (four rows per wave and pass, the four passes unrolled so that their LDS round trips and
-        // reductions overlap), reductions inside the row of 16 lanes (DPP)
-        const int sub = lane >> 4, l16 = lane & 15;
-        float4 lg[8], lb[8];                                     // this lane's slices of gamma / beta: loaded once, not once per row
+        for (int u = 0; u < MAXD / 16; ++u) sum += (xr[u].x + xr[u].y) + (xr[u].z + xr[u].w);      // (zero beyond K)
+        sum += xor16(sum); sum += xor32(sum);
+        const float mean = sum / (float)p.K;
+        float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = (i * 16 + l16) * 4;
-            lg[i] = c < p.K ? *reinterpret_cast<const float4*>(p.ln.g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            lb[i] = c < p.K ? *reinterpret_cast<const float4*>(p.ln.b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < MAXD / 16; ++u) {
+            if (u < nk16) { const float a = xr[u].x - mean, b = xr[u].y - mean, c = xr[u].z - mean, d = xr[u].w - mean; sq += (a * a + b * b) + (c * c + d * d); }
         }
+        sq += xor16(sq); sq += xor32(sq);
+        const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
 #pragma unroll
-        for (int pass = 0; pass < TL_TOK / 16; ++pass) {
-            const int tk = wave * 4 + sub + 16 * pass;
-            float* row = tl_x + tk * ldsx;
-            float4 v[8];
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = (i * 16 + l16) * 4;
-                v[i] = c < p.K ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-            }
-            sum += lane_xor<1>(sum); sum += lane_xor<2>(sum); sum += lane_xor<4>(sum); sum += lane_xor<8>(sum);
-            const float mean = sum / (float)p.K;
-            float sq = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = (i * 16 + l16) * 4;
-                if (c < p.K) { const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean; sq += (a * a + b * b) + (cc * cc + d * d); }
-            }
-            sq += lane_xor<1>(sq); sq += lane_xor<2>(sq); sq += lane_xor<4>(sq); sq += lane_xor<8>(sq);
-            const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = (i * 16 + l16) * 4;
-                if (c < p.K) {
-                    const float4 gg = lg[i], bb = lb[i];
-                    *reinterpret_cast<float4*>(row + c) = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
-                                                                      (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
-                }
+        for (int u = 0; u < MAXD / 16; ++u) {
+            if (u < nk16) {
+                const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * u + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * u + 4 * g);
+                xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
+                                    (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
             }
         }
-        __syncthreads();
     }
-    // ---- the product on the matrix pipe: D[i = token][j = output] += X[i][k] W[j][k], four k per lane and step (lane (l & 15, l >> 4)
-    // supplies k = 16 u + 4 (l >> 4) + e to MFMA e of step u on both operands); two accumulators halve the dependent chain
-    const float* xrow = tl_x + (wave * 16 + p16) * ldsx + 4 * g;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    TKTL(2);
+    // ---- D[i = token][j = output] += X[i][k] W[j][k]: MFMA e of step u takes k = 16 u + 4 (l >> 4) + e on both operands; four accumulators
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < MAXD / 16; ++u) {
         if (u < nk16) {                                          // uniform
-            const float4 xq = *reinterpret_cast<const float4*>(xrow + 16 * u);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.x, wreg[u].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.y, wreg[u].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.z, wreg[u].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xq.w, wreg[u].w, acc1, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].x, wr[u].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].y, wr[u].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].z, wr[u].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].w, wr[u].w, acc[3], 0, 0, 0);
         }
     }
-    if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the wave's tile)
+    TKTL(3);
+    if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the tile)
         const float bias = p.b[part0] ? p.b[part0][oc0 + p16] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int tok = tb + wave * 16 + 4 * g + r;
+            const int tok = tb + 4 * g + r;
             if (tok >= p.ntok) continue;
-            float v = (acc0[r] + acc1[r]) + bias;
+            float v = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + bias;
             if (p.act) v = apply_act(v, p.act);
             if (p.R) v += p.R[(int64_t)tok * p.ldr + o0 + p16];
             p.Y[(int64_t)tok * p.ldy + o0 + p16] = v;
         }
     }
+    TKTL(4);
 }
 
 // combine the per-wave partials of enc_reduce into s [ntok][He][dkv] (token = 2 b + i, i = 0 text latent, 1 time latent) and set the
@@ -800,14 +778,20 @@ int validate(const afm_cdm_weights* w, int B, int N) {
     if (w->dkv != 256 || w->dq <= 0 || w->dq > MAXD || (w->dq & 3) || w->text_dim > MAXD || w->time_dim > MAXD) return AFM_E_UNSUPPORTED;
     if (w->enc_heads != 8 || w->dec_heads != 8 || w->n_self < 0 || w->n_self > 4) return AFM_E_UNSUPPORTED;
     if (w->feat_dim <= 0 || w->contact_dim <= 0 || w->n_timesteps <= 0) return AFM_E_BADARG;
-    // the batched latent chain: 64-token x 16-output work items, rows staged with shifts (widths are powers of two >= 128)
-    if ((w->dq & (w->dq - 1)) != 0 || w->dq < 128 || (w->dq / w->enc_heads) % TL_OB != 0) return AFM_E_UNSUPPORTED;
+    // the batched latent chain: one wave per 16 tokens x 16 outputs (a head's outputs are whole tiles)
+    if ((w->dq & 15) != 0 || (w->dq / w->enc_heads) % TL_OB != 0) return AFM_E_UNSUPPORTED;
     return 0;
 }
 
 #define AFM_TRY(expr) do { int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
 
 }  // namespace
+
+#ifdef AFM_TOKLIN_TIMELINE
+extern "C" int afm_debug_toklin_timeline(unsigned long long* host_out128) {
+    return (int)hipMemcpyFromSymbol(host_out128, HIP_SYMBOL(afm_tk_tl), 128 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N) {
     if (validate(w, B, N) != 0) return AFM_E_BADARG;
@@ -929,11 +913,7 @@ int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
 }
 
 int launch_toklin(const TokLin& p, hipStream_t s) {
-    const size_t lds = (size_t)TL_TOK * (p.K + 4) * sizeof(float);
-    static const int attr = (int)hipFuncSetAttribute((const void*)toklin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     TL_TOK * (MAXD + 4) * (int)sizeof(float));
-    if (attr != 0) return attr;
-    hipLaunchKernelGGL(toklin_kernel, dim3((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(toklin_kernel, dim3((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK), dim3(64), 0, s, p);
     AFM_CHECK_LAUNCH();
     return 0;
 }
@@ -948,7 +928,6 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
     auto lin = [&](const float* X, int ldx, int K, const afm_lin& l, int N, float* Y, int ldy) {
         TokLin p = {};
         p.X = X; p.ldx = ldx; p.W[0] = l.w; p.b[0] = l.b; p.ncol = N; p.Y = Y; p.ldy = ldy; p.ntok = ntok; p.N = N; p.K = K;
-        p.kshift = 31 - __builtin_clz((unsigned)K);
         return p;
     };
     auto mlp = [&](const afm_mlp_w& m) {          // x <- x + fc2(GELU(fc1(LN(x))))
