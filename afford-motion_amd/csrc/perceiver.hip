@@ -337,43 +337,40 @@ __device__ int afm_tk_slot = 0;
 #define TKTL(i)
 #endif
 
+// NK16 = K / 16 at compile time (a run-time bound on the unrolled register arrays turns every step into compute-and-select)
+template <int NK16>
 __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
     TKTL(0);
     const int lane = threadIdx.x, p16 = lane & 15, g = lane >> 4;
     const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB;
     const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a wave lie in one weight part (ncol % TL_OB == 0)
     const bool ovalid = o0 + p16 < p.N;
-    const int nk16 = p.K >> 4;
     // A operand: token tb + p16 (clamped: rows past the end are computed and dropped); B operand: weight row o0 + p16
     const float* xrow = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0) + (int64_t)min(tb + p16, p.ntok - 1) * p.ldx + 4 * g;
     const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g;
-    float4 xr[MAXD / 16], wr[MAXD / 16];
+    float4 xr[NK16], wr[NK16];
 #pragma unroll
-    for (int u = 0; u < MAXD / 16; ++u) {
-        xr[u] = u < nk16 ? *reinterpret_cast<const float4*>(xrow + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-        wr[u] = u < nk16 ? *reinterpret_cast<const float4*>(wrow + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < NK16; ++u) {
+        xr[u] = *reinterpret_cast<const float4*>(xrow + 16 * u);
+        wr[u] = *reinterpret_cast<const float4*>(wrow + 16 * u);
     }
     TKTL(1);
     if (p.use_ln) {                                              // uniform.  Statistics over the row's four lanes (same p16, g = 0..3), two passes
         float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXD / 16; ++u) sum += (xr[u].x + xr[u].y) + (xr[u].z + xr[u].w);      // (zero beyond K)
+        for (int u = 0; u < NK16; ++u) sum += (xr[u].x + xr[u].y) + (xr[u].z + xr[u].w);
         sum += xor16(sum); sum += xor32(sum);
         const float mean = sum / (float)p.K;
         float sq = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXD / 16; ++u) {
-            if (u < nk16) { const float a = xr[u].x - mean, b = xr[u].y - mean, c = xr[u].z - mean, d = xr[u].w - mean; sq += (a * a + b * b) + (c * c + d * d); }
-        }
+        for (int u = 0; u < NK16; ++u) { const float a = xr[u].x - mean, b = xr[u].y - mean, c = xr[u].z - mean, d = xr[u].w - mean; sq += (a * a + b * b) + (c * c + d * d); }
         sq += xor16(sq); sq += xor32(sq);
         const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
 #pragma unroll
-        for (int u = 0; u < MAXD / 16; ++u) {
-            if (u < nk16) {
-                const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * u + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * u + 4 * g);
-                xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
-                                    (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
-            }
+        for (int u = 0; u < NK16; ++u) {
+            const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * u + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * u + 4 * g);
+            xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
+                                (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
         }
     }
     TKTL(2);
@@ -382,13 +379,11 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < MAXD / 16; ++u) {
-        if (u < nk16) {                                          // uniform
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].x, wr[u].x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].y, wr[u].y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].z, wr[u].z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].w, wr[u].w, acc[3], 0, 0, 0);
-        }
+    for (int u = 0; u < NK16; ++u) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].x, wr[u].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].y, wr[u].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].z, wr[u].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].w, wr[u].w, acc[3], 0, 0, 0);
     }
     TKTL(3);
     if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the tile)
@@ -779,7 +774,7 @@ int validate(const afm_cdm_weights* w, int B, int N) {
     if (w->enc_heads != 8 || w->dec_heads != 8 || w->n_self < 0 || w->n_self > 4) return AFM_E_UNSUPPORTED;
     if (w->feat_dim <= 0 || w->contact_dim <= 0 || w->n_timesteps <= 0) return AFM_E_BADARG;
     // the batched latent chain: one wave per 16 tokens x 16 outputs (a head's outputs are whole tiles)
-    if ((w->dq & 15) != 0 || (w->dq / w->enc_heads) % TL_OB != 0) return AFM_E_UNSUPPORTED;
+    if ((w->dq % 128) != 0 || (w->dq / w->enc_heads) % TL_OB != 0) return AFM_E_UNSUPPORTED;
     return 0;
 }
 
@@ -913,7 +908,14 @@ int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
 }
 
 int launch_toklin(const TokLin& p, hipStream_t s) {
-    hipLaunchKernelGGL(toklin_kernel, dim3((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK), dim3(64), 0, s, p);
+    const dim3 grid((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK);
+    switch (p.K) {                                // widths of the Perceiver's latents / point features (validate: dkv == 256, dq a multiple of 128)
+        case 128: hipLaunchKernelGGL(toklin_kernel<8>, grid, dim3(64), 0, s, p); break;
+        case 256: hipLaunchKernelGGL(toklin_kernel<16>, grid, dim3(64), 0, s, p); break;
+        case 384: hipLaunchKernelGGL(toklin_kernel<24>, grid, dim3(64), 0, s, p); break;
+        case 512: hipLaunchKernelGGL(toklin_kernel<32>, grid, dim3(64), 0, s, p); break;
+        default: return AFM_E_UNSUPPORTED;
+    }
     AFM_CHECK_LAUNCH();
     return 0;
 }
