@@ -148,8 +148,8 @@ class ContactPointTrans(nn.Module):
         from .scene import _bn_fold
         n = x.shape[0] // batch
         cat = torch.cat((x, context.repeat_interleave(n, dim=0)), 1)
-        s, b = _bn_fold(seq[1])
-        h = ops.linear(cat, seq[0].weight, seq[0].bias * s + b, scale=s, act=ffi.ACT_RELU)
+        s, b = _bn_fold(seq[1], seq[0].bias)
+        h = ops.linear(cat, seq[0].weight, b, scale=s, act=ffi.ACT_RELU)
         return ops.linear(h, seq[3].weight, seq[3].bias)
 
     def _encoder_layer_relu(self, x):
@@ -284,8 +284,9 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._ws = {}
         # Host-side tuning attributes (plain attributes: set them on the instance; nothing is read from the environment).
         self.overlap_streams = True     # layer-by-layer form: decoder-adapter GEMM on a side stream under the latent chain
-        # sub-batches of the native loop on their own streams (bit-identical results): 0 = automatic (two from B = 16 on: one sub-batch's
-        # 2-latent chain - 15 small dependent launches - runs under the other's full-chip kernels)
+        # sub-batches of the native loop on their own streams (bit-identical results): 0 = automatic = ONE.  Round 2 ran two from B = 16 on
+        # (one sub-batch's launch-latency-bound 2-latent chain under the other's full-chip kernels, +4.7 %); with round 3's chain a third
+        # as long a second stream loses (1248 vs 1308 steps/s, profiles/r03_cdm_chain.md)
         self.loop_sub_batches = 0
         if self.arch != "Perceiver":
             self.afm_native_loop = None         # other archs sample step by step
@@ -495,7 +496,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             tab = diffusion.tables(dev)
             n = diffusion.num_timesteps
             sched = torch.empty(lib.afm_cmdm_sched_scratch_bytes(n, B), dtype=torch.uint8, device=dev)
-            nsub = int(self.loop_sub_batches) or (2 if B >= 16 else 1)
+            nsub = int(self.loop_sub_batches) or 1
             nsub = max(1, min(nsub, B))
             need = 2 * nsub if nsub > 1 else (1 if self.overlap_streams else 0)
             while len(self._streams) < need:

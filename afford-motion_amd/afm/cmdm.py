@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from typing import Dict, List, Optional
 
 import torch
@@ -80,16 +79,30 @@ COND_SWITCHES = ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase")
 
 
 def _param_version(module: nn.Module) -> int:
-    """Changes whenever a parameter / buffer of `module` is written in place (optimiser step, load_state_dict, synth.fill_module_) - the key of
-    the weight packs and of the step-invariant caches.  The tensors are collected ONCE (the recursive `parameters()` walk costs 0.5 ms on the
-    282 tensors of the CMDM and ran three times per sampling call: most of a short loop's fixed cost); `_FlatParamsMixin` drops the list when
-    the tensors themselves can have been replaced (`.to()` / `.cuda()` / `load_state_dict`)."""
+    """Changes whenever a parameter / buffer of `module` is written in place (optimiser step, load_state_dict, synth.fill_module_) or
+    replaced - the key of the weight packs and of the step-invariant caches.  The tensors are collected ONCE (the recursive
+    `parameters()` walk costs 0.5 ms on the 282 tensors of the CMDM and ran three times per sampling call: most of a short loop's fixed
+    cost) as (owning dict, name, tensor) triples; every call checks that each slot still holds the SAME tensor object at the same storage
+    (a child's `.to()`, `load_state_dict(assign=True)` or `layer.weight = nn.Parameter(...)` replace tensors behind the top-level module's
+    back: the list is rebuilt and the version jumps), then sums the in-place version counters."""
     flat = module.__dict__.get("_afm_flat")
+    gen = module.__dict__.get("_afm_flat_gen", 0)
+    if flat is not None:
+        for owner, name, t, ptr in flat:
+            if owner.get(name) is not t or t.data_ptr() != ptr:
+                flat = None
+                break
     if flat is None:
-        flat = list(module.parameters()) + list(module.buffers())
-        module.__dict__["_afm_flat"] = flat
-    v = len(flat)
-    for t in flat:
+        flat = []
+        for m in module.modules():
+            for d in (m._parameters, m._buffers):
+                for name, t in d.items():
+                    if t is not None:
+                        flat.append((d, name, t, t.data_ptr()))
+        gen += 1
+        module.__dict__["_afm_flat"], module.__dict__["_afm_flat_gen"] = flat, gen
+    v = len(flat) + (gen << 40)
+    for _, _, t, _ in flat:
         v += t._version
     return v
 
@@ -179,12 +192,14 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.dropout_p = float(cfg.dropout)
         self._drop_calls = 0       # forward passes with dropout so far: every pass draws fresh masks
         self.hoist_conditions = True
-        # sub-batches of the native sampling loop, each on its own HIP stream (AFM_LOOP_STREAMS overrides)
-        self.loop_streams = int(os.environ.get("AFM_LOOP_STREAMS", "2"))
-        self.loop_streams_auto = "AFM_LOOP_STREAMS" not in os.environ       # an explicit setting is taken literally
+        # Host-side tuning attributes (plain attributes of the instance; nothing is read from the environment).
+        # sub-batches of the native sampling loop, each on its own HIP stream; `loop_streams_auto` caps them at B // 8 (below B = 16 a
+        # second stream only adds launches), set it to False to take `loop_streams` literally
+        self.loop_streams = 2
+        self.loop_streams_auto = True
         self._side_streams: List[torch.cuda.Stream] = []
         self.attn_group_waves = 0  # afm_mha_fwd_grouped workgroup shape (0 = library heuristic; results do not depend on it)
-        self.no_l0_cache = bool(os.environ.get("AFM_CMDM_NO_L0_CACHE"))      # measurement knob (host state, passed in the pack)
+        self.no_l0_cache = False   # measurement: recompute layer 0's q | k | v rows of the condition tokens every step (passed in the pack)
         self.fused_layernorm = False       # norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; measured slower on MI355X, profiles/r03_ln_fusion.md)
         self._pack = None          # (version, CmdmWeights, keep-alive tensors)
         self._cond_cache = None    # (key, cond_tokens)

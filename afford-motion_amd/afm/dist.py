@@ -89,7 +89,11 @@ def sharded_sample(sample_fn: Callable[[Dict[str, Any], int, int], torch.Tensor]
 def adm_to_amdm_condition(sample: torch.Tensor, sigma: float = 0.8, mean: float = 0.0, std: float = 1.0) -> torch.Tensor:
     """In-process ADM -> AMDM hand-off (the reference goes through .npy files): denormalise + clip to
     [1e-20, 1] (datasets/humanml3d.py:494-511), dist = sqrt(-2 ln(c) sigma^2) (utils/evaluate.py:56-66),
-    consumer c = exp(-dist^2 / (2 sigma^2)) (datasets/humanml3d.py:773-774)."""
-    contact = (sample * std + mean).clamp(1e-20, 1.0)
-    d = torch.sqrt(-2 * torch.log(contact) * sigma ** 2)
-    return torch.exp(-0.5 * d ** 2 / sigma ** 2)
+    consumer c = exp(-dist^2 / (2 sigma^2)) (datasets/humanml3d.py:773-774) - one HIP kernel (afm_contact_glue), the sample never leaves HBM."""
+    from . import ffi
+    ffi.require_gpu(sample)
+    x = ffi.f32c(sample)
+    out = torch.empty_like(x)
+    ffi.check(ffi.load().afm_contact_glue(x.data_ptr(), out.data_ptr(), x.numel(), float(sigma) ** 2, float(mean), float(std), ffi.stream_of(x)),
+              "afm_contact_glue")
+    return out

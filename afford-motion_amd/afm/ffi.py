@@ -143,6 +143,8 @@ EXPORTS = {
     "afm_layernorm_rows": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, i32, i32, i32, C.c_void_p]),
     "afm_ddpm_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
     "afm_randn": (C.c_int, [c_f32p, i32, i64, u64, i64, i32, C.c_void_p]),
+    "afm_bn_fold": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, c_f32p, i32, C.c_void_p]),
+    "afm_contact_glue": (C.c_int, [c_f32p, c_f32p, i64, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "afm_masked_mse": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, C.c_void_p]),
     "afm_transpose": (C.c_int, [c_f32p, c_f32p, i32, i32, C.c_void_p]),
     "afm_linear_wgrad_workspace_bytes": (i64, [i32, i32, i32]),

@@ -26,10 +26,30 @@ from . import autograd_points as AP
 from . import ffi, ops, pointops
 
 
-def _bn_fold(bn: nn.BatchNorm1d):
-    """eval-mode BatchNorm as y = x * scale + shift."""
-    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-    return scale, bn.bias - bn.running_mean * scale
+def _cached(module: nn.Module, slot: str, tensors, build):
+    """Per-module cache of a derived tensor pack, rebuilt when one of `tensors` was written in place, replaced or moved."""
+    key = tuple((id(t), t._version, t.data_ptr()) for t in tensors)
+    hit = module.__dict__.get(slot)
+    if hit is None or hit[0] != key:
+        hit = (key, build(), tuple(tensors))            # the tensors are held: a freed one's id / address cannot come back and match
+        module.__dict__[slot] = hit
+    return hit[1]
+
+
+def _bn_fold(bn: nn.BatchNorm1d, lin_bias: torch.Tensor = None):
+    """eval-mode BatchNorm as y = x * scale + shift (optionally with a preceding nn.Linear's bias folded in: BN(Wx + lb) = scale Wx +
+    (lb scale + shift)).  Computed by afm_bn_fold (HIP) once per weight version and cached on the module."""
+    srcs = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([lin_bias] if lin_bias is not None else [])
+
+    def build():
+        ffi.require_gpu(bn.weight)
+        w, b, m, v = (ffi.f32c(t.detach()) for t in srcs[:4])
+        lb = None if lin_bias is None else ffi.f32c(lin_bias.detach())
+        scale, shift = torch.empty_like(w), torch.empty_like(w)
+        ffi.check(ffi.load().afm_bn_fold(w.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), float(bn.eps), ffi.ptr(lb), scale.data_ptr(),
+                                         shift.data_ptr(), w.numel(), ffi.stream_of(w)), "afm_bn_fold")
+        return scale, shift
+    return _cached(bn, "_afm_fold" + ("_lb" if lin_bias is not None else ""), srcs, build)
 
 
 class PointTransformerLayer(nn.Module):
@@ -49,9 +69,9 @@ class PointTransformerLayer(nn.Module):
     def run(self, p: torch.Tensor, x: torch.Tensor, knn_idx: torch.Tensor, out_scale=None, out_shift=None, relu=False):
         """p [n,3], x [n,c], knn_idx [n,k] (global rows) -> [n,c]; optional fused y*scale+shift (+ReLU)."""
         c = self.out_planes
-        wqkv = torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], 0)
-        bqkv = torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], 0)
-        qkv = ops.linear(x, wqkv, bqkv)                                            # [n, 3c]
+        srcs = [self.linear_q.weight, self.linear_k.weight, self.linear_v.weight, self.linear_q.bias, self.linear_k.bias, self.linear_v.bias]
+        wqkv, bqkv = _cached(self, "_afm_qkv", srcs, lambda: (torch.cat([t.detach() for t in srcs[:3]], 0), torch.cat([t.detach() for t in srcs[3:]], 0)))
+        qkv = ops.linear(x, wqkv, bqkv)                                            # [n, 3c]: one GEMM on the packed q | k | v weights (packed once per weight version)
         ps, pb = _bn_fold(self.linear_p[1])
         w0s, w0b = _bn_fold(self.linear_w[0])
         w3s, w3b = _bn_fold(self.linear_w[3])
@@ -227,8 +247,8 @@ class TransitionUp(nn.Module):
 
     @staticmethod
     def _lin_bn_relu(x, lin: nn.Linear, bn: nn.BatchNorm1d):
-        s, b = _bn_fold(bn)
-        return ops.linear(x, lin.weight, lin.bias * s + b, scale=s, act=ffi.ACT_RELU)       # BN(Wx + bias) = s*Wx + (s*bias + shift)
+        s, b = _bn_fold(bn, lin.bias)                                                       # BN(Wx + bias) = s*Wx + (s*bias + shift)
+        return ops.linear(x, lin.weight, b, scale=s, act=ffi.ACT_RELU)
 
     def run_head(self, x: torch.Tensor, batch: int):
         n = x.shape[0] // batch

@@ -107,7 +107,57 @@ __global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restric
     }
 }
 
+// eval-mode BatchNorm folded into y = x * scale + shift (optionally around a preceding nn.Linear's bias: BN(W x + lb) = scale W x + (lb scale + shift)):
+// scale = w / sqrt(var + eps), shift = b - mean * scale.  Individually rounded operations (the torch expression, bit for bit).
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                                                      const float* __restrict__ var, float eps, const float* __restrict__ lin_bias,
+                                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = w[c] / sqrtf(var[c] + eps);
+    const float ms = mean[c] * sc;
+    float sh = b[c] - ms;
+    if (lin_bias) { const float lb = lin_bias[c] * sc; sh = lb + sh; }
+    scale[c] = sc;
+    shift[c] = sh;
+}
+
+// ADM -> AMDM hand-off in HBM (the reference goes through .npy files): contact = clip(sample * std + mean, 1e-20, 1)
+// (datasets/humanml3d.py:494-511), dist = sqrt(-2 ln(contact) sigma^2) (utils/evaluate.py:56-66), condition = exp(-dist^2 / (2 sigma^2))
+// (datasets/humanml3d.py:773-774) - the reference's chain of float32 operations, one element per thread.
+__global__ __launch_bounds__(256) void contact_glue_kernel(const float* __restrict__ sample, float* __restrict__ out, int64_t n, float sigma2, float mean, float std) {
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float c = sample[i] * std;
+        c = c + mean;
+        c = fminf(fmaxf(c, 1e-20f), 1.0f);
+        const float l = -2.0f * logf(c);
+        const float d = sqrtf(l * sigma2);
+        const float e = -0.5f * (d * d);
+        out[i] = expf(e / sigma2);
+    }
+}
+
 }  // namespace
+
+extern "C" int afm_bn_fold(const float* w, const float* b, const float* mean, const float* var, float eps, const float* lin_bias, float* scale,
+                           float* shift, int32_t C, void* stream) {
+    if (C == 0) return 0;
+    if (!w || !b || !mean || !var || !scale || !shift || C < 0 || !(eps >= 0.0f)) return AFM_E_BADARG;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, b, mean, var, eps, lin_bias, scale, shift, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_contact_glue(const float* sample, float* out, int64_t n, float sigma_sq, float mean, float std, void* stream) {
+    if (n == 0) return 0;
+    if (!sample || !out || n < 0 || !(sigma_sq > 0.0f)) return AFM_E_BADARG;
+    int64_t g = (n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(contact_glue_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, sample, out, n, sigma_sq, mean, std);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_mask, float* out, int32_t B,
                               int32_t L, int32_t D, void* stream) {

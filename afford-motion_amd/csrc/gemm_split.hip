@@ -7,10 +7,12 @@
 //   NPROD = 6: drops x2*w3, x3*w2, x3*w3 (|x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|: each dropped product <= 2^-24 |x||w|, rms ~2^-26, zero-mean because
 //              the split rounds to nearest - an order of magnitude below the rounding noise of the f32 accumulation itself).
 // Measured against float64 (tools/kernel_sweep.cpp, K = 512..4096): error / sum|x||w| rms 2.9e-8 for both variants vs 3.5e-8 for the
-// native f32 MFMA kernel.  Default: the exact 9-product variant on the wide GEMMs (N >= 1024: in_proj, linear1), where it is 1.26x faster than
-// the native kernel stand-alone and +7..10 % end to end (435-441 vs 400-406 steps/s, tools/ab_gemm_modes.py); the N = 512 GEMMs stay native (the split gains less there and the
-// bf16 pipe's power draw lowers the clock for everything around it, profiles/r01_gemm_investigation.md).  afm_linear_args.arith = AFM_ARITH_F32 selects the native
-// kernels everywhere; AFM_ARITH_BF16X6 with arith_min_n = 0 is the fastest setting (522-529 steps/s).
+// native f32 MFMA kernel.  Default (AFM_ARITH_DEFAULT, since round 2): the exact 9-product variant on EVERY eligible GEMM (K >= 128,
+// K % 16 == 0, 16-byte aligned operands, N >= 32) - in one call it beats the native kernel on every encoder shape (out_proj 65 vs 75 us,
+// linear2 118 vs 134, in_proj 161 vs 186) and +7.5-8 % in the loop on every box seen (profiles/r02_gemm_investigation.md).  Narrow
+// outputs (N < 32: the CDM's contact_layer products, N = contact_dim) stay on the native small-tile kernels: a 64 x 64 split tile would
+// do nine times the work on a mostly empty tile.  afm_linear_args.arith = AFM_ARITH_F32 selects the native kernels everywhere;
+// AFM_ARITH_BF16X6 (informational) is the fastest setting.  The choice never depends on M.
 //
 // Kernel: 256 threads = 2x2 waves, wave tile (BM/2)x(BN/2) of 32x32 MFMA tiles, K consumed BK at a time.
 //   global f32 -> registers (next K-tile, issued before the MFMAs of the current one) -> split in VALU, interleaved with
@@ -297,7 +299,7 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
 int afm_linear_split_mode(const afm_linear_args& a) {
     int mode, min_n;
     switch (a.arith) {
-        case AFM_ARITH_DEFAULT: mode = 9; min_n = 0; break;
+        case AFM_ARITH_DEFAULT: mode = 9; min_n = 32; break;       // narrow outputs: native small-tile kernels (a function of N only, never of M)
         case AFM_ARITH_BF16X9: mode = 9; min_n = a.arith_min_n; break;
         case AFM_ARITH_BF16X6: mode = 6; min_n = a.arith_min_n; break;
         case AFM_ARITH_BF16X1: mode = 1; min_n = a.arith_min_n; break;

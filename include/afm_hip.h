@@ -180,6 +180,18 @@ int afm_ddpm_step(const float* x0, const float* x_t, const float* noise, float* 
 int afm_randn(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0,
               int32_t step, void* stream);
 
+/* afm_bn_fold (ABI v5): eval-mode nn.BatchNorm1d as y = x * scale + shift (pointtransformer.py:31-36,56-57,111-113 call it after a
+ * Linear): scale = w / sqrt(running_var + eps), shift = b - running_mean * scale (+ lin_bias * scale when the Linear has a bias),
+ * every operation individually rounded.  All vectors [C]. */
+int afm_bn_fold(const float* w, const float* b, const float* running_mean, const float* running_var, float eps, const float* lin_bias,
+                float* scale, float* shift, int32_t C, void* stream);
+
+/* afm_contact_glue (ABI v5): the ADM -> AMDM hand-off of the two-stage pipeline kept in HBM.  The reference writes
+ * dist = sqrt(-2 ln(clip(sample * std + mean, 1e-20, 1)) sigma^2) to H3D/pred_contact/*.npy (utils/evaluate.py:41-82) and reads it back as
+ * exp(-dist^2 / (2 sigma^2)) (datasets/humanml3d.py:763-774); out[i] is that condition value, n elements.  sigma_sq = sigma^2 rounded to
+ * float32 once by the caller (the reference's Python scalar `sigma ** 2`). */
+int afm_contact_glue(const float* sample, float* out, int64_t n, float sigma_sq, float mean, float std, void* stream);
+
 /* afm_masked_mse: out[b] = sum((target - pred)^2 * keep) / (sum(keep) * D) over [L, D], keep = !frame_mask.
  * Replaces the loss reduction of training_losses (gaussian_diffusion.py:815-818, sum_flat nn.py:93-97). */
 int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_mask, float* out,

@@ -101,8 +101,15 @@ def test_two_rank_gather_matches_single_process(total):
     assert torch.equal(got[0], want) and torch.equal(got[1], want)
 
 
-def test_adm_to_amdm_glue_matches_reference_golden():
+def test_adm_to_amdm_glue_oracle_matches_reference_golden():
+    """The CPU oracle's glue (oracle/glue_ref.py) against the reference-generated golden; the product's glue is a HIP kernel
+    (afm_contact_glue), checked against the same golden in tests/test_gpu_cdm.py, and refuses CPU tensors."""
     from conftest import golden
+    from oracle import glue_ref
     g = golden("adm_to_amdm_glue")
-    cond = adist.adm_to_amdm_condition(g["sample"], sigma=float(g["sigma"]), mean=float(g["mean"]), std=float(g["std"]))
+    cond = glue_ref.adm_to_amdm_condition(g["sample"], sigma=float(g["sigma"]), mean=float(g["mean"]), std=float(g["std"]))
     assert torch.allclose(cond, g["cond"].float(), atol=1e-6)
+    import pytest
+    from afm import ffi
+    with pytest.raises(ffi.AfmError):
+        adist.adm_to_amdm_condition(g["sample"])

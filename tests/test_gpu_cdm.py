@@ -213,6 +213,18 @@ def test_two_sub_batch_loop_repeats():
         assert not bad, f"loop {r}: samples {bad} differ from the single-stream result (max {(out - ref).abs().max().item():.2e})"
 
 
+def test_adm_to_amdm_glue_kernel_vs_reference_golden():
+    """afm_contact_glue (the in-HBM ADM -> AMDM hand-off) against the golden generated from the real reference's two file-format halves."""
+    from afm import dist as adist
+    g = golden("adm_to_amdm_glue")
+    cond = adist.adm_to_amdm_condition(g["sample"].to(dev()), sigma=float(g["sigma"]), mean=float(g["mean"]), std=float(g["std"]))
+    report("ADM -> AMDM glue kernel vs reference golden", cond, g["cond"].float(), 1e-6)
+    big = synth.gaussian("glue_big", (3, 1000, 6)).to(dev()) * 2.0
+    from oracle import glue_ref
+    report("glue kernel vs oracle (clipped tails)", adist.adm_to_amdm_condition(big, sigma=0.8, mean=0.1, std=0.7),
+           glue_ref.adm_to_amdm_condition(big.cpu(), sigma=0.8, mean=0.1, std=0.7), 1e-6)
+
+
 def test_native_loop_snapshots(cdm):
     """`p_sample_loop(..., snapshots={k: None})`: the ADM's native loop cuts the chain at the requested step counts and clones x
     there - the states p_sample_loop_progressive would have yielded, bit for bit equal to running the chain only that far."""

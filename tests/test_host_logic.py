@@ -419,3 +419,29 @@ def test_clip_text_model_is_not_a_submodule(tmp_path, monkeypatch):
     feat = model.encode_text({"c_text": ["a person walks", "sits down"]})
     assert feat.shape == (2, 512)
     assert set(model.state_dict()) == before and not any("clip" in n for n, _ in model.named_modules())
+
+
+def test_param_version_sees_tensors_replaced_through_a_child_module():
+    """the weight packs and condition caches are keyed by `_param_version`, whose tensor list is cached.  In-place writes bump
+    `_version`; tensors REPLACED behind the top-level module (a child's `.to()` / `.double()`, `load_state_dict(assign=True)`,
+    `layer.weight = nn.Parameter(...)`) must change the version too."""
+    import torch.nn as nn
+    from afm.cmdm import _param_version
+    m = nn.Sequential(nn.Linear(4, 4), nn.Sequential(nn.Linear(4, 4), nn.BatchNorm1d(4)))
+    seen = [_param_version(m)]
+    assert _param_version(m) == seen[0]
+
+    def changed(what):
+        v = _param_version(m)
+        assert v not in seen, what
+        assert _param_version(m) == v
+        seen.append(v)
+    with torch.no_grad():
+        m[0].weight.add_(1)
+    changed("in-place write")
+    m[1][0].weight = nn.Parameter(torch.zeros(4, 4))
+    changed("parameter object replaced on a child")
+    m[1].double()
+    changed("child moved / cast")
+    m[1].load_state_dict({k: v.clone() for k, v in m[1].state_dict().items()}, assign=True)
+    changed("load_state_dict(assign=True) on a child")
