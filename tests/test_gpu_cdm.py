@@ -174,7 +174,7 @@ def test_config4_full_size_properties():
         assert torch.isfinite(whole[name]).all(), name
     assert whole["contact"].shape == (K, N, 6) and whole["motion"].shape == (K, L, 263)
     cond = whole["cond"]
-    assert cond.min().item() >= 1e-20 and cond.max().item() <= 1.0          # exp(-d^2 / 2 sigma^2) of a clipped contact map
+    assert cond.min().item() >= 0.9999e-20 and cond.max().item() <= 1.0      # exp(-d^2 / 2 sigma^2) of a contact map clipped to [1e-20, 1] (the log -> exp round trip is not exact)
     # the k samples share text and scene but not noise: they must differ from each other
     assert (whole["motion"][0] - whole["motion"][1]).abs().max().item() > 1e-3
     again = run(0, K)
