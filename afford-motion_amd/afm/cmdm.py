@@ -200,6 +200,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._side_streams: List[torch.cuda.Stream] = []
         self.attn_group_waves = 0  # afm_mha_fwd_grouped workgroup shape (0 = library heuristic; results do not depend on it)
         self.no_l0_cache = False   # measurement: recompute layer 0's q | k | v rows of the condition tokens every step (passed in the pack)
+        self.no_ln_fold = False            # measurement: separate LayerNorm launches instead of the statistics-carrying epilogues (afm_linear_args.a_stat ...)
         self.fused_layernorm = False       # norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; measured slower on MI355X, profiles/r03_ln_fusion.md)
         self._pack = None          # (version, CmdmWeights, keep-alive tensors)
         self._cond_cache = None    # (key, cond_tokens)
@@ -207,7 +208,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
 
     # ------------------------------------------------------------------ weight pack for the C-ABI
     def _weights(self) -> ffi.CmdmWeights:
-        ver = _param_version(self)
+        ver = (_param_version(self), self.training)
         if self._pack is not None and self._pack[0] == ver:
             return self._stamp(self._pack[1])
         dev = self.motion_adapter.weight.device
@@ -242,6 +243,19 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             lw.out_proj_w, lw.out_proj_b = P(l.self_attn.out_proj.weight), P(l.self_attn.out_proj.bias)
             lw.lin1_w, lw.lin1_b, lw.lin2_w, lw.lin2_b = P(l.linear1.weight), P(l.linear1.bias), P(l.linear2.weight), P(l.linear2.bias)
             lw.norm1_w, lw.norm1_b, lw.norm2_w, lw.norm2_b = P(l.norm1.weight), P(l.norm1.bias), P(l.norm2.weight), P(l.norm2.bias)
+        if not self.training:
+            # eval: LayerNorm folded into the linears it feeds (afm_encoder_layer_weights.lin1_wg ...): W' = W * gamma, g = row sums of W',
+            # c = b + W beta - float64 products rounded once, on the device (a few 512 x 1536 products per weight version)
+            def fold(lin_w, lin_b, norm):
+                wd, gam, bet = lin_w.detach().double(), norm.weight.detach().double(), norm.bias.detach().double()
+                wg = wd * gam[None, :]
+                return P(wg.float()), P(wg.sum(1).float()), P((lin_b.detach().double() + wd @ bet).float())
+            for i, l in enumerate(layers):
+                lw = w.layer[i]
+                lw.lin1_wg, lw.lin1_g, lw.lin1_c = fold(l.linear1.weight, l.linear1.bias, l.norm1)
+                if i > 0:
+                    lw.in_proj_wg, lw.in_proj_g, lw.in_proj_c = fold(l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, layers[i - 1].norm2)
+            w.motion_layer_wg, w.motion_layer_g, w.motion_layer_c = fold(self.motion_layer.weight, self.motion_layer.bias, layers[-1].norm2)
         self._pack = (ver, w, keep)
         return self._stamp(w)
 
@@ -249,7 +263,8 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         """Per-call settings of the pack: the host's GEMM arithmetic (afm.ops.set_gemm_split) and bit-neutral tuning fields."""
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
         w.attn_group_waves = int(self.attn_group_waves)
-        w.flags = (ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0) | (ffi.CMDM_FUSED_LN if self.fused_layernorm else 0)
+        w.flags = (ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0) | (ffi.CMDM_FUSED_LN if self.fused_layernorm else 0) | \
+            (ffi.CMDM_NO_LN_FOLD if self.no_ln_fold else 0)
         return w
 
     def _workspace(self, w: ffi.CmdmWeights, B: int, L: int, device) -> torch.Tensor:

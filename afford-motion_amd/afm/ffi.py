@@ -19,7 +19,7 @@ _lib = None
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
-CMDM_NO_L0_CACHE, CMDM_FUSED_LN = 0x1, 0x2
+CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD = 0x1, 0x2, 0x4
 CDM_NO_GEN = 0x2
 ABI_VERSION = 5
 MAX_LAYERS = 16
@@ -51,6 +51,9 @@ class LinearArgs(C.Structure):
         ("rowdot_w", c_f32p), ("rowdot_out", c_f32p), ("rowdot_n", i32),
         # fused LayerNorm of the output rows (ABI v5)
         ("ln_gamma", c_f32p), ("ln_beta", c_f32p), ("ln_out", c_f32p), ("ldo", i64), ("ln_eps", C.c_float), ("ln_counters", C.c_void_p),
+        # LayerNorm folded across kernel boundaries (ABI v5)
+        ("stat_out", c_f32p), ("a_stat", c_f32p), ("a_stat_groups", i32), ("a_fold_g", c_f32p),
+        ("res_stat", c_f32p), ("res_gamma", c_f32p), ("res_beta", c_f32p), ("ln_eps2", C.c_float),
     ]
 
 
@@ -112,7 +115,7 @@ class ProfileEntry(C.Structure):
 class EncoderLayerWeights(C.Structure):
     _fields_ = [(n, c_f32p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
-        "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
+        "norm1_w", "norm1_b", "norm2_w", "norm2_b", "lin1_wg", "lin1_g", "lin1_c", "in_proj_wg", "in_proj_g", "in_proj_c")]
 
 
 class CmdmWeights(C.Structure):
@@ -124,6 +127,7 @@ class CmdmWeights(C.Structure):
         ("layer", EncoderLayerWeights * MAX_LAYERS),
         ("gemm_arith", i32), ("gemm_arith_min_n", i32), ("attn_group_waves", i32), ("flags", i32),
         ("motion_adapter_kpad", i32),
+        ("motion_layer_wg", c_f32p), ("motion_layer_g", c_f32p), ("motion_layer_c", c_f32p),
     ]
 
 

@@ -23,7 +23,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            rows: Optional[int] = None, a_map: Optional[RowMap] = None, c_map: Optional[RowMap] = None,
            rowdot_w: Optional[torch.Tensor] = None, rowdot_out: Optional[torch.Tensor] = None, store: bool = True,
            ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, ln_out: Optional[torch.Tensor] = None,
-           ln_counters: Optional[torch.Tensor] = None) -> torch.Tensor:
+           ln_counters: Optional[torch.Tensor] = None, stat_out: Optional[torch.Tensor] = None,
+           a_stat: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+           res_stat: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None, ln_eps: float = 1e-5) -> torch.Tensor:
     """``act_post(act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)])`` on f32 MFMA.
 
     x [..., K] (or a 2-D row pool when ``a_map`` gathers rows), weight [N, K] as in nn.Linear.
@@ -32,7 +34,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     group, the dot of the output row with each of the R vectors; ``store=False`` then skips writing the output itself.
     ``ln`` = (gamma, beta, eps) + ``ln_out`` (same row layout as the output): the fused LayerNorm of the output rows (afm_linear_args.ln_*,
     the workgroup finishing the last column tile of a row block normalises it); ``ln_counters`` = zeroed int32 scratch of >= ceil(M / 32)
-    words (allocated here when omitted).  Returns the (pre-LayerNorm) output; the normalised rows are in ``ln_out``."""
+    words (allocated here when omitted).  Returns the (pre-LayerNorm) output; the normalised rows are in ``ln_out``.
+    LayerNorm folded ACROSS launches (afm_linear_args.stat_out / a_stat / res_stat): ``stat_out`` [rows, N / 64, 2] receives (mean, M2) per
+    output row and 64-column group; ``a_stat`` = (statistics of the raw input rows, g [N]) with ``weight`` = W * gamma and ``bias`` =
+    b + W beta makes this call compute W LN(x) + b from the RAW x; ``res_stat`` = (statistics, gamma, beta) adds LayerNorm(residual)."""
     lib = ffi.load()
     ffi.require_gpu(x, weight)
     x = ffi.f32c(x)
@@ -85,6 +90,24 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         assert ln_counters.dtype == torch.int32 and ln_counters.numel() >= (M + 31) // 32
         keep += [g, b, ln_out, ln_counters]
         a.ln_gamma, a.ln_beta, a.ln_out, a.ldo, a.ln_eps, a.ln_counters = g.data_ptr(), b.data_ptr(), ln_out.data_ptr(), N, float(eps), ln_counters.data_ptr()
+    if stat_out is not None:
+        assert stat_out.dtype == torch.float32 and stat_out.is_contiguous() and stat_out.numel() >= out.numel() // N * (N // 64) * 2 and N % 64 == 0
+        keep.append(stat_out)
+        a.stat_out = stat_out.data_ptr()
+    if a_stat is not None:
+        st, g = a_stat
+        st, g = ffi.f32c(st), ffi.f32c(g)
+        assert g.numel() == N and K % 64 == 0
+        keep += [st, g]
+        a.a_stat, a.a_stat_groups, a.a_fold_g = st.data_ptr(), K // 64, g.data_ptr()
+    if res_stat is not None:
+        st, g, b = res_stat
+        st, g, b = ffi.f32c(st), ffi.f32c(g), ffi.f32c(b)
+        assert residual is not None and g.numel() == N and b.numel() == N
+        keep += [st, g, b]
+        a.res_stat, a.res_gamma, a.res_beta = st.data_ptr(), g.data_ptr(), b.data_ptr()
+    if stat_out is not None or a_stat is not None or res_stat is not None:
+        a.ln_eps2 = float(ln_eps)
     fill_arith(a)
     ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
     return out

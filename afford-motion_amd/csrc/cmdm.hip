@@ -26,6 +26,7 @@ struct Workspace {
     float *seq0, *y, *x1, *tmp, *qkv, *qkv0, *att, *hid, *noise, *xpad;
     uint8_t* keymask;
     uint32_t* lncnt;          // tickets of the fused LayerNorm (one word per 32 output rows; zero between launches)
+    float *stat1, *stat2;     // folded LayerNorm: (mean, M2) per row and 64-column group of the raw out_proj / linear2 outputs
     int64_t bytes;
 };
 
@@ -46,6 +47,7 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
     ws.keymask = (uint8_t*)take(M);
     ws.lncnt = (uint32_t*)take(((M + 31) / 32) * 4);
+    ws.stat1 = (float*)take(M * (d / 64 + 1) * 2 * 4); ws.stat2 = (float*)take(M * (d / 64 + 1) * 2 * 4);
     ws.xpad = w.motion_adapter_kpad > 0 ? (float*)take((int64_t)B * L * w.motion_adapter_kpad * 4) : nullptr;      // x_t with rows padded to the GEMM's K
     ws.bytes = off;
     return ws;
@@ -130,6 +132,16 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         AFM_TRY(run_linear(w, a, s));
     }
 
+    // LayerNorm folded across the kernel boundaries (round 3): with the folded tensors in the pack (eval mode) and every GEMM of the layer on
+    // the bf16-split kernels, norm1 / norm2 are never launched and their outputs never exist: out_proj / linear2 store the RAW residual
+    // sums plus (mean, M2) per row and 64-column group, linear1 / the next in_proj / motion_layer run on the raw rows with gamma folded
+    // into their weights and apply (mean, rstd) in the epilogue, the residual adds normalise their (raw) input on the fly
+    // (afm_linear_args.stat_out / a_stat / res_stat).  10 launches and ~170 MB of traffic less per step at B = 32.
+    bool fold = !(w.flags & (AFM_CMDM_NO_LN_FOLD | AFM_CMDM_FUSED_LN)) && w.motion_layer_wg && w.motion_layer_g && w.motion_layer_c && (d % 64) == 0 &&
+                w.gemm_arith != AFM_ARITH_F32 && (w.gemm_arith == AFM_ARITH_DEFAULT || w.gemm_arith_min_n <= 32);
+    for (int li = 0; li < w.n_layers && fold; ++li)
+        fold = w.layer[li].lin1_wg && w.layer[li].lin1_g && w.layer[li].lin1_c && (li == 0 || (w.layer[li].in_proj_wg && w.layer[li].in_proj_g && w.layer[li].in_proj_c));
+    const int sg = d / 64;                            // statistic groups per row
     const float* X = ws.seq0;
     for (int li = 0; li < w.n_layers; ++li) {
         const afm_encoder_layer_weights& lw = w.layer[li];
@@ -140,6 +152,9 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         afm_linear_args a = {};
         a.A = X; a.lda = d; a.W = lw.in_proj_w; a.ldw = d; a.C = qkv; a.ldc = 3 * d;
         a.N = 3 * d; a.K = d; a.bias = lw.in_proj_b;
+        if (fold && li > 0) {                         // X = the previous layer's raw linear2 output: its norm2 is folded into W / bias
+            a.W = lw.in_proj_wg; a.bias = lw.in_proj_c; a.a_stat = ws.stat2; a.a_stat_groups = sg; a.a_fold_g = lw.in_proj_g; a.ln_eps2 = 1e-5f;
+        }
         const bool no_l0_cache = (w.flags & AFM_CMDM_NO_L0_CACHE) != 0;                  // measurement knob
         if (li == 0 && !copy_cond && w.n_cond > 0 && !no_l0_cache) {
             a.M = B; a.a_grp = 1; a.a_stride = T; a.a_off = 0; a.c_grp = 1; a.c_stride = T; a.c_off = 0;                 // time tokens
@@ -166,6 +181,25 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         // GEMM launch against 10.7 us per LayerNorm launch; B = 4: 0.679 vs 0.628 ms/step; profiles/r03_ln_fusion.md): every tile's
         // workgroup has to drain its write-through stores and wait for its ticket before it can retire.  Opt-in: AFM_CMDM_FUSED_LN.
         const bool fuse_ln = (w.flags & AFM_CMDM_FUSED_LN) != 0;
+        if (fold) {
+            a.stat_out = ws.stat1; a.ln_eps2 = 1e-5f;
+            if (li > 0) { a.res_stat = ws.stat2; a.res_gamma = w.layer[li - 1].norm2_w; a.res_beta = w.layer[li - 1].norm2_b; }     // residual = LayerNorm(raw X)
+            AFM_TRY(run_linear(w, a, s));
+            a = {};                                   // linear1 on the raw rows, norm1 folded
+            a.A = ws.tmp; a.lda = d; a.W = lw.lin1_wg; a.ldw = d; a.C = ws.hid; a.ldc = w.ff;
+            a.M = rows; a.N = w.ff; a.K = d; a.bias = lw.lin1_c; a.act = AFM_ACT_GELU;
+            a.a_stat = ws.stat1; a.a_stat_groups = sg; a.a_fold_g = lw.lin1_g; a.ln_eps2 = 1e-5f;
+            a.a_grp = g; a.a_stride = gs; a.a_off = go;
+            AFM_TRY(run_linear(w, a, s));
+            a = {};                                   // linear2 + LayerNorm1(raw) as the residual -> raw output + its statistics
+            a.A = ws.hid; a.lda = w.ff; a.W = lw.lin2_w; a.ldw = w.ff; a.C = ws.y; a.ldc = d;
+            a.M = rows; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.tmp; a.ldr = d;
+            a.res_stat = ws.stat1; a.res_gamma = lw.norm1_w; a.res_beta = lw.norm1_b; a.stat_out = ws.stat2; a.ln_eps2 = 1e-5f;
+            a.c_grp = g; a.c_stride = gs; a.c_off = go;
+            AFM_TRY(run_linear(w, a, s));
+            X = ws.y;
+            continue;
+        }
         if (fuse_ln) { a.ln_gamma = lw.norm1_w; a.ln_beta = lw.norm1_b; a.ln_out = ws.x1; a.ldo = d; a.ln_eps = 1e-5f; a.ln_counters = ws.lncnt; }
         AFM_TRY(run_linear(w, a, s));
         if (!fuse_ln) AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, rows, d, 1e-5f, g, gs, go, s));
@@ -189,6 +223,9 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.A = X; a.lda = d; a.W = w.motion_layer_w; a.ldw = d;
         a.C = x0_out; a.ldc = w.motion_dim; a.M = B * L; a.N = w.motion_dim; a.K = d;
         a.bias = w.motion_layer_b;
+        if (fold) {                                   // X = the last layer's raw linear2 output
+            a.W = w.motion_layer_wg; a.bias = w.motion_layer_c; a.a_stat = ws.stat2; a.a_stat_groups = sg; a.a_fold_g = w.motion_layer_g; a.ln_eps2 = 1e-5f;
+        }
         a.a_grp = L; a.a_stride = T; a.a_off = 1 + w.n_cond;
         if (ddpm) {
             const float* nz = ddpm->noise;

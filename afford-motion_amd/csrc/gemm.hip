@@ -417,6 +417,13 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
             a.ln_out == a.C || a.ln_out == a.A || a.ln_out == a.residual || a.ddpm_out || a.rowdot_w)
             return AFM_E_BADARG;
     }
+    const bool lnfold = a.stat_out || a.a_stat || a.res_stat;
+    if (lnfold) {                                 // LayerNorm folded across kernel boundaries (ABI v5)
+        if ((a.stat_out && (a.N % 64)) || (a.a_stat && (!a.a_fold_g || a.a_stat_groups <= 0)) || (a.res_stat && (!a.residual || !a.res_gamma || !a.res_beta || (a.N % 64))) ||
+            !(a.ln_eps2 > 0.0f) || a.scale || a.rowtab || a.preact || a.dact_z || a.drop_p > 0.0f || a.act_post || a.rowdot_w || a.ln_out)
+            return AFM_E_BADARG;
+        if (a.stat_out && (!a.C || (a.N & 3) || (a.ldc & 3) || (a.ldr & 3) || a.ddpm_out)) return AFM_E_BADARG;
+    }
     if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9 &&
         a.arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
     if (a.arith_min_n < 0) return AFM_E_BADARG;
@@ -424,6 +431,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                      (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
     if (const int mode = afm_linear_split_mode(a)) return afm_linear_split(a, mode, s);
+    if (lnfold) return AFM_E_UNSUPPORTED;         // the native kernels do not carry the row statistics
     // Native f32 MFMA.  Tile choice (measured on MI355X, profiles/r01_gemm_investigation.md): with the 64-cycle f32 MFMA neither LDS
     // nor L2 bandwidth limits; what limits is keeping every SIMD's matrix pipe busy across the barrier / load phases of its waves
     // and filling 256 CUs.  64x64 tiles (4 workgroups = 4 waves per SIMD, fine-grained tails) beat 64x128 and 128x128 on every

@@ -21,15 +21,52 @@ __device__ __forceinline__ void store_f4_sc1(float* ptr, const float4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(d) : "memory");
 }
 
+// ---- LayerNorm folded across kernel boundaries (afm_linear_args.stat_out / a_stat / res_stat, ABI v5).  A producer writes, per output
+// row and 64-column group, (mean, M2 = sum of squared deviations from that mean) of what it stores; consumers combine the groups of a row
+// in index order (Chan's parallel-variance formula): mean = avg(mean_t), M2 = sum_t M2_t + 64 sum_t (mean_t - mean)^2.
+__device__ __forceinline__ void row_stat_combine(const float* __restrict__ st, int groups, float eps, float& mean, float& rstd) {
+    float ms = 0.f;
+    for (int t = 0; t < groups; ++t) ms += st[2 * t];
+    mean = ms / (float)groups;
+    float m2 = 0.f;
+    for (int t = 0; t < groups; ++t) { const float d = st[2 * t] - mean; m2 += st[2 * t + 1] + 64.0f * (d * d); }
+    rstd = 1.0f / sqrtf(m2 / (64.0f * (float)groups) + eps);
+}
+
+// (mean, rstd) of the tile's A rows -> rowst[row], of its residual rows -> rowst[BM + row]; EVERY thread of the workgroup calls this
+// (it ends in a barrier when the launch uses the folded LayerNorm).  rowst: 2 * BM float2 of LDS behind the staged accumulators.
+template <int BM>
+__device__ __forceinline__ void gemm_rowstats(const afm_linear_args& p, float* rowst, int bm) {
+    if (!p.a_stat && !p.res_stat) return;                               // uniform
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off}, cmap{p.c_grp, p.c_stride, p.c_off};
+    for (int r = threadIdx.x; r < 2 * BM; r += blockDim.x) {
+        const bool is_res = r >= BM;
+        const int grow = bm * BM + (is_res ? r - BM : r);
+        const float* st = is_res ? p.res_stat : p.a_stat;
+        float mean = 0.f, rstd = 0.f;
+        if (st && grow < p.M) {
+            const int groups = is_res ? p.N / 64 : p.a_stat_groups;
+            row_stat_combine(st + (is_res ? cmap(grow) : amap(grow)) * (2 * groups), groups, p.ln_eps2, mean, rstd);
+        }
+        rowst[2 * r] = mean; rowst[2 * r + 1] = rstd;
+    }
+    __syncthreads();
+}
+
 // epilogue math for one output element (compact: instantiated once, looped over, never unrolled 64x)
-__device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int grow, int64_t orow, int gcol) {
+__device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int grow, int64_t orow, int gcol, const float* rowst = nullptr, int row = 0, int BM = 0) {
+    if (p.a_stat) v = rowst[2 * row + 1] * (v - rowst[2 * row] * p.a_fold_g[gcol]);       // LayerNorm of the A rows, folded: W carries gamma, bias carries W beta
     if (p.scale) v *= p.scale[gcol];
     if (p.bias) v += p.bias[gcol];
     if (p.preact) p.preact[orow * p.ldp + gcol] = v;
     if (p.act) v = apply_act(v, p.act);
     if (p.drop_p > 0.0f && !p.drop_after) v *= DropKey(p.drop_p, p.drop_seed, p.drop_id)((uint32_t)orow, (uint32_t)gcol);
     if (p.dact) v *= act_grad(p.dact_z[orow * p.ldz + gcol], p.dact);
-    if (p.residual) v += p.residual[orow * p.ldr + gcol];
+    if (p.residual) {
+        float rv = p.residual[orow * p.ldr + gcol];
+        if (p.res_stat) rv = (rv - rowst[2 * (BM + row)]) * rowst[2 * (BM + row) + 1] * p.res_gamma[gcol] + p.res_beta[gcol];      // the residual rows are raw: LayerNorm on the fly
+        v += rv;
+    }
     if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
     if (p.act_post) v = apply_act(v, p.act_post);
     if (p.drop_p > 0.0f && p.drop_after) v *= DropKey(p.drop_p, p.drop_seed, p.drop_id)((uint32_t)orow, (uint32_t)gcol);
@@ -38,7 +75,7 @@ __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int
 
 // Shared epilogue: the accumulators were staged in `lds` as a [BM][BN + 4] tile; stream rows out with 16-byte accesses.
 template <int BM, int BN, int NT = 256, int LDC = BN + 4>
-__device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const float* lds, int bm, int bn, int tid) {
+__device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const float* lds, int bm, int bn, int tid, const float* rowst = nullptr) {
     const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
     const int col0 = bn * BN;
     const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && ((p.ldp & 3) == 0) && ((p.ldz & 3) == 0) && !p.ddpm_out &&
@@ -84,6 +121,48 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
                 }
             }
         }
+    } else if (vec_out && (p.stat_out || p.a_stat || p.res_stat)) {
+        // folded-LayerNorm form (plain forward inputs only): every lane stays in the loop so that the group statistics are full 16-lane
+        // butterflies (a 64-column group of a row = 16 consecutive lanes x 4 columns; N % 64 == 0)
+        static_assert((BM * (BN / 4)) % NT == 0, "folded-LayerNorm epilogue: every lane makes the same number of trips");
+        const int ngrp = p.N / 64;
+        for (int e = tid; (BN / 4) % 16 == 0 && e < BM * (BN / 4); e += NT) {
+            const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
+            const int grow = bm * BM + row, gcol = col0 + cq;
+            const bool valid = grow < p.M && gcol < p.N;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int64_t orow = 0;
+            if (valid) {
+                v = *reinterpret_cast<const float4*>(lds + row * LDC + cq);
+                orow = cmap(grow);
+                if (p.a_stat) {
+                    const float mu = rowst[2 * row], rs = rowst[2 * row + 1];
+                    const float4 g = *reinterpret_cast<const float4*>(p.a_fold_g + gcol);
+                    v.x = rs * (v.x - mu * g.x); v.y = rs * (v.y - mu * g.y); v.z = rs * (v.z - mu * g.z); v.w = rs * (v.w - mu * g.w);
+                }
+                if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+                if (p.residual) {
+                    float4 t = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + gcol);
+                    if (p.res_stat) {
+                        const float mu = rowst[2 * (BM + row)], rs = rowst[2 * (BM + row) + 1];
+                        const float4 g = *reinterpret_cast<const float4*>(p.res_gamma + gcol), b = *reinterpret_cast<const float4*>(p.res_beta + gcol);
+                        t.x = (t.x - mu) * rs * g.x + b.x; t.y = (t.y - mu) * rs * g.y + b.y; t.z = (t.z - mu) * rs * g.z + b.z; t.w = (t.w - mu) * rs * g.w + b.w;
+                    }
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
+            }
+            if (p.stat_out) {                       // uniform
+                float sm = (v.x + v.y) + (v.z + v.w);
+                sm += lane_xor<1>(sm); sm += lane_xor<2>(sm); sm += lane_xor<4>(sm); sm += lane_xor<8>(sm);
+                const float mu = sm * (1.0f / 64.0f);
+                const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+                float m2 = (a * a + b * b) + (c * c + d * d);
+                m2 += lane_xor<1>(m2); m2 += lane_xor<2>(m2); m2 += lane_xor<4>(m2); m2 += lane_xor<8>(m2);
+                if (valid && (cq & 63) == 0) *reinterpret_cast<float2*>(p.stat_out + (orow * ngrp + gcol / 64) * 2) = make_float2(mu, m2);
+            }
+        }
     } else if (vec_out) {
         for (int e = tid; e < BM * (BN / 4); e += NT) {
             const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
@@ -111,7 +190,7 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             const int grow = bm * BM + row, gcol = col0 + c;
             if (grow >= p.M || gcol >= p.N) continue;
             const int64_t orow = cmap(grow);
-            const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol);
+            const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol, rowst, row, BM);
             if (p.C && p.ln_out) __hip_atomic_store(p.C + orow * p.ldc + gcol, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1), scalar form
             else if (p.C) p.C[orow * p.ldc + gcol] = v;
             if (p.ddpm_out) {

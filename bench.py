@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-gemm", action="store_true", help="skip the informational passes with the other GEMM arithmetic settings")
     ap.add_argument("--streams", type=int, default=None, help="sub-batch HIP streams of the native loop (default: model default)")
+    ap.add_argument("--no-ln-fold", action="store_true", help="measurement: separate LayerNorm launches instead of the statistics-carrying GEMM epilogues")
     ap.add_argument("--fused-ln", action="store_true", help="measurement: norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; slower, profiles/r03_ln_fusion.md)")
     ap.add_argument("--attn-group", type=int, default=None, help="waves per attention workgroup (bit-neutral tuning; default: library choice)")
     args = ap.parse_args()
@@ -175,6 +176,7 @@ def main():
     if args.attn_group is not None:
         model.attn_group_waves = args.attn_group
     model.fused_layernorm = bool(args.fused_ln)
+    model.no_ln_fold = bool(args.no_ln_fold)
     from afm.base import create_gaussian_diffusion
     cfg.diffusion.timestep_respacing = str(max(W, 1))
     diff_w = create_gaussian_diffusion(cfg)

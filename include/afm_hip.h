@@ -116,6 +116,19 @@ typedef struct {
      * ln_counters: >= ceil(M / 32) device words, ZERO on entry, zero again on exit.  Needs C, N % 4 == 0, N <= 1024, 16-byte rows; ln_out
      * must not alias C, A or residual. */
     const float* ln_gamma; const float* ln_beta; float* ln_out; int64_t ldo; float ln_eps; uint32_t* ln_counters;
+    /* ---- LayerNorm folded ACROSS kernel boundaries (ABI v5; all NULL = off).  In a post-LN encoder layer the LayerNorm output is only
+     * ever (i) the A operand of the next linear layer and (ii) a residual input, so it need not exist:
+     *   stat_out   [C rows][N / 64][2]  the producer writes, per stored output row and 64-column group, (mean, M2 = sum of squared
+     *              deviations from that mean).  Needs N % 64 == 0.  A fixed butterfly per group: independent of the tile shape.
+     *   a_stat     statistics of the (raw) A rows as written by their producer ([A rows][a_stat_groups][2], a_stat_groups = K / 64).
+     *              W must carry the LayerNorm weight (W[n][k] * gamma[k]), bias the term b[n] + sum_k W[n][k] beta[k], and
+     *              a_fold_g [N] = sum_k W[n][k] gamma[k]:  out = rstd * (acc - mean * a_fold_g[n]) + bias[n]  ( = W LN(a) + b ).
+     *   res_stat   statistics of the (raw) residual rows ([C rows][N / 64][2]): the residual added is LayerNorm(residual) with
+     *              res_gamma / res_beta [N].
+     * ln_eps2 = the LayerNorm epsilon.  Plain forward inputs only (no preact / dact / dropout / rowtab / act_post / scale); bf16-split
+     * kernels only (AFM_E_UNSUPPORTED when the arithmetic selects the native kernels). */
+    float* stat_out; const float* a_stat; int32_t a_stat_groups; const float* a_fold_g;
+    const float* res_stat; const float* res_gamma; const float* res_beta; float ln_eps2;
 } afm_linear_args;
 
 #define AFM_ARITH_DEFAULT 0
@@ -401,6 +414,11 @@ typedef struct {
     const float* lin2_w; const float* lin2_b;           /* [d,ff], [d]   linear2.*                */
     const float* norm1_w; const float* norm1_b;         /* [d]           norm1.*                  */
     const float* norm2_w; const float* norm2_b;         /* [d]           norm2.*                  */
+    /* ABI v5, all six or none (the host builds them in eval mode, float64 products rounded once): the layer's two LayerNorm-fed linears
+     * with the LayerNorm folded in (afm_linear_args.a_stat): W' = W * gamma (per input column), g = row sums of W', c = b + W beta.
+     * lin1_* folds norm1 of THIS layer; in_proj_* folds norm2 of the PREVIOUS layer (unused in layer 0, whose input is not normalised). */
+    const float* lin1_wg; const float* lin1_g; const float* lin1_c;             /* [ff,d], [ff], [ff]   */
+    const float* in_proj_wg; const float* in_proj_g; const float* in_proj_c;    /* [3d,d], [3d], [3d]   */
 } afm_encoder_layer_weights;
 
 #define AFM_MAX_LAYERS 16
@@ -422,9 +440,14 @@ typedef struct {
     /* ABI v5: 0, or the row length (a multiple of 4, >= motion_dim) motion_adapter_w is zero-padded to: [d, kpad].  The loop then keeps a
      * padded copy of x_t in its workspace so that the adapter (K = 263 for 'h3d') runs with K = 272 on the bf16-split GEMM. */
     int32_t motion_adapter_kpad;
+    /* ABI v5: motion_layer with the LAST layer's norm2 folded in (see afm_encoder_layer_weights.lin1_wg); NULL = not folded.  With all
+     * folded tensors present the step runs WITHOUT LayerNorm launches and without materialised LayerNorm outputs: out_proj / linear2
+     * write per-row statistics next to their raw outputs, the consumers apply them (afm_linear_args.stat_out / a_stat / res_stat). */
+    const float* motion_layer_wg; const float* motion_layer_g; const float* motion_layer_c;      /* [motion_dim,d], [motion_dim] x 2 */
 } afm_cmdm_weights;
 
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
+#define AFM_CMDM_NO_LN_FOLD  0x4           /* measurement: separate afm_layernorm launches although the folded tensors are present */
 #define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */
 
 /* bytes of workspace afm_cmdm_forward needs for (B, L). */

@@ -474,3 +474,40 @@ def test_fused_layernorm_loop_is_bit_identical_to_separate_launches():
         assert torch.isfinite(ref).all()
         for key, o in outs.items():
             assert torch.equal(o, ref), f"B={B}: fused={key[0]} streams={key[1]} differs by {(o - ref).abs().max().item():.3e}"
+
+
+def test_folded_layernorm_loop_tracks_the_separate_launches():
+    """Round 3: in eval mode norm1 / norm2 are folded across the kernel boundaries (no LayerNorm launches, statistics-carrying GEMM
+    epilogues; `model.no_ln_fold` restores the launches).  A re-association of the same arithmetic: a 100-step loop at the headline shape
+    stays within 1e-4 of the separate-launch loop on |x| <= ~4, and sub-batch streams / small batches stay bit-identical in the folded form."""
+    cfg = cmdm_cfg(num_points=8192, steps=1000, respacing="100")
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    B, L = 8, 196
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("lf_cont", (B, 128, 256)).to(dev()),
+              x_mask=synth.frame_mask(B, L, seed=6).to(dev()))
+    w = model._weights()
+    assert w.motion_layer_wg and w.layer[0].lin1_wg and w.layer[1].in_proj_wg and not w.layer[0].in_proj_wg
+    run = lambda **k: diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=dict(kw, **k), seed=44).clone()
+    folded = run()
+    try:
+        model.no_ln_fold = True
+        separate = run()
+    finally:
+        model.no_ln_fold = False
+    assert torch.isfinite(folded).all() and not torch.equal(folded, separate)
+    report("100-step loop: LayerNorm folded across launches vs separate launches", folded, separate.cpu(), 1e-4)
+    model.loop_streams, model.loop_streams_auto = 2, False
+    try:
+        assert torch.equal(run(), folded), "two sub-batch streams"
+    finally:
+        model.loop_streams, model.loop_streams_auto = 2, True
+    kw3 = {k: v[:3].contiguous() for k, v in kw.items()}
+    small = diff.p_sample_loop(model, (3, L, 263), clip_denoised=False, model_kwargs=kw3, seed=44)
+    assert torch.equal(small, folded[:3]), "a shard of 3 samples"
+    model.train()
+    try:
+        assert not model._weights().motion_layer_wg, "training mode keeps the plain weights (they change every step)"
+    finally:
+        model.eval()

@@ -110,6 +110,57 @@ def test_linear_fused_layernorm_is_bit_identical_to_two_launches(M, N, K):
     report(f"fused linear+LN {M}x{N}x{K}", ln_out, ref, 2e-4)
 
 
+@pytest.mark.parametrize("M,tile", [(10432, 0), (1304, 0), (777, 3), (5216, 5), (326, 7)])
+def test_linear_layernorm_folded_across_launches(M, tile):
+    """ABI v5 (afm_linear_args.stat_out / a_stat / res_stat): a post-LN encoder layer without LayerNorm launches.  The producer stores its
+    RAW output and per-row, per-64-column (mean, M2); the next linear runs on the raw rows with gamma folded into its weight and applies
+    (mean, rstd) in its epilogue; the residual add normalises the raw rows on the fly.  A re-association of LayerNorm -> Linear: against
+    float64 the error stays at the level of the separate-launch path."""
+    d, ff = 512, 1024
+    att = synth.gaussian("lnf_att", (M, d)); xin = synth.gaussian("lnf_x", (M, d)) * 2.0 + 0.7            # a residual stream with a non-zero mean
+    wo = synth.gaussian("lnf_wo", (d, d)) / math.sqrt(d); bo = synth.gaussian("lnf_bo", (d,)) * 0.1
+    g1 = synth.gaussian("lnf_g1", (d,)) * 0.2 + 1.0; b1 = synth.gaussian("lnf_b1", (d,)) * 0.1
+    w1 = synth.gaussian("lnf_w1", (ff, d)) / math.sqrt(d); c1 = synth.gaussian("lnf_c1", (ff,)) * 0.1
+    w2 = synth.gaussian("lnf_w2", (d, ff)) / math.sqrt(ff); c2 = synth.gaussian("lnf_c2", (d,)) * 0.1
+    D = lambda t: t.to(dev())
+    prev = ops.set_gemm_tune(tile << ffi.TUNE_TILE_SHIFT)
+    try:
+        # float64 reference of out_proj + residual -> LN1 -> linear1 (GELU) -> linear2 + LN1 output as residual
+        t1_ref = F.linear(att.double(), wo.double(), bo.double()) + xin.double()
+        x1_ref = F.layer_norm(t1_ref, (d,), g1.double(), b1.double(), 1e-5)
+        h_ref = F.gelu(F.linear(x1_ref, w1.double(), c1.double()))
+        t2_ref = F.linear(h_ref, w2.double(), c2.double()) + x1_ref
+        # separate-launch path
+        t1 = ops.linear(D(att), D(wo), D(bo), residual=D(xin))
+        x1 = ops.layernorm(t1, D(g1), D(b1), 1e-5)
+        h = ops.linear(x1, D(w1), D(c1), act=ffi.ACT_GELU)
+        t2 = ops.linear(h, D(w2), D(c2), residual=x1)
+        # folded path
+        st1 = torch.full((M, d // 64, 2), float("nan"), device=dev())
+        t1f = ops.linear(D(att), D(wo), D(bo), residual=D(xin), stat_out=st1)
+        assert torch.equal(t1f, t1)                                            # the raw output is the same GEMM
+        grp = t1.double().cpu().view(M, d // 64, 64)
+        assert (st1[..., 0].double().cpu() - grp.mean(-1)).abs().max().item() < 1e-5
+        assert ((st1[..., 1].double().cpu() - ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)).abs() / (grp.var(-1, unbiased=False) * 64 + 1e-9)).max().item() < 1e-5
+        w1g = (w1.double() * g1.double()[None, :])
+        hf = ops.linear(t1f, D(w1g.float()), D((c1.double() + w1.double() @ b1.double()).float()), act=ffi.ACT_GELU, a_stat=(st1, D(w1g.sum(1).float())))
+        st2 = torch.empty((M, d // 64, 2), device=dev())
+        t2f = ops.linear(hf, D(w2), D(c2), residual=t1f, res_stat=(st1, D(g1), D(b1)), stat_out=st2)
+    finally:
+        ops.set_gemm_tune(prev)
+    e_sep = (h.double().cpu() - h_ref).abs().max().item(), (t2.double().cpu() - t2_ref).abs().max().item()
+    e_fold = (hf.double().cpu() - h_ref).abs().max().item(), (t2f.double().cpu() - t2_ref).abs().max().item()
+    print(f"LN folded across launches M={M} tile={tile}: linear1 err {e_fold[0]:.2e} (separate {e_sep[0]:.2e}), linear2 err {e_fold[1]:.2e} (separate {e_sep[1]:.2e})")
+    assert e_fold[0] < max(4 * e_sep[0], 2e-5) and e_fold[1] < max(4 * e_sep[1], 4e-5)
+    with pytest.raises(ffi.AfmError):                                          # the native f32 kernels do not carry the statistics
+        saved = ops.get_gemm_split()
+        try:
+            ops.set_gemm_split(0, 0)
+            ops.linear(D(att), D(wo), D(bo), residual=D(xin), stat_out=st1)
+        finally:
+            ops.set_gemm_split(*saved)
+
+
 def test_linear_fused_layernorm_through_a_row_map():
     """The last encoder layer runs out_proj / FFN on the motion rows only: output rows (and their LayerNorm) are scattered by the c_* remap."""
     B, L, T, N, K = 5, 50, 83, 512, 512
