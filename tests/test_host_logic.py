@@ -219,10 +219,11 @@ def _build_hip_module():
 
 
 def test_isa_scan_flags_the_known_bad_kernel_form(tmp_path):
-    """Round 3: the build rejects the instruction shape of round 2's lat_decfold defect - a packed-f32 VALU op reading the
-    HIGH half of an SGPR pair that an `s_mov_b32 s, s` re-pack of scalar-loaded data wrote next to it (profiles/r02_decfold_nondeterminism.md).
-    The failing kernel form is kept as tools/probes/decfold_scalar_form.hip: compiled for gfx950 here (no GPU needed) it must be flagged,
-    and every object of the shipped library must be clean."""
+    """Round 3: packed-f32 VALU instructions are fenced - two kernels lost values in lanes 48..63 inside them whenever a
+    second stream was active (round 2's lat_decfold, round 3's statistics-carrying GEMM epilogue; profiles/r03_packed_f32_defect.md).  The
+    library is compiled with the `packed-fp32-ops` target feature off, and the build scans every code object: ANY v_pk_mul / v_pk_fma /
+    v_pk_add _f32 rejects it.  Round 2's failing kernel form (tools/probes/decfold_scalar_form.hip), compiled for gfx950 here WITH the
+    feature (no GPU needed), must be flagged - with the narrower round-2 shape recognised -, every object of the library must be clean."""
     import glob
     import shutil
     import subprocess
@@ -231,7 +232,9 @@ def test_isa_scan_flags_the_known_bad_kernel_form(tmp_path):
     bad = "0000000000001000 <k>:\n\ts_mov_b32 s31, s40   // 0\n\tv_pk_mul_f32 v[36:37], v[30:31], s[30:31] op_sel:[1,0] op_sel_hi:[0,1] // 1\n"
     lit = "0000000000001000 <k>:\n\ts_mov_b32 s35, 0.5   // 0\n\tv_pk_mul_f32 v[24:25], v[24:25], s[34:35] // 1\n"
     low = "0000000000001000 <k>:\n\ts_mov_b32 s13, s40   // 0\n\tv_pk_fma_f32 v[0:1], s[12:13], v[2:3], v[0:1] op_sel_hi:[0,1,1] // 1\n"
-    assert len(bh.scan_disassembly(bad)) == 1 and bh.scan_disassembly(lit) == [] and bh.scan_disassembly(low) == []
+    assert len(bh.scan_disassembly(bad)) == 1 and "lat_decfold" in bh.scan_disassembly(bad)[0][2]
+    assert len(bh.scan_disassembly(lit)) == 1 and "lat_decfold" not in bh.scan_disassembly(lit)[0][2] and len(bh.scan_disassembly(low)) == 1
+    assert bh.scan_disassembly("0000000000001000 <k>:\n\tv_fma_f32 v0, v0, v2, s2 // 0\n\tv_pk_add_u16 v0, v1, v2 // 1\n") == []
     if shutil.which("hipcc") is None or not os.path.exists(bh.OBJDUMP):
         pytest.skip("hipcc / llvm-objdump not available")
     obj = str(tmp_path / "decfold_bad.o")
@@ -239,7 +242,11 @@ def test_isa_scan_flags_the_known_bad_kernel_form(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     hits = bh.scan_object(obj)
-    assert hits and all(h[0] == "decfold_scalar_form" for h in hits), hits[:3]
+    assert hits and all(h[0] == "decfold_scalar_form" for h in hits) and any("lat_decfold" in h[2] for h in hits), hits[:3]
+    clean = str(tmp_path / "decfold_nopk.o")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + bh.NO_PACKED_F32 + ["-c", os.path.join(ROOT, "tools", "probes", "decfold_scalar_form.hip"), "-o", clean],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and bh.scan_object(clean) == [], "the build flag removes every packed-f32 instruction"
     objs = glob.glob(os.path.join(ROOT, "afford-motion_amd", "build", "*.o"))
     if not objs:
         pytest.skip("library objects not built")

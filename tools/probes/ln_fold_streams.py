@@ -1,0 +1,58 @@
+"""Does the statistics-carrying GEMM epilogue misbehave when two streams run it concurrently?  Each stream runs the encoder-layer tail
+(out_proj + stats -> linear1 with folded norm1 -> linear2 + LayerNorm(raw) residual + stats) on its own buffers; results are compared with
+the same chain run alone."""
+import math, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "afford-motion_amd")):
+    sys.path.insert(0, p)
+from afm import ffi, ops, synth
+dev = torch.device("cuda:0")
+M, d, ff = 5216, 512, 1024
+g = torch.Generator().manual_seed(1)
+R = lambda *s: torch.randn(*s, generator=g)
+wo, bo = (R(d, d) / math.sqrt(d)).to(dev), (R(d) * 0.1).to(dev)
+g1, b1 = (R(d) * 0.2 + 1).to(dev), (R(d) * 0.1).to(dev)
+w1, c1 = R(ff, d) / math.sqrt(d), R(ff) * 0.1
+w2, c2 = (R(d, ff) / math.sqrt(ff)).to(dev), (R(d) * 0.1).to(dev)
+w1g = (w1.double() * g1.double().cpu()[None, :])
+w1gf, gsum, c1f = w1g.float().to(dev), w1g.sum(1).float().to(dev), (c1.double() + w1.double() @ b1.double().cpu()).float().to(dev)
+
+win = R(3 * d, d) / math.sqrt(d)
+wing = (win.double() * g1.double().cpu()[None, :])
+wingf, ginsum, cinf = wing.float().to(dev), wing.sum(1).float().to(dev), (R(3 * d).double() * 0.1 + win.double() @ b1.double().cpu()).float().to(dev)
+
+def chain(att, xin, bufs):
+    st1, st2, t1, h, t2, qkv = bufs
+    ops.linear(att, wo, bo, residual=xin, stat_out=st1, out=t1)
+    ops.linear(t1, w1gf, c1f, act=ffi.ACT_GELU, a_stat=(st1, gsum), out=h)
+    ops.linear(h, w2, c2, residual=t1, res_stat=(st1, g1, b1), stat_out=st2, out=t2)
+    ops.linear(t2, wingf, cinf, a_stat=(st2, ginsum), out=qkv)                 # next layer's in_proj (128x128 tiles) on the raw rows
+
+def mk():
+    return (torch.empty(M, d // 64, 2, device=dev), torch.empty(M, d // 64, 2, device=dev), torch.empty(M, d, device=dev), torch.empty(M, ff, device=dev), torch.empty(M, d, device=dev), torch.empty(M, 3 * d, device=dev))
+inp = [(R(M, d).to(dev), (R(M, d) * 2 + 0.7).to(dev)) for _ in range(2)]
+ref = []
+for att, xin in inp:
+    b = mk(); chain(att, xin, b); torch.cuda.synchronize(); ref.append([t.clone() for t in b])
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+bad = {}
+for it in range(40):
+    bufs = [mk(), mk()]
+    for b in bufs:
+        for t in b: t.fill_(float("nan"))
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for s, (att, xin), b in zip(streams, inp, bufs):
+            with torch.cuda.stream(s):
+                chain(att, xin, b)
+    torch.cuda.synchronize()
+    for si in range(2):
+        for name, got, want in zip(("stat1", "stat2", "t1", "h", "t2", "qkv"), bufs[si], ref[si]):
+            if not torch.equal(got, want):
+                nbad = int((got != want).sum())
+                bad.setdefault(name, []).append((it, si, nbad, f"{(got - want).abs().max().item():.2e}"))
+                if name in ("t2", "stat2") and len(bad[name]) <= 2:
+                    nz = (got != want).view(M, -1)
+                    rows = nz.any(1).nonzero().flatten().tolist(); cols = nz.any(0).nonzero().flatten().tolist()
+                    print(name, "rows", rows[:4], "...", rows[-4:], len(rows), "cols", cols[:3], "...", cols[-3:], len(cols), "isnan", int(torch.isnan(got).sum()), flush=True)
+print("mismatches:", {k: (len(v), v[:3]) for k, v in bad.items()} or "none", flush=True)
