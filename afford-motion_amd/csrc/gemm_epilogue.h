@@ -33,24 +33,26 @@ __device__ __forceinline__ void row_stat_combine(const float* __restrict__ st, i
     rstd = 1.0f / sqrtf(m2 / (64.0f * (float)groups) + eps);
 }
 
-// (mean, rstd) of the tile's A rows -> rowst[row], of its residual rows -> rowst[BM + row]; EVERY thread of the workgroup calls this
-// (it ends in a barrier when the launch uses the folded LayerNorm).  rowst: 2 * BM float2 of LDS behind the staged accumulators.
+// (mean, rstd) of the tile's A rows (thread r < BM -> rowst[r]) and of its residual rows (thread BM + r -> rowst[BM + r]), computed in
+// the kernel's PROLOGUE into an LDS region of their own (2 * BM float2 behind the operand stages): the 16 loads of a row's group
+// statistics fly with the first operand loads and the kernel's first barrier publishes them.  (As a separate phase in front of the
+// epilogue they cost every tile a dependent memory round trip - GEMM time at B = 4: 0.49 -> 0.54 ms per step; parked in registers
+// across the K loop they spilled the 128 x 128 kernel.)
 template <int BM>
 __device__ __forceinline__ void gemm_rowstats(const afm_linear_args& p, float* rowst, int bm) {
     if (!p.a_stat && !p.res_stat) return;                               // uniform
+    const int r = threadIdx.x;
+    if (r >= 2 * BM) return;
     const RowMap amap{p.a_grp, p.a_stride, p.a_off}, cmap{p.c_grp, p.c_stride, p.c_off};
-    for (int r = threadIdx.x; r < 2 * BM; r += blockDim.x) {
-        const bool is_res = r >= BM;
-        const int grow = bm * BM + (is_res ? r - BM : r);
-        const float* st = is_res ? p.res_stat : p.a_stat;
-        float mean = 0.f, rstd = 0.f;
-        if (st && grow < p.M) {
-            const int groups = is_res ? p.N / 64 : p.a_stat_groups;
-            row_stat_combine(st + (is_res ? cmap(grow) : amap(grow)) * (2 * groups), groups, p.ln_eps2, mean, rstd);
-        }
-        rowst[2 * r] = mean; rowst[2 * r + 1] = rstd;
+    const bool is_res = r >= BM;
+    const int grow = bm * BM + (is_res ? r - BM : r);
+    const float* st = is_res ? p.res_stat : p.a_stat;
+    float mean = 0.f, rstd = 0.f;
+    if (st && grow < p.M) {
+        const int groups = is_res ? p.N / 64 : p.a_stat_groups;
+        row_stat_combine(st + (is_res ? cmap(grow) : amap(grow)) * (2 * groups), groups, p.ln_eps2, mean, rstd);
     }
-    __syncthreads();
+    rowst[2 * r] = mean; rowst[2 * r + 1] = rstd;
 }
 
 // epilogue math for one output element (compact: instantiated once, looped over, never unrolled 64x)

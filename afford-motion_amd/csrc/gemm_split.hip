@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     using Set1 = std::integral_constant<int, 1>;
     load(Set0{}, 0);
     load(Set1{}, 1);
+    float* rowst = reinterpret_cast<float*>(lds_raw + KG * 2 * STAGE);      // folded LayerNorm: row statistics, an LDS region of their own
+    gemm_rowstats<BM>(p, rowst, bm);                  // (loads in flight with the operands'; published by the barrier below)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t a1, a2, a3, b1, b2, b3;
@@ -232,8 +234,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
                     ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
     }
     __syncthreads();
-    float* rowst = ldsf + BM * LDC;                   // 2 * BM (mean, rstd) pairs behind the staged accumulators (folded LayerNorm)
-    gemm_rowstats<BM>(p, rowst, bm);
     if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid, rowst);
     gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(ldsf));
 #ifdef AFM_TIMELINE
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
 template <int BM, int BN, int BKS, int NPROD, int KG = 1>
 int launch_split(const afm_linear_args& a, hipStream_t s) {
     constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
-    constexpr int EPI_BYTES = BM * (BN + 4) * 4 + 2 * BM * 2 * 4;          // staged accumulators + row statistics of the folded LayerNorm
-    constexpr int LDS_BYTES = KG * 2 * STAGE > EPI_BYTES ? KG * 2 * STAGE : EPI_BYTES;
+    static_assert(KG * 2 * STAGE >= BM * (BN + 4) * 4, "the staged accumulators fit the operand stages");
+    constexpr int LDS_BYTES = KG * 2 * STAGE + 2 * BM * 2 * 4;             // operand stages (reused for the staged accumulators) + row statistics of the folded LayerNorm
     static const int attr = []() {
         return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }();

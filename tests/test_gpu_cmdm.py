@@ -466,10 +466,10 @@ def test_fused_layernorm_loop_is_bit_identical_to_separate_launches():
         outs = {}
         for fused in (True, False):
             for streams in (1, 2):
-                model.fused_layernorm = fused
+                model.fused_layernorm, model.no_ln_fold = fused, not fused       # reference: separate LayerNorm launches
                 model.loop_streams, model.loop_streams_auto = streams, False
                 outs[(fused, streams)] = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=33).clone()
-        model.fused_layernorm = False
+        model.fused_layernorm = model.no_ln_fold = False
         ref = outs[(False, 1)]
         assert torch.isfinite(ref).all()
         for key, o in outs.items():
