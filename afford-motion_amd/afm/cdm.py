@@ -293,6 +293,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.sub_batches = 1                    # per-call sub-batches of forward(): >1 costs more host time per step than it hides (measured)
         self._streams = []
         self.no_fold = False            # measurement: the layer-by-layer sampling form (what training-mode forward also runs)
+        self.gemm_tile = 0              # measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral)
         self.no_gen = False             # measurement: round 2's folded form (step-invariant adapter parts materialised) instead of generated rows
 
     # ------------------------------------------------------------------ weight pack
@@ -301,7 +302,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
-            w.flags = ffi.CDM_NO_GEN if self.no_gen else 0
+            w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -375,7 +376,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
-        w.flags = ffi.CDM_NO_GEN if self.no_gen else 0
+        w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):

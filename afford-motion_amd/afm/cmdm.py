@@ -198,6 +198,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.loop_streams = 2
         self.loop_streams_auto = True
         self._side_streams: List[torch.cuda.Stream] = []
+        self.gemm_tile = 0  # measurement: AFM_TUNE_TILE code forced on the wide encoder GEMMs (0 = library heuristic; bit-neutral)
         self.attn_group_waves = 0  # afm_mha_fwd_grouped workgroup shape (0 = library heuristic; results do not depend on it)
         self.no_l0_cache = False   # measurement: recompute layer 0's q | k | v rows of the condition tokens every step (passed in the pack)
         self.no_ln_fold = False            # measurement: separate LayerNorm launches instead of the statistics-carrying epilogues (afm_linear_args.a_stat ...)
@@ -264,7 +265,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
         w.attn_group_waves = int(self.attn_group_waves)
         w.flags = (ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0) | (ffi.CMDM_FUSED_LN if self.fused_layernorm else 0) | \
-            (ffi.CMDM_NO_LN_FOLD if self.no_ln_fold else 0)
+            (ffi.CMDM_NO_LN_FOLD if self.no_ln_fold else 0) | ((int(self.gemm_tile) & 0xF) << 8)
         return w
 
     def _workspace(self, w: ffi.CmdmWeights, B: int, L: int, device) -> torch.Tensor:

@@ -107,6 +107,8 @@ __global__ void expand_schedule_kernel(const int64_t* __restrict__ tmap, const f
 // every nn.Linear of the denoiser runs with the arithmetic the caller put into the weight pack (ABI v3: no process-wide switch)
 inline int run_linear(const afm_cmdm_weights& w, afm_linear_args& a, hipStream_t s) {
     a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    const int tile = (w.flags >> AFM_CMDM_WIDE_TILE_SHIFT) & 0xF;          // measurement knob (tile shapes of one arithmetic are bit-identical)
+    if (tile && a.N >= 512 && a.M >= 2048) a.tune = tile << AFM_TUNE_TILE_SHIFT;
     return afm_linear(&a, s);
 }
 

@@ -288,7 +288,10 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     // products of an output element in the same order (bit-identical), so M may enter the choice.
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const int64_t resident = 512, rounds = (tiles128 + resident - 1) / resident;
-    const bool full_rounds = tiles128 * 10 >= rounds * resident * 9;              // >= 90 % of the resident slots used over all rounds
+    // K <= 256 (one K segment, 16 K-tiles: the CDM's linear1, M = 262144, N = K = 256): the 128x128 workgroup's prologue / epilogue at two waves
+    // per SIMD weigh twice as much as at K = 512 and the 64x64 kernel (four waves per SIMD) wins, 0.367 vs 0.384 ms (configs[2]: 1323 vs 1284
+    // steps/s in one call).  Round 3 also measured 128x64 / 64x128 tiles in the CMDM loop: 431 / 437 steps/s against 449 for this rule.
+    const bool full_rounds = tiles128 * 10 >= rounds * resident * 9 && a.K > KSEG;      // >= 90 % of the resident slots used over all rounds
     if (tile == 3 || (tile != 5 && !full_rounds)) return launch_split<64, 64, 16, NPROD>(a, s);
     return launch_split<128, 128, 16, NPROD>(a, s);
 }

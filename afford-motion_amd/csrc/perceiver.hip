@@ -1018,6 +1018,7 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;
     a.rowdot_w = w.fold_w2; a.rowdot_out = ws.rdot; a.rowdot_n = cd;
     a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
+    a.tune = ((w.flags >> AFM_CDM_TILE_SHIFT) & 0xF) << AFM_TUNE_TILE_SHIFT;
     AFM_TRY(afm_linear(&a, s));
     {
         AfmProf prof(AFM_PROF_CDM, 0.0, s);

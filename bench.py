@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="sub-batch HIP streams of the native loop (default: model default)")
     ap.add_argument("--no-ln-fold", action="store_true", help="measurement: separate LayerNorm launches instead of the statistics-carrying GEMM epilogues")
     ap.add_argument("--fused-ln", action="store_true", help="measurement: norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; slower, profiles/r03_ln_fusion.md)")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="measurement: AFM_TUNE_TILE code forced on the wide encoder GEMMs (5 = 128x128; bit-neutral)")
     ap.add_argument("--attn-group", type=int, default=None, help="waves per attention workgroup (bit-neutral tuning; default: library choice)")
     args = ap.parse_args()
 
@@ -173,6 +174,7 @@ def main():
     model, diff_k, cfg = build(dev, str(K))
     if args.streams is not None:
         model.loop_streams, model.loop_streams_auto = args.streams, False
+    model.gemm_tile = args.gemm_tile
     if args.attn_group is not None:
         model.attn_group_waves = args.attn_group
     model.fused_layernorm = bool(args.fused_ln)

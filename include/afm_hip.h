@@ -448,6 +448,7 @@ typedef struct {
 
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
 #define AFM_CMDM_NO_LN_FOLD  0x4           /* measurement: separate afm_layernorm launches although the folded tensors are present */
+#define AFM_CMDM_WIDE_TILE_SHIFT 8        /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the encoder GEMMs with N >= 512 and M >= 2048 (bit-neutral) */
 #define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */
 
 /* bytes of workspace afm_cmdm_forward needs for (B, L). */
@@ -570,6 +571,7 @@ typedef struct {
     const float* gen_enc; const float* gen_dec; const float* gen_qe;
 } afm_cdm_weights;
 
+#define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
 #define AFM_CDM_NO_GEN         0x2     /* measurement: rows of the per-point kernels from the materialised step-invariant tensors (round 2's folded form) */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
