@@ -35,6 +35,13 @@ namespace {
 // the same order, so a shard computed by the split form is bit-identical to the full batch computed by the sequential form.
 constexpr int KSEG = 256;
 
+// Energy attribution builds (tools/gpu_r3n.sh only, never the library): -DAFM_ABLATE=<bits> removes one ingredient of the K loop at a time -
+// wrong results, same control flow - so that time, clock and board power can be read per ingredient (profiles/r03_power_limit.md).
+//   1 no global loads after the first two K-tiles, 2 no split arithmetic, 4 no LDS stores, 8 operand ds_reads only for the first K-tile, 16 no MFMAs
+#ifndef AFM_ABLATE
+#define AFM_ABLATE 0
+#endif
+
 template <int BM, int BN, int BKS, int NPROD, int KG = 1>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
     static_assert(BKS == 16, "one K16 MFMA step per K-tile");
@@ -100,6 +107,11 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     auto load = [&](auto SETC, int kt) {
         constexpr int S = decltype(SETC)::value;
         const int k = min(kt, nk - 1) * BKS;          // past the end: re-load the last tile (never consumed)
+        if ((AFM_ABLATE & 1) && kt >= 2) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(g[S][i]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) g[S][i] = *reinterpret_cast<const f32x4*>(src[i] + k);
     };
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     // One K-tile.  The instruction order is written out and pinned with sched_barrier fences (hipcc otherwise hoists all
     // MFMAs in front of the split and chains the nine MFMAs of one accumulator back to back): after every MFMA a piece of
     // the next tile's split (~5 VALU) issues in the shadow of the 32-cycle matrix op.
+    uint4 af[TM][3], bf[TN][3];
     auto body = [&](auto CURC, int kt) {          // K-tile kt with kt & 1 == cur: register set cur is free, set cur ^ 1 holds tile kt + 1
         constexpr int cur = decltype(CURC)::value;
         load(CURC, kt + 2);
@@ -143,18 +156,25 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
                 r0[u] = g[cur ^ 1][i][2 * c];
                 r1[u] = g[cur ^ 1][i][2 * c + 1];
             }
-            const uint32_t pk = cvt_pk_bf16(r0[u], r1[u]);
+            const uint32_t pk = (AFM_ABLATE & 2) ? __float_as_uint(lvl == 1 ? r1[u] : r0[u]) : cvt_pk_bf16(r0[u], r1[u]);
             sp[u][lvl] = pk;
             if (lvl < 2) {
-                r0[u] -= __uint_as_float(pk << 16);
-                r1[u] -= __uint_as_float(pk & 0xffff0000u);
+                if (!(AFM_ABLATE & 2)) {
+                    r0[u] -= __uint_as_float(pk << 16);
+                    r1[u] -= __uint_as_float(pk & 0xffff0000u);
+                }
             } else if (c == 1) {
                 unsigned char* d = wbase + dst[i];
+                if (AFM_ABLATE & 4) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * PLANE) = u32x2{sp[2 * i][pl], sp[2 * i + 1][pl]};
+                    for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(sp[2 * i][pl]), "v"(sp[2 * i + 1][pl]), "v"(d));
+                } else {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * PLANE) = u32x2{sp[2 * i][pl], sp[2 * i + 1][pl]};
+                }
             }
         };
-        uint4 af[TM][3], bf[TN][3];
+        if (!(AFM_ABLATE & 8) || kt == 0)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -169,7 +189,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = mfma_bf16(af[tm][AFM_PA[q]], bf[tn][AFM_PB[q]], acc[tm][tn]);
+                    if (AFM_ABLATE & 16) asm volatile("" : "+v"(acc[tm][tn][q]) : "v"(af[tm][AFM_PA[q]].x), "v"(af[tm][AFM_PA[q]].w), "v"(bf[tn][AFM_PB[q]].x), "v"(bf[tn][AFM_PB[q]].w));
+                    else acc[tm][tn] = mfma_bf16(af[tm][AFM_PA[q]], bf[tn][AFM_PB[q]], acc[tm][tn]);
                     ++m;
 #pragma unroll
                     for (int t = 0; t < NPIECE; ++t)
