@@ -22,7 +22,6 @@ TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD = 0x1, 0x2, 0x4
 CDM_NO_GEN = 0x2
 ABI_VERSION = 5
-STAT_GROUP = 32                  # AFM_STAT_GROUP: columns per (mean, M2) record of the folded LayerNorm
 MAX_LAYERS = 16
 
 c_f32p = C.c_void_p

@@ -35,7 +35,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     ``ln`` = (gamma, beta, eps) + ``ln_out`` (same row layout as the output): the fused LayerNorm of the output rows (afm_linear_args.ln_*,
     the workgroup finishing the last column tile of a row block normalises it); ``ln_counters`` = zeroed int32 scratch of >= ceil(M / 32)
     words (allocated here when omitted).  Returns the (pre-LayerNorm) output; the normalised rows are in ``ln_out``.
-    LayerNorm folded ACROSS launches (afm_linear_args.stat_out / a_stat / res_stat): ``stat_out`` [rows, N / 32, 2] receives (mean, M2) per
+    LayerNorm folded ACROSS launches (afm_linear_args.stat_out / a_stat / res_stat): ``stat_out`` [rows, N / 64, 2] receives (mean, M2) per
     output row and 64-column group; ``a_stat`` = (statistics of the raw input rows, g [N]) with ``weight`` = W * gamma and ``bias`` =
     b + W beta makes this call compute W LN(x) + b from the RAW x; ``res_stat`` = (statistics, gamma, beta) adds LayerNorm(residual)."""
     lib = ffi.load()
@@ -91,15 +91,15 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         keep += [g, b, ln_out, ln_counters]
         a.ln_gamma, a.ln_beta, a.ln_out, a.ldo, a.ln_eps, a.ln_counters = g.data_ptr(), b.data_ptr(), ln_out.data_ptr(), N, float(eps), ln_counters.data_ptr()
     if stat_out is not None:
-        assert stat_out.dtype == torch.float32 and stat_out.is_contiguous() and stat_out.numel() >= out.numel() // N * (N // ffi.STAT_GROUP) * 2 and N % ffi.STAT_GROUP == 0
+        assert stat_out.dtype == torch.float32 and stat_out.is_contiguous() and stat_out.numel() >= out.numel() // N * (N // 64) * 2 and N % 64 == 0
         keep.append(stat_out)
         a.stat_out = stat_out.data_ptr()
     if a_stat is not None:
         st, g = a_stat
         st, g = ffi.f32c(st), ffi.f32c(g)
-        assert g.numel() == N and K % ffi.STAT_GROUP == 0
+        assert g.numel() == N and K % 64 == 0
         keep += [st, g]
-        a.a_stat, a.a_stat_groups, a.a_fold_g = st.data_ptr(), K // ffi.STAT_GROUP, g.data_ptr()
+        a.a_stat, a.a_stat_groups, a.a_fold_g = st.data_ptr(), K // 64, g.data_ptr()
     if res_stat is not None:
         st, g, b = res_stat
         st, g, b = ffi.f32c(st), ffi.f32c(g), ffi.f32c(b)

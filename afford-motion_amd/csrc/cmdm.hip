@@ -47,7 +47,7 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
     ws.keymask = (uint8_t*)take(M);
     ws.lncnt = (uint32_t*)take(((M + 31) / 32) * 4);
-    ws.stat1 = (float*)take(M * (d / AFM_STAT_GROUP + 1) * 2 * 4); ws.stat2 = (float*)take(M * (d / AFM_STAT_GROUP + 1) * 2 * 4);
+    ws.stat1 = (float*)take(M * (d / 64 + 1) * 2 * 4); ws.stat2 = (float*)take(M * (d / 64 + 1) * 2 * 4);
     ws.xpad = w.motion_adapter_kpad > 0 ? (float*)take((int64_t)B * L * w.motion_adapter_kpad * 4) : nullptr;      // x_t with rows padded to the GEMM's K
     ws.bytes = off;
     return ws;
@@ -139,11 +139,11 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
     // sums plus (mean, M2) per row and 64-column group, linear1 / the next in_proj / motion_layer run on the raw rows with gamma folded
     // into their weights and apply (mean, rstd) in the epilogue, the residual adds normalise their (raw) input on the fly
     // (afm_linear_args.stat_out / a_stat / res_stat).  10 launches and ~170 MB of traffic less per step at B = 32.
-    bool fold = !(w.flags & (AFM_CMDM_NO_LN_FOLD | AFM_CMDM_FUSED_LN)) && w.motion_layer_wg && w.motion_layer_g && w.motion_layer_c && (d % AFM_STAT_GROUP) == 0 &&
+    bool fold = !(w.flags & (AFM_CMDM_NO_LN_FOLD | AFM_CMDM_FUSED_LN)) && w.motion_layer_wg && w.motion_layer_g && w.motion_layer_c && (d % 64) == 0 &&
                 w.gemm_arith != AFM_ARITH_F32 && (w.gemm_arith == AFM_ARITH_DEFAULT || w.gemm_arith_min_n <= 32);
     for (int li = 0; li < w.n_layers && fold; ++li)
         fold = w.layer[li].lin1_wg && w.layer[li].lin1_g && w.layer[li].lin1_c && (li == 0 || (w.layer[li].in_proj_wg && w.layer[li].in_proj_g && w.layer[li].in_proj_c));
-    const int sg = d / AFM_STAT_GROUP;                            // statistic groups per row
+    const int sg = d / 64;                            // statistic groups per row
     const float* X = ws.seq0;
     for (int li = 0; li < w.n_layers; ++li) {
         const afm_encoder_layer_weights& lw = w.layer[li];

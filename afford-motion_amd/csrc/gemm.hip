@@ -419,7 +419,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     }
     const bool lnfold = a.stat_out || a.a_stat || a.res_stat;
     if (lnfold) {                                 // LayerNorm folded across kernel boundaries (ABI v5)
-        if ((a.stat_out && (a.N % AFM_STAT_GROUP)) || (a.a_stat && (!a.a_fold_g || a.a_stat_groups <= 0)) || (a.res_stat && (!a.residual || !a.res_gamma || !a.res_beta || (a.N % AFM_STAT_GROUP))) ||
+        if ((a.stat_out && (a.N % 64)) || (a.a_stat && (!a.a_fold_g || a.a_stat_groups <= 0)) || (a.res_stat && (!a.residual || !a.res_gamma || !a.res_beta || (a.N % 64))) ||
             !(a.ln_eps2 > 0.0f) || a.scale || a.rowtab || a.preact || a.dact_z || a.drop_p > 0.0f || a.act_post || a.rowdot_w || a.ln_out)
             return AFM_E_BADARG;
         if (a.stat_out && (!a.C || (a.N & 3) || (a.ldc & 3) || (a.ldr & 3) || a.ddpm_out)) return AFM_E_BADARG;

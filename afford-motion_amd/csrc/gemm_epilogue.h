@@ -22,25 +22,15 @@ __device__ __forceinline__ void store_f4_sc1(float* ptr, const float4& v) {
 }
 
 // ---- LayerNorm folded across kernel boundaries (afm_linear_args.stat_out / a_stat / res_stat, ABI v5).  A producer writes, per output
-// row and group of AFM_STAT_GROUP = 32 columns, (mean, M2 = sum of squared deviations from that mean) of what it stores; consumers combine
-// the groups of a row in index order (Chan's parallel-variance formula): mean = avg(mean_t), M2 = sum_t M2_t + 32 sum_t (mean_t - mean)^2.
-// Two kernels produce and consume these records (the LDS-staged tiles here, one column quad per lane; gemm_slab.hip, one column per lane):
-// the group reduction is the SAME tree in both - columns c ^ 1, ^ 2 (in-lane here), then ^ 4, ^ 8, ^ 16 across lanes, squares rounded before
-// they are added - and the per-element formulas below are written with explicit fma / rounding so that both compile to the same arithmetic.
-constexpr float STAT_GROUP_F = (float)AFM_STAT_GROUP;
-__device__ __forceinline__ float ep_sq(float d) {               // d * d, rounded: never fused into the addition that follows (HIP's __fmul_rn is a plain `*`)
-#pragma clang fp contract(off)
-    return d * d;
-}
-__device__ __forceinline__ float ep_fold_a(float v, float mu, float rs, float g) { return rs * __builtin_fmaf(-mu, g, v); }          // LayerNorm of the A rows, folded
-__device__ __forceinline__ float ep_norm_res(float t, float mu, float rs, float g, float b) { return __builtin_fmaf((t - mu) * rs, g, b); }      // LayerNorm(raw residual)
+// row and 64-column group, (mean, M2 = sum of squared deviations from that mean) of what it stores; consumers combine the groups of a row
+// in index order (Chan's parallel-variance formula): mean = avg(mean_t), M2 = sum_t M2_t + 64 sum_t (mean_t - mean)^2.
 __device__ __forceinline__ void row_stat_combine(const float* __restrict__ st, int groups, float eps, float& mean, float& rstd) {
     float ms = 0.f;
     for (int t = 0; t < groups; ++t) ms += st[2 * t];
     mean = ms / (float)groups;
     float m2 = 0.f;
-    for (int t = 0; t < groups; ++t) { const float d = st[2 * t] - mean; m2 += st[2 * t + 1] + STAT_GROUP_F * (d * d); }
-    rstd = 1.0f / sqrtf(m2 / (STAT_GROUP_F * (float)groups) + eps);
+    for (int t = 0; t < groups; ++t) { const float d = st[2 * t] - mean; m2 += st[2 * t + 1] + 64.0f * (d * d); }
+    rstd = 1.0f / sqrtf(m2 / (64.0f * (float)groups) + eps);
 }
 
 // (mean, rstd) of the tile's A rows (thread r < BM -> rowst[r]) and of its residual rows (thread BM + r -> rowst[BM + r]), computed in
@@ -59,7 +49,7 @@ __device__ __forceinline__ void gemm_rowstats(const afm_linear_args& p, float* r
     const float* st = is_res ? p.res_stat : p.a_stat;
     float mean = 0.f, rstd = 0.f;
     if (st && grow < p.M) {
-        const int groups = is_res ? p.N / AFM_STAT_GROUP : p.a_stat_groups;
+        const int groups = is_res ? p.N / 64 : p.a_stat_groups;
         row_stat_combine(st + (is_res ? cmap(grow) : amap(grow)) * (2 * groups), groups, p.ln_eps2, mean, rstd);
     }
     rowst[2 * r] = mean; rowst[2 * r + 1] = rstd;
@@ -67,7 +57,7 @@ __device__ __forceinline__ void gemm_rowstats(const afm_linear_args& p, float* r
 
 // epilogue math for one output element (compact: instantiated once, looped over, never unrolled 64x)
 __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int grow, int64_t orow, int gcol, const float* rowst = nullptr, int row = 0, int BM = 0) {
-    if (p.a_stat) v = ep_fold_a(v, rowst[2 * row], rowst[2 * row + 1], p.a_fold_g[gcol]);       // LayerNorm of the A rows, folded: W carries gamma, bias carries W beta
+    if (p.a_stat) v = rowst[2 * row + 1] * (v - rowst[2 * row] * p.a_fold_g[gcol]);       // LayerNorm of the A rows, folded: W carries gamma, bias carries W beta
     if (p.scale) v *= p.scale[gcol];
     if (p.bias) v += p.bias[gcol];
     if (p.preact) p.preact[orow * p.ldp + gcol] = v;
@@ -76,7 +66,7 @@ __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int
     if (p.dact) v *= act_grad(p.dact_z[orow * p.ldz + gcol], p.dact);
     if (p.residual) {
         float rv = p.residual[orow * p.ldr + gcol];
-        if (p.res_stat) rv = ep_norm_res(rv, rowst[2 * (BM + row)], rowst[2 * (BM + row) + 1], p.res_gamma[gcol], p.res_beta[gcol]);      // the residual rows are raw: LayerNorm on the fly
+        if (p.res_stat) rv = (rv - rowst[2 * (BM + row)]) * rowst[2 * (BM + row) + 1] * p.res_gamma[gcol] + p.res_beta[gcol];      // the residual rows are raw: LayerNorm on the fly
         v += rv;
     }
     if (p.rowtab) v += p.rowtab[(int64_t)(grow % p.rowtab_period) * p.N + gcol];
@@ -134,10 +124,10 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             }
         }
     } else if (vec_out && (p.stat_out || p.a_stat || p.res_stat)) {
-        // folded-LayerNorm form (plain forward inputs only): every lane stays in the loop so that the group statistics are full 8-lane
-        // butterflies (a 32-column group of a row = 8 consecutive lanes x 4 columns; N % 32 == 0)
+        // folded-LayerNorm form (plain forward inputs only): every lane stays in the loop so that the group statistics are full 16-lane
+        // butterflies (a 64-column group of a row = 16 consecutive lanes x 4 columns; N % 64 == 0)
         static_assert((BM * (BN / 4)) % NT == 0, "folded-LayerNorm epilogue: every lane makes the same number of trips");
-        const int ngrp = p.N / AFM_STAT_GROUP;
+        const int ngrp = p.N / 64;
         for (int e = tid; (BN / 4) % 16 == 0 && e < BM * (BN / 4); e += NT) {
             const int row = e / (BN / 4), cq = (e % (BN / 4)) * 4;
             const int grow = bm * BM + row, gcol = col0 + cq;
@@ -150,7 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
                 if (p.a_stat) {
                     const float mu = rowst[2 * row], rs = rowst[2 * row + 1];
                     const float4 g = *reinterpret_cast<const float4*>(p.a_fold_g + gcol);
-                    v.x = ep_fold_a(v.x, mu, rs, g.x); v.y = ep_fold_a(v.y, mu, rs, g.y); v.z = ep_fold_a(v.z, mu, rs, g.z); v.w = ep_fold_a(v.w, mu, rs, g.w);
+                    v.x = rs * (v.x - mu * g.x); v.y = rs * (v.y - mu * g.y); v.z = rs * (v.z - mu * g.z); v.w = rs * (v.w - mu * g.w);
                 }
                 if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
                 if (p.act) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
@@ -159,7 +149,7 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
                     if (p.res_stat) {
                         const float mu = rowst[2 * (BM + row)], rs = rowst[2 * (BM + row) + 1];
                         const float4 g = *reinterpret_cast<const float4*>(p.res_gamma + gcol), b = *reinterpret_cast<const float4*>(p.res_beta + gcol);
-                        t.x = ep_norm_res(t.x, mu, rs, g.x, b.x); t.y = ep_norm_res(t.y, mu, rs, g.y, b.y); t.z = ep_norm_res(t.z, mu, rs, g.z, b.z); t.w = ep_norm_res(t.w, mu, rs, g.w, b.w);
+                        t.x = (t.x - mu) * rs * g.x + b.x; t.y = (t.y - mu) * rs * g.y + b.y; t.z = (t.z - mu) * rs * g.z + b.z; t.w = (t.w - mu) * rs * g.w + b.w;
                     }
                     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
                 }
@@ -167,17 +157,12 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             }
             if (p.stat_out) {                       // uniform
                 float sm = (v.x + v.y) + (v.z + v.w);
-                sm += lane_xor<1>(sm); sm += lane_xor<2>(sm); sm += lane_xor<4>(sm);
-                const float mu = sm * (1.0f / STAT_GROUP_F);
+                sm += lane_xor<1>(sm); sm += lane_xor<2>(sm); sm += lane_xor<4>(sm); sm += lane_xor<8>(sm);
+                const float mu = sm * (1.0f / 64.0f);
                 const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
-                float m2;
-                {
-#pragma clang fp contract(off)
-                    const float aa = ep_sq(a), bb = ep_sq(b), cc = ep_sq(c), dd = ep_sq(d);      // no contraction: see the header
-                    m2 = (aa + bb) + (cc + dd);
-                }
-                m2 += lane_xor<1>(m2); m2 += lane_xor<2>(m2); m2 += lane_xor<4>(m2);
-                if (valid && (cq & 31) == 0) *reinterpret_cast<float2*>(p.stat_out + (orow * ngrp + gcol / AFM_STAT_GROUP) * 2) = make_float2(mu, m2);
+                float m2 = (a * a + b * b) + (c * c + d * d);
+                m2 += lane_xor<1>(m2); m2 += lane_xor<2>(m2); m2 += lane_xor<4>(m2); m2 += lane_xor<8>(m2);
+                if (valid && (cq & 63) == 0) *reinterpret_cast<float2*>(p.stat_out + (orow * ngrp + gcol / 64) * 2) = make_float2(mu, m2);
             }
         }
     } else if (vec_out) {

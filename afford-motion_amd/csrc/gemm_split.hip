@@ -26,9 +26,6 @@
 #include "gemm_epilogue.h"
 #include "bf16split.h"
 
-bool afm_linear_slab_ok(const afm_linear_args& a);              // gemm_slab.hip
-int afm_linear_slab(const afm_linear_args& a, hipStream_t s);
-
 namespace {
 
 // K is summed in SEGMENTS of KSEG = 256: every segment accumulates from zero and the segment sums are added left to right,
@@ -37,8 +34,6 @@ namespace {
 // the sums meet in LDS - the serial chain of a 32x32 MFMA tile drops from K to 256 deep.  Both forms add exactly the same numbers in
 // the same order, so a shard computed by the split form is bit-identical to the full batch computed by the sequential form.
 constexpr int KSEG = 256;
-constexpr bool AFM_SLAB_DEFAULT = true;               // heuristic use of the weight-stationary form
-constexpr int AFM_SLAB_MIN_M = 2048;
 
 // Energy attribution builds (tools/gpu_r3n.sh only, never the library): -DAFM_ABLATE=<bits> removes one ingredient of the K loop at a time -
 // wrong results, same control flow - so that time, clock and board power can be read per ingredient (profiles/r03_power_limit.md).
@@ -290,10 +285,7 @@ int launch_split(const afm_linear_args& a, hipStream_t s) {
 
 template <int NPROD>
 int dispatch_split(const afm_linear_args& a, hipStream_t s) {
-    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 7 = 64x64 split-K, 8 = weight-stationary slabs, 0 = heuristic
-    // Large launches with K <= 512 and a plain epilogue: the weight-stationary form (gemm_slab.hip; bit-identical, no LDS staging of A, no barrier)
-    if (NPROD == 9 && (tile == 8 || (tile == 0 && AFM_SLAB_DEFAULT && a.M >= AFM_SLAB_MIN_M && a.N <= 1024 && a.K == 512)) && afm_linear_slab_ok(a)) return afm_linear_slab(a, s);
-    if (tile == 8) return AFM_E_UNSUPPORTED;
+    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 7 = 64x64 split-K, 0 = heuristic
     // Small launches (every 64x64 tile resident at once, at most two per CU): the launch is bound by the serial K chain of one MFMA
     // tile, so the K segments of a tile go to separate 256-thread groups of one workgroup (bit-identical, see the kernel's header).
     // Measured (profiles/r02_kernel_sweep_splitk.txt, us, sequential -> split): M = 1304: out_proj 20.0 -> 16.6, ffn2 (K = 1024, four groups)

@@ -118,13 +118,12 @@ typedef struct {
     const float* ln_gamma; const float* ln_beta; float* ln_out; int64_t ldo; float ln_eps; uint32_t* ln_counters;
     /* ---- LayerNorm folded ACROSS kernel boundaries (ABI v5; all NULL = off).  In a post-LN encoder layer the LayerNorm output is only
      * ever (i) the A operand of the next linear layer and (ii) a residual input, so it need not exist:
-     *   stat_out   [C rows][N / 32][2]  the producer writes, per stored output row and group of AFM_STAT_GROUP = 32 columns, (mean, M2 = sum
-     *              of squared deviations from that mean).  Needs N % 32 == 0.  A fixed reduction tree per group (columns c ^ 1, ^ 2, ^ 4,
-     *              ^ 8, ^ 16 in that order, products rounded before they are added): independent of the kernel and tile shape that ran.
-     *   a_stat     statistics of the (raw) A rows as written by their producer ([A rows][a_stat_groups][2], a_stat_groups = K / 32).
+     *   stat_out   [C rows][N / 64][2]  the producer writes, per stored output row and 64-column group, (mean, M2 = sum of squared
+     *              deviations from that mean).  Needs N % 64 == 0.  A fixed butterfly per group: independent of the tile shape.
+     *   a_stat     statistics of the (raw) A rows as written by their producer ([A rows][a_stat_groups][2], a_stat_groups = K / 64).
      *              W must carry the LayerNorm weight (W[n][k] * gamma[k]), bias the term b[n] + sum_k W[n][k] beta[k], and
      *              a_fold_g [N] = sum_k W[n][k] gamma[k]:  out = rstd * (acc - mean * a_fold_g[n]) + bias[n]  ( = W LN(a) + b ).
-     *   res_stat   statistics of the (raw) residual rows ([C rows][N / 32][2]): the residual added is LayerNorm(residual) with
+     *   res_stat   statistics of the (raw) residual rows ([C rows][N / 64][2]): the residual added is LayerNorm(residual) with
      *              res_gamma / res_beta [N].
      * ln_eps2 = the LayerNorm epsilon.  Plain forward inputs only (no preact / dact / dropout / rowtab / act_post / scale); bf16-split
      * kernels only (AFM_E_UNSUPPORTED when the arithmetic selects the native kernels). */
@@ -139,8 +138,7 @@ typedef struct {
 #define AFM_ARITH_BF16X9  9
 
 #define AFM_TUNE_NO_DMA      0x1     /* register-staged operand loads instead of global_load_lds                         */
-#define AFM_STAT_GROUP       32      /* columns per (mean, M2) record of the folded LayerNorm (stat_out / a_stat / res_stat) */
-#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128, 7 = 64x64 with the K segments split over wave groups, 8 = weight-stationary 32-column slabs (bf16-split arithmetic) */
+#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128, 7 = 64x64 with the K segments split over wave groups (bf16-split arithmetic) */
 #define AFM_TUNE_TILE_MASK   0xF0
 
 int afm_linear(const afm_linear_args* args, void* stream);
@@ -202,7 +200,7 @@ int afm_bn_fold(const float* w, const float* b, const float* running_mean, const
                 float* scale, float* shift, int32_t C, void* stream);
 
 /* afm_contact_glue (ABI v5): the ADM -> AMDM hand-off of the two-stage pipeline kept in HBM.  The reference writes
- * dist = sqrt(-2 ln(clip(sample * std + mean, 1e-20, 1)) sigma^2) to H3D/pred_contact/<id>.npy (utils/evaluate.py:41-82) and reads it back as
+ * dist = sqrt(-2 ln(clip(sample * std + mean, 1e-20, 1)) sigma^2) to H3D/pred_contact/*.npy (utils/evaluate.py:41-82) and reads it back as
  * exp(-dist^2 / (2 sigma^2)) (datasets/humanml3d.py:763-774); out[i] is that condition value, n elements.  sigma_sq = sigma^2 rounded to
  * float32 once by the caller (the reference's Python scalar `sigma ** 2`). */
 int afm_contact_glue(const float* sample, float* out, int64_t n, float sigma_sq, float mean, float std, void* stream);

@@ -40,12 +40,11 @@ static double time_us(F&& launch, int reps = 15) {
 
 struct GemmCfg { int arith, min_n, tile; const char* name; int flags = 0; };
 
-static bool g_x9_only = false;
 static void gemm_sweep(const std::vector<int>& batches) {
     const int T = 326, L = 196;
     const GemmCfg cfgs[] = {{AFM_ARITH_F32, 0, 0, "f32 auto"},   {AFM_ARITH_F32, 0, 1, "f32 32x32"},   {AFM_ARITH_F32, 0, 2, "f32 32x64"},
                             {AFM_ARITH_F32, 0, 3, "f32 64x64"},  {AFM_ARITH_F32, 0, 4, "f32 64x128"},  {AFM_ARITH_F32, 0, 5, "f32 128x128"},
-                            {AFM_ARITH_BF16X9, 0, 0, "x9 auto"}, {AFM_ARITH_BF16X9, 0, 3, "x9 64x64"}, {AFM_ARITH_BF16X9, 0, 7, "x9 64x64 split-K"}, {AFM_ARITH_BF16X9, 0, 5, "x9 128x128"}, {AFM_ARITH_BF16X9, 0, 8, "x9 slab"},
+                            {AFM_ARITH_BF16X9, 0, 0, "x9 auto"}, {AFM_ARITH_BF16X9, 0, 3, "x9 64x64"}, {AFM_ARITH_BF16X9, 0, 7, "x9 64x64 split-K"}, {AFM_ARITH_BF16X9, 0, 5, "x9 128x128"},
                             {AFM_ARITH_BF16X6, 0, 0, "x6 auto"}};
     std::mt19937 rng(7);
     std::normal_distribution<float> nd(0.f, 1.f);
@@ -67,7 +66,6 @@ static void gemm_sweep(const std::vector<int>& batches) {
             CK(hipMemset(dR, 0, nc * 4));
             int last_arith = -1;
             for (const GemmCfg& c : cfgs) {
-                if (g_x9_only && c.arith != AFM_ARITH_BF16X9) continue;
                 afm_linear_args a;
                 memset(&a, 0, sizeof a);
                 a.A = dA; a.lda = sh.K; a.W = dW; a.ldw = sh.K; a.C = dC; a.ldc = sh.N; a.bias = dB; a.residual = dR; a.ldr = sh.N;
@@ -169,7 +167,6 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     if (what == "one") return one_gemm(argc, argv);
-    if (what == "x9") { g_x9_only = true; gemm_sweep(batches); return 0; }
     if (what == "gemm" || what == "all") gemm_sweep(batches);
     if (what == "mha" || what == "all") mha_sweep(batches);
     return 0;

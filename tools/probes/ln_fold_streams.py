@@ -29,7 +29,7 @@ def chain(att, xin, bufs):
     ops.linear(t2, wingf, cinf, a_stat=(st2, ginsum), out=qkv)                 # next layer's in_proj (128x128 tiles) on the raw rows
 
 def mk():
-    return (torch.empty(M, d // ffi.STAT_GROUP, 2, device=dev), torch.empty(M, d // ffi.STAT_GROUP, 2, device=dev), torch.empty(M, d, device=dev), torch.empty(M, ff, device=dev), torch.empty(M, d, device=dev), torch.empty(M, 3 * d, device=dev))
+    return (torch.empty(M, d // 64, 2, device=dev), torch.empty(M, d // 64, 2, device=dev), torch.empty(M, d, device=dev), torch.empty(M, ff, device=dev), torch.empty(M, d, device=dev), torch.empty(M, 3 * d, device=dev))
 inp = [(R(M, d).to(dev), (R(M, d) * 2 + 0.7).to(dev)) for _ in range(2)]
 ref = []
 for att, xin in inp:
