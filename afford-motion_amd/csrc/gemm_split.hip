@@ -26,6 +26,9 @@
 #include "gemm_epilogue.h"
 #include "bf16split.h"
 
+bool afm_linear_rowdot_slab_ok(const afm_linear_args& a);       // gemm_slab.hip
+int afm_linear_rowdot_slab(const afm_linear_args& a, hipStream_t s);
+
 namespace {
 
 // K is summed in SEGMENTS of KSEG = 256: every segment accumulates from zero and the segment sums are added left to right,
@@ -285,7 +288,10 @@ int launch_split(const afm_linear_args& a, hipStream_t s) {
 
 template <int NPROD>
 int dispatch_split(const afm_linear_args& a, hipStream_t s) {
-    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 7 = 64x64 split-K, 0 = heuristic
+    const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 7 = 64x64 split-K, 8 = weight-stationary slabs, 0 = heuristic
+    // Row-dot launches with K = 256 (the CDM's linear1): the weight-stationary form (gemm_slab.hip) whatever M is
+    if (NPROD == 9 && (tile == 0 || tile == 8) && afm_linear_rowdot_slab_ok(a)) return afm_linear_rowdot_slab(a, s);
+    if (tile == 8) return AFM_E_UNSUPPORTED;
     // Small launches (every 64x64 tile resident at once, at most two per CU): the launch is bound by the serial K chain of one MFMA
     // tile, so the K segments of a tile go to separate 256-thread groups of one workgroup (bit-identical, see the kernel's header).
     // Measured (profiles/r02_kernel_sweep_splitk.txt, us, sequential -> split): M = 1304: out_proj 20.0 -> 16.6, ffn2 (K = 1024, four groups)
