@@ -38,7 +38,7 @@ namespace {
 // the same order, so a shard computed by the split form is bit-identical to the full batch computed by the sequential form.
 constexpr int KSEG = 256;
 
-// Energy attribution builds (tools/gpu_r3n.sh only, never the library): -DAFM_ABLATE=<bits> removes one ingredient of the K loop at a time -
+// Energy attribution builds (tools/gpu_power_ablate.sh only, never the library): -DAFM_ABLATE=<bits> removes one ingredient of the K loop at a time -
 // wrong results, same control flow - so that time, clock and board power can be read per ingredient (profiles/r03_power_limit.md).
 //   1 no global loads after the first two K-tiles, 2 no split arithmetic, 4 no LDS stores, 8 operand ds_reads only for the first K-tile, 16 no MFMAs
 #ifndef AFM_ABLATE

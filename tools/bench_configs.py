@@ -132,10 +132,11 @@ def config2(quick):
     return {"config": "configs[2] CDM Perceiver, B=32, N=8192, text token, 1 MI355X", "metric": "denoising steps/sec", "value": round(1 / dt, 2),
             "ms_per_step": round(1e3 * dt, 4), "dtype": "f32",
             "as_written_tflops": round(313.4e9 / dt / 1e12, 1), "executed_gflop_per_step": 43.0,
-            "formulation": ("2-latent cross-attentions evaluated folded (no K/V over the points); sampling form of the per-point chain: the step-invariant "
-                            "parts of encoder_adapter / decoder_adapter computed once per loop, linear2 + residual + contact_layer collapsed into row-dots "
-                            "fused into linear1's epilogue (afm_cdm_weights.fold_*); executed per step: linear1 34.4 GF (nine bf16 products per f32 product) + 8.6 GF of "
-                            "f32 MFMA in enc_reduce / dec_attend (16x16x4); AFM_CDM_NO_FOLD=1 runs the layer-by-layer form (115 GF per step)"),
+            "formulation": ("2-latent cross-attentions evaluated folded (no K/V over the points); sampling form of the per-point chain: the rows of "
+                            "encoder_adapter / decoder_adapter are generated on the matrix pipe from [x_t | xyz | 1] inside enc_reduce / dec_attend (never "
+                            "materialised), linear2 + residual + contact_layer collapsed into row-dots fused into linear1's epilogue (afm_cdm_weights.fold_* / "
+                            "gen_*); executed per step: linear1 34.4 GF (nine bf16 products per f32 product, weight-stationary form) + ~10 GF of f32 MFMA in "
+                            "enc_reduce / dec_attend (16x16x4); CDM.no_fold = True runs the layer-by-layer form (115 GF per step)"),
             "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items()}}
 
 

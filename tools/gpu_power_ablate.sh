@@ -2,7 +2,7 @@
 # energy attribution of the 64x64 nine-product GEMM: the library built with one K-loop ingredient removed at a time (tools/probes/ablate/, -DAFM_ABLATE)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r3n; mkdir -p $O
+O=gpurun_out/power_ablate; mkdir -p $O
 sample() {
   tag=$1; shift
   "$@" > $O/$tag.out 2> $O/$tag.err &

@@ -2,7 +2,7 @@
 # is the sampling loop power-limited?  board power / shader clock sampled while the loop runs
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r3l; mkdir -p $O
+O=gpurun_out/power_loop; mkdir -p $O
 rocm-smi --showmaxpower 2>&1 | grep -i "power" | head -3 > $O/cap.txt
 sample() {
   tag=$1; shift

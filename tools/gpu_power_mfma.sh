@@ -2,7 +2,7 @@
 # board power / shader clock of the bf16 matrix pipe alone at several duty cycles, next to the GEMM kernels alone
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r3m; mkdir -p $O
+O=gpurun_out/power_mfma; mkdir -p $O
 sample() {
   tag=$1; shift
   "$@" > $O/$tag.out 2> $O/$tag.err &

@@ -1,7 +1,7 @@
 // What does the bf16 matrix pipe cost in board power?  (measurement tooling, not part of the product)
 // Every wave issues v_mfma_f32_32x32x16_bf16 on four independent accumulators with pseudo-random operand bits and no memory traffic;
 // `gap` s_sleep units (64 cycles each) between groups of 36 MFMAs set the duty cycle.  Runs each setting for `secs` seconds and prints the
-// achieved rate; tools/gpu_r3m.sh samples rocm-smi next to it.
+// achieved rate; tools/gpu_power_mfma.sh samples rocm-smi next to it.
 //   hipcc -O2 --offload-arch=gfx950 tools/probes/mfma_power.hip -o tools/probes/mfma_power
 //   tools/probes/mfma_power <waves_per_simd> <gap> <secs>
 #include <hip/hip_runtime.h>
