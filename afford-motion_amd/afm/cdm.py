@@ -294,6 +294,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._streams = []
         self.no_fold = False            # measurement: the layer-by-layer sampling form (what training-mode forward also runs)
         self.gemm_tile = 0              # measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral)
+        self.no_fuse = False            # measurement: dec_attend + linear1 GEMM + output kernel instead of the fused decoder kernel
         self.no_gen = False             # measurement: round 2's folded form (step-invariant adapter parts materialised) instead of generated rows
 
     # ------------------------------------------------------------------ weight pack
@@ -302,7 +303,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
-            w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+            w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | (ffi.CDM_NO_FUSE if self.no_fuse else 0) | ((int(self.gemm_tile) & 0xF) << 8)
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -370,13 +371,22 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 gen_dec = torch.zeros(12, cm.dkv, dtype=torch.float64)
                 gen_dec[:F_] = (wd @ we).t(); gen_dec[F_] = wd @ be + bd
                 folds.update(gen_enc=gen_enc, gen_dec=gen_dec, gen_qe=wc @ gen_dec.t())
+                # the decoder of a point in one kernel (afm_cdm_weights.dec_*): everything between the attention weights and linear1 is linear
+                # in [a | inputs]; rows of the inputs (step-invariant) here, rows of the attention weights per step on the device
+                mlp_m = cm.decoder_cross_attn[1].module
+                g2, b2, w1, b1 = f64(mlp_m[0].weight), f64(mlp_m[0].bias), f64(mlp_m[1].weight), f64(mlp_m[1].bias)
+                tx = gen_dec.clone()
+                tx[F_] += bo                                                       # the attention's output bias rides on the constant input
+                xc = tx - tx.mean(1, keepdim=True)
+                w1g = w1 * g2[None, :]
+                folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv)
             dev = cl.weight.device
             for name, t in folds.items():
                 setattr(w, name, P(t.float().contiguous().to(dev)))
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
-        w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+        w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | (ffi.CDM_NO_FUSE if self.no_fuse else 0) | ((int(self.gemm_tile) & 0xF) << 8)
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):

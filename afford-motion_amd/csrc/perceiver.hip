@@ -742,9 +742,250 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     }
 }
 
+
+// ---------------------------------------------------------------- the whole decoder of a point in ONE kernel (round 3; GEN inputs)
+// After the attention weights a[p, jh] of a point are known, everything up to linear1 is LINEAR in u[p] = [a[p, 0..15] | x_t | features | 1]:
+//   h1[p, c] = sum_jh P[jh, c] a[p, jh] + b_o[c] + e[p, c],  e = the generated query row       = sum_m u[p, m] T[m, c]   (T = [P ; gen_dec (+ b_o)])
+//   z = LayerNorm_mlp(h1): h1 - mean_c(h1) = sum_m u[p, m] Tc[m, c]  (Tc = T minus its row means),  var_c(h1) = u Qc u^T,  Qc = Tc Tc^T / 256
+//   linear1(z)[n] = rstd[p] * sum_m u[p, m] TWc[m, n] + C[n],   TWc = Tc (W1 * gamma_mlp)^T,  C = b1 + W1 beta_mlp
+// so the 256-wide rows h1 and z never exist and linear1 is a K = 28 product instead of K = 256 (x 9 bf16 products): per 16 points
+// 112 + 14 f32 MFMAs against 64 (P V) + 576 (linear1 on the bf16 pipe).  The hidden row GELU(linear1) lives one 16-channel tile at a time
+// and goes straight into the row-dots with w2 = contact_layer.w fc2.w (64 MFMAs, the contact channel as the output row), to which the
+// attention part (WP a) and the query part (gen_qe . inputs) of contact_layer.w . h1 are added in the same accumulator: the kernel reads
+// 9 floats per point and writes the 6 of x_0 / x_{t-1}.  Per sample and step the rows of P enter through two small launches in front:
+// lat_dectab_kernel (centred rows Pc, the [28 x 28] quadratic form in operand order) and one toklin launch (TWc rows of P = Pc W1g^T);
+// the rows of the inputs are step-invariant and come from the host (afm_cdm_weights.dec_*).  Same function as the layer-by-layer form up
+// to f32 re-association (tests/test_gpu_cdm.py).
+constexpr int DP_LDG = 260, DP_LDX = 272, DP_LDQ = 36, DP_LDW = 260;
+constexpr int DP_QTAB = 32 * DP_LDQ;                              // floats of a sample's quadratic-form table
+constexpr int DP_LDS_FLOATS = 16 * DP_LDG + 16 * DP_LDG + 12 * DP_LDX + DP_QTAB + 8 * DP_LDW + 256 + 16 + 8 * 16 + 8 * 16 + 16 + 12 * 256 + 4 * 16 * 17;
+
+// grid B, block 256 (thread = channel c).  pc [B][16][256] = P - rowmean(P); qtab [B][32][DP_LDQ]: entry (cs, 16 t + i) = Qc[m'(t, i)][m(cs)] with
+// the K index in operand order (cs < 16: attention weight cs; cs = 16 + 4 g + ks: input 4 ks + g) and the output rows of tile 1 permuted so
+// that lane (p, g) register r meets input 4 r + g (dec_point_kernel).
+__global__ __launch_bounds__(256) void lat_dectab_kernel(const float* __restrict__ dec_lat, const float* __restrict__ xc, const float* __restrict__ qxx,
+                                                         float* __restrict__ pc, float* __restrict__ qtab) {
+    __shared__ float Ts[28][257];
+    __shared__ float red[4][16];
+    __shared__ float Q[28][29];
+    const int b = blockIdx.x, c = threadIdx.x, wave = c >> 6, lane = c & 63;
+    const float* P = dec_lat + (int64_t)b * DEC_LAT_STRIDE(16) + 16 * 256;
+    float p[16];
+#pragma unroll
+    for (int jh = 0; jh < 16; ++jh) p[jh] = P[jh * 256 + c];
+#pragma unroll
+    for (int jh = 0; jh < 16; ++jh) {
+        const float sm = wave_sum(p[jh]);
+        if (lane == 0) red[wave][jh] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jh = 0; jh < 16; ++jh) {
+        const float mean = ((red[0][jh] + red[1][jh]) + (red[2][jh] + red[3][jh])) * (1.0f / 256.0f);
+        const float v = p[jh] - mean;
+        Ts[jh][c] = v;
+        pc[((int64_t)b * 16 + jh) * 256 + c] = v;
+    }
+    for (int k = 0; k < 12; ++k) Ts[16 + k][c] = xc[k * 256 + c];
+    __syncthreads();
+    for (int idx = c; idx < 16 * 28; idx += 256) {
+        const int m = idx / 28, m2 = idx - m * 28;
+        float d = 0.f;
+        for (int cc = 0; cc < 256; ++cc) d += Ts[m][cc] * Ts[m2][cc];
+        d *= (1.0f / 256.0f);
+        Q[m][m2] = d;
+        if (m2 >= 16) Q[m2][m] = d;
+    }
+    if (c < 144) Q[16 + c / 12][16 + c % 12] = qxx[c];
+    __syncthreads();
+    for (int e = c; e < DP_QTAB; e += 256) {
+        const int cs = e / DP_LDQ, col = e - cs * DP_LDQ;
+        float v = 0.f;
+        if (col < 32) {
+            const int i = col & 15, x = cs - 16;
+            const int m2 = col < 16 ? i : ((i & 3) < 3 ? 16 + 4 * (i & 3) + (i >> 2) : -1);
+            const int m = cs < 16 ? cs : ((x & 3) < 3 ? 16 + 4 * (x & 3) + (x >> 2) : -1);
+            if (m >= 0 && m2 >= 0) v = Q[m2][m];
+        }
+        qtab[(int64_t)b * DP_QTAB + e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restrict__ dec_lat, const float* __restrict__ twp, const float* __restrict__ qtab,
+                                                           afm_ln qn, const float* __restrict__ gen_dec, const float* __restrict__ twx,
+                                                           const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe,
+                                                           const float* __restrict__ c0, int N, int cd, const float* xt, const float* __restrict__ feat, int fd,
+                                                           float* __restrict__ x0_out, const float* __restrict__ noise, float* x_next,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma) {
+    constexpr int NJH = 16, LDG = DP_LDG;
+    extern __shared__ __attribute__((aligned(16))) float dp_sm[];
+    float* Gs = dp_sm;                                            // [16][LDG]  gamma_q * G
+    float* TWs = Gs + 16 * LDG;                                   // [16][LDG]  TWc rows of the attention weights
+    float* TXs = TWs + 16 * LDG;                                  // [12][LDX]  TWc rows of the inputs, row 3 g + ks = input 4 ks + g
+    float* Qs = TXs + 12 * DP_LDX;                                // [32][LDQ]  quadratic form, operand order (lat_dectab_kernel)
+    float* W2s = Qs + DP_QTAB;                                    // [8][LDW]   contact_layer.w fc2.w  (rows >= cd: 0)
+    float* Cv = W2s + 8 * DP_LDW;                                 // [256]      b1 + W1 beta_mlp
+    float* gcs = Cv + 256;                                        // [16]       beta_q . G[jh] + cb[jh]
+    float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P
+    float* QEs = WPs + 8 * 16;                                    // [8][16]    contact_layer.w . gen_dec^T  (columns >= 12: 0)
+    float* c0s = QEs + 8 * 16;                                    // [16]
+    float* xvs = c0s + 16;                                        // [3][16][64] generator table of the query rows in operand order
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    float* aT = xvs + 12 * 256 + wave * 16 * 17;                  // [16 points][17] attention weights of the tile, transposed
+    const float* rec = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
+    for (int i = threadIdx.x; i < NJH * 64; i += 256) {            // (row, float4) items
+        const int jh = i >> 6, c = (i & 63) * 4;
+        const float4 gv = *reinterpret_cast<const float4*>(rec + jh * 256 + c), gm = *reinterpret_cast<const float4*>(qn.g + c);
+        *reinterpret_cast<float4*>(Gs + jh * LDG + c) = make_float4(gv.x * gm.x, gv.y * gm.y, gv.z * gm.z, gv.w * gm.w);
+        *reinterpret_cast<float4*>(TWs + jh * LDG + c) = *reinterpret_cast<const float4*>(twp + ((int64_t)b * 16 + jh) * 256 + c);
+    }
+    for (int i = threadIdx.x; i < 12 * 64; i += 256) {
+        const int k = i >> 6, c = (i & 63) * 4;
+        *reinterpret_cast<float4*>(TXs + (3 * (k & 3) + (k >> 2)) * DP_LDX + c) = *reinterpret_cast<const float4*>(twx + k * 256 + c);
+    }
+    for (int i = threadIdx.x; i < DP_QTAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_QTAB + i];
+    for (int i = threadIdx.x; i < 8 * 256; i += 256) W2s[(i >> 8) * DP_LDW + (i & 255)] = (i >> 8) < cd ? w2f[i] : 0.f;
+    for (int jh = wave; jh < NJH; jh += 4) {
+        const float4 gv = *reinterpret_cast<const float4*>(rec + jh * 256 + lane * 4), bt = *reinterpret_cast<const float4*>(qn.b + lane * 4);
+        const float d = wave_sum((gv.x * bt.x + gv.y * bt.y) + (gv.z * bt.z + gv.w * bt.w));
+        if (lane == 0) gcs[jh] = d + rec[2 * NJH * 256 + jh];
+    }
+    Cv[threadIdx.x] = cvec[threadIdx.x];
+    if (threadIdx.x < 8 * 16) {
+        const int j = threadIdx.x >> 4, k = threadIdx.x & 15;
+        WPs[threadIdx.x] = j < cd ? rec[2 * NJH * 256 + NJH + threadIdx.x] : 0.f;
+        QEs[threadIdx.x] = (j < cd && k < GEN_K) ? gen_qe[j * GEN_K + k] : 0.f;
+    }
+    if (threadIdx.x < 16) c0s[threadIdx.x] = (int)threadIdx.x < cd ? c0[threadIdx.x] : 0.f;
+    for (int i = threadIdx.x; i < GEN_K * 256; i += 256) {
+        const int l = i & 63, jj = (i >> 6) & 15, ks = i >> 10;
+        xvs[i] = gen_dec[(4 * ks + (l >> 4)) * 256 + 16 * jj + (l & 15)];
+    }
+    __syncthreads();
+    const float gconst = gcs[p16];
+
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    const int wper = ((per + 3) / 4 + 15) & ~15;                  // points per wave, whole tiles
+    const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
+
+    float xin[3], xnext[3];
+    auto fetch = [&](int nb, float (&dst)[3]) {                    // inputs k = 4 ks + g of point nb + p16
+        const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = 4 * ks + g;
+            const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
+            dst[ks] = k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
+        }
+    };
+    if (w0 < w1) fetch(w0, xnext);
+    for (int nb = w0; nb < w1; nb += 16) {
+        const int64_t pt = (int64_t)b * N + nb + p16;
+        const bool pvalid = nb + p16 < w1;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) xin[ks] = xnext[ks];
+        if (nb + 16 < w1) fetch(nb + 16, xnext);
+        // ---- query rows (generated), their LayerNorm statistics, scores against the folded keys, softmax over the two keys of a head
+        float4 e[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(xvs[(ks * 16 + jj) * 64 + lane], xin[ks], d, 0, 0, 0);
+            e[jj] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += (e[j].x + e[j].y) + (e[j].z + e[j].w);
+        sum += xor16(sum); sum += xor32(sum);
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float a0 = e[j].x - mean, a1 = e[j].y - mean, a2 = e[j].z - mean, a3 = e[j].w - mean;
+            sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        sq += xor16(sq); sq += xor32(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + 1e-5f);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sc1 = sc, sc2 = sc, sc3 = sc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 g4 = *reinterpret_cast<const float4*>(Gs + p16 * LDG + 16 * j + 4 * g);        // lane (jh = p16, g)
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].x - mean) * rstd, g4.x, sc, 0, 0, 0);
+            sc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].y - mean) * rstd, g4.y, sc1, 0, 0, 0);
+            sc2 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].z - mean) * rstd, g4.z, sc2, 0, 0, 0);
+            sc3 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].w - mean) * rstd, g4.w, sc3, 0, 0, 0);
+        }
+        sc = (sc + sc1) + (sc2 + sc3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s_own = sc[r] + gconst, s_oth = lane_xor<8>(s_own);
+            const float mx = fmaxf(s_own, s_oth);
+            const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
+            aT[(4 * g + r) * 17 + p16] = e_own / (e_own + e_oth);
+        }
+        float aB[4];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) aB[sI] = aT[p16 * 17 + 4 * g + sI];       // lane (p = p16, g): a[p, jh = 4 g + s]
+        // ---- variance of the MLP's LayerNorm input: u Qc u^T (y = Qc u on the matrix pipe, the dot with u in the lane + across g)
+        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = y0;
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(4 * g + sI) * DP_LDQ + p16], aB[sI], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(4 * g + sI) * DP_LDQ + 16 + p16], aB[sI], y1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 + 4 * g + ks) * DP_LDQ + p16], xin[ks], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 + 4 * g + ks) * DP_LDQ + 16 + p16], xin[ks], y1, 0, 0, 0);
+        }
+        float var = ((y0[0] * aB[0] + y0[1] * aB[1]) + (y0[2] * aB[2] + y0[3] * aB[3])) + ((y1[0] * xin[0] + y1[1] * xin[1]) + y1[2] * xin[2]);
+        var += xor16(var); var += xor32(var);
+        const float rstd2 = 1.0f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
+        // ---- linear1 (K = 28) one 16-channel tile at a time -> GELU -> row-dots with w2; then the attention and query parts of contact_layer.w . h1
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int tt = 0; tt < 16; ++tt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(TWs[(4 * g + sI) * LDG + 16 * tt + p16], aB[sI], acc, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(TXs[(3 * g + ks) * DP_LDX + 16 * tt + p16], xin[ks], acc, 0, 0, 0);
+            const float4 cv = *reinterpret_cast<const float4*>(Cv + 16 * tt + 4 * g);
+            const float h0 = gelu_erf(rstd2 * acc[0] + cv.x), h1v = gelu_erf(rstd2 * acc[1] + cv.y), h2 = gelu_erf(rstd2 * acc[2] + cv.z), h3 = gelu_erf(rstd2 * acc[3] + cv.w);
+            const float* wrow = W2s + p16 * DP_LDW + 16 * tt + 4 * g;
+            const float4 w4 = p16 < 8 ? *reinterpret_cast<const float4*>(wrow) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, h0, sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, h1v, sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, h2, sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, h3, sa, 0, 0, 0);
+        }
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) sa = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? WPs[p16 * 16 + 4 * g + sI] : 0.f, aB[sI], sa, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) sa = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? QEs[p16 * 16 + 4 * ks + g] : 0.f, xin[ks], sa, 0, 0, 0);
+        if (pvalid) {                                              // lane (point p16, g): contact channels 4 g + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * g + r;
+                if (j < cd) {
+                    const int64_t i = pt * cd + j;
+                    const float v = sa[r] + c0s[j];
+                    if (x0_out) x0_out[i] = v;
+                    if (x_next) x_next[i] = (c1[b] * v + c2[b] * xt[i]) + sigma[b] * noise[i];
+                }
+            }
+        }
+    }
+}
+
 struct CdmWs {
     float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
     float *lat_s, *lat_x, *lat_t1, *lat_t2, *lat_qkv, *lat_kv;     // batched latent chain: [2B] token rows
+    float *pc, *twp, *qtab;                                        // fused decoder: centred P rows, their TWc rows [16 B][256], quadratic forms [B][DP_QTAB]
     int64_t bytes;
 };
 
@@ -764,6 +1005,7 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     const int64_t ntok = 2 * (int64_t)B;
     s.lat_s = take(ntok * w.enc_heads * w.dkv * 4); s.lat_x = take(ntok * w.dq * 4); s.lat_t1 = take(ntok * w.dq * 4);
     s.lat_t2 = take(ntok * w.dq * 4); s.lat_qkv = take(ntok * 3 * w.dq * 4); s.lat_kv = take(ntok * 2 * w.dkv * 4);
+    s.pc = take((int64_t)B * 16 * 256 * 4); s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * DP_QTAB * 4);
     s.bytes = off;
     return s;
 }
@@ -907,6 +1149,29 @@ int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
     return 0;
 }
 
+int launch_toklin(const TokLin& p, hipStream_t s);
+
+// the fused decoder (mode 3): per-sample tables of the step (two small launches), then one kernel over the points
+int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
+                     const afm_ddpm_args* ddpm, hipStream_t s) {
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    constexpr int LDS = DP_LDS_FLOATS * (int)sizeof(float);
+    static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
+    if (attr != 0) return attr;
+    hipLaunchKernelGGL(lat_dectab_kernel, dim3(B), dim3(256), 0, s, ws.dec_lat, w.dec_xc, w.dec_qxx, ws.pc, ws.qtab);
+    AFM_CHECK_LAUNCH();
+    TokLin p = {};                                    // TWc rows of the attention weights: Pc (W1 * gamma_mlp)^T
+    p.X = ws.pc; p.ldx = 256; p.W[0] = w.dec_w1g; p.ncol = 256; p.Y = ws.twp; p.ldy = 256; p.ntok = 16 * B; p.N = 256; p.K = 256;
+    AFM_TRY(launch_toklin(p, s));
+    int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
+    if (chunks > 16) chunks = 16;
+    hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.dec_lat, ws.twp, ws.qtab, w.dec_q_norm, w.gen_dec, w.dec_twx, w.dec_c,
+                       w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
+                       ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_toklin(const TokLin& p, hipStream_t s) {
     const dim3 grid((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK);
     switch (p.K) {                                // widths of the Perceiver's latents / point features (validate: dkv == 256, dq a multiple of 128)
@@ -976,12 +1241,14 @@ int cdm_latents(const afm_cdm_weights& w, const float* text_q0, const int64_t* t
     return cdm_latent_chain(w, text_q0, t, ws, B, s);
 }
 
-// sampling form of the per-point kernels: 2 = GEN (generator tables present, feat_dim + 1 <= GEN_K), 1 = FOLD, 0 = layer by layer
+// sampling form of the per-point kernels: 3 = GEN encoder side + the fused decoder (dec_point_kernel), 2 = GEN (generator tables present,
+// feat_dim + 1 <= GEN_K), 1 = FOLD, 0 = layer by layer
 inline int cdm_mode(const afm_cdm_weights& w) {
     const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
     if (!folded) return 0;
     const bool gen = w.gen_enc && w.gen_dec && w.gen_qe && w.feat_dim + 1 <= GEN_K && !(w.flags & AFM_CDM_NO_GEN);
-    return gen ? 2 : 1;
+    const bool fused = gen && w.dec_w1g && w.dec_c && w.dec_xc && w.dec_twx && w.dec_qxx && w.dec_heads == 8 && w.dkv == 256 && !(w.flags & AFM_CDM_NO_FUSE);
+    return fused ? 3 : (gen ? 2 : 1);
 }
 inline bool cdm_folded(const afm_cdm_weights& w) { return cdm_mode(w) != 0; }
 
@@ -1011,8 +1278,9 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
                        bool prepared, hipStream_t s) {
     const int M = B * N, dkv = w.dkv, cd = w.contact_dim, mode = cdm_mode(w);
     if (mode == 1 && !prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
-    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, feat, mode, s));
+    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, feat, mode >= 2 ? 2 : mode, s));
     AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
+    if (mode == 3) return launch_dec_point(w, B, N, ws, x_t, feat, x0_out, ddpm, s);
     AFM_TRY(launch_dec_attend(w, B, N, ws, x_t, feat, mode, s));
     afm_linear_args a = {};                 // GELU(linear1 z) . w2 per 64-column group; the hidden activations are never stored
     a.A = ws.z; a.lda = dkv; a.W = w.dec_mlp.fc1.w; a.ldw = dkv; a.M = M; a.N = dkv; a.K = dkv; a.bias = w.dec_mlp.fc1.b; a.act = AFM_ACT_GELU;

@@ -569,9 +569,18 @@ typedef struct {
      *   gen_dec [12, dkv]          row k: (decoder_adapter.w @ encoder_adapter.w)[:, k]; row feat_dim: decoder_adapter.w @ enc.b + dec.b
      *   gen_qe  [contact_dim, 12]  contact_layer.w @ gen_dec^T */
     const float* gen_enc; const float* gen_dec; const float* gen_qe;
+    /* ABI v5 (all five or none, next to gen_*): the decoder of a point in one kernel.  With the attention weights a[p, 0..15] known, everything
+     * up to linear1 is linear in u = [a | x_t | features | 1]: h1 = u T with T = [P ; gen_dec (+ dec_attn.o.b on the row of the constant 1)],
+     * LayerNorm_mlp(h1) = rstd (u Tc) * gamma + beta with Tc = T minus its row means and var = u (Tc Tc^T / dkv) u^T, hence
+     * linear1(z) = rstd * u (Tc (W1 * gamma)^T) + (b1 + W1 beta): a K = 28 product; h1 and z are never materialised.  Step-invariant parts:
+     *   dec_w1g [dkv, dkv]  dec_mlp.fc1.w * dec_mlp.norm.w (columns scaled)      dec_c   [dkv]      dec_mlp.fc1.b + dec_mlp.fc1.w @ dec_mlp.norm.b
+     *   dec_xc  [12, dkv]   the input rows of Tc (gen_dec + o.b, centred)         dec_twx [12, dkv]  dec_xc @ dec_w1g^T
+     *   dec_qxx [12, 12]    dec_xc @ dec_xc^T / dkv */
+    const float* dec_w1g; const float* dec_c; const float* dec_xc; const float* dec_twx; const float* dec_qxx;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
+#define AFM_CDM_NO_FUSE        0x4     /* measurement: dec_attend + linear1 GEMM + output kernel (round 3 first half) instead of the fused decoder */
 #define AFM_CDM_NO_GEN         0x2     /* measurement: rows of the per-point kernels from the materialised step-invariant tensors (round 2's folded form) */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
