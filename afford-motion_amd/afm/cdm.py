@@ -379,7 +379,13 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 tx[F_] += bo                                                       # the attention's output bias rides on the constant input
                 xc = tx - tx.mean(1, keepdim=True)
                 w1g = w1 * g2[None, :]
-                folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv)
+                dc = gen_dec - gen_dec.mean(1, keepdim=True)                       # the query row's LayerNorm: var = x Qd x^T, in MFMA operand order
+                qd = dc @ dc.t() / cm.dkv
+                qdd = torch.zeros(16, 16, dtype=torch.float64)
+                for i in range(16):
+                    if (i & 3) < 3:
+                        qdd[:12, i] = qd[4 * (i & 3) + (i >> 2), :]
+                folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv, dec_dc=dc, dec_qdd=qdd)
             dev = cl.weight.device
             for name, t in folds.items():
                 setattr(w, name, P(t.float().contiguous().to(dev)))

@@ -756,15 +756,19 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
 // lat_dectab_kernel (centred rows Pc, the [28 x 28] quadratic form in operand order) and one toklin launch (TWc rows of P = Pc W1g^T);
 // the rows of the inputs are step-invariant and come from the host (afm_cdm_weights.dec_*).  Same function as the layer-by-layer form up
 // to f32 re-association (tests/test_gpu_cdm.py).
+// The attention scores fold the same way: LayerNorm_q(e) . G'[jh] = rstd_q (x . EG[:, jh]) + const with x = the 12 inputs, EG = Dc G'^T
+// (Dc = gen_dec minus its row means, per sample and step: lat_dectab_kernel) and var_q = x Qd x^T (step-invariant): the query row e is
+// never generated either.
 constexpr int DP_LDG = 260, DP_LDX = 272, DP_LDQ = 36, DP_LDW = 260;
 constexpr int DP_QTAB = 32 * DP_LDQ;                              // floats of a sample's quadratic-form table
-constexpr int DP_LDS_FLOATS = 16 * DP_LDG + 16 * DP_LDG + 12 * DP_LDX + DP_QTAB + 8 * DP_LDW + 256 + 16 + 8 * 16 + 8 * 16 + 16 + 12 * 256 + 4 * 16 * 17;
+constexpr int DP_TAB = DP_QTAB + 16 * 16 + 16;                    // + EG [12 -> 16][16] + gconst [16]: a sample's table of the step
+constexpr int DP_LDS_FLOATS = 16 * DP_LDG + 12 * DP_LDX + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
 
 // grid B, block 256 (thread = channel c).  pc [B][16][256] = P - rowmean(P); qtab [B][32][DP_LDQ]: entry (cs, 16 t + i) = Qc[m'(t, i)][m(cs)] with
 // the K index in operand order (cs < 16: attention weight cs; cs = 16 + 4 g + ks: input 4 ks + g) and the output rows of tile 1 permuted so
 // that lane (p, g) register r meets input 4 r + g (dec_point_kernel).
 __global__ __launch_bounds__(256) void lat_dectab_kernel(const float* __restrict__ dec_lat, const float* __restrict__ xc, const float* __restrict__ qxx,
-                                                         float* __restrict__ pc, float* __restrict__ qtab) {
+                                                         const float* __restrict__ dc, afm_ln qn, float* __restrict__ pc, float* __restrict__ qtab) {
     __shared__ float Ts[28][257];
     __shared__ float red[4][16];
     __shared__ float Q[28][29];
@@ -807,60 +811,74 @@ __global__ __launch_bounds__(256) void lat_dectab_kernel(const float* __restrict
             const int m = cs < 16 ? cs : ((x & 3) < 3 ? 16 + 4 * (x & 3) + (x >> 2) : -1);
             if (m >= 0 && m2 >= 0) v = Q[m2][m];
         }
-        qtab[(int64_t)b * DP_QTAB + e] = v;
+        qtab[(int64_t)b * DP_TAB + e] = v;
+    }
+    // ---- scores: EG[k][jh] = Dc[k] . (gamma_q * G[jh]),  gconst[jh] = beta_q . G[jh] + cb[jh]   (rows of Ts reused)
+    __syncthreads();
+    const float* G = dec_lat + (int64_t)b * DEC_LAT_STRIDE(16);
+    {
+        const float gm = qn.g[c], bt = qn.b[c];
+#pragma unroll
+        for (int jh = 0; jh < 16; ++jh) {
+            const float gv = G[jh * 256 + c];
+            Ts[jh][c] = gv * gm;
+            const float sm = wave_sum(gv * bt);
+            if (lane == 0) red[wave][jh] = sm;
+        }
+    }
+    for (int k = 0; k < 12; ++k) Ts[16 + k][c] = dc[k * 256 + c];
+    __syncthreads();
+    {
+        const int k = c >> 4, jh = c & 15;                        // 256 threads = the [16][16] table (rows k >= 12: 0)
+        float d = 0.f;
+        if (k < 12)
+            for (int cc = 0; cc < 256; ++cc) d += Ts[16 + k][cc] * Ts[jh][cc];
+        qtab[(int64_t)b * DP_TAB + DP_QTAB + c] = d;
+        if (c < 16) qtab[(int64_t)b * DP_TAB + DP_QTAB + 256 + c] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + G[2 * 16 * 256 + c];
     }
 }
 
-__global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restrict__ dec_lat, const float* __restrict__ twp, const float* __restrict__ qtab,
-                                                           afm_ln qn, const float* __restrict__ gen_dec, const float* __restrict__ twx,
+__global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restrict__ dec_lat, const float* __restrict__ twp, const float* __restrict__ qtab,
+                                                           const float* __restrict__ qdd, const float* __restrict__ twx,
                                                            const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe,
                                                            const float* __restrict__ c0, int N, int cd, const float* xt, const float* __restrict__ feat, int fd,
                                                            float* __restrict__ x0_out, const float* __restrict__ noise, float* x_next,
                                                            const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma) {
     constexpr int NJH = 16, LDG = DP_LDG;
     extern __shared__ __attribute__((aligned(16))) float dp_sm[];
-    float* Gs = dp_sm;                                            // [16][LDG]  gamma_q * G
-    float* TWs = Gs + 16 * LDG;                                   // [16][LDG]  TWc rows of the attention weights
+    float* TWs = dp_sm;                                           // [16][LDG]  TWc rows of the attention weights
     float* TXs = TWs + 16 * LDG;                                  // [12][LDX]  TWc rows of the inputs, row 3 g + ks = input 4 ks + g
-    float* Qs = TXs + 12 * DP_LDX;                                // [32][LDQ]  quadratic form, operand order (lat_dectab_kernel)
-    float* W2s = Qs + DP_QTAB;                                    // [8][LDW]   contact_layer.w fc2.w  (rows >= cd: 0)
+    float* Qs = TXs + 12 * DP_LDX;                                // [32][LDQ]  quadratic form of the MLP's LayerNorm, operand order (lat_dectab_kernel)
+    float* EGs = Qs + DP_QTAB;                                    // [16][16]   scores: row k = input, column jh
+    float* gcs = EGs + 16 * 16;                                   // [16]       beta_q . G[jh] + cb[jh]
+    float* W2s = gcs + 16;                                        // [8][LDW]   contact_layer.w fc2.w  (rows >= cd: 0)
     float* Cv = W2s + 8 * DP_LDW;                                 // [256]      b1 + W1 beta_mlp
-    float* gcs = Cv + 256;                                        // [16]       beta_q . G[jh] + cb[jh]
-    float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P
+    float* QDs = Cv + 256;                                        // [16][16]   quadratic form of the query's LayerNorm, operand order (host)
+    float* WPs = QDs + 16 * 16;                                   // [8][16]    contact_layer.w . P
     float* QEs = WPs + 8 * 16;                                    // [8][16]    contact_layer.w . gen_dec^T  (columns >= 12: 0)
     float* c0s = QEs + 8 * 16;                                    // [16]
-    float* xvs = c0s + 16;                                        // [3][16][64] generator table of the query rows in operand order
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
-    float* aT = xvs + 12 * 256 + wave * 16 * 17;                  // [16 points][17] attention weights of the tile, transposed
+    float* aT = c0s + 16 + wave * 16 * 17;                        // [16 points][17] attention weights of the tile, transposed
+    float* tr = c0s + 16 + 4 * 16 * 17 + wave * 16;               // [16] a per-point scalar from lanes (p, .) to lanes (., g)
     const float* rec = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
     for (int i = threadIdx.x; i < NJH * 64; i += 256) {            // (row, float4) items
         const int jh = i >> 6, c = (i & 63) * 4;
-        const float4 gv = *reinterpret_cast<const float4*>(rec + jh * 256 + c), gm = *reinterpret_cast<const float4*>(qn.g + c);
-        *reinterpret_cast<float4*>(Gs + jh * LDG + c) = make_float4(gv.x * gm.x, gv.y * gm.y, gv.z * gm.z, gv.w * gm.w);
         *reinterpret_cast<float4*>(TWs + jh * LDG + c) = *reinterpret_cast<const float4*>(twp + ((int64_t)b * 16 + jh) * 256 + c);
     }
     for (int i = threadIdx.x; i < 12 * 64; i += 256) {
         const int k = i >> 6, c = (i & 63) * 4;
         *reinterpret_cast<float4*>(TXs + (3 * (k & 3) + (k >> 2)) * DP_LDX + c) = *reinterpret_cast<const float4*>(twx + k * 256 + c);
     }
-    for (int i = threadIdx.x; i < DP_QTAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_QTAB + i];
+    for (int i = threadIdx.x; i < DP_TAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_TAB + i];      // Qs | EGs | gcs are contiguous, like the table
     for (int i = threadIdx.x; i < 8 * 256; i += 256) W2s[(i >> 8) * DP_LDW + (i & 255)] = (i >> 8) < cd ? w2f[i] : 0.f;
-    for (int jh = wave; jh < NJH; jh += 4) {
-        const float4 gv = *reinterpret_cast<const float4*>(rec + jh * 256 + lane * 4), bt = *reinterpret_cast<const float4*>(qn.b + lane * 4);
-        const float d = wave_sum((gv.x * bt.x + gv.y * bt.y) + (gv.z * bt.z + gv.w * bt.w));
-        if (lane == 0) gcs[jh] = d + rec[2 * NJH * 256 + jh];
-    }
     Cv[threadIdx.x] = cvec[threadIdx.x];
+    QDs[threadIdx.x] = qdd[threadIdx.x];
     if (threadIdx.x < 8 * 16) {
         const int j = threadIdx.x >> 4, k = threadIdx.x & 15;
         WPs[threadIdx.x] = j < cd ? rec[2 * NJH * 256 + NJH + threadIdx.x] : 0.f;
         QEs[threadIdx.x] = (j < cd && k < GEN_K) ? gen_qe[j * GEN_K + k] : 0.f;
     }
     if (threadIdx.x < 16) c0s[threadIdx.x] = (int)threadIdx.x < cd ? c0[threadIdx.x] : 0.f;
-    for (int i = threadIdx.x; i < GEN_K * 256; i += 256) {
-        const int l = i & 63, jj = (i >> 6) & 15, ks = i >> 10;
-        xvs[i] = gen_dec[(4 * ks + (l >> 4)) * 256 + 16 * jj + (l & 15)];
-    }
     __syncthreads();
     const float gconst = gcs[p16];
 
@@ -886,43 +904,20 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) xin[ks] = xnext[ks];
         if (nb + 16 < w1) fetch(nb + 16, xnext);
-        // ---- query rows (generated), their LayerNorm statistics, scores against the folded keys, softmax over the two keys of a head
-        float4 e[16];
+        // ---- LayerNorm statistics of the (never generated) query row: var_q = x Qd x^T; scores = rstd_q (x . EG) + const; softmax over the
+        // two keys of a head (jh and jh ^ 8: eight lanes apart)
+        f32x4 yq = {0.f, 0.f, 0.f, 0.f}, sc = yq;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(xvs[(ks * 16 + jj) * 64 + lane], xin[ks], d, 0, 0, 0);
-            e[jj] = make_float4(d[0], d[1], d[2], d[3]);
+        for (int ks = 0; ks < 3; ++ks) {
+            yq = __builtin_amdgcn_mfma_f32_16x16x4f32(QDs[(4 * ks + g) * 16 + p16], xin[ks], yq, 0, 0, 0);       // lane (p, g) reg r: input 4 r + g
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xin[ks], EGs[(4 * ks + g) * 16 + p16], sc, 0, 0, 0);       // lane (jh = p16, g) reg r: point 4 g + r
         }
-        __builtin_amdgcn_sched_barrier(0);
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sum += (e[j].x + e[j].y) + (e[j].z + e[j].w);
-        sum += xor16(sum); sum += xor32(sum);
-        const float mean = sum * (1.0f / 256.0f);
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float a0 = e[j].x - mean, a1 = e[j].y - mean, a2 = e[j].z - mean, a3 = e[j].w - mean;
-            sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
-        sq += xor16(sq); sq += xor32(sq);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + 1e-5f);
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sc1 = sc, sc2 = sc, sc3 = sc;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 g4 = *reinterpret_cast<const float4*>(Gs + p16 * LDG + 16 * j + 4 * g);        // lane (jh = p16, g)
-            sc = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].x - mean) * rstd, g4.x, sc, 0, 0, 0);
-            sc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].y - mean) * rstd, g4.y, sc1, 0, 0, 0);
-            sc2 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].z - mean) * rstd, g4.z, sc2, 0, 0, 0);
-            sc3 = __builtin_amdgcn_mfma_f32_16x16x4f32((e[j].w - mean) * rstd, g4.w, sc3, 0, 0, 0);
-        }
-        sc = (sc + sc1) + (sc2 + sc3);
-        __builtin_amdgcn_sched_barrier(0);
+        float varq = (yq[0] * xin[0] + yq[1] * xin[1]) + yq[2] * xin[2];
+        varq += xor16(varq); varq += xor32(varq);
+        if (g == 0) tr[p16] = 1.0f / sqrtf(fmaxf(varq, 0.f) + 1e-5f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float s_own = sc[r] + gconst, s_oth = lane_xor<8>(s_own);
+            const float s_own = tr[4 * g + r] * sc[r] + gconst, s_oth = lane_xor<8>(s_own);
             const float mx = fmaxf(s_own, s_oth);
             const float e_own = __expf(s_own - mx), e_oth = __expf(s_oth - mx);
             aT[(4 * g + r) * 17 + p16] = e_own / (e_own + e_oth);
@@ -955,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(TXs[(3 * g + ks) * DP_LDX + 16 * tt + p16], xin[ks], acc, 0, 0, 0);
             const float4 cv = *reinterpret_cast<const float4*>(Cv + 16 * tt + 4 * g);
-            const float h0 = gelu_erf(rstd2 * acc[0] + cv.x), h1v = gelu_erf(rstd2 * acc[1] + cv.y), h2 = gelu_erf(rstd2 * acc[2] + cv.z), h3 = gelu_erf(rstd2 * acc[3] + cv.w);
+            const float h0 = gelu_erf_fast(rstd2 * acc[0] + cv.x), h1v = gelu_erf_fast(rstd2 * acc[1] + cv.y), h2 = gelu_erf_fast(rstd2 * acc[2] + cv.z), h3 = gelu_erf_fast(rstd2 * acc[3] + cv.w);
             const float* wrow = W2s + p16 * DP_LDW + 16 * tt + 4 * g;
             const float4 w4 = p16 < 8 ? *reinterpret_cast<const float4*>(wrow) : make_float4(0.f, 0.f, 0.f, 0.f);
             sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, h0, sa, 0, 0, 0);
@@ -985,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 struct CdmWs {
     float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
     float *lat_s, *lat_x, *lat_t1, *lat_t2, *lat_qkv, *lat_kv;     // batched latent chain: [2B] token rows
-    float *pc, *twp, *qtab;                                        // fused decoder: centred P rows, their TWc rows [16 B][256], quadratic forms [B][DP_QTAB]
+    float *pc, *twp, *qtab;                                        // fused decoder: centred P rows, their TWc rows [16 B][256], per-sample tables [B][DP_TAB]
     int64_t bytes;
 };
 
@@ -1005,7 +1000,7 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     const int64_t ntok = 2 * (int64_t)B;
     s.lat_s = take(ntok * w.enc_heads * w.dkv * 4); s.lat_x = take(ntok * w.dq * 4); s.lat_t1 = take(ntok * w.dq * 4);
     s.lat_t2 = take(ntok * w.dq * 4); s.lat_qkv = take(ntok * 3 * w.dq * 4); s.lat_kv = take(ntok * 2 * w.dkv * 4);
-    s.pc = take((int64_t)B * 16 * 256 * 4); s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * DP_QTAB * 4);
+    s.pc = take((int64_t)B * 16 * 256 * 4); s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * DP_TAB * 4);
     s.bytes = off;
     return s;
 }
@@ -1158,14 +1153,14 @@ int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, co
     constexpr int LDS = DP_LDS_FLOATS * (int)sizeof(float);
     static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
-    hipLaunchKernelGGL(lat_dectab_kernel, dim3(B), dim3(256), 0, s, ws.dec_lat, w.dec_xc, w.dec_qxx, ws.pc, ws.qtab);
+    hipLaunchKernelGGL(lat_dectab_kernel, dim3(B), dim3(256), 0, s, ws.dec_lat, w.dec_xc, w.dec_qxx, w.dec_dc, w.dec_q_norm, ws.pc, ws.qtab);
     AFM_CHECK_LAUNCH();
     TokLin p = {};                                    // TWc rows of the attention weights: Pc (W1 * gamma_mlp)^T
     p.X = ws.pc; p.ldx = 256; p.W[0] = w.dec_w1g; p.ncol = 256; p.Y = ws.twp; p.ldy = 256; p.ntok = 16 * B; p.N = 256; p.K = 256;
     AFM_TRY(launch_toklin(p, s));
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
     if (chunks > 16) chunks = 16;
-    hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.dec_lat, ws.twp, ws.qtab, w.dec_q_norm, w.gen_dec, w.dec_twx, w.dec_c,
+    hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.dec_lat, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
                        ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);
     AFM_CHECK_LAUNCH();
@@ -1247,7 +1242,7 @@ inline int cdm_mode(const afm_cdm_weights& w) {
     const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
     if (!folded) return 0;
     const bool gen = w.gen_enc && w.gen_dec && w.gen_qe && w.feat_dim + 1 <= GEN_K && !(w.flags & AFM_CDM_NO_GEN);
-    const bool fused = gen && w.dec_w1g && w.dec_c && w.dec_xc && w.dec_twx && w.dec_qxx && w.dec_heads == 8 && w.dkv == 256 && !(w.flags & AFM_CDM_NO_FUSE);
+    const bool fused = gen && w.dec_w1g && w.dec_c && w.dec_xc && w.dec_twx && w.dec_qxx && w.dec_dc && w.dec_qdd && w.dec_heads == 8 && w.dkv == 256 && !(w.flags & AFM_CDM_NO_FUSE);
     return fused ? 3 : (gen ? 2 : 1);
 }
 inline bool cdm_folded(const afm_cdm_weights& w) { return cdm_mode(w) != 0; }

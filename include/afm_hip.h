@@ -575,8 +575,11 @@ typedef struct {
      * linear1(z) = rstd * u (Tc (W1 * gamma)^T) + (b1 + W1 beta): a K = 28 product; h1 and z are never materialised.  Step-invariant parts:
      *   dec_w1g [dkv, dkv]  dec_mlp.fc1.w * dec_mlp.norm.w (columns scaled)      dec_c   [dkv]      dec_mlp.fc1.b + dec_mlp.fc1.w @ dec_mlp.norm.b
      *   dec_xc  [12, dkv]   the input rows of Tc (gen_dec + o.b, centred)         dec_twx [12, dkv]  dec_xc @ dec_w1g^T
-     *   dec_qxx [12, 12]    dec_xc @ dec_xc^T / dkv */
-    const float* dec_w1g; const float* dec_c; const float* dec_xc; const float* dec_twx; const float* dec_qxx;
+     *   dec_qxx [12, 12]    dec_xc @ dec_xc^T / dkv
+     * The attention scores fold the same way (the query row is LayerNorm_q of a linear map of the inputs): dec_dc [12, dkv] = gen_dec minus
+     * its row means, dec_qdd [16, 16] = dec_dc dec_dc^T / dkv in MFMA operand order (entry (k, i) = Qd[4 (i & 3) + (i >> 2)][k], 0 where
+     * an index is >= 12). */
+    const float* dec_w1g; const float* dec_c; const float* dec_xc; const float* dec_twx; const float* dec_qxx; const float* dec_dc; const float* dec_qdd;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
