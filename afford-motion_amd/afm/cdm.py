@@ -380,11 +380,15 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 xc = tx - tx.mean(1, keepdim=True)
                 w1g = w1 * g2[None, :]
                 dc = gen_dec - gen_dec.mean(1, keepdim=True)                       # the query row's LayerNorm: var = x Qd x^T, in MFMA operand order
-                qd = dc @ dc.t() / cm.dkv
-                qdd = torch.zeros(16, 16, dtype=torch.float64)
-                for i in range(16):
-                    if (i & 3) < 3:
-                        qdd[:12, i] = qd[4 * (i & 3) + (i >> 2), :]
+                def operand_order(q):                                              # [12, 12] -> [16, 16]: entry (k, i) = q[4 (i & 3) + (i >> 2)][k]
+                    o = torch.zeros(16, 16, dtype=torch.float64)
+                    for i in range(16):
+                        if (i & 3) < 3:
+                            o[:12, i] = q[4 * (i & 3) + (i >> 2), :]
+                    return o
+                qdd = operand_order(dc @ dc.t() / cm.dkv)
+                ec = gen_enc - gen_enc.mean(1, keepdim=True)                       # the encoder side: rows the latents attend over
+                folds.update(enc_ec=ec, enc_qee=operand_order(ec @ ec.t() / cm.dkv))
                 folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv, dec_dc=dc, dec_qdd=qdd)
             dev = cl.weight.device
             for name, t in folds.items():

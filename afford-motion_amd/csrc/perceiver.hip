@@ -305,6 +305,101 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
     }
 }
 
+
+// ---------------------------------------------------------------- enc_reduce without rows (round 3; GEN inputs)
+// The rows the two latents attend over are LayerNorm_kv of a linear map of the point's 12 inputs x = [x_t | features | 1], so, exactly as in
+// the decoder (dec_point_kernel): var = x Qe x^T (step-invariant 12 x 12 form), score[q] = rstd (x . EU[:, q]) + const with EU = Ec U'^T
+// (Ec = gen_enc minus its row means; 12 x 16 per sample and step, built in the prologue), and the attention-weighted sum of the normalised rows
+// is linear in sum_n p[n, q] rstd[n] x[n]: a wave accumulates 16 x 12 numbers instead of 16 x 256 and never generates a row.  Per 16 points:
+// 10 MFMAs (16x16x4) instead of 176; the partial (max, sum, 12-vector) records are merged and expanded by lat_combine_kernel.
+constexpr int EP_WAVES = 8, EP_SPLIT = NPART / EP_WAVES;
+__global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, const float* __restrict__ u_text, const float* __restrict__ cu_text,
+                                                                  const float* __restrict__ u_time, const float* __restrict__ cu_time,
+                                                                  const int64_t* __restrict__ t, int n_t, int N, float* __restrict__ pm, float* __restrict__ pl,
+                                                                  float* __restrict__ pacc12, const float* __restrict__ xt, int cd, const float* __restrict__ feat,
+                                                                  int fd, const float* __restrict__ ec, const float* __restrict__ qee) {
+    constexpr int NQ = 16;
+    __shared__ float EUs[16 * 16], QEs[16 * 16], ccs[16], trs[EP_WAVES][16];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    float* tr = trs[wave];
+    int64_t ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
+    if (threadIdx.x < 256) { QEs[threadIdx.x] = qee[threadIdx.x]; EUs[threadIdx.x] = 0.f; }
+    __syncthreads();
+    for (int q = wave; q < NQ; q += EP_WAVES) {                    // one wave per folded query: u' = gamma * u_q, its 12 dots with Ec, beta . u_q
+        const float* up = q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256;
+        const float4 u = *reinterpret_cast<const float4*>(up + lane * 4), gm = *reinterpret_cast<const float4*>(kvn.g + lane * 4),
+                     bt = *reinterpret_cast<const float4*>(kvn.b + lane * 4);
+        const float4 ug = make_float4(u.x * gm.x, u.y * gm.y, u.z * gm.z, u.w * gm.w);
+        const float d = wave_sum((u.x * bt.x + u.y * bt.y) + (u.z * bt.z + u.w * bt.w));
+        if (lane == 0) ccs[q] = d + (q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]);
+        for (int k = 0; k < GEN_K; ++k) {
+            const float4 e4 = *reinterpret_cast<const float4*>(ec + k * 256 + lane * 4);
+            const float dk = wave_sum((e4.x * ug.x + e4.y * ug.y) + (e4.z * ug.z + e4.w * ug.w));
+            if (lane == 0) EUs[k * 16 + q] = dk;
+        }
+    }
+    __syncthreads();
+    const float cconst = ccs[p16];
+
+    const int per = (N + EP_SPLIT - 1) / EP_SPLIT;
+    const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
+    const int wper = ((per + EP_WAVES - 1) / EP_WAVES + 15) & ~15;      // points per wave, whole tiles
+    const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
+
+    f32x4 wacc = {0.f, 0.f, 0.f, 0.f};                            // lane (q = p16, g): sum_n p[n, q] rstd[n] x[n][k = 4 g + r]
+    float m_run = -INFINITY, l_run = 0.f;                          // of query p16, replicated over g
+    auto input = [&](unsigned pti, int k) {                        // x[k] of point pti: x_t, features, the constant 1, zeros
+        const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
+        return k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
+    };
+    for (int nb = w0; nb < w1; nb += 16) {
+        float xin[3], xT[4];
+        {
+            const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) xin[ks] = input(pti, 4 * ks + g);           // lane (p, g): inputs 4 ks + g of point p
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xT[r] = input((unsigned)(b * N + min(nb + 4 * g + r, n1 - 1)), p16);      // lane (k = p16, g): input k of point 4 g + r
+        }
+        f32x4 yq = {0.f, 0.f, 0.f, 0.f}, sc = yq;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            yq = __builtin_amdgcn_mfma_f32_16x16x4f32(QEs[(4 * ks + g) * 16 + p16], xin[ks], yq, 0, 0, 0);       // lane (p, g) reg r: input 4 r + g
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xin[ks], EUs[(4 * ks + g) * 16 + p16], sc, 0, 0, 0);       // lane (q = p16, g) reg r: point 4 g + r
+        }
+        float varq = (yq[0] * xin[0] + yq[1] * xin[1]) + yq[2] * xin[2];
+        varq += xor16(varq); varq += xor32(varq);
+        if (g == 0) tr[p16] = 1.0f / sqrtf(fmaxf(varq, 0.f) + 1e-5f);
+        float rq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rq[r] = tr[4 * g + r];
+        const int nvalid = w1 - nb;                                // points 4 g + r >= nvalid do not exist
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = (4 * g + r < nvalid) ? rq[r] * sc[r] + cconst : -INFINITY;
+            mt = fmaxf(mt, sc[r]);
+        }
+        mt = fmaxf(mt, xor16(mt)); mt = fmaxf(mt, xor32(mt));
+        const float mn = fmaxf(m_run, mt);                         // finite: every processed tile has a valid point
+        const float alpha = __expf(m_run - mn);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = __expf(sc[r] - mn); ls += sc[r]; }
+        ls += xor16(ls); ls += xor32(ls);
+        l_run = l_run * alpha + ls;
+        m_run = mn;
+        wacc[0] *= alpha; wacc[1] *= alpha; wacc[2] *= alpha; wacc[3] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xT[r], sc[r] * rq[r], wacc, 0, 0, 0);
+    }
+    const int part = blockIdx.x * EP_WAVES + wave;
+    const int64_t base = ((int64_t)b * NPART + part) * NQ;
+    if (g == 0) { pm[base + p16] = m_run; pl[base + p16] = l_run; }
+    *reinterpret_cast<float4*>(pacc12 + (base + p16) * 16 + 4 * g) = make_float4(wacc[0], wacc[1], wacc[2], wacc[3]);
+}
+
 // ---------------------------------------------------------------- latent chain, batched over the samples
 // The 2-latent chain (cross-attention output, o_proj, MLP, self-attention blocks, decoder K / V folding) is ~16 dependent
 // matrix-vector stages per sample.  It runs batched over all 2 B latent tokens as a sequence of small launches: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
@@ -406,8 +501,9 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
 __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                           const float* __restrict__ pacc, int nih, int dkv, const float* __restrict__ q0_text,
                                                           const float* __restrict__ q0_time, const int64_t* __restrict__ t, int n_t, int dq,
-                                                          float* __restrict__ sbuf, float* __restrict__ x0) {
+                                                          float* __restrict__ sbuf, float* __restrict__ x0, const float* __restrict__ ec, afm_ln kvn) {
     __shared__ float wq[NPART];
+    __shared__ float a12[16];
     const int b = blockIdx.x, ih = blockIdx.y;
     if (threadIdx.x < 64) {                                       // wave 0: NPART = 64 partial (max, sum) pairs
         const int pi = threadIdx.x;
@@ -421,7 +517,21 @@ __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restric
     }
     __syncthreads();
     const int c = threadIdx.x;
-    if (c < dkv) {
+    if (ec) {                                                     // uniform.  enc_point_kernel's partials: 12-vectors (stride 16), expanded here:
+        if (c < 16) {                                             // sum_n a_n LayerNorm_kv(row_n) = gamma * (sum_k a12[k] Ec[k]) + beta
+            float a = 0.f;
+            for (int pi = 0; pi < NPART; ++pi) a += wq[pi] * pacc[(((int64_t)b * NPART + pi) * nih + ih) * 16 + c];
+            a12[c] = a;
+        }
+        __syncthreads();
+        if (c < dkv) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < GEN_K; ++k) a += a12[k] * ec[k * dkv + c];
+            const int He = nih / 2, i = ih / He, h = ih % He;
+            sbuf[(((int64_t)b * 2 + i) * He + h) * dkv + c] = kvn.g[c] * a + kvn.b[c];
+        }
+    } else if (c < dkv) {
         float a = 0.f;
         for (int pi = 0; pi < NPART; ++pi) a += wq[pi] * pacc[(((int64_t)b * NPART + pi) * nih + ih) * dkv + c];
         const int He = nih / 2, i = ih / He, h = ih % He;
@@ -1111,6 +1221,12 @@ int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* 
         return rc ? rc : (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }();
     if (attr != 0) return attr;
+    if (mode == 3) {                                  // no rows at all: 12-vector partials in ws.pacc (stride 16)
+        hipLaunchKernelGGL(enc_point_kernel, dim3(EP_SPLIT, B), dim3(64 * EP_WAVES), 0, s, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t, w.n_timesteps, N,
+                           ws.pm, ws.pl, ws.pacc, x_t, w.contact_dim, feat, w.feat_dim, w.enc_ec, w.enc_qee);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
     const dim3 grid(ERM_SPLIT, B), block(64 * ERM_WAVES);
     if (mode == 2) hipLaunchKernelGGL(enc_reduce_mfma_kernel<2>, grid, block, LDS, s, (const float*)nullptr, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
                                       w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.gen_enc, w.contact_dim, feat, w.feat_dim);
@@ -1181,11 +1297,11 @@ int launch_toklin(const TokLin& p, hipStream_t s) {
 }
 
 // enc_reduce partials -> dec_lat records, as 17 small launches over all 2 B latent tokens (see toklin_kernel; 14-18 us each, ~2 us apart)
-int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s) {
+int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool enc12 = false) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
     hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
-                       ws.lat_s, ws.lat_x);
+                       ws.lat_s, ws.lat_x, enc12 ? w.enc_ec : (const float*)nullptr, w.enc_kv_norm);
     AFM_CHECK_LAUNCH();
     auto lin = [&](const float* X, int ldx, int K, const afm_lin& l, int N, float* Y, int ldy) {
         TokLin p = {};
@@ -1232,8 +1348,8 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
     return 0;
 }
 
-int cdm_latents(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s) {
-    return cdm_latent_chain(w, text_q0, t, ws, B, s);
+int cdm_latents(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool enc12 = false) {
+    return cdm_latent_chain(w, text_q0, t, ws, B, s, enc12);
 }
 
 // sampling form of the per-point kernels: 3 = GEN encoder side + the fused decoder (dec_point_kernel), 2 = GEN (generator tables present,
@@ -1242,7 +1358,7 @@ inline int cdm_mode(const afm_cdm_weights& w) {
     const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
     if (!folded) return 0;
     const bool gen = w.gen_enc && w.gen_dec && w.gen_qe && w.feat_dim + 1 <= GEN_K && !(w.flags & AFM_CDM_NO_GEN);
-    const bool fused = gen && w.dec_w1g && w.dec_c && w.dec_xc && w.dec_twx && w.dec_qxx && w.dec_dc && w.dec_qdd && w.dec_heads == 8 && w.dkv == 256 && !(w.flags & AFM_CDM_NO_FUSE);
+    const bool fused = gen && w.dec_w1g && w.dec_c && w.dec_xc && w.dec_twx && w.dec_qxx && w.dec_dc && w.dec_qdd && w.enc_ec && w.enc_qee && w.dec_heads == 8 && w.dkv == 256 && !(w.flags & AFM_CDM_NO_FUSE);
     return fused ? 3 : (gen ? 2 : 1);
 }
 inline bool cdm_folded(const afm_cdm_weights& w) { return cdm_mode(w) != 0; }
@@ -1273,8 +1389,8 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
                        bool prepared, hipStream_t s) {
     const int M = B * N, dkv = w.dkv, cd = w.contact_dim, mode = cdm_mode(w);
     if (mode == 1 && !prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
-    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, feat, mode >= 2 ? 2 : mode, s));
-    AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s));
+    AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, feat, mode, s));
+    AFM_TRY(cdm_latents(w, text_q0, t, ws, B, s, mode == 3));
     if (mode == 3) return launch_dec_point(w, B, N, ws, x_t, feat, x0_out, ddpm, s);
     AFM_TRY(launch_dec_attend(w, B, N, ws, x_t, feat, mode, s));
     afm_linear_args a = {};                 // GELU(linear1 z) . w2 per 64-column group; the hidden activations are never stored

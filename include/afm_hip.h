@@ -580,6 +580,9 @@ typedef struct {
      * its row means, dec_qdd [16, 16] = dec_dc dec_dc^T / dkv in MFMA operand order (entry (k, i) = Qd[4 (i & 3) + (i >> 2)][k], 0 where
      * an index is >= 12). */
     const float* dec_w1g; const float* dec_c; const float* dec_xc; const float* dec_twx; const float* dec_qxx; const float* dec_dc; const float* dec_qdd;
+    /* and so does the encoder side (the rows the latents attend over are LayerNorm_kv of a linear map of the inputs): enc_ec [12, dkv] =
+     * gen_enc minus its row means, enc_qee [16, 16] = enc_ec enc_ec^T / dkv in the same operand order as dec_qdd. */
+    const float* enc_ec; const float* enc_qee;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
