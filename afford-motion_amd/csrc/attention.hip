@@ -541,7 +541,7 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     }
     const size_t lds = (size_t)2 * KVSTAGE + (size_t)nkb * KB * sizeof(float) + (size_t)nkb * sizeof(int);
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~25000 keys
-    AfmProf prof(AFM_PROF_MHA, 4.0 * B * H * (double)Tq * T * dh, s);
+    AfmProf prof(AFM_PROF_MHA_SPLIT, 4.0 * B * H * (double)Tq * T * dh, s);
     switch (nw) {
         case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
         case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
