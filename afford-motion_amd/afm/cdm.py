@@ -389,6 +389,17 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 qdd = operand_order(dc @ dc.t() / cm.dkv)
                 ec = gen_enc - gen_enc.mean(1, keepdim=True)                       # the encoder side: rows the latents attend over
                 folds.update(enc_ec=ec, enc_qee=operand_order(ec @ ec.t() / cm.dkv))
+                # head of the latent chain: x1 = q0 + o_proj(v_proj(LayerNorm_kv-weighted sums)) is linear in the 8 x 12 numbers enc_point_kernel accumulates
+                ea = cm.encoder_cross_attn[0].module
+                gk, bk = f64(ea.kv_norm.weight), f64(ea.kv_norm.bias)
+                wv, bv, wo, bo_e = f64(ea.attention.v_proj.weight), f64(ea.attention.v_proj.bias), f64(ea.attention.o_proj.weight), f64(ea.attention.o_proj.bias)
+                hd = cm.dq // 8                                                    # the kernel is written for the reference's 8 encoder heads
+                wve = (ec * gk[None, :]) @ wv.t()                                  # [12, dq]: v_proj of gamma * Ec[k]
+                wove = torch.zeros(8 * 12, cm.dq, dtype=torch.float64)
+                for h in range(8):
+                    blk = slice(h * hd, (h + 1) * hd)
+                    wove[12 * h:12 * h + 12] = wve[:, blk] @ wo[:, blk].t()
+                folds.update(enc_wove=wove, enc_c1=bo_e + wo @ (wv @ bk + bv))
                 folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv, dec_dc=dc, dec_qdd=qdd)
             dev = cl.weight.device
             for name, t in folds.items():

@@ -106,7 +106,7 @@ class CdmWeights(C.Structure):
         ("fold_xu", c_f32p), ("fold_xv", c_f32p), ("fold_w2", c_f32p), ("flags", i32), ("fold_q", c_f32p), ("fold_c0", c_f32p),
         # generator tables of the two adapters (ABI v5; all three or none)
         ("gen_enc", c_f32p), ("gen_dec", c_f32p), ("gen_qe", c_f32p),
-        ("dec_w1g", c_f32p), ("dec_c", c_f32p), ("dec_xc", c_f32p), ("dec_twx", c_f32p), ("dec_qxx", c_f32p), ("dec_dc", c_f32p), ("dec_qdd", c_f32p), ("enc_ec", c_f32p), ("enc_qee", c_f32p),
+        ("dec_w1g", c_f32p), ("dec_c", c_f32p), ("dec_xc", c_f32p), ("dec_twx", c_f32p), ("dec_qxx", c_f32p), ("dec_dc", c_f32p), ("dec_qdd", c_f32p), ("enc_ec", c_f32p), ("enc_qee", c_f32p), ("enc_wove", c_f32p), ("enc_c1", c_f32p),
     ]
 
 

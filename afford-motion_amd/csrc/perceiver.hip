@@ -545,6 +545,48 @@ __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restric
     }
 }
 
+// The head of the chain in one launch (fused sampling form): merge enc_point_kernel's partials of the 8 heads of a latent token into the
+// 8 x 12 numbers a12[h][k] = sum_n a[n] rstd[n] x[n][k], then apply everything that is linear behind them at once -
+//   x1 = q0 + o_proj(v_proj(gamma_kv * (a12 Ec) + beta_kv)) = q0 + c1 + sum_{h, k} a12[h][k] WOVE[12 h + k]
+// with WOVE [96][dq] = W_o (per-head blocks) W_v (gamma_kv * Ec)^T and c1 = b_o + W_o (W_v beta_kv + b_v) from the host (float64).
+// Replaces lat_combine + the v-proj and o-proj toklin launches.  grid (B, 2 latents), block 256.
+__global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__ pm, const float* __restrict__ pl, const float* __restrict__ pacc12,
+                                                       const float* __restrict__ q0_text, const float* __restrict__ q0_time,
+                                                       const int64_t* __restrict__ t, int n_t, int dq, const float* __restrict__ wove,
+                                                       const float* __restrict__ c1, float* __restrict__ x1) {
+    __shared__ float a12[8 * GEN_K];
+    const int b = blockIdx.x, i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = wave; h < 8; h += 4) {                            // lane = one of the NPART = 64 partials
+        const int ih = i * 8 + h;
+        const int64_t base = ((int64_t)b * NPART + lane) * 16 + ih;
+        const float mm = pm[base];
+        float M = mm;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+        const float ww = (mm == -INFINITY) ? 0.f : __expf(mm - M);
+        const float L = wave_sum(pl[base] * ww);
+        const float wq = ww * (1.0f / L);
+        const float4* pa = reinterpret_cast<const float4*>(pacc12 + base * 16);
+        const float4 v0 = pa[0], v1 = pa[1], v2 = pa[2];
+        const float vals[GEN_K] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int k = 0; k < GEN_K; ++k) {
+            const float sk = wave_sum(wq * vals[k]);
+            if (lane == 0) a12[h * GEN_K + k] = sk;
+        }
+    }
+    __syncthreads();
+    int64_t ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
+    const float* q0 = i == 0 ? q0_text + (int64_t)b * dq : q0_time + ti * dq;
+    for (int n = threadIdx.x; n < dq; n += 256) {
+        float v = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 8 * GEN_K; ++j) v += a12[j] * wove[(int64_t)j * dq + n];
+        x1[((int64_t)b * 2 + i) * dq + n] = (q0[n] + c1[n]) + v;
+    }
+}
+
 // self-attention of the two latent tokens of a sample (modules.py:544-648): qkv [ntok][3 dq] -> out [ntok][dq].  grid B, block 256.
 __global__ __launch_bounds__(256) void lat_selfattn_kernel(const float* __restrict__ qkv, int dq, int He, float* __restrict__ out) {
     __shared__ float sc[64], aw[64];
@@ -1300,8 +1342,10 @@ int launch_toklin(const TokLin& p, hipStream_t s) {
 int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool enc12 = false) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
-    hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
-                       ws.lat_s, ws.lat_x, enc12 ? w.enc_ec : (const float*)nullptr, w.enc_kv_norm);
+    const bool head = enc12 && w.enc_wove && w.enc_c1 && He == 8;       // combine + v-proj + o-proj as one launch (lat_head_kernel)
+    if (head) hipLaunchKernelGGL(lat_head_kernel, dim3(B, 2), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
+    else hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
+                            ws.lat_s, ws.lat_x, enc12 ? w.enc_ec : (const float*)nullptr, w.enc_kv_norm);
     AFM_CHECK_LAUNCH();
     auto lin = [&](const float* X, int ldx, int K, const afm_lin& l, int N, float* Y, int ldy) {
         TokLin p = {};
@@ -1316,7 +1360,9 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
         p.R = ws.lat_x; p.ldr = dq;
         return launch_toklin(p, s);
     };
-    {   // attention output of the encoder cross-attention: o[tok, h hd + r] = W_v[h hd + r] . s[tok, h] + b_v, then o_proj + residual, MLP
+    if (head) {
+        AFM_TRY(mlp(w.enc_mlp));
+    } else {   // attention output of the encoder cross-attention: o[tok, h hd + r] = W_v[h hd + r] . s[tok, h] + b_v, then o_proj + residual, MLP
         TokLin p = lin(ws.lat_s, He * dkv, dkv, w.enc_attn.v, dq, ws.lat_t1, dq);
         p.head_out = dq / He; p.x_head_stride = dkv;
         AFM_TRY(launch_toklin(p, s));

@@ -583,6 +583,9 @@ typedef struct {
     /* and so does the encoder side (the rows the latents attend over are LayerNorm_kv of a linear map of the inputs): enc_ec [12, dkv] =
      * gen_enc minus its row means, enc_qee [16, 16] = enc_ec enc_ec^T / dkv in the same operand order as dec_qdd. */
     const float* enc_ec; const float* enc_qee;
+    /* optional, with enc_ec: the head of the latent chain as one launch.  enc_wove [8 * 12, dq]: row 12 h + k = o_proj (columns of head h) applied to
+     * v_proj (rows of head h) applied to enc_kv_norm.w * enc_ec[k]; enc_c1 [dq] = o_proj.b + o_proj.w (v_proj.w enc_kv_norm.b + v_proj.b). */
+    const float* enc_wove; const float* enc_c1;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
