@@ -400,6 +400,15 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                     blk = slice(h * hd, (h + 1) * hd)
                     wove[12 * h:12 * h + 12] = wve[:, blk] @ wo[:, blk].t()
                 folds.update(enc_wove=wove, enc_c1=bo_e + wo @ (wv @ bk + bv))
+                # tail of the chain: the fused decoder's per-sample tables are linear / bilinear in the latents' decoder keys and values
+                da_m = cm.decoder_cross_attn[0].module
+                gq, bq_n = f64(da_m.q_norm.weight), f64(da_m.q_norm.bias)
+                wq_d, bq_d, wo_d = f64(da_m.attention.q_proj.weight), f64(da_m.attention.q_proj.bias), f64(da_m.attention.o_proj.weight)
+                woc = wo_d - wo_d.mean(0, keepdim=True)
+                wco = torch.zeros(8, cm.dkv, dtype=torch.float64)
+                wco[:cd] = wc @ wo_d
+                folds.update(dec_dwq=(dc * gq[None, :]) @ wq_d.t(), dec_wqb=wq_d @ bq_n + bq_d, dec_wco=wco, dec_wow=woc.t() @ w1g.t(),
+                             dec_wog=woc.t() @ woc / cm.dkv, dec_xwo=xc @ woc / cm.dkv)
                 folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv, dec_dc=dc, dec_qdd=qdd)
             dev = cl.weight.device
             for name, t in folds.items():

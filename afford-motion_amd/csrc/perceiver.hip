@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restric
 // 8 x 12 numbers a12[h][k] = sum_n a[n] rstd[n] x[n][k], then apply everything that is linear behind them at once -
 //   x1 = q0 + o_proj(v_proj(gamma_kv * (a12 Ec) + beta_kv)) = q0 + c1 + sum_{h, k} a12[h][k] WOVE[12 h + k]
 // with WOVE [96][dq] = W_o (per-head blocks) W_v (gamma_kv * Ec)^T and c1 = b_o + W_o (W_v beta_kv + b_v) from the host (float64).
-// Replaces lat_combine + the v-proj and o-proj toklin launches.  grid (B, 2 latents), block 256.
+// Replaces lat_combine + the v-proj and o-proj toklin launches.  grid (B, 2 latents, dq / 256), block 256.
 __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__ pm, const float* __restrict__ pl, const float* __restrict__ pacc12,
                                                        const float* __restrict__ q0_text, const float* __restrict__ q0_time,
                                                        const int64_t* __restrict__ t, int n_t, int dq, const float* __restrict__ wove,
@@ -579,11 +579,15 @@ __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__
     int64_t ti = t[b];
     ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
     const float* q0 = i == 0 ? q0_text + (int64_t)b * dq : q0_time + ti * dq;
-    for (int n = threadIdx.x; n < dq; n += 256) {
-        float v = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < 8 * GEN_K; ++j) v += a12[j] * wove[(int64_t)j * dq + n];
-        x1[((int64_t)b * 2 + i) * dq + n] = (q0[n] + c1[n]) + v;
+    const int n = blockIdx.z * 256 + threadIdx.x;                 // one output per thread: the 96 loads of its column are independent
+    if (n < dq) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8 * GEN_K; j += 4) {
+            v0 += a12[j] * wove[(int64_t)j * dq + n]; v1 += a12[j + 1] * wove[(int64_t)(j + 1) * dq + n];
+            v2 += a12[j + 2] * wove[(int64_t)(j + 2) * dq + n]; v3 += a12[j + 3] * wove[(int64_t)(j + 3) * dq + n];
+        }
+        x1[((int64_t)b * 2 + i) * dq + n] = (q0[n] + c1[n]) + ((v0 + v1) + (v2 + v3));
     }
 }
 
@@ -913,8 +917,8 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
 // never generated either.
 constexpr int DP_LDG = 260, DP_LDX = 272, DP_LDQ = 36, DP_LDW = 260;
 constexpr int DP_QTAB = 32 * DP_LDQ;                              // floats of a sample's quadratic-form table
-constexpr int DP_TAB = DP_QTAB + 16 * 16 + 16;                    // + EG [12 -> 16][16] + gconst [16]: a sample's table of the step
-constexpr int DP_LDS_FLOATS = 16 * DP_LDG + 12 * DP_LDX + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
+constexpr int DP_TAB = DP_QTAB + 16 * 16 + 16 + 8 * 16;           // + EG [12 -> 16][16] + gconst [16] + WP [8][16]: a sample's table of the step
+constexpr int DP_LDS_FLOATS = 16 * DP_LDG + 12 * DP_LDX + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
 
 // grid B, block 256 (thread = channel c).  pc [B][16][256] = P - rowmean(P); qtab [B][32][DP_LDQ]: entry (cs, 16 t + i) = Qc[m'(t, i)][m(cs)] with
 // the K index in operand order (cs < 16: attention weight cs; cs = 16 + 4 g + ks: input 4 ks + g) and the output rows of tile 1 permuted so
@@ -987,10 +991,97 @@ __global__ __launch_bounds__(256) void lat_dectab_kernel(const float* __restrict
             for (int cc = 0; cc < 256; ++cc) d += Ts[16 + k][cc] * Ts[jh][cc];
         qtab[(int64_t)b * DP_TAB + DP_QTAB + c] = d;
         if (c < 16) qtab[(int64_t)b * DP_TAB + DP_QTAB + 256 + c] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + G[2 * 16 * 256 + c];
+        if (c < 128) qtab[(int64_t)b * DP_TAB + DP_QTAB + 256 + 16 + c] = G[2 * 16 * 256 + 16 + c];      // WP [8][16] as lat_decfold_kernel left it (rows >= contact_dim unused)
     }
 }
 
-__global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restrict__ dec_lat, const float* __restrict__ twp, const float* __restrict__ qtab,
+// All per-sample tables of dec_point_kernel straight from the decoder keys / values of the sample's two latents (lat_kv, 2 x 2 x 256 numbers) and
+// step-invariant matrices (afm_cdm_weights.dec_*; o = 32 h + r runs over a head's 32 key / value entries, jh = 8 j + h):
+//   EG[k][jh]     = scd sum_r kd_j[o] DWQ[k][o]            gconst[jh] = scd sum_r kd_j[o] wqb[o]            WP[r'][jh] = sum_r vd_j[o] WCO[r'][o]
+//   TWc[jh][n]    = sum_r vd_j[o] WOW[o][n]                (centred P rows times (W1 gamma)^T, P itself is never formed)
+//   Qc[jh][jh']   = sum_{r, r'} vd_j[o] WoG[o][o'] vd_j'[o'],  Qc[jh][16 + k] = sum_r vd_j[o] XWO[k][o],  Qc[16 + k][16 + k'] = qxx
+// Replaces lat_decfold + lat_dectab + the TWc toklin launch of the fused form.  grid B, block 1024 (the two [256][256] products: thread =
+// (column, pair of heads), 64 independent row loads each; the small tables on the first 256 threads).
+__global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __restrict__ lat_kv, const float* __restrict__ dwq, const float* __restrict__ wqb,
+                                                            const float* __restrict__ wco, const float* __restrict__ wow, const float* __restrict__ wog,
+                                                            const float* __restrict__ xwo, const float* __restrict__ qxx, int cd,
+                                                            float* __restrict__ twp, float* __restrict__ tab) {
+    __shared__ float kd[2][256], vd[2][256];
+    __shared__ float tv[16][257];
+    __shared__ float Q[28][29];
+    const int b = blockIdx.x, c = threadIdx.x & 255, gq4 = threadIdx.x >> 8;
+    const float scd = 0.17677669529663687f;                       // 1 / sqrt(32)
+    if (gq4 < 2) {
+        kd[gq4][c] = lat_kv[((int64_t)b * 2 + gq4) * 512 + c];
+        vd[gq4][c] = lat_kv[((int64_t)b * 2 + gq4) * 512 + 256 + c];
+    }
+    __syncthreads();
+    {   // column c of the two [256][256] matrices against the value vectors of heads 2 gq4, 2 gq4 + 1: TWc rows (to memory), tv = vd WoG (to LDS)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * gq4 + hh;
+            float t0 = 0.f, t1 = 0.f, g0 = 0.f, g1 = 0.f;
+#pragma unroll 16
+            for (int r = 0; r < 32; ++r) {
+                const int o = 32 * h + r;
+                const float w1 = wow[o * 256 + c], w2 = wog[o * 256 + c], v0 = vd[0][o], v1 = vd[1][o];
+                t0 += v0 * w1; t1 += v1 * w1;
+                g0 += v0 * w2; g1 += v1 * w2;
+            }
+            twp[((int64_t)b * 16 + h) * 256 + c] = t0; twp[((int64_t)b * 16 + 8 + h) * 256 + c] = t1;
+            tv[h][c] = g0; tv[8 + h][c] = g1;
+        }
+    }
+    float* T = tab + (int64_t)b * DP_TAB;
+    if (gq4 > 0) {
+        // (the small tables below belong to the first 256 threads)
+    } else if (c < 192) {                                                // EG [12][16] and the attention-weight x input block of Qc
+        const int k = c >> 4, jh = c & 15, j = jh >> 3, h = jh & 7;
+        float e = 0.f, q = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) { e += kd[j][32 * h + r] * dwq[k * 256 + 32 * h + r]; q += vd[j][32 * h + r] * xwo[k * 256 + 32 * h + r]; }
+        T[DP_QTAB + c] = e * scd;
+        Q[jh][16 + k] = q; Q[16 + k][jh] = q;
+    } else {
+        T[DP_QTAB + c] = 0.f;                                      // rows k >= 12 of the EG table
+    }
+    if (gq4 == 0 && c < 16) {
+        const int j = c >> 3, h = c & 7;
+        float gq = 0.f;
+        for (int r = 0; r < 32; ++r) gq += kd[j][32 * h + r] * wqb[32 * h + r];
+        T[DP_QTAB + 256 + c] = gq * scd;
+    }
+    if (gq4 == 0 && c < 128) {                                    // WP [8][16]
+        const int rr = c >> 4, jh = c & 15, j = jh >> 3, h = jh & 7;
+        float wp = 0.f;
+        if (rr < cd)
+            for (int r = 0; r < 32; ++r) wp += vd[j][32 * h + r] * wco[rr * 256 + 32 * h + r];
+        T[DP_QTAB + 256 + 16 + c] = wp;
+    }
+    if (gq4 == 1 && c < 144) Q[16 + c / 12][16 + c % 12] = qxx[c];
+    __syncthreads();
+    if (gq4 == 0) {   // Qc[jh][jh'] = tv[jh] (head block of jh') . vd_j'
+        const int jh = c >> 4, jh2 = c & 15, j2 = jh2 >> 3, h2 = jh2 & 7;
+        float q = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) q += tv[jh][32 * h2 + r] * vd[j2][32 * h2 + r];
+        Q[jh][jh2] = q;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < DP_QTAB; e += 1024) {
+        const int cs = e / DP_LDQ, col = e - cs * DP_LDQ;
+        float v = 0.f;
+        if (col < 32) {
+            const int i = col & 15, x = cs - 16;
+            const int m2 = col < 16 ? i : ((i & 3) < 3 ? 16 + 4 * (i & 3) + (i >> 2) : -1);
+            const int m = cs < 16 ? cs : ((x & 3) < 3 ? 16 + 4 * (x & 3) + (x >> 2) : -1);
+            if (m >= 0 && m2 >= 0) v = Q[m2][m];
+        }
+        T[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab,
                                                            const float* __restrict__ qdd, const float* __restrict__ twx,
                                                            const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe,
                                                            const float* __restrict__ c0, int N, int cd, const float* xt, const float* __restrict__ feat, int fd,
@@ -1003,16 +1094,15 @@ __global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restri
     float* Qs = TXs + 12 * DP_LDX;                                // [32][LDQ]  quadratic form of the MLP's LayerNorm, operand order (lat_dectab_kernel)
     float* EGs = Qs + DP_QTAB;                                    // [16][16]   scores: row k = input, column jh
     float* gcs = EGs + 16 * 16;                                   // [16]       beta_q . G[jh] + cb[jh]
-    float* W2s = gcs + 16;                                        // [8][LDW]   contact_layer.w fc2.w  (rows >= cd: 0)
+    float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P
+    float* W2s = WPs + 8 * 16;                                    // [8][LDW]   contact_layer.w fc2.w  (rows >= cd: 0)
     float* Cv = W2s + 8 * DP_LDW;                                 // [256]      b1 + W1 beta_mlp
     float* QDs = Cv + 256;                                        // [16][16]   quadratic form of the query's LayerNorm, operand order (host)
-    float* WPs = QDs + 16 * 16;                                   // [8][16]    contact_layer.w . P
-    float* QEs = WPs + 8 * 16;                                    // [8][16]    contact_layer.w . gen_dec^T  (columns >= 12: 0)
+    float* QEs = QDs + 16 * 16;                                   // [8][16]    contact_layer.w . gen_dec^T  (columns >= 12: 0)
     float* c0s = QEs + 8 * 16;                                    // [16]
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* aT = c0s + 16 + wave * 16 * 17;                        // [16 points][17] attention weights of the tile, transposed
     float* tr = c0s + 16 + 4 * 16 * 17 + wave * 16;               // [16] a per-point scalar from lanes (p, .) to lanes (., g)
-    const float* rec = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
     for (int i = threadIdx.x; i < NJH * 64; i += 256) {            // (row, float4) items
         const int jh = i >> 6, c = (i & 63) * 4;
         *reinterpret_cast<float4*>(TWs + jh * LDG + c) = *reinterpret_cast<const float4*>(twp + ((int64_t)b * 16 + jh) * 256 + c);
@@ -1021,13 +1111,12 @@ __global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restri
         const int k = i >> 6, c = (i & 63) * 4;
         *reinterpret_cast<float4*>(TXs + (3 * (k & 3) + (k >> 2)) * DP_LDX + c) = *reinterpret_cast<const float4*>(twx + k * 256 + c);
     }
-    for (int i = threadIdx.x; i < DP_TAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_TAB + i];      // Qs | EGs | gcs are contiguous, like the table
+    for (int i = threadIdx.x; i < DP_TAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_TAB + i];      // Qs | EGs | gcs | WPs are contiguous, like the table
     for (int i = threadIdx.x; i < 8 * 256; i += 256) W2s[(i >> 8) * DP_LDW + (i & 255)] = (i >> 8) < cd ? w2f[i] : 0.f;
     Cv[threadIdx.x] = cvec[threadIdx.x];
     QDs[threadIdx.x] = qdd[threadIdx.x];
     if (threadIdx.x < 8 * 16) {
         const int j = threadIdx.x >> 4, k = threadIdx.x & 15;
-        WPs[threadIdx.x] = j < cd ? rec[2 * NJH * 256 + NJH + threadIdx.x] : 0.f;
         QEs[threadIdx.x] = (j < cd && k < GEN_K) ? gen_qe[j * GEN_K + k] : 0.f;
     }
     if (threadIdx.x < 16) c0s[threadIdx.x] = (int)threadIdx.x < cd ? c0[threadIdx.x] : 0.f;
@@ -1303,6 +1392,7 @@ int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
 }
 
 int launch_toklin(const TokLin& p, hipStream_t s);
+inline bool dec_tables_from_kv(const afm_cdm_weights& w) { return w.dec_wow && w.dec_wog && w.dec_dwq && w.dec_wqb && w.dec_wco && w.dec_xwo; }
 
 // the fused decoder (mode 3): per-sample tables of the step (two small launches), then one kernel over the points
 int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
@@ -1311,14 +1401,20 @@ int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, co
     constexpr int LDS = DP_LDS_FLOATS * (int)sizeof(float);
     static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
-    hipLaunchKernelGGL(lat_dectab_kernel, dim3(B), dim3(256), 0, s, ws.dec_lat, w.dec_xc, w.dec_qxx, w.dec_dc, w.dec_q_norm, ws.pc, ws.qtab);
-    AFM_CHECK_LAUNCH();
-    TokLin p = {};                                    // TWc rows of the attention weights: Pc (W1 * gamma_mlp)^T
-    p.X = ws.pc; p.ldx = 256; p.W[0] = w.dec_w1g; p.ncol = 256; p.Y = ws.twp; p.ldy = 256; p.ntok = 16 * B; p.N = 256; p.K = 256;
-    AFM_TRY(launch_toklin(p, s));
+    if (dec_tables_from_kv(w)) {                      // all tables from the latents' keys / values in one launch
+        hipLaunchKernelGGL(lat_dectables_kernel, dim3(B), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
+                           w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
+        AFM_CHECK_LAUNCH();
+    } else {                                          // (the chain ended with lat_decfold_kernel)
+        hipLaunchKernelGGL(lat_dectab_kernel, dim3(B), dim3(256), 0, s, ws.dec_lat, w.dec_xc, w.dec_qxx, w.dec_dc, w.dec_q_norm, ws.pc, ws.qtab);
+        AFM_CHECK_LAUNCH();
+        TokLin p = {};                                // TWc rows of the attention weights: Pc (W1 * gamma_mlp)^T
+        p.X = ws.pc; p.ldx = 256; p.W[0] = w.dec_w1g; p.ncol = 256; p.Y = ws.twp; p.ldy = 256; p.ntok = 16 * B; p.N = 256; p.K = 256;
+        AFM_TRY(launch_toklin(p, s));
+    }
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
     if (chunks > 16) chunks = 16;
-    hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.dec_lat, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
+    hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
                        ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);
     AFM_CHECK_LAUNCH();
@@ -1343,7 +1439,7 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
     const bool head = enc12 && w.enc_wove && w.enc_c1 && He == 8;       // combine + v-proj + o-proj as one launch (lat_head_kernel)
-    if (head) hipLaunchKernelGGL(lat_head_kernel, dim3(B, 2), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
+    if (head) hipLaunchKernelGGL(lat_head_kernel, dim3(B, 2, (dq + 255) / 256), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
     else hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
                             ws.lat_s, ws.lat_x, enc12 ? w.enc_ec : (const float*)nullptr, w.enc_kv_norm);
     AFM_CHECK_LAUNCH();
@@ -1388,8 +1484,10 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
         p.W[1] = w.dec_attn.v.w; p.b[1] = w.dec_attn.v.b; p.ncol = dkv;
         p.ln = w.dec_kv_norm; p.use_ln = 1;
         AFM_TRY(launch_toklin(p, s));
-        hipLaunchKernelGGL(lat_decfold_kernel, dim3(B, w.dec_heads), dim3(256), 0, s, w, ws.lat_kv, ws.dec_lat);
-        AFM_CHECK_LAUNCH();
+        if (!(enc12 && dec_tables_from_kv(w))) {      // the fused form builds its tables from lat_kv itself (lat_dectables_kernel)
+            hipLaunchKernelGGL(lat_decfold_kernel, dim3(B, w.dec_heads), dim3(256), 0, s, w, ws.lat_kv, ws.dec_lat);
+            AFM_CHECK_LAUNCH();
+        }
     }
     return 0;
 }

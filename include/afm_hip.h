@@ -586,6 +586,11 @@ typedef struct {
     /* optional, with enc_ec: the head of the latent chain as one launch.  enc_wove [8 * 12, dq]: row 12 h + k = o_proj (columns of head h) applied to
      * v_proj (rows of head h) applied to enc_kv_norm.w * enc_ec[k]; enc_c1 [dq] = o_proj.b + o_proj.w (v_proj.w enc_kv_norm.b + v_proj.b). */
     const float* enc_wove; const float* enc_c1;
+    /* optional, with dec_*: every per-sample table of the fused decoder straight from the decoder keys / values of the two latents (o = 32 h + r over
+     * a head's entries; Woc = dec_attn.o.w minus its column means):  dec_dwq [12, dkv] = (dec_dc * dec_q_norm.w) dec_attn.q.w^T,
+     * dec_wqb [dkv] = dec_attn.q.w dec_q_norm.b + dec_attn.q.b,  dec_wco [8, dkv] = contact_layer.w dec_attn.o.w (zero rows >= contact_dim),
+     * dec_wow [dkv, dkv] = Woc^T dec_w1g^T,  dec_wog [dkv, dkv] = Woc^T Woc / dkv,  dec_xwo [12, dkv] = dec_xc Woc / dkv. */
+    const float* dec_dwq; const float* dec_wqb; const float* dec_wco; const float* dec_wow; const float* dec_wog; const float* dec_xwo;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
