@@ -17,6 +17,7 @@
 // and run on the f32-MFMA GEMM; the kernels here are streaming / latency kernels (one wave per point).
 #include "common.h"
 #include "profile.h"
+#include "bf16split.h"
 
 extern "C" int afm_linear(const afm_linear_args*, void*);
 
@@ -918,7 +919,8 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
 constexpr int DP_LDG = 260, DP_LDX = 272, DP_LDQ = 36, DP_LDW = 260;
 constexpr int DP_QTAB = 32 * DP_LDQ;                              // floats of a sample's quadratic-form table
 constexpr int DP_TAB = DP_QTAB + 16 * 16 + 16 + 8 * 16;           // + EG [12 -> 16][16] + gconst [16] + WP [8][16]: a sample's table of the step
-constexpr int DP_LDS_FLOATS = 16 * DP_LDG + 12 * DP_LDX + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
+constexpr int DP_TWP_FLOATS = 16 * 3 * 64 * 4;                    // linear1 operand planes: [16 channel tiles][3 bf16 planes][64 lanes][8 bf16]
+constexpr int DP_LDS_FLOATS = DP_TWP_FLOATS + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
 
 // grid B, block 256 (thread = channel c).  pc [B][16][256] = P - rowmean(P); qtab [B][32][DP_LDQ]: entry (cs, 16 t + i) = Qc[m'(t, i)][m(cs)] with
 // the K index in operand order (cs < 16: attention weight cs; cs = 16 + 4 g + ks: input 4 ks + g) and the output rows of tile 1 permuted so
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab,
+__global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab,
                                                            const float* __restrict__ qdd, const float* __restrict__ twx,
                                                            const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe,
                                                            const float* __restrict__ c0, int N, int cd, const float* xt, const float* __restrict__ feat, int fd,
@@ -1089,9 +1091,11 @@ __global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restri
                                                            const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma) {
     constexpr int NJH = 16, LDG = DP_LDG;
     extern __shared__ __attribute__((aligned(16))) float dp_sm[];
-    float* TWs = dp_sm;                                           // [16][LDG]  TWc rows of the attention weights
-    float* TXs = TWs + 16 * LDG;                                  // [12][LDX]  TWc rows of the inputs, row 3 g + ks = input 4 ks + g
-    float* Qs = TXs + 12 * DP_LDX;                                // [32][LDQ]  quadratic form of the MLP's LayerNorm, operand order (lat_dectab_kernel)
+    // linear1 runs on the bf16 pipe with the exact three-way split (csrc/bf16split.h): the f32 MFMA issues at the vector rate and does not
+    // overlap with the VALU work of the GELUs (122 us with all products in f32: VALU + f32 MFMA cycles add up), v_mfma_f32_16x16x32_bf16 does.
+    // Operand order of its K = 32: lane group g carries k = {a[4 g .. 4 g + 3], x[g], x[4 + g], x[8 + g], 0}, i.e. what lane (p, g) already holds.
+    uint4* TWP = reinterpret_cast<uint4*>(dp_sm);                 // [16 tiles][3 planes][64 lanes] 8 bf16: TWc rows in that order, split once per workgroup
+    float* Qs = dp_sm + DP_TWP_FLOATS;                            // [32][LDQ]  quadratic form of the MLP's LayerNorm, operand order (lat_dectab_kernel)
     float* EGs = Qs + DP_QTAB;                                    // [16][16]   scores: row k = input, column jh
     float* gcs = EGs + 16 * 16;                                   // [16]       beta_q . G[jh] + cb[jh]
     float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P
@@ -1103,13 +1107,14 @@ __global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restri
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* aT = c0s + 16 + wave * 16 * 17;                        // [16 points][17] attention weights of the tile, transposed
     float* tr = c0s + 16 + 4 * 16 * 17 + wave * 16;               // [16] a per-point scalar from lanes (p, .) to lanes (., g)
-    for (int i = threadIdx.x; i < NJH * 64; i += 256) {            // (row, float4) items
-        const int jh = i >> 6, c = (i & 63) * 4;
-        *reinterpret_cast<float4*>(TWs + jh * LDG + c) = *reinterpret_cast<const float4*>(twp + ((int64_t)b * 16 + jh) * 256 + c);
-    }
-    for (int i = threadIdx.x; i < 12 * 64; i += 256) {
-        const int k = i >> 6, c = (i & 63) * 4;
-        *reinterpret_cast<float4*>(TXs + (3 * (k & 3) + (k >> 2)) * DP_LDX + c) = *reinterpret_cast<const float4*>(twx + k * 256 + c);
+    for (int it = threadIdx.x; it < 16 * 64; it += 256) {          // (channel tile, lane) items: 8 operand values -> three planes
+        const int tt = it >> 6, l = it & 63, n = 16 * tt + (l & 15), gg = l >> 4;
+        const float* tp = twp + ((int64_t)b * 16 + 4 * gg) * 256 + n;
+        const float v0 = tp[0], v1 = tp[256], v2 = tp[512], v3 = tp[768];
+        const float v4 = twx[gg * 256 + n], v5 = twx[(4 + gg) * 256 + n], v6 = twx[(8 + gg) * 256 + n];
+        uint4 p1, p2, p3;
+        split2(v0, v1, p1.x, p2.x, p3.x); split2(v2, v3, p1.y, p2.y, p3.y); split2(v4, v5, p1.z, p2.z, p3.z); split2(v6, 0.f, p1.w, p2.w, p3.w);
+        TWP[(tt * 3 + 0) * 64 + l] = p1; TWP[(tt * 3 + 1) * 64 + l] = p2; TWP[(tt * 3 + 2) * 64 + l] = p3;
     }
     for (int i = threadIdx.x; i < DP_TAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_TAB + i];      // Qs | EGs | gcs | WPs are contiguous, like the table
     for (int i = threadIdx.x; i < 8 * 256; i += 256) W2s[(i >> 8) * DP_LDW + (i & 255)] = (i >> 8) < cd ? w2f[i] : 0.f;
@@ -1182,34 +1187,66 @@ __global__ __launch_bounds__(256, 3) void dec_point_kernel(const float* __restri
         var += xor16(var); var += xor32(var);
         const float rstd2 = 1.0f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
         // ---- linear1 (K = 28) one 16-channel tile at a time -> GELU -> row-dots with w2; then the attention and query parts of contact_layer.w . h1
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int tt = 0; tt < 16; ++tt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // Four 16-channel tiles at a time, phase by phase (operand reads, four interleaved MFMA chains, 16 independent GELUs, four row-dot
+        // accumulators): tile by tile the wave would sit through an LDS round trip, a 7-long dependent MFMA chain and a GELU dependency chain
+        // per tile (31 k cycles per 16 points measured, for 6.5 k cycles of matrix work).
+        uint4 ub[3];                                               // u = [a | x] of this lane's point, three bf16 planes in linear1's operand order
+        split2(aB[0], aB[1], ub[0].x, ub[1].x, ub[2].x); split2(aB[2], aB[3], ub[0].y, ub[1].y, ub[2].y);
+        split2(xin[0], xin[1], ub[0].z, ub[1].z, ub[2].z); split2(xin[2], 0.f, ub[0].w, ub[1].w, ub[2].w);
+        f32x4 sa[4];
 #pragma unroll
-            for (int sI = 0; sI < 4; ++sI) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(TWs[(4 * g + sI) * LDG + 16 * tt + p16], aB[sI], acc, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) sa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t4 = 0; t4 < 16; t4 += 4) {
+            uint4 wp[4][3];
+            float4 cv[4], w4[4];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(TXs[(3 * g + ks) * DP_LDX + 16 * tt + p16], xin[ks], acc, 0, 0, 0);
-            const float4 cv = *reinterpret_cast<const float4*>(Cv + 16 * tt + 4 * g);
-            const float h0 = gelu_erf_fast(rstd2 * acc[0] + cv.x), h1v = gelu_erf_fast(rstd2 * acc[1] + cv.y), h2 = gelu_erf_fast(rstd2 * acc[2] + cv.z), h3 = gelu_erf_fast(rstd2 * acc[3] + cv.w);
-            const float* wrow = W2s + p16 * DP_LDW + 16 * tt + 4 * g;
-            const float4 w4 = p16 < 8 ? *reinterpret_cast<const float4*>(wrow) : make_float4(0.f, 0.f, 0.f, 0.f);
-            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, h0, sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, h1v, sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, h2, sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, h3, sa, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const int tt = t4 + q;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wp[q][pl] = TWP[(tt * 3 + pl) * 64 + lane];
+                cv[q] = *reinterpret_cast<const float4*>(Cv + 16 * tt + 4 * g);
+                w4[q] = p16 < 8 ? *reinterpret_cast<const float4*>(W2s + p16 * DP_LDW + 16 * tt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pq = 0; pq < 9; ++pq)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[q][AFM_PA[pq]]), __builtin_bit_cast(bf16x8, ub[AFM_PB[pq]]), acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            float hid[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hid[q][0] = gelu_erf_fast(rstd2 * acc[q][0] + cv[q].x); hid[q][1] = gelu_erf_fast(rstd2 * acc[q][1] + cv[q].y);
+                hid[q][2] = gelu_erf_fast(rstd2 * acc[q][2] + cv[q].z); hid[q][3] = gelu_erf_fast(rstd2 * acc[q][3] + cv[q].w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].x, hid[q][0], sa[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].y, hid[q][1], sa[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].z, hid[q][2], sa[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].w, hid[q][3], sa[q], 0, 0, 0);
         }
 #pragma unroll
-        for (int sI = 0; sI < 4; ++sI) sa = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? WPs[p16 * 16 + 4 * g + sI] : 0.f, aB[sI], sa, 0, 0, 0);
+        for (int sI = 0; sI < 4; ++sI) sa[sI & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? WPs[p16 * 16 + 4 * g + sI] : 0.f, aB[sI], sa[sI & 1], 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) sa = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? QEs[p16 * 16 + 4 * ks + g] : 0.f, xin[ks], sa, 0, 0, 0);
+        for (int ks = 0; ks < 3; ++ks) sa[2 + (ks & 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? QEs[p16 * 16 + 4 * ks + g] : 0.f, xin[ks], sa[2 + (ks & 1)], 0, 0, 0);
+        const f32x4 sat = (sa[0] + sa[1]) + (sa[2] + sa[3]);
         if (pvalid) {                                              // lane (point p16, g): contact channels 4 g + r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 4 * g + r;
                 if (j < cd) {
                     const int64_t i = pt * cd + j;
-                    const float v = sa[r] + c0s[j];
+                    const float v = sat[r] + c0s[j];
                     if (x0_out) x0_out[i] = v;
                     if (x_next) x_next[i] = (c1[b] * v + c2[b] * xt[i]) + sigma[b] * noise[i];
                 }
@@ -1413,7 +1450,7 @@ int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, co
         AFM_TRY(launch_toklin(p, s));
     }
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
-    if (chunks > 16) chunks = 16;
+    if (chunks > 16) chunks = 16;                     // (three workgroups per CU measured slower: the kernel is bound by VALU + f32 MFMA issue, not by latency)
     hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
                        ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);
