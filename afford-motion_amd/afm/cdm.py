@@ -294,8 +294,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._streams = []
         self.no_fold = False            # measurement: the layer-by-layer sampling form (what training-mode forward also runs)
         self.gemm_tile = 0              # measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral)
-        self.no_fuse = False            # measurement: dec_attend + linear1 GEMM + output kernel instead of the fused decoder kernel
-        self.no_gen = False             # measurement: round 2's folded form (step-invariant adapter parts materialised) instead of generated rows
+        self.no_gen = False             # measurement: round 2's folded form (per-point rows) instead of the row-less sampling form
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
@@ -303,7 +302,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
-            w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | (ffi.CDM_NO_FUSE if self.no_fuse else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+            w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -370,7 +369,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 gen_enc[:F_] = we.t(); gen_enc[F_] = be
                 gen_dec = torch.zeros(12, cm.dkv, dtype=torch.float64)
                 gen_dec[:F_] = (wd @ we).t(); gen_dec[F_] = wd @ be + bd
-                folds.update(gen_enc=gen_enc, gen_dec=gen_dec, gen_qe=wc @ gen_dec.t())
+                folds.update(gen_qe=wc @ gen_dec.t())
                 # the decoder of a point in one kernel (afm_cdm_weights.dec_*): everything between the attention weights and linear1 is linear
                 # in [a | inputs]; rows of the inputs (step-invariant) here, rows of the attention weights per step on the device
                 mlp_m = cm.decoder_cross_attn[1].module
@@ -409,14 +408,14 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 wco[:cd] = wc @ wo_d
                 folds.update(dec_dwq=(dc * gq[None, :]) @ wq_d.t(), dec_wqb=wq_d @ bq_n + bq_d, dec_wco=wco, dec_wow=woc.t() @ w1g.t(),
                              dec_wog=woc.t() @ woc / cm.dkv, dec_xwo=xc @ woc / cm.dkv)
-                folds.update(dec_w1g=w1g, dec_c=b1 + w1 @ b2, dec_xc=xc, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv, dec_dc=dc, dec_qdd=qdd)
+                folds.update(dec_c=b1 + w1 @ b2, dec_twx=xc @ w1g.t(), dec_qxx=xc @ xc.t() / cm.dkv, dec_qdd=qdd)
             dev = cl.weight.device
             for name, t in folds.items():
                 setattr(w, name, P(t.float().contiguous().to(dev)))
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
-        w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | (ffi.CDM_NO_FUSE if self.no_fuse else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+        w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
         return w
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):

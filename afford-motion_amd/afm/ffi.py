@@ -21,7 +21,6 @@ ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6,
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD = 0x1, 0x2, 0x4
 CDM_NO_GEN = 0x2
-CDM_NO_FUSE = 0x4
 ABI_VERSION = 5
 MAX_LAYERS = 16
 
@@ -105,8 +104,9 @@ class CdmWeights(C.Structure):
         # weight products of the folded sampling form (ABI v4; all five or none)
         ("fold_xu", c_f32p), ("fold_xv", c_f32p), ("fold_w2", c_f32p), ("flags", i32), ("fold_q", c_f32p), ("fold_c0", c_f32p),
         # generator tables of the two adapters (ABI v5; all three or none)
-        ("gen_enc", c_f32p), ("gen_dec", c_f32p), ("gen_qe", c_f32p),
-        ("dec_w1g", c_f32p), ("dec_c", c_f32p), ("dec_xc", c_f32p), ("dec_twx", c_f32p), ("dec_qxx", c_f32p), ("dec_dc", c_f32p), ("dec_qdd", c_f32p), ("enc_ec", c_f32p), ("enc_qee", c_f32p), ("enc_wove", c_f32p), ("enc_c1", c_f32p),
+        ("gen_qe", c_f32p),
+        ("dec_c", c_f32p), ("dec_twx", c_f32p), ("dec_qxx", c_f32p), ("dec_qdd", c_f32p),
+        ("enc_ec", c_f32p), ("enc_qee", c_f32p), ("enc_wove", c_f32p), ("enc_c1", c_f32p),
         ("dec_dwq", c_f32p), ("dec_wqb", c_f32p), ("dec_wco", c_f32p), ("dec_wow", c_f32p), ("dec_wog", c_f32p), ("dec_xwo", c_f32p),
     ]
 

@@ -131,26 +131,22 @@ constexpr int ERM_LDS_FLOATS = ERM_WAVES * 16 * ERM_LDY + 16 * ERM_LDY + 12 * 25
 // One workgroup of 8 waves per CU (158 KB of LDS: eight transposition tiles, the 16 folded queries u' = gamma * u_q shared by the
 // waves - they are all of one sample -, the contact columns of the adapter); registers: 64 (rows) + 64 (sums) per lane.
 // MODE 0: rows read from `enc_kv`; MODE 1 (FOLD): rows = enc_kv[n] + sum_j x_t[n, j] xu[j] (step-invariant part materialised once per
-// loop); MODE 2 (GEN, round 3): rows are never materialised - the adapter is a K <= 12 linear map of [x_t | features | 1], so a tile's
-// rows are GENERATED on the matrix pipe straight into layout A: D[i][j] = sum_k G[k][16 jj + i] in[j][k] with the channel as the output
-// row (lane (p, g) receives channels 16 jj + 4 g + r of point p: exactly e[jj]), 3 K4 steps x 16 column tiles = 48 MFMAs per 16 points
-// instead of 1 KB of HBM reads per point.  The table G[k][c] (weight column k, bias as the row of the constant input 1, zero rows up to
-// 12) is the A operand, read from LDS in operand order; the B operand is three input values per lane.
-constexpr int GEN_K = 12;
+// loop).  (Inputs of at most 11 channels do not come here at all: enc_point_kernel.)
+constexpr int GEN_K = 12;                                         // inputs [x_t | features | 1] of the row-less forms, zero-padded
 template <int MODE>
 __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
                                                                            const float* __restrict__ cu_text, const float* __restrict__ u_time,
                                                                            const float* __restrict__ cu_time, const int64_t* __restrict__ t, int n_t,
                                                                            int N, float* __restrict__ pm, float* __restrict__ pl,
                                                                            float* __restrict__ pacc, const float* __restrict__ xt,
-                                                                           const float* __restrict__ xu, int cd, const float* __restrict__ feat, int fd) {
-    constexpr bool FOLD = MODE == 1, GEN = MODE == 2;
+                                                                           const float* __restrict__ xu, int cd) {
+    constexpr bool FOLD = MODE == 1;
     constexpr int NQ = 16, LDY = ERM_LDY, NT = 64 * ERM_WAVES;
     extern __shared__ __attribute__((aligned(16))) float er_sm[];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* ytile = er_sm + wave * 16 * LDY;                       // this wave's transposition tile
     float* ups = er_sm + ERM_WAVES * 16 * LDY;                    // [16][LDY] u'_q = gamma * u_q
-    float* xus = ups + 16 * LDY;                                  // FOLD: [8][256] contact columns of the adapter; GEN: [3][16][64] generator table in operand order
+    float* xus = ups + 16 * LDY;                                  // FOLD: [8][256] contact columns of the adapter
     float* ccs = xus + 12 * 256;                                  // [16] beta . u_q + c_q
     float* tr = ccs + 16 + wave * 16;                             // 16 floats per wave: a 16-vector from lanes (q, .) to lanes (., g)
     int64_t ti = t[b];
@@ -170,12 +166,6 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
     if (FOLD) {
         for (int i = threadIdx.x; i < 8 * 256; i += NT) xus[i] = i < cd * 256 ? xu[i] : 0.f;
     }
-    if (GEN) {            // xus[(ks * 16 + jj) * 64 + lane] = G[k = 4 ks + (lane >> 4)][c = 16 jj + (lane & 15)]  (xu = the [GEN_K][256] table)
-        for (int i = threadIdx.x; i < GEN_K * 256; i += NT) {
-            const int l = i & 63, jj = (i >> 6) & 15, ks = i >> 10;
-            xus[i] = xu[(4 * ks + (l >> 4)) * 256 + 16 * jj + (l & 15)];
-        }
-    }
     __syncthreads();
     const float cconst = ccs[p16];
 
@@ -191,18 +181,8 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
 
     float4 e[16];
     float xrow[8];
-    float xin[3];                                                  // GEN: inputs k = 4 ks + g of point p16 (the B operand of the generating product)
     auto fetch = [&](int nb) {                                     // rows of tile [nb, nb + 16): this lane's 64 channels of point nb + p16
         const int64_t pt = (int64_t)b * N + min(nb + p16, n1 - 1);
-        if (GEN) {                                                 // in[k]: k < cd from x_t, k < fd from the feature row, k == fd the constant 1, 0 beyond
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const int k = 4 * ks + g;
-                const float vx = xt[pt * cd + min(k, cd - 1)], vf = feat[pt * fd + min(k, fd - 1)];        // unconditional, clamped
-                xin[ks] = k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = *reinterpret_cast<const float4*>(enc_kv + pt * 256 + 16 * j + 4 * g);
         if (FOLD) {
@@ -212,15 +192,6 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
     };
     if (w0 < w1) fetch(w0);
     for (int nb = w0; nb < w1; nb += 16) {
-        if (GEN) {
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(xus[(ks * 16 + jj) * 64 + lane], xin[ks], d, 0, 0, 0);
-                e[jj] = make_float4(d[0], d[1], d[2], d[3]);
-            }
-        }
         if (FOLD) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -260,7 +231,7 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
         }
         sc = (sc + sc1) + (sc2 + sc3);
         const int nvalid = w1 - nb;                                // points 4 g + r >= nvalid do not exist
-        if (nb + 16 < w1) fetch(nb + 16);                          // e[] is free: the next tile's rows (GEN: inputs) fly under the second product
+        if (nb + 16 < w1) fetch(nb + 16);                          // e[] is free: the next tile's rows fly under the second product
         float mt = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -502,9 +473,8 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
 __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                           const float* __restrict__ pacc, int nih, int dkv, const float* __restrict__ q0_text,
                                                           const float* __restrict__ q0_time, const int64_t* __restrict__ t, int n_t, int dq,
-                                                          float* __restrict__ sbuf, float* __restrict__ x0, const float* __restrict__ ec, afm_ln kvn) {
+                                                          float* __restrict__ sbuf, float* __restrict__ x0) {
     __shared__ float wq[NPART];
-    __shared__ float a12[16];
     const int b = blockIdx.x, ih = blockIdx.y;
     if (threadIdx.x < 64) {                                       // wave 0: NPART = 64 partial (max, sum) pairs
         const int pi = threadIdx.x;
@@ -518,21 +488,7 @@ __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restric
     }
     __syncthreads();
     const int c = threadIdx.x;
-    if (ec) {                                                     // uniform.  enc_point_kernel's partials: 12-vectors (stride 16), expanded here:
-        if (c < 16) {                                             // sum_n a_n LayerNorm_kv(row_n) = gamma * (sum_k a12[k] Ec[k]) + beta
-            float a = 0.f;
-            for (int pi = 0; pi < NPART; ++pi) a += wq[pi] * pacc[(((int64_t)b * NPART + pi) * nih + ih) * 16 + c];
-            a12[c] = a;
-        }
-        __syncthreads();
-        if (c < dkv) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < GEN_K; ++k) a += a12[k] * ec[k * dkv + c];
-            const int He = nih / 2, i = ih / He, h = ih % He;
-            sbuf[(((int64_t)b * 2 + i) * He + h) * dkv + c] = kvn.g[c] * a + kvn.b[c];
-        }
-    } else if (c < dkv) {
+    if (c < dkv) {
         float a = 0.f;
         for (int pi = 0; pi < NPART; ++pi) a += wq[pi] * pacc[(((int64_t)b * NPART + pi) * nih + ih) * dkv + c];
         const int He = nih / 2, i = ih / He, h = ih % He;
@@ -704,15 +660,13 @@ __global__ __launch_bounds__(256) void lat_decfold_kernel(const afm_cdm_weights 
 constexpr int DAM_LDG = 260;
 constexpr int DAM_LDS_FLOATS = 2 * 16 * DAM_LDG + 3 * 256 + 16 + 8 * 16 + 12 * 256 + 4 * 16 * 17;
 
-// MODE 0 / 1 / 2 as in enc_reduce_mfma_kernel: query rows from memory / + the contact columns (FOLD) / generated on the matrix pipe from
-// [x_t | features | 1] and the [GEN_K][256] table xv = (decoder_adapter o encoder_adapter) (GEN: the decoder query is never materialised).
+// MODE 0 / 1 as in enc_reduce_mfma_kernel: query rows from memory / + the contact columns (FOLD).  Inputs of at most 11 channels: dec_point_kernel.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __restrict__ dec_q0, const float* __restrict__ dec_lat, afm_ln qn,
                                                                 const float* __restrict__ bo, afm_ln mlpn, int N, float* __restrict__ h1,
                                                                 float* __restrict__ z, const float* __restrict__ xt,
-                                                                const float* __restrict__ xv, int cd, float* __restrict__ s1,
-                                                                const float* __restrict__ feat, int fd) {
-    constexpr bool FOLD = MODE == 1 || MODE == 2, GEN = MODE == 2;      // FOLD also covers what both share: h1 is not stored, s1 is
+                                                                const float* __restrict__ xv, int cd, float* __restrict__ s1) {
+    constexpr bool FOLD = MODE == 1;                              // h1 is not stored, s1 is
     constexpr int NJH = 16, LDG = DAM_LDG;
     extern __shared__ __attribute__((aligned(16))) float da_sm[];
     float* Gs = da_sm;                                            // [16][LDG]  gamma_q * G
@@ -720,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     float* vec3 = Ps + 16 * LDG;                                  // [3][256]   b_o, gamma_mlp, beta_mlp
     float* gcs = vec3 + 3 * 256;                                  // [16]       beta_q . G[jh] + cb[jh]
     float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P  (rows >= cd: 0)
-    float* xvs = WPs + 8 * 16;                                    // FOLD: [8][256] contact columns of the decoder query; GEN: [3][16][64] generator table in operand order
+    float* xvs = WPs + 8 * 16;                                    // FOLD: [8][256] contact columns of the decoder query
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* aT = xvs + 12 * 256 + wave * 16 * 17;                  // [16 points][17] attention weights of the tile, transposed
     const float* rec = dec_lat + (int64_t)b * DEC_LAT_STRIDE(NJH);
@@ -738,14 +692,8 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     }
     for (int i = threadIdx.x; i < 256; i += 256) { vec3[i] = bo[i]; vec3[256 + i] = mlpn.g[i]; vec3[512 + i] = mlpn.b[i]; }
     if (threadIdx.x < 8 * 16) WPs[threadIdx.x] = (FOLD && (int)(threadIdx.x >> 4) < cd) ? rec[2 * NJH * 256 + NJH + threadIdx.x] : 0.f;
-    if (FOLD && !GEN) {
+    if (FOLD) {
         for (int i = threadIdx.x; i < 8 * 256; i += 256) xvs[i] = i < cd * 256 ? xv[i] : 0.f;
-    }
-    if (GEN) {
-        for (int i = threadIdx.x; i < GEN_K * 256; i += 256) {
-            const int l = i & 63, jj = (i >> 6) & 15, ks = i >> 10;
-            xvs[i] = xv[(4 * ks + (l >> 4)) * 256 + 16 * jj + (l & 15)];
-        }
     }
     __syncthreads();
     const float gconst = gcs[p16];
@@ -757,18 +705,8 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
 
     float4 e[16];
     float xrow[8];
-    float xin[3];
     auto fetch = [&](int nb) {                                     // 32-bit element offsets from the uniform bases (one address register per load)
         const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
-        if (GEN) {
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const int k = 4 * ks + g;
-                const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
-                xin[ks] = k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
-            }
-            return;
-        }
         const unsigned ro = pti * 256u + 4u * (unsigned)g;
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = *reinterpret_cast<const float4*>(dec_q0 + (ro + 16u * j));
@@ -782,16 +720,7 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
     for (int nb = w0; nb < w1; nb += 16) {
         const int64_t pt = (int64_t)b * N + nb + p16;
         const bool pvalid = nb + p16 < w1;
-        if (GEN) {
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(xvs[(ks * 16 + jj) * 64 + lane], xin[ks], d, 0, 0, 0);
-                e[jj] = make_float4(d[0], d[1], d[2], d[3]);
-            }
-        }
-        if (FOLD && !GEN) {
+        if (FOLD) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j >= cd) break;                                // wave-uniform
@@ -921,81 +850,6 @@ constexpr int DP_QTAB = 32 * DP_LDQ;                              // floats of a
 constexpr int DP_TAB = DP_QTAB + 16 * 16 + 16 + 8 * 16;           // + EG [12 -> 16][16] + gconst [16] + WP [8][16]: a sample's table of the step
 constexpr int DP_TWP_FLOATS = 16 * 3 * 64 * 4;                    // linear1 operand planes: [16 channel tiles][3 bf16 planes][64 lanes][8 bf16]
 constexpr int DP_LDS_FLOATS = DP_TWP_FLOATS + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
-
-// grid B, block 256 (thread = channel c).  pc [B][16][256] = P - rowmean(P); qtab [B][32][DP_LDQ]: entry (cs, 16 t + i) = Qc[m'(t, i)][m(cs)] with
-// the K index in operand order (cs < 16: attention weight cs; cs = 16 + 4 g + ks: input 4 ks + g) and the output rows of tile 1 permuted so
-// that lane (p, g) register r meets input 4 r + g (dec_point_kernel).
-__global__ __launch_bounds__(256) void lat_dectab_kernel(const float* __restrict__ dec_lat, const float* __restrict__ xc, const float* __restrict__ qxx,
-                                                         const float* __restrict__ dc, afm_ln qn, float* __restrict__ pc, float* __restrict__ qtab) {
-    __shared__ float Ts[28][257];
-    __shared__ float red[4][16];
-    __shared__ float Q[28][29];
-    const int b = blockIdx.x, c = threadIdx.x, wave = c >> 6, lane = c & 63;
-    const float* P = dec_lat + (int64_t)b * DEC_LAT_STRIDE(16) + 16 * 256;
-    float p[16];
-#pragma unroll
-    for (int jh = 0; jh < 16; ++jh) p[jh] = P[jh * 256 + c];
-#pragma unroll
-    for (int jh = 0; jh < 16; ++jh) {
-        const float sm = wave_sum(p[jh]);
-        if (lane == 0) red[wave][jh] = sm;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jh = 0; jh < 16; ++jh) {
-        const float mean = ((red[0][jh] + red[1][jh]) + (red[2][jh] + red[3][jh])) * (1.0f / 256.0f);
-        const float v = p[jh] - mean;
-        Ts[jh][c] = v;
-        pc[((int64_t)b * 16 + jh) * 256 + c] = v;
-    }
-    for (int k = 0; k < 12; ++k) Ts[16 + k][c] = xc[k * 256 + c];
-    __syncthreads();
-    for (int idx = c; idx < 16 * 28; idx += 256) {
-        const int m = idx / 28, m2 = idx - m * 28;
-        float d = 0.f;
-        for (int cc = 0; cc < 256; ++cc) d += Ts[m][cc] * Ts[m2][cc];
-        d *= (1.0f / 256.0f);
-        Q[m][m2] = d;
-        if (m2 >= 16) Q[m2][m] = d;
-    }
-    if (c < 144) Q[16 + c / 12][16 + c % 12] = qxx[c];
-    __syncthreads();
-    for (int e = c; e < DP_QTAB; e += 256) {
-        const int cs = e / DP_LDQ, col = e - cs * DP_LDQ;
-        float v = 0.f;
-        if (col < 32) {
-            const int i = col & 15, x = cs - 16;
-            const int m2 = col < 16 ? i : ((i & 3) < 3 ? 16 + 4 * (i & 3) + (i >> 2) : -1);
-            const int m = cs < 16 ? cs : ((x & 3) < 3 ? 16 + 4 * (x & 3) + (x >> 2) : -1);
-            if (m >= 0 && m2 >= 0) v = Q[m2][m];
-        }
-        qtab[(int64_t)b * DP_TAB + e] = v;
-    }
-    // ---- scores: EG[k][jh] = Dc[k] . (gamma_q * G[jh]),  gconst[jh] = beta_q . G[jh] + cb[jh]   (rows of Ts reused)
-    __syncthreads();
-    const float* G = dec_lat + (int64_t)b * DEC_LAT_STRIDE(16);
-    {
-        const float gm = qn.g[c], bt = qn.b[c];
-#pragma unroll
-        for (int jh = 0; jh < 16; ++jh) {
-            const float gv = G[jh * 256 + c];
-            Ts[jh][c] = gv * gm;
-            const float sm = wave_sum(gv * bt);
-            if (lane == 0) red[wave][jh] = sm;
-        }
-    }
-    for (int k = 0; k < 12; ++k) Ts[16 + k][c] = dc[k * 256 + c];
-    __syncthreads();
-    {
-        const int k = c >> 4, jh = c & 15;                        // 256 threads = the [16][16] table (rows k >= 12: 0)
-        float d = 0.f;
-        if (k < 12)
-            for (int cc = 0; cc < 256; ++cc) d += Ts[16 + k][cc] * Ts[jh][cc];
-        qtab[(int64_t)b * DP_TAB + DP_QTAB + c] = d;
-        if (c < 16) qtab[(int64_t)b * DP_TAB + DP_QTAB + 256 + c] = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + G[2 * 16 * 256 + c];
-        if (c < 128) qtab[(int64_t)b * DP_TAB + DP_QTAB + 256 + 16 + c] = G[2 * 16 * 256 + 16 + c];      // WP [8][16] as lat_decfold_kernel left it (rows >= contact_dim unused)
-    }
-}
 
 // All per-sample tables of dec_point_kernel straight from the decoder keys / values of the sample's two latents (lat_kv, 2 x 2 x 256 numbers) and
 // step-invariant matrices (afm_cdm_weights.dec_*; o = 32 h + r runs over a head's 32 key / value entries, jh = 8 j + h):
@@ -1258,7 +1112,7 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 struct CdmWs {
     float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
     float *lat_s, *lat_x, *lat_t1, *lat_t2, *lat_qkv, *lat_kv;     // batched latent chain: [2B] token rows
-    float *pc, *twp, *qtab;                                        // fused decoder: centred P rows, their TWc rows [16 B][256], per-sample tables [B][DP_TAB]
+    float *twp, *qtab;                                             // fused decoder: TWc rows of the attention weights [16 B][256], per-sample tables [B][DP_TAB]
     int64_t bytes;
 };
 
@@ -1278,7 +1132,7 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     const int64_t ntok = 2 * (int64_t)B;
     s.lat_s = take(ntok * w.enc_heads * w.dkv * 4); s.lat_x = take(ntok * w.dq * 4); s.lat_t1 = take(ntok * w.dq * 4);
     s.lat_t2 = take(ntok * w.dq * 4); s.lat_qkv = take(ntok * 3 * w.dq * 4); s.lat_kv = take(ntok * 2 * w.dkv * 4);
-    s.pc = take((int64_t)B * 16 * 256 * 4); s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * DP_TAB * 4);
+    s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * DP_TAB * 4);
     s.bytes = off;
     return s;
 }
@@ -1328,14 +1182,12 @@ namespace {
 // out[n, j] = (((p0 + p1) + p2) + p3) + s1[n, j] + (E[n, j] + q[j] . x_t[n]) + c0[j] from the row-dot partials of the fc1 GEMM, optional DDPM
 // update IN PLACE.  Every output channel needs the point's whole contact row (through q), so a block owns WHOLE rows (256 / cd of
 // them per trip, one thread per element) and all its reads of x_t happen before a barrier, its writes after.
-// GEN form (feat != NULL): nothing of the decoder query is materialised, its part of the output is fq [cd][GEN_K] . [x_t | features | 1]
-// (fq = contact_layer.w folded through the generator table of the query); qe is unused.
 __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict__ rdot, int ngrp, const float* __restrict__ s1,
                                                          const float* __restrict__ qe, const float* __restrict__ fq,
                                                          const float* __restrict__ c0, int cd, int64_t rows, int rows_per_sample,
                                                          float* __restrict__ x0_out, const float* xt, const float* __restrict__ noise,
                                                          float* x_next, const float* __restrict__ c1, const float* __restrict__ c2,
-                                                         const float* __restrict__ sigma, const float* __restrict__ feat, int fd) {
+                                                         const float* __restrict__ sigma) {
     const int rpb = 256 / cd;                                     // rows per block and trip
     const int lr = threadIdx.x / cd, j = threadIdx.x - lr * cd;
     const bool act = lr < rpb;
@@ -1348,15 +1200,7 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
             v = rdot[(r * ngrp) * cd + j];                                         // w2 . GELU(linear1 z), 64 columns per partial
             for (int g = 1; g < ngrp; ++g) v += rdot[(r * ngrp + g) * cd + j];
             float q;                                                                // contact_layer.w . decoder query = invariant part + x_t part
-            if (feat) {
-                q = fq[j * GEN_K + fd];                                             // the constant input 1 (bias row of the generator)
-                for (int k = 0; k < cd; ++k) {
-                    const float xk = xt[r * cd + k];
-                    q += xk * fq[j * GEN_K + k];
-                    if (k == j) xj = xk;
-                }
-                for (int k = cd; k < fd; ++k) q += feat[r * fd + k] * fq[j * GEN_K + k];
-            } else {
+            {
                 q = qe[i];
                 for (int k = 0; k < cd; ++k) {
                     const float xk = xt[r * cd + k];
@@ -1378,15 +1222,14 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
 }
 
 // per-point kernels: mode 0 = rows from memory (layer-by-layer form), 1 = FOLD (step-invariant part materialised once per loop + contact
-// columns), 2 = GEN (rows generated on the matrix pipe from [x_t | features | 1]; nothing materialised)
+// columns), 3 = no rows at all (enc_point_kernel / dec_point_kernel: inputs of at most 11 channels)
 int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* text_u, const float* text_cu, const int64_t* t, int B, int N,
                       const CdmWs& ws, const float* x_t, const float* feat, int mode, hipStream_t s) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     constexpr int LDS = ERM_LDS_FLOATS * (int)sizeof(float);
     static const int attr = []() {
         int rc = (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (!rc) rc = (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        return rc ? rc : (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        return rc ? rc : (int)hipFuncSetAttribute((const void*)enc_reduce_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }();
     if (attr != 0) return attr;
     if (mode == 3) {                                  // no rows at all: 12-vector partials in ws.pacc (stride 16)
@@ -1396,12 +1239,10 @@ int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* 
         return 0;
     }
     const dim3 grid(ERM_SPLIT, B), block(64 * ERM_WAVES);
-    if (mode == 2) hipLaunchKernelGGL(enc_reduce_mfma_kernel<2>, grid, block, LDS, s, (const float*)nullptr, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                                      w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.gen_enc, w.contact_dim, feat, w.feat_dim);
-    else if (mode == 1) hipLaunchKernelGGL(enc_reduce_mfma_kernel<1>, grid, block, LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                                           w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.fold_xu, w.contact_dim, (const float*)nullptr, 0);
+    if (mode == 1) hipLaunchKernelGGL(enc_reduce_mfma_kernel<1>, grid, block, LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
+                                      w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, x_t, w.fold_xu, w.contact_dim);
     else hipLaunchKernelGGL(enc_reduce_mfma_kernel<0>, grid, block, LDS, s, rows, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t,
-                            w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0);
+                            w.n_timesteps, N, ws.pm, ws.pl, ws.pacc, (const float*)nullptr, (const float*)nullptr, 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }
@@ -1411,25 +1252,21 @@ int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
     constexpr int LDS = DAM_LDS_FLOATS * (int)sizeof(float);
     static const int attr = []() {
         int rc = (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (!rc) rc = (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        return rc ? rc : (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        return rc ? rc : (int)hipFuncSetAttribute((const void*)dec_attend_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }();
     if (attr != 0) return attr;
     int chunks = (N + 511) / 512;                                  // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
     if (chunks > 16) chunks = 16;
     const dim3 grid(chunks, B), block(256);
-    if (mode == 2) hipLaunchKernelGGL(dec_attend_mfma_kernel<2>, grid, block, LDS, s, (const float*)nullptr, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                                      (float*)nullptr, ws.z, x_t, w.gen_dec, w.contact_dim, ws.s1, feat, w.feat_dim);
-    else if (mode == 1) hipLaunchKernelGGL(dec_attend_mfma_kernel<1>, grid, block, LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                                           (float*)nullptr, ws.z, x_t, w.fold_xv, w.contact_dim, ws.s1, (const float*)nullptr, 0);
+    if (mode == 1) hipLaunchKernelGGL(dec_attend_mfma_kernel<1>, grid, block, LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
+                                      (float*)nullptr, ws.z, x_t, w.fold_xv, w.contact_dim, ws.s1);
     else hipLaunchKernelGGL(dec_attend_mfma_kernel<0>, grid, block, LDS, s, ws.bufB, ws.dec_lat, w.dec_q_norm, w.dec_attn.o.b, w.dec_mlp.norm, N,
-                            ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, (const float*)nullptr, 0);
+                            ws.h1, ws.z, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
     AFM_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_toklin(const TokLin& p, hipStream_t s);
-inline bool dec_tables_from_kv(const afm_cdm_weights& w) { return w.dec_wow && w.dec_wog && w.dec_dwq && w.dec_wqb && w.dec_wco && w.dec_xwo; }
 
 // the fused decoder (mode 3): per-sample tables of the step (two small launches), then one kernel over the points
 int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
@@ -1438,17 +1275,9 @@ int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, co
     constexpr int LDS = DP_LDS_FLOATS * (int)sizeof(float);
     static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
-    if (dec_tables_from_kv(w)) {                      // all tables from the latents' keys / values in one launch
-        hipLaunchKernelGGL(lat_dectables_kernel, dim3(B), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
-                           w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
-        AFM_CHECK_LAUNCH();
-    } else {                                          // (the chain ended with lat_decfold_kernel)
-        hipLaunchKernelGGL(lat_dectab_kernel, dim3(B), dim3(256), 0, s, ws.dec_lat, w.dec_xc, w.dec_qxx, w.dec_dc, w.dec_q_norm, ws.pc, ws.qtab);
-        AFM_CHECK_LAUNCH();
-        TokLin p = {};                                // TWc rows of the attention weights: Pc (W1 * gamma_mlp)^T
-        p.X = ws.pc; p.ldx = 256; p.W[0] = w.dec_w1g; p.ncol = 256; p.Y = ws.twp; p.ldy = 256; p.ntok = 16 * B; p.N = 256; p.K = 256;
-        AFM_TRY(launch_toklin(p, s));
-    }
+    hipLaunchKernelGGL(lat_dectables_kernel, dim3(B), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
+                       w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
+    AFM_CHECK_LAUNCH();
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
     if (chunks > 16) chunks = 16;                     // (three workgroups per CU measured slower: the kernel is bound by VALU + f32 MFMA issue, not by latency)
     hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
@@ -1475,10 +1304,10 @@ int launch_toklin(const TokLin& p, hipStream_t s) {
 int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool enc12 = false) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
-    const bool head = enc12 && w.enc_wove && w.enc_c1 && He == 8;       // combine + v-proj + o-proj as one launch (lat_head_kernel)
+    const bool head = enc12;                          // fused form: combine + v-proj + o-proj as one launch (lat_head_kernel)
     if (head) hipLaunchKernelGGL(lat_head_kernel, dim3(B, 2, (dq + 255) / 256), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
     else hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
-                            ws.lat_s, ws.lat_x, enc12 ? w.enc_ec : (const float*)nullptr, w.enc_kv_norm);
+                            ws.lat_s, ws.lat_x);
     AFM_CHECK_LAUNCH();
     auto lin = [&](const float* X, int ldx, int K, const afm_lin& l, int N, float* Y, int ldy) {
         TokLin p = {};
@@ -1521,7 +1350,7 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
         p.W[1] = w.dec_attn.v.w; p.b[1] = w.dec_attn.v.b; p.ncol = dkv;
         p.ln = w.dec_kv_norm; p.use_ln = 1;
         AFM_TRY(launch_toklin(p, s));
-        if (!(enc12 && dec_tables_from_kv(w))) {      // the fused form builds its tables from lat_kv itself (lat_dectables_kernel)
+        if (!enc12) {                                 // the fused form builds its tables from lat_kv itself (lat_dectables_kernel)
             hipLaunchKernelGGL(lat_decfold_kernel, dim3(B, w.dec_heads), dim3(256), 0, s, w, ws.lat_kv, ws.dec_lat);
             AFM_CHECK_LAUNCH();
         }
@@ -1533,14 +1362,15 @@ int cdm_latents(const afm_cdm_weights& w, const float* text_q0, const int64_t* t
     return cdm_latent_chain(w, text_q0, t, ws, B, s, enc12);
 }
 
-// sampling form of the per-point kernels: 3 = GEN encoder side + the fused decoder (dec_point_kernel), 2 = GEN (generator tables present,
-// feat_dim + 1 <= GEN_K), 1 = FOLD, 0 = layer by layer
+// sampling form of the per-point kernels: 3 = no rows (enc_point_kernel, lat_head_kernel, lat_dectables_kernel, dec_point_kernel: every fused
+// table present and feat_dim + 1 <= GEN_K), 1 = FOLD (round 2: step-invariant adapter parts materialised once per loop), 0 = layer by layer
 inline int cdm_mode(const afm_cdm_weights& w) {
     const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
     if (!folded) return 0;
-    const bool gen = w.gen_enc && w.gen_dec && w.gen_qe && w.feat_dim + 1 <= GEN_K && !(w.flags & AFM_CDM_NO_GEN);
-    const bool fused = gen && w.dec_w1g && w.dec_c && w.dec_xc && w.dec_twx && w.dec_qxx && w.dec_dc && w.dec_qdd && w.enc_ec && w.enc_qee && w.dec_heads == 8 && w.dkv == 256 && !(w.flags & AFM_CDM_NO_FUSE);
-    return fused ? 3 : (gen ? 2 : 1);
+    const bool fused = w.gen_qe && w.dec_c && w.dec_twx && w.dec_qxx && w.dec_qdd && w.enc_ec && w.enc_qee && w.enc_wove && w.enc_c1 && w.dec_dwq && w.dec_wqb &&
+                       w.dec_wco && w.dec_wow && w.dec_wog && w.dec_xwo && w.feat_dim + 1 <= GEN_K && w.enc_heads == 8 && w.dec_heads == 8 && w.dkv == 256 &&
+                       !(w.flags & AFM_CDM_NO_GEN);
+    return fused ? 3 : 1;
 }
 inline bool cdm_folded(const afm_cdm_weights& w) { return cdm_mode(w) != 0; }
 
@@ -1584,10 +1414,9 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
         AfmProf prof(AFM_PROF_CDM, 0.0, s);
         const int rpb = 256 / cd;
         int64_t g = ((int64_t)M + rpb - 1) / rpb; if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, dkv / 64, ws.s1, mode == 2 ? (const float*)nullptr : ws.qe,
-                           mode == 2 ? w.gen_qe : w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
+        hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, dkv / 64, ws.s1, ws.qe, w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
                            ddpm ? ddpm->noise : nullptr, ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr,
-                           ddpm ? ddpm->sigma : nullptr, mode == 2 ? feat : (const float*)nullptr, w.feat_dim);
+                           ddpm ? ddpm->sigma : nullptr);
         AFM_CHECK_LAUNCH();
     }
     return 0;

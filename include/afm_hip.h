@@ -561,41 +561,34 @@ typedef struct {
     int32_t flags;             /* AFM_CDM_* bits (ABI v4)                                                       */
     const float* fold_q;       /* [contact_dim, contact_dim]  contact_layer.w @ fold_xv^T                     */
     const float* fold_c0;      /* [contact_dim]  contact_layer.w @ (dec_mlp.fc2.b + dec_attn.o.b) + contact_layer.b */
-    /* ABI v5 (all three or none; built by the host next to fold_* when feat_dim + 1 <= 12, i.e. the H3D variant's 9 input channels):
-     * GENERATOR tables.  Both adapters are linear maps of the K = feat_dim + 1 <= 12 inputs [x_t | point features, xyz | 1], so neither
-     * enc_kv nor dec_q0 is ever materialised: the per-point kernels generate a tile's rows on the matrix pipe from the point's inputs
-     * (16x16x4 f32 MFMA, the channel as the output row), and the output layer takes its query part straight from the inputs.
-     *   gen_enc [12, dkv]          row k < feat_dim: encoder_adapter.w[:, k]; row feat_dim: encoder_adapter.b; zero rows after
-     *   gen_dec [12, dkv]          row k: (decoder_adapter.w @ encoder_adapter.w)[:, k]; row feat_dim: decoder_adapter.w @ enc.b + dec.b
-     *   gen_qe  [contact_dim, 12]  contact_layer.w @ gen_dec^T */
-    const float* gen_enc; const float* gen_dec; const float* gen_qe;
-    /* ABI v5 (all five or none, next to gen_*): the decoder of a point in one kernel.  With the attention weights a[p, 0..15] known, everything
-     * up to linear1 is linear in u = [a | x_t | features | 1]: h1 = u T with T = [P ; gen_dec (+ dec_attn.o.b on the row of the constant 1)],
-     * LayerNorm_mlp(h1) = rstd (u Tc) * gamma + beta with Tc = T minus its row means and var = u (Tc Tc^T / dkv) u^T, hence
-     * linear1(z) = rstd * u (Tc (W1 * gamma)^T) + (b1 + W1 beta): a K = 28 product; h1 and z are never materialised.  Step-invariant parts:
-     *   dec_w1g [dkv, dkv]  dec_mlp.fc1.w * dec_mlp.norm.w (columns scaled)      dec_c   [dkv]      dec_mlp.fc1.b + dec_mlp.fc1.w @ dec_mlp.norm.b
-     *   dec_xc  [12, dkv]   the input rows of Tc (gen_dec + o.b, centred)         dec_twx [12, dkv]  dec_xc @ dec_w1g^T
-     *   dec_qxx [12, 12]    dec_xc @ dec_xc^T / dkv
-     * The attention scores fold the same way (the query row is LayerNorm_q of a linear map of the inputs): dec_dc [12, dkv] = gen_dec minus
-     * its row means, dec_qdd [16, 16] = dec_dc dec_dc^T / dkv in MFMA operand order (entry (k, i) = Qd[4 (i & 3) + (i >> 2)][k], 0 where
-     * an index is >= 12). */
-    const float* dec_w1g; const float* dec_c; const float* dec_xc; const float* dec_twx; const float* dec_qxx; const float* dec_dc; const float* dec_qdd;
-    /* and so does the encoder side (the rows the latents attend over are LayerNorm_kv of a linear map of the inputs): enc_ec [12, dkv] =
-     * gen_enc minus its row means, enc_qee [16, 16] = enc_ec enc_ec^T / dkv in the same operand order as dec_qdd. */
-    const float* enc_ec; const float* enc_qee;
-    /* optional, with enc_ec: the head of the latent chain as one launch.  enc_wove [8 * 12, dq]: row 12 h + k = o_proj (columns of head h) applied to
-     * v_proj (rows of head h) applied to enc_kv_norm.w * enc_ec[k]; enc_c1 [dq] = o_proj.b + o_proj.w (v_proj.w enc_kv_norm.b + v_proj.b). */
-    const float* enc_wove; const float* enc_c1;
-    /* optional, with dec_*: every per-sample table of the fused decoder straight from the decoder keys / values of the two latents (o = 32 h + r over
-     * a head's entries; Woc = dec_attn.o.w minus its column means):  dec_dwq [12, dkv] = (dec_dc * dec_q_norm.w) dec_attn.q.w^T,
-     * dec_wqb [dkv] = dec_attn.q.w dec_q_norm.b + dec_attn.q.b,  dec_wco [8, dkv] = contact_layer.w dec_attn.o.w (zero rows >= contact_dim),
-     * dec_wow [dkv, dkv] = Woc^T dec_w1g^T,  dec_wog [dkv, dkv] = Woc^T Woc / dkv,  dec_xwo [12, dkv] = dec_xc Woc / dkv. */
+    /* ABI v5 (all or none; built by the host next to fold_* when feat_dim + 1 <= 12, i.e. the H3D variant's 9 input channels): the sampling form
+     * without per-point rows.  A point is x = [x_t | point features, xyz | 1] (12 numbers, zero-padded) and everything between the nonlinearities is
+     * linear in x and in the 16 attention weights a[jh] of the decoder:
+     *   encoder side   the rows the two latents attend over are LayerNorm_kv(x G_enc): var = x Qe x^T, any dot with a vector u is rstd (x . (Ec u)),
+     *                  the attention-weighted row sum is linear in sum_n a_n rstd_n x_n (enc_point_kernel accumulates 16 x 12 numbers per wave):
+     *     enc_ec  [12, dkv]  G_enc = [encoder_adapter.w^T ; encoder_adapter.b ; 0] minus its row means
+     *     enc_qee [16, 16]   enc_ec enc_ec^T / dkv in MFMA operand order: entry (k, i) = Q[4 (i & 3) + (i >> 2)][k], 0 where an index is >= 12
+     *     enc_wove [8 * 12, dq], enc_c1 [dq]   head of the latent chain: x1 = q0 + o_proj(v_proj(.)) as one product with the 8 x 12 accumulated numbers
+     *                  (row 12 h + k = o_proj.w[:, head h] v_proj.w[head h] (enc_kv_norm.w * enc_ec[k]); enc_c1 = o_proj.b + o_proj.w (v_proj.w enc_kv_norm.b + v_proj.b))
+     *   decoder side   with G_dec = [(decoder_adapter.w encoder_adapter.w)^T ; decoder_adapter.w encoder_adapter.b + decoder_adapter.b ; 0]:
+     *                  scores = rstd_q (x . EG) + const, var_q = x Qd x^T;  h1 = [a | x] T with T = [P ; G_dec + dec_attn.o.b on the constant's row];
+     *                  LayerNorm_mlp(h1) W1^T = rstd ([a | x] TWc) + C, var = [a | x] Qc [a | x]^T: linear1 is a K = 28 product.  Step-invariant parts:
+     *     dec_qdd [16, 16]   (G_dec - row means)(...)^T / dkv in operand order        dec_c   [dkv]      dec_mlp.fc1.b + dec_mlp.fc1.w dec_mlp.norm.b
+     *     dec_twx [12, dkv]  Xc (dec_mlp.fc1.w * dec_mlp.norm.w)^T, Xc = centred input rows of T     dec_qxx [12, 12]   Xc Xc^T / dkv
+     *     gen_qe  [contact_dim, 12]  contact_layer.w G_dec^T
+     *                  and the parts that depend on the sample's latents come from their decoder keys / values (o = 32 h + r over a head's entries,
+     *                  Woc = dec_attn.o.w minus its column means) through
+     *     dec_dwq [12, dkv] = ((G_dec - row means) * dec_q_norm.w) dec_attn.q.w^T      dec_wqb [dkv] = dec_attn.q.w dec_q_norm.b + dec_attn.q.b
+     *     dec_wco [8, dkv]  = contact_layer.w dec_attn.o.w (zero rows >= contact_dim)   dec_wow [dkv, dkv] = Woc^T (dec_mlp.fc1.w * dec_mlp.norm.w)^T
+     *     dec_wog [dkv, dkv] = Woc^T Woc / dkv                                          dec_xwo [12, dkv] = Xc Woc / dkv */
+    const float* gen_qe;
+    const float* dec_c; const float* dec_twx; const float* dec_qxx; const float* dec_qdd;
+    const float* enc_ec; const float* enc_qee; const float* enc_wove; const float* enc_c1;
     const float* dec_dwq; const float* dec_wqb; const float* dec_wco; const float* dec_wow; const float* dec_wog; const float* dec_xwo;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
-#define AFM_CDM_NO_FUSE        0x4     /* measurement: dec_attend + linear1 GEMM + output kernel (round 3 first half) instead of the fused decoder */
-#define AFM_CDM_NO_GEN         0x2     /* measurement: rows of the per-point kernels from the materialised step-invariant tensors (round 2's folded form) */
+#define AFM_CDM_NO_GEN         0x2     /* measurement: round 2's folded form (step-invariant adapter parts materialised, per-point rows) although the row-less tables are present */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
 

@@ -250,11 +250,11 @@ def test_two_stream_loop_soak():
 
 
 def test_sampling_forms_agree_with_each_other_and_the_oracle(cdm):
-    """The CDM samples in one of four forms, all re-associations of the same f32 arithmetic:
-      default   encoder rows GENERATED on the matrix pipe from [x_t | xyz | 1] and the whole decoder of a point in ONE kernel (round 3:
-                linear1 as a K = 28 product of [attention weights | inputs]; neither adapter output, nor h1, z or the hidden row is materialised);
-      no_fuse   generated rows, but dec_attend -> z -> linear1 GEMM with the row-dot epilogue -> output kernel (round 3, first half);
-      no_gen    round 2's folded form (step-invariant adapter parts materialised once per loop);
+    """The CDM samples in one of three forms, all re-associations of the same f32 arithmetic:
+      default   no per-point rows (round 3): a point is its 12 inputs [x_t | xyz | 1] and the decoder's 16 attention weights between the
+                nonlinearities - the encoder reduction accumulates 16 x 12 numbers per wave, the whole decoder of a point is one kernel with
+                linear1 as a K = 28 product; neither adapter output, nor h1, z or the hidden row is materialised;
+      no_gen    round 2's folded form (step-invariant adapter parts materialised once per loop, per-point rows, linear1 as a GEMM);
       layered   the layer-by-layer form (what a training-mode forward runs).
     Against the CPU oracle a forward agrees to 2e-4 (measured ~5e-6); among each other to 2e-5, an 8-step loop to 1e-4."""
     from oracle import denoiser_ref as dr, shapes as sh
@@ -266,23 +266,22 @@ def test_sampling_forms_agree_with_each_other_and_the_oracle(cdm):
     d8 = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="8"))
     res = {}
     try:
-        for tag, (no_fold, no_gen, no_fuse) in dict(default=(False, False, False), no_fuse=(False, False, True), no_gen=(False, True, False), layered=(True, False, False)).items():
-            cdm.no_fold, cdm.no_gen, cdm.no_fuse = no_fold, no_gen, no_fuse
+        for tag, (no_fold, no_gen) in dict(default=(False, False), no_gen=(False, True), layered=(True, False)).items():
+            cdm.no_fold, cdm.no_gen = no_fold, no_gen
             with torch.no_grad():
                 f = cdm(x.to(dev()), t.to(dev()), **kw)
             res[tag] = (f, d8.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=5))
     finally:
-        cdm.no_fold = cdm.no_gen = cdm.no_fuse = False
+        cdm.no_fold = cdm.no_gen = False
     w = cdm._weights()
-    assert w.fold_xu and w.fold_w2 and w.fold_q and w.gen_enc and w.gen_dec and w.gen_qe and w.dec_w1g and w.dec_twx and w.dec_qxx, "eval-mode pack carries the folded products and the generator tables"
+    assert w.fold_xu and w.fold_w2 and w.fold_q and w.gen_qe and w.dec_twx and w.dec_wow and w.enc_wove, "eval-mode pack carries the folded products and the row-less tables"
     want = dr.cdm_forward(sh.weights(sh.cdm()), x, t, text, xyz)
     for tag, (f, _) in res.items():
         report(f"CDM forward ({tag}) vs oracle", f, want, 2e-4)
-    for tag in ("no_fuse", "no_gen", "layered"):
+    for tag in ("no_gen", "layered"):
         report(f"CDM forward: default vs {tag}", res["default"][0], res[tag][0].cpu(), 2e-5)
         report(f"CDM 8-step loop: default vs {tag}", res["default"][1], res[tag][1].cpu(), 1e-4)
     assert not torch.equal(res["default"][0], res["no_gen"][0]) and not torch.equal(res["default"][0], res["layered"][0])      # other code really ran
-    assert not torch.equal(res["default"][0], res["no_fuse"][0])
     cdm.train()
     try:
         assert not cdm._weights().fold_xu, "training mode keeps the layer-by-layer form (weights change every step)"

@@ -50,13 +50,11 @@ def measure(m, d, kw, tag, **attrs):
 
 m, d = build(False)
 kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev))
-base = dict(no_gen=False, loop_sub_batches=1, no_fold=False, gemm_tile=0, no_fuse=False)
-measure(m, d, kw, "H3D default: generated encoder rows + fused decoder kernel, one stream", **base)
-measure(m, d, kw, "H3D generated rows, dec_attend -> z -> weight-stationary linear1 -> output kernel, one stream", **dict(base, no_fuse=True))
-measure(m, d, kw, "H3D generated rows, two sub-batch streams", **dict(base, loop_sub_batches=2))
-measure(m, d, kw, "H3D generated rows, unfused, linear1 on staged 64x64 tiles", **dict(base, no_fuse=True, gemm_tile=3))
-measure(m, d, kw, "H3D folded rows (round 2 per-point kernels), one stream", **dict(base, no_gen=True))
-measure(m, d, kw, "H3D folded rows, two sub-batch streams", **dict(base, no_gen=True, loop_sub_batches=2))
+base = dict(no_gen=False, loop_sub_batches=1, no_fold=False, gemm_tile=0)
+measure(m, d, kw, "H3D default: no per-point rows (enc_point / lat_head / lat_dectables / dec_point), one stream", **base)
+measure(m, d, kw, "H3D default form, two sub-batch streams", **dict(base, loop_sub_batches=2))
+measure(m, d, kw, "H3D folded rows (round 2 form; linear1 weight-stationary), one stream", **dict(base, no_gen=True))
+measure(m, d, kw, "H3D folded rows, linear1 on staged 64x64 tiles", **dict(base, no_gen=True, gemm_tile=3))
 del m
 mh, dh = build(True)
 kwh = dict(kw, c_pc_feat=synth.gaussian("cdm_ab_feat", (B, N, 32)).to(dev))
