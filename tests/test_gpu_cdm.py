@@ -249,6 +249,28 @@ def test_two_stream_loop_soak():
     assert not bad, f"{len(bad)} of 50 two-stream loops differ from the single-stream result: {bad[:4]}"
 
 
+@pytest.mark.parametrize("B,N", [(3, 1000), (1, 37), (9, 272)])
+def test_row_less_form_on_ragged_shapes(cdm, B, N):
+    """The row-less sampling form (enc_point / lat_head / lat_dectables / dec_point) against the layer-by-layer form where its tiling is ragged:
+    N not a multiple of the 16-point tiles or of the per-wave ranges, a last token block of fewer than 16 latent tokens, one sample."""
+    xyz, text = synth.scene_cloud(B, N, seed=B + N), synth.text_feature(B)
+    kw = dict(c_text_feat=text.to(dev()), c_pc_xyz=xyz.to(dev()))
+    x = synth.gaussian(f"ragged_x_{B}_{N}", (B, N, 6))
+    t = torch.arange(B) * 53 % 500
+    d4 = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="4"))
+    out = {}
+    try:
+        for tag, no_fold in (("default", False), ("layered", True)):
+            cdm.no_fold = no_fold
+            with torch.no_grad():
+                out[tag] = (cdm(x.to(dev()), t.to(dev()), **kw), d4.p_sample_loop(cdm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=7))
+    finally:
+        cdm.no_fold = False
+    assert torch.isfinite(out["default"][0]).all() and torch.isfinite(out["default"][1]).all()
+    report(f"CDM forward B={B} N={N}: row-less vs layered", out["default"][0], out["layered"][0].cpu(), 2e-5)
+    report(f"CDM 4-step loop B={B} N={N}: row-less vs layered", out["default"][1], out["layered"][1].cpu(), 1e-4)
+
+
 def test_sampling_forms_agree_with_each_other_and_the_oracle(cdm):
     """The CDM samples in one of three forms, all re-associations of the same f32 arithmetic:
       default   no per-point rows (round 3): a point is its 12 inputs [x_t | xyz | 1] and the decoder's 16 attention weights between the
