@@ -412,6 +412,26 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             dev = cl.weight.device
             for name, t in folds.items():
                 setattr(w, name, P(t.float().contiguous().to(dev)))
+            # LayerNorm folded into the latent-chain stages that follow one (afm_cdm_weights.lat_fold: 19 slots of (W * gamma, row sums, b + W beta))
+            slots = [None] * 19
+
+            def fold_ln(slot, lin_m, ln_m):
+                wl, bl, gl, btl = f64(lin_m.weight), f64(lin_m.bias), f64(ln_m.weight), f64(ln_m.bias)
+                wg = wl * gl[None, :]
+                slots[slot] = (wg, wg.sum(1), bl + wl @ btl)
+            fold_ln(0, cm.encoder_cross_attn[1].module[1], cm.encoder_cross_attn[1].module[0])
+            for li, layer in enumerate(cm.encoder_self_attn):
+                sa_m, mlp_l = layer[0].module, layer[1].module
+                fold_ln(1 + 4 * li, sa_m.attention.q_proj, sa_m.norm); fold_ln(2 + 4 * li, sa_m.attention.k_proj, sa_m.norm)
+                fold_ln(3 + 4 * li, sa_m.attention.v_proj, sa_m.norm); fold_ln(4 + 4 * li, mlp_l[1], mlp_l[0])
+            da_kv = cm.decoder_cross_attn[0].module
+            fold_ln(17, da_kv.attention.k_proj, da_kv.kv_norm); fold_ln(18, da_kv.attention.v_proj, da_kv.kv_norm)
+            table = (C.c_void_p * (3 * 19))()
+            for si, trip in enumerate(slots):
+                for j in range(3):
+                    table[3 * si + j] = P(trip[j].float().contiguous().to(dev)) if trip is not None else None
+            keep.append(table)
+            w.lat_fold = C.cast(table, C.c_void_p)
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()

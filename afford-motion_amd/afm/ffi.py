@@ -108,6 +108,7 @@ class CdmWeights(C.Structure):
         ("dec_c", c_f32p), ("dec_twx", c_f32p), ("dec_qxx", c_f32p), ("dec_qdd", c_f32p),
         ("enc_ec", c_f32p), ("enc_qee", c_f32p), ("enc_wove", c_f32p), ("enc_c1", c_f32p),
         ("dec_dwq", c_f32p), ("dec_wqb", c_f32p), ("dec_wco", c_f32p), ("dec_wow", c_f32p), ("dec_wog", c_f32p), ("dec_xwo", c_f32p),
+        ("lat_fold", C.c_void_p),
     ]
 
 

@@ -389,7 +389,8 @@ struct TokLin {
     int head_out, x_head_stride;             // head_out > 0: outputs [h * head_out, (h + 1) * head_out) read X + h * x_head_stride (per-head inputs)
     const float* W[3]; const float* b[3];    // up to three stacked weight matrices [ncol, K] (q | k | v), ncol outputs each
     int ncol;
-    afm_ln ln; int use_ln;                   // LayerNorm (eps 1e-5) of the input rows
+    afm_ln ln; int use_ln;                   // 1: LayerNorm (eps 1e-5) of the input rows; 2: the same FOLDED - W carries gamma, b carries W beta,
+    const float* gsum[3];                    //    gsum[part][o] = sum_k W[o][k]: Y = rstd (W x - mean gsum) + b, the products do not wait for the statistics
     int act;                                 // AFM_ACT_*
     const float* R; int ldr;                 // residual rows or NULL (may be Y: every element is read and written by the same lane)
     float* Y; int ldy;
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
         wr[u] = *reinterpret_cast<const float4*>(wrow + 16 * u);
     }
     TKTL(1);
+    float ln_mean = 0.f, ln_rstd = 1.f;                          // folded form: statistics of token p16 (all four lanes of the row hold them)
     if (p.use_ln) {                                              // uniform.  Statistics over the row's four lanes (same p16, g = 0..3), two passes
         float sum = 0.f;
 #pragma unroll
@@ -433,8 +435,10 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
         for (int u = 0; u < NK16; ++u) { const float a = xr[u].x - mean, b = xr[u].y - mean, c = xr[u].z - mean, d = xr[u].w - mean; sq += (a * a + b * b) + (c * c + d * d); }
         sq += xor16(sq); sq += xor32(sq);
         const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
+        ln_mean = mean; ln_rstd = rstd;
 #pragma unroll
         for (int u = 0; u < NK16; ++u) {
+            if (p.use_ln == 2) break;                            // uniform: the rows stay raw
             const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * u + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * u + 4 * g);
             xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
                                 (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
@@ -453,13 +457,21 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].w, wr[u].w, acc[3], 0, 0, 0);
     }
     TKTL(3);
+    float mt[4] = {0.f, 0.f, 0.f, 0.f}, rt[4] = {1.f, 1.f, 1.f, 1.f};
+    if (p.use_ln == 2) {                                         // uniform: the statistics of token 4 g + r live in lane 4 g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mt[r] = __shfl(ln_mean, 4 * g + r); rt[r] = __shfl(ln_rstd, 4 * g + r); }
+    }
     if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the tile)
         const float bias = p.b[part0] ? p.b[part0][oc0 + p16] : 0.f;
+        const float gs = p.use_ln == 2 ? p.gsum[part0][oc0 + p16] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tok = tb + 4 * g + r;
+            float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            if (p.use_ln == 2) v = rt[r] * (v - mt[r] * gs);
             if (tok >= p.ntok) continue;
-            float v = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + bias;
+            v += bias;
             if (p.act) v = apply_act(v, p.act);
             if (p.R) v += p.R[(int64_t)tok * p.ldr + o0 + p16];
             p.Y[(int64_t)tok * p.ldy + o0 + p16] = v;
@@ -1314,16 +1326,21 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
         p.X = X; p.ldx = ldx; p.W[0] = l.w; p.b[0] = l.b; p.ncol = N; p.Y = Y; p.ldy = ldy; p.ntok = ntok; p.N = N; p.K = K;
         return p;
     };
-    auto mlp = [&](const afm_mlp_w& m) {          // x <- x + fc2(GELU(fc1(LN(x))))
+    const bool lnf = w.lat_fold != nullptr;          // LayerNorm folded into the weights of the stages that follow one (afm_cdm_weights.lat_fold)
+    auto folded = [&](TokLin& p, int part, int slot) {            // slot: index into lat_fold ([wg, g, c] triples)
+        p.W[part] = w.lat_fold[3 * slot]; p.gsum[part] = w.lat_fold[3 * slot + 1]; p.b[part] = w.lat_fold[3 * slot + 2]; p.use_ln = 2;
+    };
+    auto mlp = [&](const afm_mlp_w& m, int slot) {    // x <- x + fc2(GELU(fc1(LN(x))))
         TokLin p = lin(ws.lat_x, dq, dq, m.fc1, dq, ws.lat_t2, dq);
         p.ln = m.norm; p.use_ln = 1; p.act = AFM_ACT_GELU;
+        if (lnf) folded(p, 0, slot);
         AFM_TRY(launch_toklin(p, s));
         p = lin(ws.lat_t2, dq, dq, m.fc2, dq, ws.lat_x, dq);
         p.R = ws.lat_x; p.ldr = dq;
         return launch_toklin(p, s);
     };
     if (head) {
-        AFM_TRY(mlp(w.enc_mlp));
+        AFM_TRY(mlp(w.enc_mlp, 0));
     } else {   // attention output of the encoder cross-attention: o[tok, h hd + r] = W_v[h hd + r] . s[tok, h] + b_v, then o_proj + residual, MLP
         TokLin p = lin(ws.lat_s, He * dkv, dkv, w.enc_attn.v, dq, ws.lat_t1, dq);
         p.head_out = dq / He; p.x_head_stride = dkv;
@@ -1331,24 +1348,26 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
         p = lin(ws.lat_t1, dq, dq, w.enc_attn.o, dq, ws.lat_x, dq);
         p.R = ws.lat_x; p.ldr = dq;
         AFM_TRY(launch_toklin(p, s));
-        AFM_TRY(mlp(w.enc_mlp));
+        AFM_TRY(mlp(w.enc_mlp, 0));
     }
     for (int li = 0; li < w.n_self; ++li) {        // self-attention block on the two latents of every sample (modules.py:544-648)
         TokLin p = lin(ws.lat_x, dq, dq, w.self_attn[li].q, 3 * dq, ws.lat_qkv, 3 * dq);
         p.W[1] = w.self_attn[li].k.w; p.b[1] = w.self_attn[li].k.b; p.W[2] = w.self_attn[li].v.w; p.b[2] = w.self_attn[li].v.b; p.ncol = dq;
         p.ln = w.self_norm[li]; p.use_ln = 1;
+        if (lnf) { folded(p, 0, 1 + 4 * li); folded(p, 1, 2 + 4 * li); folded(p, 2, 3 + 4 * li); }
         AFM_TRY(launch_toklin(p, s));
         hipLaunchKernelGGL(lat_selfattn_kernel, dim3(B), dim3(256), 0, s, ws.lat_qkv, dq, He, ws.lat_t1);
         AFM_CHECK_LAUNCH();
         p = lin(ws.lat_t1, dq, dq, w.self_attn[li].o, dq, ws.lat_x, dq);
         p.R = ws.lat_x; p.ldr = dq;
         AFM_TRY(launch_toklin(p, s));
-        AFM_TRY(mlp(w.self_mlp[li]));
+        AFM_TRY(mlp(w.self_mlp[li], 4 + 4 * li));
     }
     {   // decoder keys / values of the two latents, folded through W_q / W_o of the decoder attention
         TokLin p = lin(ws.lat_x, dq, dq, w.dec_attn.k, 2 * dkv, ws.lat_kv, 2 * dkv);
         p.W[1] = w.dec_attn.v.w; p.b[1] = w.dec_attn.v.b; p.ncol = dkv;
         p.ln = w.dec_kv_norm; p.use_ln = 1;
+        if (lnf) { folded(p, 0, 17); folded(p, 1, 18); }
         AFM_TRY(launch_toklin(p, s));
         if (!enc12) {                                 // the fused form builds its tables from lat_kv itself (lat_dectables_kernel)
             hipLaunchKernelGGL(lat_decfold_kernel, dim3(B, w.dec_heads), dim3(256), 0, s, w, ws.lat_kv, ws.dec_lat);

@@ -585,6 +585,11 @@ typedef struct {
     const float* dec_c; const float* dec_twx; const float* dec_qxx; const float* dec_qdd;
     const float* enc_ec; const float* enc_qee; const float* enc_wove; const float* enc_c1;
     const float* dec_dwq; const float* dec_wqb; const float* dec_wco; const float* dec_wow; const float* dec_wog; const float* dec_xwo;
+    /* optional (any sampling form): LayerNorm folded into the six kinds of latent-chain stages that follow one.  lat_fold[3 s + 0 / 1 / 2] =
+     * (W * gamma [N, K], g[n] = sum_k (W * gamma)[n, k], b + W beta) for slot s: 0 enc_mlp.fc1; 1 + 4 l .. 3 + 4 l the q / k / v projections of
+     * self-attention layer l (self_norm[l]); 4 + 4 l self_mlp[l].fc1; 17 / 18 dec_attn.k / dec_attn.v (dec_kv_norm).  The stage then computes
+     * rstd (W' x - mean g) + c on the RAW rows: its matrix products do not wait for the statistics. */
+    const float* const* lat_fold;
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
