@@ -197,14 +197,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // t = 1 / (1 + 0.3275911 |z|).  For x < 0 the small factor 1 + erf(z) is that product itself (no cancellation).  ~14 VALU with two
 // transcendentals against ~45 for erff: the fused CDM decoder evaluates 256 of these per point (dec_point_kernel).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float az = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
-    float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    pl = __builtin_fmaf(pl, t, 1.421413741f);
-    pl = __builtin_fmaf(pl, t, -0.284496736f);
-    pl = __builtin_fmaf(pl, t, 0.254829592f);
-    const float q = pl * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);      // 1 - erf(|z|);  exp(-z^2) = 2^(-x^2 log2(e) / 2)
-    return 0.5f * x * (x < 0.f ? q : 2.0f - q);
+    // GELU(x) = max(x, 0) - |x| q / 2 with q = 1 - erf(|z|) = poly(t) exp(-z^2) (both signs of x; the 1/2 is inside the coefficients)
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float pl = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    pl = __builtin_fmaf(pl, t, 0.5f * 1.421413741f);
+    pl = __builtin_fmaf(pl, t, 0.5f * -0.284496736f);
+    pl = __builtin_fmaf(pl, t, 0.5f * 0.254829592f);
+    const float qh = pl * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);      // q / 2;  exp(-z^2) = 2^(-x^2 log2(e) / 2)
+    return __builtin_fmaf(-ax, qh, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
