@@ -194,7 +194,7 @@ __device__ __forceinline__ void layernorm_row(const float* __restrict__ xp, cons
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // The same function with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at f32 rounding level): 1 - erf(|z|) = poly(t) exp(-z^2),
-// t = 1 / (1 + 0.3275911 |z|).  For x < 0 the small factor 1 + erf(z) is that product itself (no cancellation).  ~14 VALU with two
+// t = 1 / (1 + 0.3275911 |z|).  For x < 0 the small factor 1 + erf(z) is that product itself (no cancellation).  12 VALU with two
 // transcendentals against ~45 for erff: the fused CDM decoder evaluates 256 of these per point (dec_point_kernel).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
     // GELU(x) = max(x, 0) - |x| q / 2 with q = 1 - erf(|z|) = poly(t) exp(-z^2) (both signs of x; the 1/2 is inside the coefficients)

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __rest
         for (int hh = 0; hh < 2; ++hh) {
             const int h = 2 * gq4 + hh;
             float t0 = 0.f, t1 = 0.f, g0 = 0.f, g1 = 0.f;
-#pragma unroll 16
+#pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int o = 32 * h + r;
                 const float w1 = wow[o * 256 + c], w2 = wog[o * 256 + c], v0 = vd[0][o], v1 = vd[1][o];
