@@ -362,12 +362,13 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             bo = f64(cm.decoder_cross_attn[0].module.attention.o_proj.bias)
             folds = dict(fold_xu=xu, fold_xv=xv, fold_w2=wc @ f64(fc2.weight), fold_q=wc @ xv.t(),
                          fold_c0=wc @ (f64(fc2.bias) + bo) + f64(cl.bias))
-            if cm.feat_dim + 1 <= 12:
+            if cm.feat_dim + 1 <= 44:
+                K = 12 if cm.feat_dim + 1 <= 12 else 44                           # inputs of the row-less kernels, padded (RowLess<3> / RowLess<11> in perceiver.hip)
                 # generator tables (afm_cdm_weights.gen_*): both adapters as maps of the K = feat_dim + 1 inputs [x_t | features | 1]
                 F_, be, bd = cm.feat_dim, f64(cm.encoder_adapter.bias), f64(cm.decoder_adapter.bias)
-                gen_enc = torch.zeros(12, cm.dkv, dtype=torch.float64)
+                gen_enc = torch.zeros(K, cm.dkv, dtype=torch.float64)
                 gen_enc[:F_] = we.t(); gen_enc[F_] = be
-                gen_dec = torch.zeros(12, cm.dkv, dtype=torch.float64)
+                gen_dec = torch.zeros(K, cm.dkv, dtype=torch.float64)
                 gen_dec[:F_] = (wd @ we).t(); gen_dec[F_] = wd @ be + bd
                 folds.update(gen_qe=wc @ gen_dec.t())
                 # the decoder of a point in one kernel (afm_cdm_weights.dec_*): everything between the attention weights and linear1 is linear
@@ -379,25 +380,28 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 xc = tx - tx.mean(1, keepdim=True)
                 w1g = w1 * g2[None, :]
                 dc = gen_dec - gen_dec.mean(1, keepdim=True)                       # the query row's LayerNorm: var = x Qd x^T, in MFMA operand order
-                def operand_order(q):                                              # [12, 12] -> [16, 16]: entry (k, i) = q[4 (i & 3) + (i >> 2)][k]
-                    o = torch.zeros(16, 16, dtype=torch.float64)
-                    for i in range(16):
-                        if (i & 3) < 3:
-                            o[:12, i] = q[4 * (i & 3) + (i >> 2), :]
+                def operand_order(q):                                              # [K, K] -> [K, 16 NT]: entry (k, 16 t + i) = q[4 (4 t + (i & 3)) + (i >> 2)][k]
+                    nt = (K + 15) // 16
+                    o = torch.zeros(K, 16 * nt, dtype=torch.float64)
+                    for c in range(16 * nt):
+                        t, i = divmod(c, 16)
+                        src = 4 * (4 * t + (i & 3)) + (i >> 2)
+                        if src < K:
+                            o[:, c] = q[src, :]
                     return o
                 qdd = operand_order(dc @ dc.t() / cm.dkv)
                 ec = gen_enc - gen_enc.mean(1, keepdim=True)                       # the encoder side: rows the latents attend over
                 folds.update(enc_ec=ec, enc_qee=operand_order(ec @ ec.t() / cm.dkv))
-                # head of the latent chain: x1 = q0 + o_proj(v_proj(LayerNorm_kv-weighted sums)) is linear in the 8 x 12 numbers enc_point_kernel accumulates
+                # head of the latent chain: x1 = q0 + o_proj(v_proj(LayerNorm_kv-weighted sums)) is linear in the 8 x K numbers enc_point_kernel accumulates
                 ea = cm.encoder_cross_attn[0].module
                 gk, bk = f64(ea.kv_norm.weight), f64(ea.kv_norm.bias)
                 wv, bv, wo, bo_e = f64(ea.attention.v_proj.weight), f64(ea.attention.v_proj.bias), f64(ea.attention.o_proj.weight), f64(ea.attention.o_proj.bias)
                 hd = cm.dq // 8                                                    # the kernel is written for the reference's 8 encoder heads
-                wve = (ec * gk[None, :]) @ wv.t()                                  # [12, dq]: v_proj of gamma * Ec[k]
-                wove = torch.zeros(8 * 12, cm.dq, dtype=torch.float64)
+                wve = (ec * gk[None, :]) @ wv.t()                                  # [K, dq]: v_proj of gamma * Ec[k]
+                wove = torch.zeros(8 * K, cm.dq, dtype=torch.float64)
                 for h in range(8):
                     blk = slice(h * hd, (h + 1) * hd)
-                    wove[12 * h:12 * h + 12] = wve[:, blk] @ wo[:, blk].t()
+                    wove[K * h:K * h + K] = wve[:, blk] @ wo[:, blk].t()
                 folds.update(enc_wove=wove, enc_c1=bo_e + wo @ (wv @ bk + bv))
                 # tail of the chain: the fused decoder's per-sample tables are linear / bilinear in the latents' decoder keys and values
                 da_m = cm.decoder_cross_attn[0].module

@@ -132,7 +132,22 @@ constexpr int ERM_LDS_FLOATS = ERM_WAVES * 16 * ERM_LDY + 16 * ERM_LDY + 12 * 25
 // waves - they are all of one sample -, the contact columns of the adapter); registers: 64 (rows) + 64 (sums) per lane.
 // MODE 0: rows read from `enc_kv`; MODE 1 (FOLD): rows = enc_kv[n] + sum_j x_t[n, j] xu[j] (step-invariant part materialised once per
 // loop).  (Inputs of at most 11 channels do not come here at all: enc_point_kernel.)
-constexpr int GEN_K = 12;                                         // inputs [x_t | features | 1] of the row-less forms, zero-padded
+// The row-less forms see a point as 4 NKS inputs [x_t | features | 1 | 0 ...]: NKS = 3 (12 inputs: the H3D variant's 9 channels) or 11 (44: the
+// HUMANISE variant's 41).  Lane (p, g) of a 16-point tile holds inputs 4 ks + g, ks < NKS.  An MFMA output indexed by inputs has NT 16-row tiles;
+// row i of tile t stands for input 4 (4 t + (i & 3)) + (i >> 2), so that register r of lane (p, g) meets the lane's own input 4 (4 t + r) + g.
+template <int NKS> struct RowLess {
+    static_assert(NKS == 3 || NKS == 11, "NKS");
+    static constexpr int K = 4 * NKS;                             // inputs, zero-padded
+    static constexpr int NT = (K + 15) / 16;                      // input tiles of an MFMA output
+    static constexpr int XS = NKS <= 4 ? 4 : 12;                  // operand-order column of input 4 ks + g: 16 + XS g + ks (XS LDQ = 16 mod 32: no bank conflicts)
+    static constexpr int QCOL = 16 + 4 * XS;                      // K index of the decoder's variance form: 16 attention weights, then the inputs
+    static constexpr int LDQ = 16 + 16 * NT + 4;                  // its output columns (one tile of attention weights + NT input tiles), padded
+    static constexpr int QTAB = QCOL * LDQ;
+    static constexpr int TAB = QTAB + K * 16 + 16 + 8 * 16;       // + EG [K][16] + gconst [16] + WP [8][16]: a sample's table of the step (lat_dectables_kernel)
+    static constexpr int NSTEP = NKS <= 4 ? 1 : 2;                // K = 32 steps of linear1 on the bf16 pipe: lane group g carries {a[4 g .. + 3], x[ks < 4]} | {x[4 <= ks < 12]}
+    static constexpr int NW = NKS <= 4 ? 4 : 8;                   // waves of a dec_point workgroup (LDS: two workgroups per CU / one)
+};
+__host__ __device__ constexpr int rowless_nks(int feat_dim) { return feat_dim + 1 <= 12 ? 3 : (feat_dim + 1 <= 44 ? 11 : 0); }
 template <int MODE>
 __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(const float* __restrict__ enc_kv, afm_ln kvn, const float* __restrict__ u_text,
                                                                            const float* __restrict__ cu_text, const float* __restrict__ u_time,
@@ -285,27 +300,27 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
 // is linear in sum_n p[n, q] rstd[n] x[n]: a wave accumulates 16 x 12 numbers instead of 16 x 256 and never generates a row.  Per 16 points:
 // 10 MFMAs (16x16x4) instead of 176; the partial (max, sum, 12-vector) records are merged and expanded by lat_combine_kernel.
 constexpr int EP_WAVES = 8, EP_SPLIT = NPART / EP_WAVES;
+template <int NKS>
 __global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, const float* __restrict__ u_text, const float* __restrict__ cu_text,
                                                                   const float* __restrict__ u_time, const float* __restrict__ cu_time,
                                                                   const int64_t* __restrict__ t, int n_t, int N, float* __restrict__ pm, float* __restrict__ pl,
                                                                   float* __restrict__ pacc12, const float* __restrict__ xt, int cd, const float* __restrict__ feat,
                                                                   int fd, const float* __restrict__ ec, const float* __restrict__ qee) {
-    constexpr int NQ = 16;
-    __shared__ float EUs[16 * 16], QEs[16 * 16], ccs[16], trs[EP_WAVES][16];
+    constexpr int NQ = 16, K = RowLess<NKS>::K, NT = RowLess<NKS>::NT;
+    __shared__ float EUs[K * 16], QEs[K * 16 * NT], ccs[16], trs[EP_WAVES][16];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* tr = trs[wave];
     int64_t ti = t[b];
     ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
-    if (threadIdx.x < 256) { QEs[threadIdx.x] = qee[threadIdx.x]; EUs[threadIdx.x] = 0.f; }
-    __syncthreads();
-    for (int q = wave; q < NQ; q += EP_WAVES) {                    // one wave per folded query: u' = gamma * u_q, its 12 dots with Ec, beta . u_q
+    for (int i = threadIdx.x; i < K * 16 * NT; i += 64 * EP_WAVES) QEs[i] = qee[i];
+    for (int q = wave; q < NQ; q += EP_WAVES) {                    // one wave per folded query: u' = gamma * u_q, its K dots with Ec, beta . u_q
         const float* up = q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256;
         const float4 u = *reinterpret_cast<const float4*>(up + lane * 4), gm = *reinterpret_cast<const float4*>(kvn.g + lane * 4),
                      bt = *reinterpret_cast<const float4*>(kvn.b + lane * 4);
         const float4 ug = make_float4(u.x * gm.x, u.y * gm.y, u.z * gm.z, u.w * gm.w);
         const float d = wave_sum((u.x * bt.x + u.y * bt.y) + (u.z * bt.z + u.w * bt.w));
         if (lane == 0) ccs[q] = d + (q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]);
-        for (int k = 0; k < GEN_K; ++k) {
+        for (int k = 0; k < K; ++k) {
             const float4 e4 = *reinterpret_cast<const float4*>(ec + k * 256 + lane * 4);
             const float dk = wave_sum((e4.x * ug.x + e4.y * ug.y) + (e4.z * ug.z + e4.w * ug.w));
             if (lane == 0) EUs[k * 16 + q] = dk;
@@ -319,28 +334,38 @@ __global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, co
     const int wper = ((per + EP_WAVES - 1) / EP_WAVES + 15) & ~15;      // points per wave, whole tiles
     const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
 
-    f32x4 wacc = {0.f, 0.f, 0.f, 0.f};                            // lane (q = p16, g): sum_n p[n, q] rstd[n] x[n][k = 4 g + r]
+    f32x4 wacc[NT];                                               // lane (q = p16, g), tile t: sum_n p[n, q] rstd[n] x[n][k = 16 t + 4 g + r]
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) wacc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;                          // of query p16, replicated over g
     auto input = [&](unsigned pti, int k) {                        // x[k] of point pti: x_t, features, the constant 1, zeros
         const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
         return k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
     };
     for (int nb = w0; nb < w1; nb += 16) {
-        float xin[3], xT[4];
+        float xin[NKS], xT[NT][4];
         {
             const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) xin[ks] = input(pti, 4 * ks + g);           // lane (p, g): inputs 4 ks + g of point p
+            for (int ks = 0; ks < NKS; ++ks) xin[ks] = input(pti, 4 * ks + g);         // lane (p, g): inputs 4 ks + g of point p
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xT[r] = input((unsigned)(b * N + min(nb + 4 * g + r, n1 - 1)), p16);      // lane (k = p16, g): input k of point 4 g + r
-        }
-        f32x4 yq = {0.f, 0.f, 0.f, 0.f}, sc = yq;
+            for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            yq = __builtin_amdgcn_mfma_f32_16x16x4f32(QEs[(4 * ks + g) * 16 + p16], xin[ks], yq, 0, 0, 0);       // lane (p, g) reg r: input 4 r + g
-            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xin[ks], EUs[(4 * ks + g) * 16 + p16], sc, 0, 0, 0);       // lane (q = p16, g) reg r: point 4 g + r
+                for (int r = 0; r < 4; ++r) xT[tt][r] = input((unsigned)(b * N + min(nb + 4 * g + r, n1 - 1)), 16 * tt + p16);      // lane (k = p16, g): input 16 t + k of point 4 g + r
         }
-        float varq = (yq[0] * xin[0] + yq[1] * xin[1]) + yq[2] * xin[2];
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        float varq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xin[ks], EUs[(4 * ks + g) * 16 + p16], sc, 0, 0, 0);       // lane (q = p16, g) reg r: point 4 g + r
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            f32x4 yq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) yq = __builtin_amdgcn_mfma_f32_16x16x4f32(QEs[(4 * ks + g) * (16 * NT) + 16 * tt + p16], xin[ks], yq, 0, 0, 0);       // reg r: input 4 (4 t + r) + g
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * tt + r < NKS) varq += yq[r] * xin[4 * tt + r];
+        }
         varq += xor16(varq); varq += xor32(varq);
         if (g == 0) tr[p16] = 1.0f / sqrtf(fmaxf(varq, 0.f) + 1e-5f);
         float rq[4];
@@ -362,14 +387,19 @@ __global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, co
         ls += xor16(ls); ls += xor32(ls);
         l_run = l_run * alpha + ls;
         m_run = mn;
-        wacc[0] *= alpha; wacc[1] *= alpha; wacc[2] *= alpha; wacc[3] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xT[r], sc[r] * rq[r], wacc, 0, 0, 0);
+        for (int tt = 0; tt < NT; ++tt) {
+            wacc[tt][0] *= alpha; wacc[tt][1] *= alpha; wacc[tt][2] *= alpha; wacc[tt][3] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wacc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xT[tt][r], sc[r] * rq[r], wacc[tt], 0, 0, 0);
+        }
     }
     const int part = blockIdx.x * EP_WAVES + wave;
     const int64_t base = ((int64_t)b * NPART + part) * NQ;
     if (g == 0) { pm[base + p16] = m_run; pl[base + p16] = l_run; }
-    *reinterpret_cast<float4*>(pacc12 + (base + p16) * 16 + 4 * g) = make_float4(wacc[0], wacc[1], wacc[2], wacc[3]);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+        *reinterpret_cast<float4*>(pacc12 + (base + p16) * (16 * NT) + 16 * tt + 4 * g) = make_float4(wacc[tt][0], wacc[tt][1], wacc[tt][2], wacc[tt][3]);
 }
 
 // ---------------------------------------------------------------- latent chain, batched over the samples
@@ -519,11 +549,13 @@ __global__ __launch_bounds__(256) void lat_combine_kernel(const float* __restric
 //   x1 = q0 + o_proj(v_proj(gamma_kv * (a12 Ec) + beta_kv)) = q0 + c1 + sum_{h, k} a12[h][k] WOVE[12 h + k]
 // with WOVE [96][dq] = W_o (per-head blocks) W_v (gamma_kv * Ec)^T and c1 = b_o + W_o (W_v beta_kv + b_v) from the host (float64).
 // Replaces lat_combine + the v-proj and o-proj toklin launches.  grid (B, 2 latents, dq / 256), block 256.
+template <int NKS>
 __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__ pm, const float* __restrict__ pl, const float* __restrict__ pacc12,
                                                        const float* __restrict__ q0_text, const float* __restrict__ q0_time,
                                                        const int64_t* __restrict__ t, int n_t, int dq, const float* __restrict__ wove,
                                                        const float* __restrict__ c1, float* __restrict__ x1) {
-    __shared__ float a12[8 * GEN_K];
+    constexpr int K = RowLess<NKS>::K, NT = RowLess<NKS>::NT;
+    __shared__ float a12[8 * K];
     const int b = blockIdx.x, i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int h = wave; h < 8; h += 4) {                            // lane = one of the NPART = 64 partials
         const int ih = i * 8 + h;
@@ -535,13 +567,12 @@ __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__
         const float ww = (mm == -INFINITY) ? 0.f : __expf(mm - M);
         const float L = wave_sum(pl[base] * ww);
         const float wq = ww * (1.0f / L);
-        const float4* pa = reinterpret_cast<const float4*>(pacc12 + base * 16);
-        const float4 v0 = pa[0], v1 = pa[1], v2 = pa[2];
-        const float vals[GEN_K] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        const float4* pa = reinterpret_cast<const float4*>(pacc12 + base * (16 * NT));
 #pragma unroll
-        for (int k = 0; k < GEN_K; ++k) {
-            const float sk = wave_sum(wq * vals[k]);
-            if (lane == 0) a12[h * GEN_K + k] = sk;
+        for (int k4 = 0; k4 < NKS; ++k4) {
+            const float4 v = pa[k4];
+            const float s0 = wave_sum(wq * v.x), s1 = wave_sum(wq * v.y), s2 = wave_sum(wq * v.z), s3 = wave_sum(wq * v.w);
+            if (lane == 0) { a12[h * K + 4 * k4] = s0; a12[h * K + 4 * k4 + 1] = s1; a12[h * K + 4 * k4 + 2] = s2; a12[h * K + 4 * k4 + 3] = s3; }
         }
     }
     __syncthreads();
@@ -551,10 +582,14 @@ __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__
     const int n = blockIdx.z * 256 + threadIdx.x;                 // one output per thread: the 96 loads of its column are independent
     if (n < dq) {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        constexpr int CH = NKS <= 4 ? 8 * K : 2 * K;              // loads in flight per thread: 96 (all of them) / 88 (four rounds)
+        for (int j0 = 0; j0 < 8 * K; j0 += CH) {
 #pragma unroll
-        for (int j = 0; j < 8 * GEN_K; j += 4) {
-            v0 += a12[j] * wove[(int64_t)j * dq + n]; v1 += a12[j + 1] * wove[(int64_t)(j + 1) * dq + n];
-            v2 += a12[j + 2] * wove[(int64_t)(j + 2) * dq + n]; v3 += a12[j + 3] * wove[(int64_t)(j + 3) * dq + n];
+            for (int jj = 0; jj < CH; jj += 4) {
+                const int j = j0 + jj;
+                v0 += a12[j] * wove[(int64_t)j * dq + n]; v1 += a12[j + 1] * wove[(int64_t)(j + 1) * dq + n];
+                v2 += a12[j + 2] * wove[(int64_t)(j + 2) * dq + n]; v3 += a12[j + 3] * wove[(int64_t)(j + 3) * dq + n];
+            }
         }
         x1[((int64_t)b * 2 + i) * dq + n] = (q0[n] + c1[n]) + ((v0 + v1) + (v2 + v3));
     }
@@ -857,26 +892,27 @@ __global__ __launch_bounds__(256, 2) void dec_attend_mfma_kernel(const float* __
 // The attention scores fold the same way: LayerNorm_q(e) . G'[jh] = rstd_q (x . EG[:, jh]) + const with x = the 12 inputs, EG = Dc G'^T
 // (Dc = gen_dec minus its row means, per sample and step: lat_dectab_kernel) and var_q = x Qd x^T (step-invariant): the query row e is
 // never generated either.
-constexpr int DP_LDG = 260, DP_LDX = 272, DP_LDQ = 36, DP_LDW = 260;
-constexpr int DP_QTAB = 32 * DP_LDQ;                              // floats of a sample's quadratic-form table
-constexpr int DP_TAB = DP_QTAB + 16 * 16 + 16 + 8 * 16;           // + EG [12 -> 16][16] + gconst [16] + WP [8][16]: a sample's table of the step
-constexpr int DP_TWP_FLOATS = 16 * 3 * 64 * 4;                    // linear1 operand planes: [16 channel tiles][3 bf16 planes][64 lanes][8 bf16]
-constexpr int DP_LDS_FLOATS = DP_TWP_FLOATS + DP_TAB + 8 * DP_LDW + 256 + 16 * 16 + 8 * 16 + 16 + 4 * 16 * 17 + 4 * 16;
+constexpr int DP_LDW = 260;
 
 // All per-sample tables of dec_point_kernel straight from the decoder keys / values of the sample's two latents (lat_kv, 2 x 2 x 256 numbers) and
-// step-invariant matrices (afm_cdm_weights.dec_*; o = 32 h + r runs over a head's 32 key / value entries, jh = 8 j + h):
+// step-invariant matrices (afm_cdm_weights.dec_*; o = 32 h + r runs over a head's 32 key / value entries, jh = 8 j + h, k = an input):
 //   EG[k][jh]     = scd sum_r kd_j[o] DWQ[k][o]            gconst[jh] = scd sum_r kd_j[o] wqb[o]            WP[r'][jh] = sum_r vd_j[o] WCO[r'][o]
 //   TWc[jh][n]    = sum_r vd_j[o] WOW[o][n]                (centred P rows times (W1 gamma)^T, P itself is never formed)
 //   Qc[jh][jh']   = sum_{r, r'} vd_j[o] WoG[o][o'] vd_j'[o'],  Qc[jh][16 + k] = sum_r vd_j[o] XWO[k][o],  Qc[16 + k][16 + k'] = qxx
-// Replaces lat_decfold + lat_dectab + the TWc toklin launch of the fused form.  grid B, block 1024 (the two [256][256] products: thread =
-// (column, pair of heads), 64 independent row loads each; the small tables on the first 256 threads).
+// Qc goes out in MFMA operand order (RowLess<NKS>): entry (cs, 16 t + i) = Qc[m'(t, i)][m(cs)] - K index cs < 16: attention weight cs, cs = 16 +
+// XS g + ks: input 4 ks + g; output rows of tile 0: attention weights, of tile 1 + t: input 4 (4 t + (i & 3)) + (i >> 2).
+// Replaces lat_decfold + the TWc launch of the fused form.  grid B, block 1024 (the two [256][256] products: thread = (column, pair of heads),
+// 64 independent row loads each).
+template <int NKS>
 __global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __restrict__ lat_kv, const float* __restrict__ dwq, const float* __restrict__ wqb,
                                                             const float* __restrict__ wco, const float* __restrict__ wow, const float* __restrict__ wog,
                                                             const float* __restrict__ xwo, const float* __restrict__ qxx, int cd,
                                                             float* __restrict__ twp, float* __restrict__ tab) {
+    using RL = RowLess<NKS>;
+    constexpr int K = RL::K, NQ = 16 + K;
     __shared__ float kd[2][256], vd[2][256];
     __shared__ float tv[16][257];
-    __shared__ float Q[28][29];
+    __shared__ float Q[NQ][NQ + 1];
     const int b = blockIdx.x, c = threadIdx.x & 255, gq4 = threadIdx.x >> 8;
     const float scd = 0.17677669529663687f;                       // 1 / sqrt(32)
     if (gq4 < 2) {
@@ -900,35 +936,31 @@ __global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __rest
             tv[h][c] = g0; tv[8 + h][c] = g1;
         }
     }
-    float* T = tab + (int64_t)b * DP_TAB;
-    if (gq4 > 0) {
-        // (the small tables below belong to the first 256 threads)
-    } else if (c < 192) {                                                // EG [12][16] and the attention-weight x input block of Qc
-        const int k = c >> 4, jh = c & 15, j = jh >> 3, h = jh & 7;
-        float e = 0.f, q = 0.f;
+    float* T = tab + (int64_t)b * RL::TAB;
+    for (int e = threadIdx.x; e < K * 16; e += 1024) {            // EG [K][16] and the attention-weight x input block of Qc
+        const int k = e >> 4, jh = e & 15, j = jh >> 3, h = jh & 7;
+        float eg = 0.f, q = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) { e += kd[j][32 * h + r] * dwq[k * 256 + 32 * h + r]; q += vd[j][32 * h + r] * xwo[k * 256 + 32 * h + r]; }
-        T[DP_QTAB + c] = e * scd;
+        for (int r = 0; r < 32; ++r) { eg += kd[j][32 * h + r] * dwq[k * 256 + 32 * h + r]; q += vd[j][32 * h + r] * xwo[k * 256 + 32 * h + r]; }
+        T[RL::QTAB + e] = eg * scd;
         Q[jh][16 + k] = q; Q[16 + k][jh] = q;
-    } else {
-        T[DP_QTAB + c] = 0.f;                                      // rows k >= 12 of the EG table
     }
-    if (gq4 == 0 && c < 16) {
-        const int j = c >> 3, h = c & 7;
+    if (threadIdx.x < 16) {
+        const int j = threadIdx.x >> 3, h = threadIdx.x & 7;
         float gq = 0.f;
         for (int r = 0; r < 32; ++r) gq += kd[j][32 * h + r] * wqb[32 * h + r];
-        T[DP_QTAB + 256 + c] = gq * scd;
+        T[RL::QTAB + K * 16 + threadIdx.x] = gq * scd;
     }
-    if (gq4 == 0 && c < 128) {                                    // WP [8][16]
-        const int rr = c >> 4, jh = c & 15, j = jh >> 3, h = jh & 7;
+    if (threadIdx.x >= 256 && threadIdx.x < 256 + 128) {          // WP [8][16]
+        const int e = threadIdx.x - 256, rr = e >> 4, jh = e & 15, j = jh >> 3, h = jh & 7;
         float wp = 0.f;
         if (rr < cd)
             for (int r = 0; r < 32; ++r) wp += vd[j][32 * h + r] * wco[rr * 256 + 32 * h + r];
-        T[DP_QTAB + 256 + 16 + c] = wp;
+        T[RL::QTAB + K * 16 + 16 + e] = wp;
     }
-    if (gq4 == 1 && c < 144) Q[16 + c / 12][16 + c % 12] = qxx[c];
+    for (int e = threadIdx.x; e < K * K; e += 1024) Q[16 + e / K][16 + e % K] = qxx[e];
     __syncthreads();
-    if (gq4 == 0) {   // Qc[jh][jh'] = tv[jh] (head block of jh') . vd_j'
+    if (threadIdx.x < 256) {   // Qc[jh][jh'] = tv[jh] (head block of jh') . vd_j'
         const int jh = c >> 4, jh2 = c & 15, j2 = jh2 >> 3, h2 = jh2 & 7;
         float q = 0.f;
 #pragma unroll 8
@@ -936,59 +968,70 @@ __global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __rest
         Q[jh][jh2] = q;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < DP_QTAB; e += 1024) {
-        const int cs = e / DP_LDQ, col = e - cs * DP_LDQ;
+    for (int e = threadIdx.x; e < RL::QTAB; e += 1024) {
+        const int cs = e / RL::LDQ, col = e - cs * RL::LDQ;
         float v = 0.f;
-        if (col < 32) {
-            const int i = col & 15, x = cs - 16;
-            const int m2 = col < 16 ? i : ((i & 3) < 3 ? 16 + 4 * (i & 3) + (i >> 2) : -1);
-            const int m = cs < 16 ? cs : ((x & 3) < 3 ? 16 + 4 * (x & 3) + (x >> 2) : -1);
+        if (col < 16 + 16 * RL::NT) {
+            const int i = col & 15, tt = (col >> 4) - 1, x = cs - 16, xg = x / RL::XS, xk = x - xg * RL::XS;
+            const int m2 = col < 16 ? i : (4 * tt + (i & 3) < NKS ? 16 + 4 * (4 * tt + (i & 3)) + (i >> 2) : -1);
+            const int m = cs < 16 ? cs : (xk < NKS ? 16 + 4 * xk + xg : -1);
             if (m >= 0 && m2 >= 0) v = Q[m2][m];
         }
         T[e] = v;
     }
 }
 
-__global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab,
-                                                           const float* __restrict__ qdd, const float* __restrict__ twx,
-                                                           const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe,
-                                                           const float* __restrict__ c0, int N, int cd, const float* xt, const float* __restrict__ feat, int fd,
-                                                           float* __restrict__ x0_out, const float* __restrict__ noise, float* x_next,
-                                                           const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma) {
-    constexpr int NJH = 16, LDG = DP_LDG;
+template <int NKS> constexpr int dp_lds_floats() {
+    using RL = RowLess<NKS>;
+    return 16 * RL::NSTEP * 3 * 64 * 4 + RL::TAB + 8 * DP_LDW + 256 + RL::K * 16 * RL::NT + 8 * 16 * RL::NT + 16 + RL::NW * 16 * 17 + RL::NW * 16;
+}
+
+template <int NKS>
+__global__ __launch_bounds__(64 * RowLess<NKS>::NW, NKS <= 4 ? 2 : 1)
+void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab, const float* __restrict__ qdd, const float* __restrict__ twx,
+                      const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe, const float* __restrict__ c0, int N, int cd,
+                      const float* xt, const float* __restrict__ feat, int fd, float* __restrict__ x0_out, const float* __restrict__ noise, float* x_next,
+                      const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma) {
+    using RL = RowLess<NKS>;
+    constexpr int K = RL::K, NT = RL::NT, LDQ = RL::LDQ, XS = RL::XS, NSTEP = RL::NSTEP, NW = RL::NW, NTH = 64 * NW, QEW = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) float dp_sm[];
     // linear1 runs on the bf16 pipe with the exact three-way split (csrc/bf16split.h): the f32 MFMA issues at the vector rate and does not
     // overlap with the VALU work of the GELUs (122 us with all products in f32: VALU + f32 MFMA cycles add up), v_mfma_f32_16x16x32_bf16 does.
-    // Operand order of its K = 32: lane group g carries k = {a[4 g .. 4 g + 3], x[g], x[4 + g], x[8 + g], 0}, i.e. what lane (p, g) already holds.
-    uint4* TWP = reinterpret_cast<uint4*>(dp_sm);                 // [16 tiles][3 planes][64 lanes] 8 bf16: TWc rows in that order, split once per workgroup
-    float* Qs = dp_sm + DP_TWP_FLOATS;                            // [32][LDQ]  quadratic form of the MLP's LayerNorm, operand order (lat_dectab_kernel)
-    float* EGs = Qs + DP_QTAB;                                    // [16][16]   scores: row k = input, column jh
-    float* gcs = EGs + 16 * 16;                                   // [16]       beta_q . G[jh] + cb[jh]
+    // Operand order of its K = 32 steps: lane group g carries k = {a[4 g .. 4 g + 3], x[ks = 0 .. 3]} in step 0 and x[ks = 4 .. 11] in step 1 (x[ks] =
+    // input 4 ks + g, zeros past NKS), i.e. what lane (p, g) already holds.
+    uint4* TWP = reinterpret_cast<uint4*>(dp_sm);                 // [16 tiles][NSTEP][3 planes][64 lanes] 8 bf16: TWc rows in that order, split once per workgroup
+    float* Qs = dp_sm + 16 * NSTEP * 3 * 64 * 4;                  // [QCOL][LDQ] quadratic form of the MLP's LayerNorm, operand order (lat_dectables_kernel)
+    float* EGs = Qs + RL::QTAB;                                   // [K][16]    scores: row k = input, column jh
+    float* gcs = EGs + K * 16;                                    // [16]       beta_q . G[jh] + cb[jh]
     float* WPs = gcs + 16;                                        // [8][16]    contact_layer.w . P
     float* W2s = WPs + 8 * 16;                                    // [8][LDW]   contact_layer.w fc2.w  (rows >= cd: 0)
     float* Cv = W2s + 8 * DP_LDW;                                 // [256]      b1 + W1 beta_mlp
-    float* QDs = Cv + 256;                                        // [16][16]   quadratic form of the query's LayerNorm, operand order (host)
-    float* QEs = QDs + 16 * 16;                                   // [8][16]    contact_layer.w . gen_dec^T  (columns >= 12: 0)
-    float* c0s = QEs + 8 * 16;                                    // [16]
+    float* QDs = Cv + 256;                                        // [K][16 NT] quadratic form of the query's LayerNorm, operand order (host)
+    float* QEs = QDs + K * 16 * NT;                               // [8][16 NT] contact_layer.w . G_dec^T  (columns >= feat_dim + 1: 0)
+    float* c0s = QEs + 8 * QEW;                                   // [16]
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* aT = c0s + 16 + wave * 16 * 17;                        // [16 points][17] attention weights of the tile, transposed
-    float* tr = c0s + 16 + 4 * 16 * 17 + wave * 16;               // [16] a per-point scalar from lanes (p, .) to lanes (., g)
-    for (int it = threadIdx.x; it < 16 * 64; it += 256) {          // (channel tile, lane) items: 8 operand values -> three planes
-        const int tt = it >> 6, l = it & 63, n = 16 * tt + (l & 15), gg = l >> 4;
-        const float* tp = twp + ((int64_t)b * 16 + 4 * gg) * 256 + n;
-        const float v0 = tp[0], v1 = tp[256], v2 = tp[512], v3 = tp[768];
-        const float v4 = twx[gg * 256 + n], v5 = twx[(4 + gg) * 256 + n], v6 = twx[(8 + gg) * 256 + n];
+    float* tr = c0s + 16 + NW * 16 * 17 + wave * 16;              // [16] a per-point scalar from lanes (p, .) to lanes (., g)
+    for (int it = threadIdx.x; it < 16 * NSTEP * 64; it += NTH) { // (channel tile, K32 step, lane) items: 8 operand values -> three planes
+        const int l = it & 63, st = (it >> 6) % NSTEP, tt = it / (64 * NSTEP), n = 16 * tt + (l & 15), gg = l >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int slot = 8 * st + e;                           // slots 0..3: attention weights 4 g + e; slot 4 + ks: input 4 ks + g
+            v[e] = slot < 4 ? twp[((int64_t)b * 16 + 4 * gg + slot) * 256 + n] : (slot - 4 < NKS ? twx[(4 * (slot - 4) + gg) * 256 + n] : 0.f);
+        }
         uint4 p1, p2, p3;
-        split2(v0, v1, p1.x, p2.x, p3.x); split2(v2, v3, p1.y, p2.y, p3.y); split2(v4, v5, p1.z, p2.z, p3.z); split2(v6, 0.f, p1.w, p2.w, p3.w);
-        TWP[(tt * 3 + 0) * 64 + l] = p1; TWP[(tt * 3 + 1) * 64 + l] = p2; TWP[(tt * 3 + 2) * 64 + l] = p3;
+        split2(v[0], v[1], p1.x, p2.x, p3.x); split2(v[2], v[3], p1.y, p2.y, p3.y); split2(v[4], v[5], p1.z, p2.z, p3.z); split2(v[6], v[7], p1.w, p2.w, p3.w);
+        uint4* d = TWP + ((tt * NSTEP + st) * 3) * 64 + l;
+        d[0] = p1; d[64] = p2; d[128] = p3;
     }
-    for (int i = threadIdx.x; i < DP_TAB; i += 256) Qs[i] = qtab[(int64_t)b * DP_TAB + i];      // Qs | EGs | gcs | WPs are contiguous, like the table
-    for (int i = threadIdx.x; i < 8 * 256; i += 256) W2s[(i >> 8) * DP_LDW + (i & 255)] = (i >> 8) < cd ? w2f[i] : 0.f;
-    Cv[threadIdx.x] = cvec[threadIdx.x];
-    QDs[threadIdx.x] = qdd[threadIdx.x];
-    if (threadIdx.x < 8 * 16) {
-        const int j = threadIdx.x >> 4, k = threadIdx.x & 15;
-        QEs[threadIdx.x] = (j < cd && k < GEN_K) ? gen_qe[j * GEN_K + k] : 0.f;
+    for (int i = threadIdx.x; i < RL::TAB; i += NTH) Qs[i] = qtab[(int64_t)b * RL::TAB + i];      // Qs | EGs | gcs | WPs are contiguous, like the table
+    for (int i = threadIdx.x; i < 8 * 256; i += NTH) W2s[(i >> 8) * DP_LDW + (i & 255)] = (i >> 8) < cd ? w2f[i] : 0.f;
+    for (int i = threadIdx.x; i < 256; i += NTH) Cv[i] = cvec[i];
+    for (int i = threadIdx.x; i < K * 16 * NT; i += NTH) QDs[i] = qdd[i];
+    for (int i = threadIdx.x; i < 8 * QEW; i += NTH) {
+        const int j = i / QEW, k = i - j * QEW;
+        QEs[i] = (j < cd && k < K) ? gen_qe[j * K + k] : 0.f;
     }
     if (threadIdx.x < 16) c0s[threadIdx.x] = (int)threadIdx.x < cd ? c0[threadIdx.x] : 0.f;
     __syncthreads();
@@ -996,14 +1039,14 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 
     const int per = (N + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
-    const int wper = ((per + 3) / 4 + 15) & ~15;                  // points per wave, whole tiles
+    const int wper = ((per + NW - 1) / NW + 15) & ~15;            // points per wave, whole tiles
     const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
 
-    float xin[3], xnext[3];
-    auto fetch = [&](int nb, float (&dst)[3]) {                    // inputs k = 4 ks + g of point nb + p16
+    float xin[NKS], xnext[NKS];
+    auto fetch = [&](int nb, float (&dst)[NKS]) {                  // inputs k = 4 ks + g of point nb + p16
         const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             const int k = 4 * ks + g;
             const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
             dst[ks] = k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
@@ -1014,17 +1057,23 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
         const int64_t pt = (int64_t)b * N + nb + p16;
         const bool pvalid = nb + p16 < w1;
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) xin[ks] = xnext[ks];
+        for (int ks = 0; ks < NKS; ++ks) xin[ks] = xnext[ks];
         if (nb + 16 < w1) fetch(nb + 16, xnext);
         // ---- LayerNorm statistics of the (never generated) query row: var_q = x Qd x^T; scores = rstd_q (x . EG) + const; softmax over the
         // two keys of a head (jh and jh ^ 8: eight lanes apart)
-        f32x4 yq = {0.f, 0.f, 0.f, 0.f}, sc = yq;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        float varq = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            yq = __builtin_amdgcn_mfma_f32_16x16x4f32(QDs[(4 * ks + g) * 16 + p16], xin[ks], yq, 0, 0, 0);       // lane (p, g) reg r: input 4 r + g
-            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xin[ks], EGs[(4 * ks + g) * 16 + p16], sc, 0, 0, 0);       // lane (jh = p16, g) reg r: point 4 g + r
+        for (int ks = 0; ks < NKS; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xin[ks], EGs[(4 * ks + g) * 16 + p16], sc, 0, 0, 0);       // lane (jh = p16, g) reg r: point 4 g + r
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            f32x4 yq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) yq = __builtin_amdgcn_mfma_f32_16x16x4f32(QDs[(4 * ks + g) * (16 * NT) + 16 * tt + p16], xin[ks], yq, 0, 0, 0);       // reg r: input 4 (4 t + r) + g
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * tt + r < NKS) varq += yq[r] * xin[4 * tt + r];
         }
-        float varq = (yq[0] * xin[0] + yq[1] * xin[1]) + yq[2] * xin[2];
         varq += xor16(varq); varq += xor32(varq);
         if (g == 0) tr[p16] = 1.0f / sqrtf(fmaxf(varq, 0.f) + 1e-5f);
 #pragma unroll
@@ -1038,73 +1087,86 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) aB[sI] = aT[p16 * 17 + 4 * g + sI];       // lane (p = p16, g): a[p, jh = 4 g + s]
         // ---- variance of the MLP's LayerNorm input: u Qc u^T (y = Qc u on the matrix pipe, the dot with u in the lane + across g)
-        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = y0;
+        float var = 0.f;
 #pragma unroll
-        for (int sI = 0; sI < 4; ++sI) {
-            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(4 * g + sI) * DP_LDQ + p16], aB[sI], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(4 * g + sI) * DP_LDQ + 16 + p16], aB[sI], y1, 0, 0, 0);
-        }
+        for (int tt = 0; tt < 1 + NT; ++tt) {                      // output tile 0: attention weights; 1 + t: inputs 4 (4 t + r) + g
+            f32x4 y = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 + 4 * g + ks) * DP_LDQ + p16], xin[ks], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 + 4 * g + ks) * DP_LDQ + 16 + p16], xin[ks], y1, 0, 0, 0);
+            for (int sI = 0; sI < 4; ++sI) y = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(4 * g + sI) * LDQ + 16 * tt + p16], aB[sI], y, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) y = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 + XS * g + ks) * LDQ + 16 * tt + p16], xin[ks], y, 0, 0, 0);
+            if (tt == 0) var += (y[0] * aB[0] + y[1] * aB[1]) + (y[2] * aB[2] + y[3] * aB[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * (tt - 1) + r < NKS) var += y[r] * xin[4 * (tt - 1) + r];
+            }
         }
-        float var = ((y0[0] * aB[0] + y0[1] * aB[1]) + (y0[2] * aB[2] + y0[3] * aB[3])) + ((y1[0] * xin[0] + y1[1] * xin[1]) + y1[2] * xin[2]);
         var += xor16(var); var += xor32(var);
         const float rstd2 = 1.0f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
-        // ---- linear1 (K = 28) one 16-channel tile at a time -> GELU -> row-dots with w2; then the attention and query parts of contact_layer.w . h1
-        // Four 16-channel tiles at a time, phase by phase (operand reads, four interleaved MFMA chains, 16 independent GELUs, four row-dot
-        // accumulators): tile by tile the wave would sit through an LDS round trip, a 7-long dependent MFMA chain and a GELU dependency chain
-        // per tile (31 k cycles per 16 points measured, for 6.5 k cycles of matrix work).
-        uint4 ub[3];                                               // u = [a | x] of this lane's point, three bf16 planes in linear1's operand order
-        split2(aB[0], aB[1], ub[0].x, ub[1].x, ub[2].x); split2(aB[2], aB[3], ub[0].y, ub[1].y, ub[2].y);
-        split2(xin[0], xin[1], ub[0].z, ub[1].z, ub[2].z); split2(xin[2], 0.f, ub[0].w, ub[1].w, ub[2].w);
+        // ---- linear1 (K = 16 + 4 NKS) -> GELU -> row-dots with w2; then the attention and query parts of contact_layer.w . h1.
+        // TG 16-channel tiles at a time, phase by phase (operand reads, interleaved MFMA chains, independent GELUs, separate row-dot accumulators):
+        // tile by tile the wave would sit through an LDS round trip, a dependent MFMA chain and a GELU dependency chain per tile.
+        uint4 ub[NSTEP][3];                                        // u = [a | x] of this lane's point, three bf16 planes in linear1's operand order
+        {
+            float v[8 * NSTEP];
+#pragma unroll
+            for (int e = 0; e < 8 * NSTEP; ++e) v[e] = e < 4 ? aB[e] : (e - 4 < NKS ? xin[e - 4 < NKS ? e - 4 : 0] : 0.f);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                split2(v[8 * st + 0], v[8 * st + 1], ub[st][0].x, ub[st][1].x, ub[st][2].x); split2(v[8 * st + 2], v[8 * st + 3], ub[st][0].y, ub[st][1].y, ub[st][2].y);
+                split2(v[8 * st + 4], v[8 * st + 5], ub[st][0].z, ub[st][1].z, ub[st][2].z); split2(v[8 * st + 6], v[8 * st + 7], ub[st][0].w, ub[st][1].w, ub[st][2].w);
+            }
+        }
+        constexpr int TG = NSTEP == 1 ? 4 : 2;                     // channel tiles in flight (registers: TG x NSTEP x 3 operand vectors)
         f32x4 sa[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) sa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t4 = 0; t4 < 16; t4 += 4) {
-            uint4 wp[4][3];
-            float4 cv[4], w4[4];
+        for (int t4 = 0; t4 < 16; t4 += TG) {
+            uint4 wp[TG][NSTEP][3];
+            float4 cv[TG], w4[TG];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < TG; ++q) {
                 const int tt = t4 + q;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wp[q][pl] = TWP[(tt * 3 + pl) * 64 + lane];
+                for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wp[q][st][pl] = TWP[((tt * NSTEP + st) * 3 + pl) * 64 + lane];
                 cv[q] = *reinterpret_cast<const float4*>(Cv + 16 * tt + 4 * g);
                 w4[q] = p16 < 8 ? *reinterpret_cast<const float4*>(W2s + p16 * DP_LDW + 16 * tt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[4];
+            f32x4 acc[TG];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < TG; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int pq = 0; pq < 9; ++pq)
+            for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[q][AFM_PA[pq]]), __builtin_bit_cast(bf16x8, ub[AFM_PB[pq]]), acc[q], 0, 0, 0);
+                for (int pq = 0; pq < 9; ++pq)
+#pragma unroll
+                    for (int q = 0; q < TG; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[q][st][AFM_PA[pq]]), __builtin_bit_cast(bf16x8, ub[st][AFM_PB[pq]]), acc[q], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            float hid[4][4];
+            float hid[TG][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < TG; ++q) {
                 hid[q][0] = gelu_erf_fast(rstd2 * acc[q][0] + cv[q].x); hid[q][1] = gelu_erf_fast(rstd2 * acc[q][1] + cv[q].y);
                 hid[q][2] = gelu_erf_fast(rstd2 * acc[q][2] + cv[q].z); hid[q][3] = gelu_erf_fast(rstd2 * acc[q][3] + cv[q].w);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].x, hid[q][0], sa[q], 0, 0, 0);
-            }
+            for (int q = 0; q < TG; ++q) sa[q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].x, hid[q][0], sa[q & 3], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].y, hid[q][1], sa[q], 0, 0, 0);
+            for (int q = 0; q < TG; ++q) sa[(q + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].y, hid[q][1], sa[(q + 2) & 3], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].z, hid[q][2], sa[q], 0, 0, 0);
+            for (int q = 0; q < TG; ++q) sa[q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].z, hid[q][2], sa[q & 3], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sa[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].w, hid[q][3], sa[q], 0, 0, 0);
+            for (int q = 0; q < TG; ++q) sa[(q + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[q].w, hid[q][3], sa[(q + 2) & 3], 0, 0, 0);
         }
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) sa[sI & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? WPs[p16 * 16 + 4 * g + sI] : 0.f, aB[sI], sa[sI & 1], 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) sa[2 + (ks & 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? QEs[p16 * 16 + 4 * ks + g] : 0.f, xin[ks], sa[2 + (ks & 1)], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) sa[2 + (ks & 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(p16 < 8 ? QEs[p16 * QEW + 4 * ks + g] : 0.f, xin[ks], sa[2 + (ks & 1)], 0, 0, 0);
         const f32x4 sat = (sa[0] + sa[1]) + (sa[2] + sa[3]);
         if (pvalid) {                                              // lane (point p16, g): contact channels 4 g + r
 #pragma unroll
@@ -1124,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void dec_point_kernel(const float* __restri
 struct CdmWs {
     float *enc_kv, *bufB, *h1, *z, *pm, *pl, *pacc, *dec_lat, *s1, *rdot, *qe;
     float *lat_s, *lat_x, *lat_t1, *lat_t2, *lat_qkv, *lat_kv;     // batched latent chain: [2B] token rows
-    float *twp, *qtab;                                             // fused decoder: TWc rows of the attention weights [16 B][256], per-sample tables [B][DP_TAB]
+    float *twp, *qtab;                                             // fused decoder: TWc rows of the attention weights [16 B][256], per-sample tables [B][RowLess::TAB]
     int64_t bytes;
 };
 
@@ -1144,7 +1206,7 @@ CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
     const int64_t ntok = 2 * (int64_t)B;
     s.lat_s = take(ntok * w.enc_heads * w.dkv * 4); s.lat_x = take(ntok * w.dq * 4); s.lat_t1 = take(ntok * w.dq * 4);
     s.lat_t2 = take(ntok * w.dq * 4); s.lat_qkv = take(ntok * 3 * w.dq * 4); s.lat_kv = take(ntok * 2 * w.dkv * 4);
-    s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * DP_TAB * 4);
+    s.twp = take((int64_t)B * 16 * 256 * 4); s.qtab = take((int64_t)B * RowLess<11>::TAB * 4);
     s.bytes = off;
     return s;
 }
@@ -1245,8 +1307,12 @@ int launch_enc_reduce(const afm_cdm_weights& w, const float* rows, const float* 
     }();
     if (attr != 0) return attr;
     if (mode == 3) {                                  // no rows at all: 12-vector partials in ws.pacc (stride 16)
-        hipLaunchKernelGGL(enc_point_kernel, dim3(EP_SPLIT, B), dim3(64 * EP_WAVES), 0, s, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t, w.n_timesteps, N,
-                           ws.pm, ws.pl, ws.pacc, x_t, w.contact_dim, feat, w.feat_dim, w.enc_ec, w.enc_qee);
+        if (rowless_nks(w.feat_dim) == 3)
+            hipLaunchKernelGGL(enc_point_kernel<3>, dim3(EP_SPLIT, B), dim3(64 * EP_WAVES), 0, s, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t, w.n_timesteps, N,
+                               ws.pm, ws.pl, ws.pacc, x_t, w.contact_dim, feat, w.feat_dim, w.enc_ec, w.enc_qee);
+        else
+            hipLaunchKernelGGL(enc_point_kernel<11>, dim3(EP_SPLIT, B), dim3(64 * EP_WAVES), 0, s, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t, w.n_timesteps, N,
+                               ws.pm, ws.pl, ws.pacc, x_t, w.contact_dim, feat, w.feat_dim, w.enc_ec, w.enc_qee);
         AFM_CHECK_LAUNCH();
         return 0;
     }
@@ -1280,19 +1346,30 @@ int launch_dec_attend(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
 
 int launch_toklin(const TokLin& p, hipStream_t s);
 
-// the fused decoder (mode 3): per-sample tables of the step (two small launches), then one kernel over the points
+template <int NKS>
+int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
+                       const afm_ddpm_args* ddpm, hipStream_t s);
+
+// the fused decoder (mode 3): the per-sample tables of the step (one launch), then one kernel over the points
 int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
                      const afm_ddpm_args* ddpm, hipStream_t s) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
-    constexpr int LDS = DP_LDS_FLOATS * (int)sizeof(float);
-    static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
+    return rowless_nks(w.feat_dim) == 3 ? launch_dec_point_t<3>(w, B, N, ws, x_t, feat, x0_out, ddpm, s) : launch_dec_point_t<11>(w, B, N, ws, x_t, feat, x0_out, ddpm, s);
+}
+
+template <int NKS>
+int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
+                       const afm_ddpm_args* ddpm, hipStream_t s) {
+    constexpr int LDS = dp_lds_floats<NKS>() * (int)sizeof(float);
+    static_assert(LDS <= 160 * 1024, "dec_point_kernel's tables fit the LDS");
+    static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
-    hipLaunchKernelGGL(lat_dectables_kernel, dim3(B), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
+    hipLaunchKernelGGL(lat_dectables_kernel<NKS>, dim3(B), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
                        w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
     AFM_CHECK_LAUNCH();
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
     if (chunks > 16) chunks = 16;                     // (three workgroups per CU measured slower: the kernel is bound by VALU + f32 MFMA issue, not by latency)
-    hipLaunchKernelGGL(dec_point_kernel, dim3(chunks, B), dim3(256), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
+    hipLaunchKernelGGL(dec_point_kernel<NKS>, dim3(chunks, B), dim3(64 * RowLess<NKS>::NW), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
                        ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);
     AFM_CHECK_LAUNCH();
@@ -1317,7 +1394,10 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
     const bool head = enc12;                          // fused form: combine + v-proj + o-proj as one launch (lat_head_kernel)
-    if (head) hipLaunchKernelGGL(lat_head_kernel, dim3(B, 2, (dq + 255) / 256), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
+    if (head && rowless_nks(w.feat_dim) == 3)
+        hipLaunchKernelGGL(lat_head_kernel<3>, dim3(B, 2, (dq + 255) / 256), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
+    else if (head)
+        hipLaunchKernelGGL(lat_head_kernel<11>, dim3(B, 2, (dq + 255) / 256), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, text_q0, w.time_q0, t, w.n_timesteps, dq, w.enc_wove, w.enc_c1, ws.lat_x);
     else hipLaunchKernelGGL(lat_combine_kernel, dim3(B, 2 * He), dim3(256), 0, s, ws.pm, ws.pl, ws.pacc, 2 * He, dkv, text_q0, w.time_q0, t, w.n_timesteps, dq,
                             ws.lat_s, ws.lat_x);
     AFM_CHECK_LAUNCH();
@@ -1387,7 +1467,7 @@ inline int cdm_mode(const afm_cdm_weights& w) {
     const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
     if (!folded) return 0;
     const bool fused = w.gen_qe && w.dec_c && w.dec_twx && w.dec_qxx && w.dec_qdd && w.enc_ec && w.enc_qee && w.enc_wove && w.enc_c1 && w.dec_dwq && w.dec_wqb &&
-                       w.dec_wco && w.dec_wow && w.dec_wog && w.dec_xwo && w.feat_dim + 1 <= GEN_K && w.enc_heads == 8 && w.dec_heads == 8 && w.dkv == 256 &&
+                       w.dec_wco && w.dec_wow && w.dec_wog && w.dec_xwo && rowless_nks(w.feat_dim) != 0 && w.enc_heads == 8 && w.dec_heads == 8 && w.dkv == 256 &&
                        !(w.flags & AFM_CDM_NO_GEN);
     return fused ? 3 : 1;
 }

@@ -249,12 +249,23 @@ def test_two_stream_loop_soak():
     assert not bad, f"{len(bad)} of 50 two-stream loops differ from the single-stream result: {bad[:4]}"
 
 
-@pytest.mark.parametrize("B,N", [(3, 1000), (1, 37), (9, 272)])
-def test_row_less_form_on_ragged_shapes(cdm, B, N):
+@pytest.fixture(scope="module")
+def cdm_feat():
+    m = create_model(cdm_cfg(point_feats=True), device=dev())
+    load_named_weights(m)
+    return m.to(dev()).eval()
+
+
+@pytest.mark.parametrize("B,N,feats", [(3, 1000, False), (1, 37, False), (9, 272, False), (3, 1000, True), (2, 53, True), (5, 4096, True)])
+def test_row_less_form_on_ragged_shapes(cdm, cdm_feat, B, N, feats):
     """The row-less sampling form (enc_point / lat_head / lat_dectables / dec_point) against the layer-by-layer form where its tiling is ragged:
-    N not a multiple of the 16-point tiles or of the per-wave ranges, a last token block of fewer than 16 latent tokens, one sample."""
+    N not a multiple of the 16-point tiles or of the per-wave ranges, a last token block of fewer than 16 latent tokens, one sample; both
+    instantiations of the kernels (12 inputs: the H3D variant; 44 inputs: 32 scene features per point, the HUMANISE variant)."""
+    cdm = cdm_feat if feats else cdm
     xyz, text = synth.scene_cloud(B, N, seed=B + N), synth.text_feature(B)
     kw = dict(c_text_feat=text.to(dev()), c_pc_xyz=xyz.to(dev()))
+    if feats:
+        kw["c_pc_feat"] = synth.gaussian(f"ragged_feat_{B}_{N}", (B, N, 32)).to(dev())
     x = synth.gaussian(f"ragged_x_{B}_{N}", (B, N, 6))
     t = torch.arange(B) * 53 % 500
     d4 = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="4"))

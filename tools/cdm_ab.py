@@ -58,5 +58,6 @@ measure(m, d, kw, "H3D folded rows, linear1 on staged 64x64 tiles", **dict(base,
 del m
 mh, dh = build(True)
 kwh = dict(kw, c_pc_feat=synth.gaussian("cdm_ab_feat", (B, N, 32)).to(dev))
-measure(mh, dh, kwh, "HUMANISE variant (41 input channels, backbone features hoisted): folded rows, one stream", **base)
+measure(mh, dh, kwh, "HUMANISE variant (41 input channels, backbone features hoisted): no per-point rows (K = 44 inputs), one stream", **base)
 measure(mh, dh, kwh, "HUMANISE variant, two sub-batch streams", **dict(base, loop_sub_batches=2))
+measure(mh, dh, kwh, "HUMANISE variant, folded rows (round 2 form), one stream", **dict(base, no_gen=True))

@@ -1,6 +1,7 @@
 """Lean target for rocprofv3 --pmc / --kernel-trace passes: 12 native steps at the bench shape, single stream, no profiler events.
     python tools/pmc_target.py          -> CMDM trans_enc loop (BASELINE configs[1]: B = 32, L = 196, T = 326)
-    python tools/pmc_target.py cdm      -> CDM Perceiver loop  (BASELINE configs[2]: B = 32, N = 8192 points + text token)"""
+    python tools/pmc_target.py cdm      -> CDM Perceiver loop  (BASELINE configs[2]: B = 32, N = 8192 points + text token)
+    python tools/pmc_target.py cdm_h    -> the same loop, HUMANISE variant (41 input channels: 32 hoisted scene features per point)"""
 import os
 import sys
 
@@ -16,10 +17,12 @@ from afm.config import load_config  # noqa: E402
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "cmdm"
 B = 32
-if which == "cdm":
+if which in ("cdm", "cdm_h"):
     N = 8192
-    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.scene_model.use_scene_model=False", "model.input_feats=6",
-                                                            "model.text_model.max_length=20", "diffusion.steps=500", "diffusion.timestep_respacing='12'"])
+    scene = (["model.scene_model.use_scene_model=True", "model.scene_model.use_openscene=True", "model.scene_model.point_feat_dim=32",
+              "model.scene_model.pretrained_weight=''", "task.dataset.use_openscene=True"] if which == "cdm_h" else ["model.scene_model.use_scene_model=False"])
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.input_feats=6", "model.text_model.max_length=20",
+                                                            "diffusion.steps=500", "diffusion.timestep_respacing='12'"] + scene)
     model, diff = create_model_and_diffusion(cfg, device=dev)
     synth.fill_module_(model)
     model = model.to(dev).eval()
@@ -27,6 +30,8 @@ if which == "cdm":
     # other (the product default from B = 16 on is two streams; steps/s is quoted on that)
     model.loop_sub_batches = int(os.environ.get("AFM_PROFILE_SUBBATCH", "1"))
     kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev))
+    if which == "cdm_h":
+        kw["c_pc_feat"] = synth.gaussian("pmc_feat", (B, N, 32)).to(dev)
     for _ in range(2):
         diff.p_sample_loop(model, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=1)
 else:
