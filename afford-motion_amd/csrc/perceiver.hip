@@ -294,11 +294,12 @@ __global__ __launch_bounds__(64 * ERM_WAVES, 1) void enc_reduce_mfma_kernel(cons
 
 
 // ---------------------------------------------------------------- enc_reduce without rows (round 3; GEN inputs)
-// The rows the two latents attend over are LayerNorm_kv of a linear map of the point's 12 inputs x = [x_t | features | 1], so, exactly as in
-// the decoder (dec_point_kernel): var = x Qe x^T (step-invariant 12 x 12 form), score[q] = rstd (x . EU[:, q]) + const with EU = Ec U'^T
-// (Ec = gen_enc minus its row means; 12 x 16 per sample and step, built in the prologue), and the attention-weighted sum of the normalised rows
-// is linear in sum_n p[n, q] rstd[n] x[n]: a wave accumulates 16 x 12 numbers instead of 16 x 256 and never generates a row.  Per 16 points:
-// 10 MFMAs (16x16x4) instead of 176; the partial (max, sum, 12-vector) records are merged and expanded by lat_combine_kernel.
+// The rows the two latents attend over are LayerNorm_kv of a linear map of the point's K inputs x = [x_t | features | 1 | 0..] (K = 12: the
+// H3D variant, K = 44: 32 scene features per point, the HUMANISE variant), so, exactly as in the decoder (dec_point_kernel): var = x Qe x^T
+// (step-invariant K x K form), score[q] = rstd (x . EU[:, q]) + const with EU = Ec U'^T (Ec = gen_enc minus its row means; K x 16 per
+// sample and step, built in the prologue), and the attention-weighted sum of the normalised rows is linear in sum_n p[n, q] rstd[n] x[n]: a
+// wave accumulates 16 x K numbers instead of 16 x 256 and never generates a row.  Per 16 points at K = 12: 10 MFMAs (16x16x4) instead of
+// 176; the partial (max, sum, K-vector) records are merged and taken through v-proj and o-proj by lat_head_kernel.
 constexpr int EP_WAVES = 8, EP_SPLIT = NPART / EP_WAVES;
 template <int NKS>
 __global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, const float* __restrict__ u_text, const float* __restrict__ cu_text,
@@ -307,52 +308,95 @@ __global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, co
                                                                   float* __restrict__ pacc12, const float* __restrict__ xt, int cd, const float* __restrict__ feat,
                                                                   int fd, const float* __restrict__ ec, const float* __restrict__ qee) {
     constexpr int NQ = 16, K = RowLess<NKS>::K, NT = RowLess<NKS>::NT;
+    constexpr int UGS_LD = 260;
     __shared__ float EUs[K * 16], QEs[K * 16 * NT], ccs[16], trs[EP_WAVES][16];
+    __shared__ __align__(16) float ugs[16 * UGS_LD];
+    constexpr int LD = K + 1;
+    __shared__ float tiles[EP_WAVES][16 * LD];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
     float* tr = trs[wave];
     int64_t ti = t[b];
     ti = ti < 0 ? 0 : (ti >= n_t ? n_t - 1 : ti);
-    for (int i = threadIdx.x; i < K * 16 * NT; i += 64 * EP_WAVES) QEs[i] = qee[i];
-    for (int q = wave; q < NQ; q += EP_WAVES) {                    // one wave per folded query: u' = gamma * u_q, its K dots with Ec, beta . u_q
-        const float* up = q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256;
-        const float4 u = *reinterpret_cast<const float4*>(up + lane * 4), gm = *reinterpret_cast<const float4*>(kvn.g + lane * 4),
-                     bt = *reinterpret_cast<const float4*>(kvn.b + lane * 4);
-        const float4 ug = make_float4(u.x * gm.x, u.y * gm.y, u.z * gm.z, u.w * gm.w);
-        const float d = wave_sum((u.x * bt.x + u.y * bt.y) + (u.z * bt.z + u.w * bt.w));
-        if (lane == 0) ccs[q] = d + (q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]);
-        for (int k = 0; k < K; ++k) {
-            const float4 e4 = *reinterpret_cast<const float4*>(ec + k * 256 + lane * 4);
-            const float dk = wave_sum((e4.x * ug.x + e4.y * ug.y) + (e4.z * ug.z + e4.w * ug.w));
-            if (lane == 0) EUs[k * 16 + q] = dk;
-        }
-    }
-    __syncthreads();
-    const float cconst = ccs[p16];
-
     const int per = (N + EP_SPLIT - 1) / EP_SPLIT;
     const int n0 = blockIdx.x * per, n1 = min(N, n0 + per);
     const int wper = ((per + EP_WAVES - 1) / EP_WAVES + 15) & ~15;      // points per wave, whole tiles
     const int w0 = n0 + wave * wper, w1 = min(n1, w0 + wper);
+    // The inputs of a 16-point tile are two contiguous pieces of global memory (16 fd floats of the features, 16 cd of x_t): a wave reads
+    // them as whole 256-byte lines, one tile ahead of the one it computes on (they are cold: the previous step's dec_point wrote x_t from
+    // other XCDs), and re-shapes them through a wave-private [16][LD] tile in LDS into the two operand layouts - instead of 2 (NKS + 4 NT)
+    // scattered dword loads per tile at the head of each tile's dependent chain.
+    float* T = tiles[wave];
+    constexpr int NLF = (16 * (K - 1) + 63) / 64, NLX = 2;        // floats per lane of a tile's features (fd <= K - 1) and contacts (cd <= 8)
+    int of[NLF], ox[NLX];                                          // where this lane's j-th float goes in T (-1: nowhere)
+#pragma unroll
+    for (int j = 0; j < NLF; ++j) {
+        const int e = lane + 64 * j, pt = e / fd, col = e - pt * fd;
+        of[j] = (e < 16 * fd && col >= cd) ? pt * LD + col : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+        const int e = lane + 64 * j, pt = e / cd, col = e - pt * cd;
+        ox[j] = e < 16 * cd ? pt * LD + col : -1;
+    }
+    for (int i = lane; i < 16 * LD; i += 64) T[i] = (i % LD) == fd ? 1.0f : 0.0f;      // the constant input and the padding: written once
+    float fr[NLF], xr[NLX];
+    const unsigned flast = (unsigned)(b * N + n1) * (unsigned)fd - 1u, xlast = (unsigned)(b * N + n1) * (unsigned)cd - 1u;
+    auto fetch = [&](int nb) {                                     // clamped to the sample's last float: points past w1 are masked below
+        const unsigned fb = (unsigned)(b * N + nb) * (unsigned)fd + lane, xb = (unsigned)(b * N + nb) * (unsigned)cd + lane;
+#pragma unroll
+        for (int j = 0; j < NLF; ++j) fr[j] = feat[min(fb + 64u * j, flast)];
+#pragma unroll
+        for (int j = 0; j < NLX; ++j) xr[j] = xt[min(xb + 64u * j, xlast)];
+    };
+    fetch(min(w0, n1 - 1));
+    for (int i = threadIdx.x; i < K * 16 * NT; i += 64 * EP_WAVES) QEs[i] = qee[i];
+    for (int q = wave; q < NQ; q += EP_WAVES) {                    // one wave per folded query: u' = gamma * u_q (staged for the dots below), beta . u_q
+        const float* up = q < NQ / 2 ? u_text + ((int64_t)b * (NQ / 2) + q) * 256 : u_time + (ti * (NQ / 2) + (q - NQ / 2)) * 256;
+        const float4 u = *reinterpret_cast<const float4*>(up + lane * 4), gm = *reinterpret_cast<const float4*>(kvn.g + lane * 4),
+                     bt = *reinterpret_cast<const float4*>(kvn.b + lane * 4);
+        *reinterpret_cast<float4*>(&ugs[q * UGS_LD + lane * 4]) = make_float4(u.x * gm.x, u.y * gm.y, u.z * gm.z, u.w * gm.w);
+        const float d = wave_sum((u.x * bt.x + u.y * bt.y) + (u.z * bt.z + u.w * bt.w));
+        if (lane == 0) ccs[q] = d + (q < NQ / 2 ? cu_text[(int64_t)b * (NQ / 2) + q] : cu_time[ti * (NQ / 2) + (q - NQ / 2)]);
+    }
+    __syncthreads();
+    // EU[k][q] = Ec[k] . u'_q: one thread per dot, its 64 float4 of Ec all independent loads (one wave per query with a cross-lane sum per k
+    // was K dependent L2 round trips: 68 -> 50 us for the kernel at K = 44, nothing at K = 12); 16 lanes share an Ec row (broadcast), the
+    // staged u' rows are UGS_LD = 260 floats apart so that the 16 queries of a wave read 16 different bank groups
+    for (int idx = threadIdx.x; idx < K * 16; idx += 64 * EP_WAVES) {
+        const int k = idx >> 4, q = idx & 15;
+        const float4* e4 = reinterpret_cast<const float4*>(ec + k * 256);
+        const float4* u4 = reinterpret_cast<const float4*>(&ugs[q * UGS_LD]);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) {
+            const float4 e = e4[j], u = u4[j];
+            a0 = fmaf(e.x, u.x, a0); a1 = fmaf(e.y, u.y, a1); a2 = fmaf(e.z, u.z, a2); a3 = fmaf(e.w, u.w, a3);
+        }
+        EUs[idx] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    const float cconst = ccs[p16];
+
 
     f32x4 wacc[NT];                                               // lane (q = p16, g), tile t: sum_n p[n, q] rstd[n] x[n][k = 16 t + 4 g + r]
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) wacc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;                          // of query p16, replicated over g
-    auto input = [&](unsigned pti, int k) {                        // x[k] of point pti: x_t, features, the constant 1, zeros
-        const float vx = xt[pti * (unsigned)cd + (unsigned)min(k, cd - 1)], vf = feat[pti * (unsigned)fd + (unsigned)min(k, fd - 1)];
-        return k < cd ? vx : (k < fd ? vf : (k == fd ? 1.0f : 0.0f));
-    };
     for (int nb = w0; nb < w1; nb += 16) {
         float xin[NKS], xT[NT][4];
-        {
-            const unsigned pti = (unsigned)(b * N + min(nb + p16, n1 - 1));
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) xin[ks] = input(pti, 4 * ks + g);         // lane (p, g): inputs 4 ks + g of point p
+        for (int j = 0; j < NLF; ++j)
+            if (of[j] >= 0) T[of[j]] = fr[j];
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
+        for (int j = 0; j < NLX; ++j)
+            if (ox[j] >= 0) T[ox[j]] = xr[j];
+        fetch(min(nb + 16, n1 - 1));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xT[tt][r] = input((unsigned)(b * N + min(nb + 4 * g + r, n1 - 1)), 16 * tt + p16);      // lane (k = p16, g): input 16 t + k of point 4 g + r
-        }
+        for (int ks = 0; ks < NKS; ++ks) xin[ks] = T[p16 * LD + 4 * ks + g];           // lane (p, g): inputs 4 ks + g of point p
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xT[tt][r] = (16 * tt + p16 < K) ? T[(4 * g + r) * LD + min(16 * tt + p16, K - 1)] : 0.f;      // lane (k = p16, g): input 16 t + k of point 4 g + r
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
         float varq = 0.f;
 #pragma unroll
@@ -555,24 +599,33 @@ __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__
                                                        const int64_t* __restrict__ t, int n_t, int dq, const float* __restrict__ wove,
                                                        const float* __restrict__ c1, float* __restrict__ x1) {
     constexpr int K = RowLess<NKS>::K, NT = RowLess<NKS>::NT;
-    __shared__ float a12[8 * K];
+    __shared__ __align__(16) float a12[8 * K];
     const int b = blockIdx.x, i = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int h = wave; h < 8; h += 4) {                            // lane = one of the NPART = 64 partials
-        const int ih = i * 8 + h;
-        const int64_t base = ((int64_t)b * NPART + lane) * 16 + ih;
-        const float mm = pm[base];
-        float M = mm;
+    // lane = one of the NPART = 64 partials; a wave merges heads wave and wave + 4.  Every load of both heads is issued before the first
+    // reduction (they are cold in L2 - dec_point streamed the whole cloud since they were written - and were 22 dependent round trips otherwise)
+    float mm[2], ll[2];
+    float4 v[2][NKS];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
-        const float ww = (mm == -INFINITY) ? 0.f : __expf(mm - M);
-        const float L = wave_sum(pl[base] * ww);
-        const float wq = ww * (1.0f / L);
+    for (int hh = 0; hh < 2; ++hh) {
+        const int64_t base = ((int64_t)b * NPART + lane) * 16 + (i * 8 + wave + 4 * hh);
+        mm[hh] = pm[base]; ll[hh] = pl[base];
         const float4* pa = reinterpret_cast<const float4*>(pacc12 + base * (16 * NT));
 #pragma unroll
+        for (int k4 = 0; k4 < NKS; ++k4) v[hh][k4] = pa[k4];
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = wave + 4 * hh;
+        float M = mm[hh];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+        const float ww = (mm[hh] == -INFINITY) ? 0.f : __expf(mm[hh] - M);
+        const float L = wave_sum(ll[hh] * ww);
+        const float wq = ww * (1.0f / L);
+#pragma unroll
         for (int k4 = 0; k4 < NKS; ++k4) {
-            const float4 v = pa[k4];
-            const float s0 = wave_sum(wq * v.x), s1 = wave_sum(wq * v.y), s2 = wave_sum(wq * v.z), s3 = wave_sum(wq * v.w);
-            if (lane == 0) { a12[h * K + 4 * k4] = s0; a12[h * K + 4 * k4 + 1] = s1; a12[h * K + 4 * k4 + 2] = s2; a12[h * K + 4 * k4 + 3] = s3; }
+            const float s0 = wave_sum(wq * v[hh][k4].x), s1 = wave_sum(wq * v[hh][k4].y), s2 = wave_sum(wq * v[hh][k4].z), s3 = wave_sum(wq * v[hh][k4].w);
+            if (lane == 0) *reinterpret_cast<float4*>(&a12[h * K + 4 * k4]) = make_float4(s0, s1, s2, s3);
         }
     }
     __syncthreads();
