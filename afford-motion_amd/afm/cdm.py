@@ -1,6 +1,6 @@
 """CDM / ADM denoiser (`Perceiver`): drop-in for the reference's `models.cdm.CDM`
 (reference models/cdm.py:411-513 with `ContactPerceiver` :88-188) - same registry name, constructor,
-config keys, call signature and state-dict keys; forward on the HIP path (csrc/perceiver.hip).
+config keys, call signature and state-dict keys; forward on the HIP path (csrc/perceiver*.hip).
 
 Only `arch='Perceiver'` is built (every shipped script selects it); the scene
 backbone of the HUMANISE variant (`use_scene_model=True` without openscene features) is a "next" row, so

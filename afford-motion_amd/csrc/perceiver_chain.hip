@@ -1,0 +1,224 @@
+// CDM / ContactPerceiver denoiser: the chain of the two latent tokens of every sample between the reduction over the points and the decoder
+// (reference models/modules.py:234-661: cross-attention output, o_proj, MLP, self-attention blocks, decoder keys / values), batched over
+// the samples as a sequence of small launches.
+#include "perceiver_internal.h"
+
+using namespace afm_cdm;
+
+namespace {
+
+// ---------------------------------------------------------------- latent chain, batched over the samples
+// The 2-latent chain (cross-attention output, o_proj, MLP, self-attention blocks, decoder K / V folding) is ~16 dependent
+// matrix-vector stages per sample.  It runs batched over all 2 B latent tokens as a sequence of small launches: a stage is Y[tok, o] = epi(b[o] + W[o, :] . pro(X[tok, :])) for all tokens, N / 8
+// workgroups per stage (every weight row is read once per token block, by one workgroup), ~5 us per launch.
+//   toklin_kernel: ONE WAVE per 16 tokens x 16 outputs, everything in registers, no LDS, no barrier (round 3; the phase timelines of the
+//   earlier forms - VALU with LDS-staged rows and weights: 15 us per work item; matrix pipe with LDS-staged rows: staging 4-8 us,
+//   LayerNorm 4 us, product 3-8 us - are in profiles/r03_cdm_chain.md).  The 16 x 16 output tile is K / 4 v_mfma_f32_16x16x4_f32; both
+//   operands want "row (l & 15), four consecutive k at 16 u + 4 (l >> 4)" per lane, which is how a lane reads its 16-byte pieces of an
+//   input row and of a weight row straight from global memory: K / 16 float4 each, all issued at kernel entry.  A token's row is then
+//   spread over the four lanes (l & 15) + 16 g, so the LayerNorm statistics are a per-lane sum plus two cross-lane steps and the
+//   normalisation happens in registers.
+struct TokLin {
+    const float* X; int ldx;                 // input rows: token tok at X + tok * ldx (+ head offset)
+    int head_out, x_head_stride;             // head_out > 0: outputs [h * head_out, (h + 1) * head_out) read X + h * x_head_stride (per-head inputs)
+    const float* W[3]; const float* b[3];    // up to three stacked weight matrices [ncol, K] (q | k | v), ncol outputs each
+    int ncol;
+    afm_ln ln; int use_ln;                   // 1: LayerNorm (eps 1e-5) of the input rows; 2: the same FOLDED - W carries gamma, b carries W beta,
+    const float* gsum[3];                    //    gsum[part][o] = sum_k W[o][k]: Y = rstd (W x - mean gsum) + b, the products do not wait for the statistics
+    int act;                                 // AFM_ACT_*
+    const float* R; int ldr;                 // residual rows or NULL (may be Y: every element is read and written by the same lane)
+    float* Y; int ldy;
+    int ntok, N, K;                          // K % 16 == 0, K <= MAXD
+};
+
+#ifdef AFM_TOKLIN_TIMELINE      // tools/probes/toklin_timeline.py only (a debug build of this file); never compiled into the library
+__device__ unsigned long long afm_tk_tl[16 * 8];      // [launch slot][stamp]
+__device__ int afm_tk_slot = 0;
+#define TKTL(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { afm_tk_tl[(afm_tk_slot & 15) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 4) afm_tk_slot = afm_tk_slot + 1; } } while (0)
+#else
+#define TKTL(i)
+#endif
+
+// NK16 = K / 16 at compile time (a run-time bound on the unrolled register arrays turns every step into compute-and-select)
+template <int NK16>
+__global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
+    TKTL(0);
+    const int lane = threadIdx.x, p16 = lane & 15, g = lane >> 4;
+    const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB;
+    const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a wave lie in one weight part (ncol % TL_OB == 0)
+    const bool ovalid = o0 + p16 < p.N;
+    // A operand: token tb + p16 (clamped: rows past the end are computed and dropped); B operand: weight row o0 + p16
+    const float* xrow = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0) + (int64_t)min(tb + p16, p.ntok - 1) * p.ldx + 4 * g;
+    const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g;
+    float4 xr[NK16], wr[NK16];
+#pragma unroll
+    for (int u = 0; u < NK16; ++u) {
+        xr[u] = *reinterpret_cast<const float4*>(xrow + 16 * u);
+        wr[u] = *reinterpret_cast<const float4*>(wrow + 16 * u);
+    }
+    TKTL(1);
+    float ln_mean = 0.f, ln_rstd = 1.f;                          // folded form: statistics of token p16 (all four lanes of the row hold them)
+    if (p.use_ln) {                                              // uniform.  Statistics over the row's four lanes (same p16, g = 0..3), two passes
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < NK16; ++u) sum += (xr[u].x + xr[u].y) + (xr[u].z + xr[u].w);
+        sum += xor16(sum); sum += xor32(sum);
+        const float mean = sum / (float)p.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < NK16; ++u) { const float a = xr[u].x - mean, b = xr[u].y - mean, c = xr[u].z - mean, d = xr[u].w - mean; sq += (a * a + b * b) + (c * c + d * d); }
+        sq += xor16(sq); sq += xor32(sq);
+        const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
+        ln_mean = mean; ln_rstd = rstd;
+#pragma unroll
+        for (int u = 0; u < NK16; ++u) {
+            if (p.use_ln == 2) break;                            // uniform: the rows stay raw
+            const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * u + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * u + 4 * g);
+            xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
+                                (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
+        }
+    }
+    TKTL(2);
+    // ---- D[i = token][j = output] += X[i][k] W[j][k]: MFMA e of step u takes k = 16 u + 4 (l >> 4) + e on both operands; four accumulators
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NK16; ++u) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].x, wr[u].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].y, wr[u].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].z, wr[u].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].w, wr[u].w, acc[3], 0, 0, 0);
+    }
+    TKTL(3);
+    float mt[4] = {0.f, 0.f, 0.f, 0.f}, rt[4] = {1.f, 1.f, 1.f, 1.f};
+    if (p.use_ln == 2) {                                         // uniform: the statistics of token 4 g + r live in lane 4 g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mt[r] = __shfl(ln_mean, 4 * g + r); rt[r] = __shfl(ln_rstd, 4 * g + r); }
+    }
+    if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the tile)
+        const float bias = p.b[part0] ? p.b[part0][oc0 + p16] : 0.f;
+        const float gs = p.use_ln == 2 ? p.gsum[part0][oc0 + p16] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tok = tb + 4 * g + r;
+            float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            if (p.use_ln == 2) v = rt[r] * (v - mt[r] * gs);
+            if (tok >= p.ntok) continue;
+            v += bias;
+            if (p.act) v = apply_act(v, p.act);
+            if (p.R) v += p.R[(int64_t)tok * p.ldr + o0 + p16];
+            p.Y[(int64_t)tok * p.ldy + o0 + p16] = v;
+        }
+    }
+    TKTL(4);
+}
+
+// self-attention of the two latent tokens of a sample (modules.py:544-648): qkv [ntok][3 dq] -> out [ntok][dq].  grid B, block 256.
+__global__ __launch_bounds__(256) void lat_selfattn_kernel(const float* __restrict__ qkv, int dq, int He, float* __restrict__ out) {
+    __shared__ float sc[64], aw[64];
+    const int b = blockIdx.x, hd = dq / He;
+    const float* q = qkv + (int64_t)b * 2 * 3 * dq;               // token rows 2 b, 2 b + 1: [q | k | v]
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (threadIdx.x < He * 4) {                                   // (h, i, j) scores
+        const int h = threadIdx.x >> 2, i = (threadIdx.x >> 1) & 1, j = threadIdx.x & 1;
+        float a = 0.f;
+        for (int r = 0; r < hd; ++r) a += (q[i * 3 * dq + h * hd + r] * scale) * q[j * 3 * dq + dq + h * hd + r];
+        sc[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < He * 2) {                                   // softmax over the 2 keys
+        const int base = threadIdx.x * 2;
+        const float a0 = sc[base], a1 = sc[base + 1], mx = fmaxf(a0, a1);
+        const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
+        aw[base] = e0 * inv; aw[base + 1] = e1 * inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * dq; e += blockDim.x) {
+        const int i = e / dq, c = e % dq, h = c / hd;
+        out[((int64_t)b * 2 + i) * dq + c] = aw[(h * 2 + i) * 2 + 0] * q[2 * dq + c] + aw[(h * 2 + i) * 2 + 1] * q[3 * dq + 2 * dq + c];
+    }
+}
+
+int launch_toklin(const TokLin& p, hipStream_t s) {
+    const dim3 grid((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK);
+    switch (p.K) {                                // widths of the Perceiver's latents / point features (validate: dkv == 256, dq a multiple of 128)
+        case 128: hipLaunchKernelGGL(toklin_kernel<8>, grid, dim3(64), 0, s, p); break;
+        case 256: hipLaunchKernelGGL(toklin_kernel<16>, grid, dim3(64), 0, s, p); break;
+        case 384: hipLaunchKernelGGL(toklin_kernel<24>, grid, dim3(64), 0, s, p); break;
+        case 512: hipLaunchKernelGGL(toklin_kernel<32>, grid, dim3(64), 0, s, p); break;
+        default: return AFM_E_UNSUPPORTED;
+    }
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+#ifdef AFM_TOKLIN_TIMELINE
+extern "C" int afm_debug_toklin_timeline(unsigned long long* host_out128) {
+    return (int)hipMemcpyFromSymbol(host_out128, HIP_SYMBOL(afm_tk_tl), 128 * sizeof(unsigned long long));
+}
+#endif
+namespace afm_cdm {
+
+// enc_reduce partials -> dec_lat records, as 17 small launches over all 2 B latent tokens (see toklin_kernel; 14-18 us each, ~2 us apart)
+int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool enc12) {
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
+    const bool head = enc12;                          // fused form: combine + v-proj + o-proj as one launch (lat_head_kernel)
+    if (head) AFM_TRY(launch_lat_head(w, text_q0, t, ws, B, s));
+    else AFM_TRY(launch_lat_combine(w, text_q0, t, ws, B, s));
+    auto lin = [&](const float* X, int ldx, int K, const afm_lin& l, int N, float* Y, int ldy) {
+        TokLin p = {};
+        p.X = X; p.ldx = ldx; p.W[0] = l.w; p.b[0] = l.b; p.ncol = N; p.Y = Y; p.ldy = ldy; p.ntok = ntok; p.N = N; p.K = K;
+        return p;
+    };
+    const bool lnf = w.lat_fold != nullptr;          // LayerNorm folded into the weights of the stages that follow one (afm_cdm_weights.lat_fold)
+    auto folded = [&](TokLin& p, int part, int slot) {            // slot: index into lat_fold ([wg, g, c] triples)
+        p.W[part] = w.lat_fold[3 * slot]; p.gsum[part] = w.lat_fold[3 * slot + 1]; p.b[part] = w.lat_fold[3 * slot + 2]; p.use_ln = 2;
+    };
+    auto mlp = [&](const afm_mlp_w& m, int slot) {    // x <- x + fc2(GELU(fc1(LN(x))))
+        TokLin p = lin(ws.lat_x, dq, dq, m.fc1, dq, ws.lat_t2, dq);
+        p.ln = m.norm; p.use_ln = 1; p.act = AFM_ACT_GELU;
+        if (lnf) folded(p, 0, slot);
+        AFM_TRY(launch_toklin(p, s));
+        p = lin(ws.lat_t2, dq, dq, m.fc2, dq, ws.lat_x, dq);
+        p.R = ws.lat_x; p.ldr = dq;
+        return launch_toklin(p, s);
+    };
+    if (head) {
+        AFM_TRY(mlp(w.enc_mlp, 0));
+    } else {   // attention output of the encoder cross-attention: o[tok, h hd + r] = W_v[h hd + r] . s[tok, h] + b_v, then o_proj + residual, MLP
+        TokLin p = lin(ws.lat_s, He * dkv, dkv, w.enc_attn.v, dq, ws.lat_t1, dq);
+        p.head_out = dq / He; p.x_head_stride = dkv;
+        AFM_TRY(launch_toklin(p, s));
+        p = lin(ws.lat_t1, dq, dq, w.enc_attn.o, dq, ws.lat_x, dq);
+        p.R = ws.lat_x; p.ldr = dq;
+        AFM_TRY(launch_toklin(p, s));
+        AFM_TRY(mlp(w.enc_mlp, 0));
+    }
+    for (int li = 0; li < w.n_self; ++li) {        // self-attention block on the two latents of every sample (modules.py:544-648)
+        TokLin p = lin(ws.lat_x, dq, dq, w.self_attn[li].q, 3 * dq, ws.lat_qkv, 3 * dq);
+        p.W[1] = w.self_attn[li].k.w; p.b[1] = w.self_attn[li].k.b; p.W[2] = w.self_attn[li].v.w; p.b[2] = w.self_attn[li].v.b; p.ncol = dq;
+        p.ln = w.self_norm[li]; p.use_ln = 1;
+        if (lnf) { folded(p, 0, 1 + 4 * li); folded(p, 1, 2 + 4 * li); folded(p, 2, 3 + 4 * li); }
+        AFM_TRY(launch_toklin(p, s));
+        hipLaunchKernelGGL(lat_selfattn_kernel, dim3(B), dim3(256), 0, s, ws.lat_qkv, dq, He, ws.lat_t1);
+        AFM_CHECK_LAUNCH();
+        p = lin(ws.lat_t1, dq, dq, w.self_attn[li].o, dq, ws.lat_x, dq);
+        p.R = ws.lat_x; p.ldr = dq;
+        AFM_TRY(launch_toklin(p, s));
+        AFM_TRY(mlp(w.self_mlp[li], 4 + 4 * li));
+    }
+    {   // decoder keys / values of the two latents, folded through W_q / W_o of the decoder attention
+        TokLin p = lin(ws.lat_x, dq, dq, w.dec_attn.k, 2 * dkv, ws.lat_kv, 2 * dkv);
+        p.W[1] = w.dec_attn.v.w; p.b[1] = w.dec_attn.v.b; p.ncol = dkv;
+        p.ln = w.dec_kv_norm; p.use_ln = 1;
+        if (lnf) { folded(p, 0, 17); folded(p, 1, 18); }
+        AFM_TRY(launch_toklin(p, s));
+        if (!enc12) AFM_TRY(launch_lat_decfold(w, ws, B, s));      // the row-less form builds its tables from lat_kv itself (lat_dectables_kernel)
+    }
+    return 0;
+}
+
+}  // namespace afm_cdm

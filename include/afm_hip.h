@@ -200,7 +200,7 @@ int afm_bn_fold(const float* w, const float* b, const float* running_mean, const
                 float* scale, float* shift, int32_t C, void* stream);
 
 /* afm_contact_glue (ABI v5): the ADM -> AMDM hand-off of the two-stage pipeline kept in HBM.  The reference writes
- * dist = sqrt(-2 ln(clip(sample * std + mean, 1e-20, 1)) sigma^2) to H3D/pred_contact/*.npy (utils/evaluate.py:41-82) and reads it back as
+ * dist = sqrt(-2 ln(clip(sample * std + mean, 1e-20, 1)) sigma^2) to H3D/pred_contact/<id>.npy (utils/evaluate.py:41-82) and reads it back as
  * exp(-dist^2 / (2 sigma^2)) (datasets/humanml3d.py:763-774); out[i] is that condition value, n elements.  sigma_sq = sigma^2 rounded to
  * float32 once by the caller (the reference's Python scalar `sigma ** 2`). */
 int afm_contact_glue(const float* sample, float* out, int64_t n, float sigma_sq, float mean, float std, void* stream);
