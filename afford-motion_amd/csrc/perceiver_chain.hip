@@ -39,43 +39,62 @@ __device__ int afm_tk_slot = 0;
 #define TKTL(i)
 #endif
 
-// NK16 = K / 16 at compile time (a run-time bound on the unrolled register arrays turns every step into compute-and-select)
+// NK16 = K / 16 at compile time (a run-time bound on the unrolled register arrays turns every step into compute-and-select).
+// Workgroup = FOUR waves on one 16 x 16 output tile, wave w taking the K quarter [w K / 4, (w + 1) K / 4): a single wave spent 1.3 us issuing
+// its 2 x K / 16 loads, 1.8 us issuing K / 4 MFMAs on one SIMD (32 cycles each) and 1.3 us on an epilogue whose side inputs (bias, row sums,
+// residual) were requested after the product (profiles/r03_toklin_timeline.txt).  Now every wave issues a quarter of the loads and of the
+// MFMAs, the epilogue's inputs are requested at kernel entry, the partial tiles and the per-quarter LayerNorm statistics (mean, M2 about that
+// mean: combined with Chan's formula in wave order) meet in LDS behind ONE barrier and wave w finishes token 4 g + w of every lane's four.
 template <int NK16>
-__global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
+__global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     TKTL(0);
-    const int lane = threadIdx.x, p16 = lane & 15, g = lane >> 4;
+    static_assert(NK16 % 4 == 0, "K is split over the four waves in whole K16 steps");
+    constexpr int NQ = NK16 / 4;
+    __shared__ float part[4][64][4], stat[4][16][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
     const int tb = blockIdx.y * TL_TOK, o0 = blockIdx.x * TL_OB;
-    const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a wave lie in one weight part (ncol % TL_OB == 0)
+    const int part0 = o0 / p.ncol, oc0 = o0 - part0 * p.ncol;    // the TL_OB outputs of a workgroup lie in one weight part (ncol % TL_OB == 0)
     const bool ovalid = o0 + p16 < p.N;
-    // A operand: token tb + p16 (clamped: rows past the end are computed and dropped); B operand: weight row o0 + p16
-    const float* xrow = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0) + (int64_t)min(tb + p16, p.ntok - 1) * p.ldx + 4 * g;
-    const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g;
-    float4 xr[NK16], wr[NK16];
+    // A operand: token tb + p16 (clamped: rows past the end are computed and dropped); B operand: weight row o0 + p16; this wave's K quarter
+    const float* xrow = p.X + (p.head_out ? (o0 / p.head_out) * p.x_head_stride : 0) + (int64_t)min(tb + p16, p.ntok - 1) * p.ldx + 4 * g + 16 * NQ * wave;
+    const float* wrow = p.W[part0] + (int64_t)(ovalid ? oc0 + p16 : 0) * p.K + 4 * g + 16 * NQ * wave;
+    float4 xr[NQ], wr[NQ];
 #pragma unroll
-    for (int u = 0; u < NK16; ++u) {
+    for (int u = 0; u < NQ; ++u) {
         xr[u] = *reinterpret_cast<const float4*>(xrow + 16 * u);
         wr[u] = *reinterpret_cast<const float4*>(wrow + 16 * u);
     }
+    // the epilogue's side inputs of this lane's element (output o0 + p16 of token tb + 4 g + wave), requested with the operands
+    const int tok = tb + 4 * g + wave, ocol = ovalid ? oc0 + p16 : 0;
+    const bool tvalid = ovalid && tok < p.ntok;
+    const float bias = p.b[part0] ? p.b[part0][ocol] : 0.f;
+    const float gs = p.use_ln == 2 ? p.gsum[part0][ocol] : 0.f;
+    const float res = (p.R && tvalid) ? p.R[(int64_t)tok * p.ldr + o0 + p16] : 0.f;
     TKTL(1);
-    float ln_mean = 0.f, ln_rstd = 1.f;                          // folded form: statistics of token p16 (all four lanes of the row hold them)
-    if (p.use_ln) {                                              // uniform.  Statistics over the row's four lanes (same p16, g = 0..3), two passes
+    if (p.use_ln) {                                              // uniform.  This quarter of the row of token p16: (mean, M2 about it) over the row's four lanes
         float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < NK16; ++u) sum += (xr[u].x + xr[u].y) + (xr[u].z + xr[u].w);
+        for (int u = 0; u < NQ; ++u) sum += (xr[u].x + xr[u].y) + (xr[u].z + xr[u].w);
         sum += xor16(sum); sum += xor32(sum);
-        const float mean = sum / (float)p.K;
+        const float mq = sum / (float)(16 * NQ);
         float sq = 0.f;
 #pragma unroll
-        for (int u = 0; u < NK16; ++u) { const float a = xr[u].x - mean, b = xr[u].y - mean, c = xr[u].z - mean, d = xr[u].w - mean; sq += (a * a + b * b) + (c * c + d * d); }
+        for (int u = 0; u < NQ; ++u) { const float a = xr[u].x - mq, b = xr[u].y - mq, c = xr[u].z - mq, d = xr[u].w - mq; sq += (a * a + b * b) + (c * c + d * d); }
         sq += xor16(sq); sq += xor32(sq);
-        const float rstd = 1.0f / sqrtf(sq / (float)p.K + 1e-5f);
-        ln_mean = mean; ln_rstd = rstd;
+        if (g == 0) { stat[wave][p16][0] = mq; stat[wave][p16][1] = sq; }
+        if (p.use_ln == 1) {                                     // uniform: unfolded form, the rows are normalised before the product
+            __syncthreads();
+            const float mean = ((stat[0][p16][0] + stat[1][p16][0]) + (stat[2][p16][0] + stat[3][p16][0])) * 0.25f;
+            float m2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < NK16; ++u) {
-            if (p.use_ln == 2) break;                            // uniform: the rows stay raw
-            const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * u + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * u + 4 * g);
-            xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
-                                (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
+            for (int w = 0; w < 4; ++w) { const float d = stat[w][p16][0] - mean; m2 += stat[w][p16][1] + (float)(16 * NQ) * (d * d); }
+            const float rstd = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const float4 gg = *reinterpret_cast<const float4*>(p.ln.g + 16 * (NQ * wave + u) + 4 * g), bb = *reinterpret_cast<const float4*>(p.ln.b + 16 * (NQ * wave + u) + 4 * g);
+                xr[u] = make_float4((xr[u].x - mean) * rstd * gg.x + bb.x, (xr[u].y - mean) * rstd * gg.y + bb.y,
+                                    (xr[u].z - mean) * rstd * gg.z + bb.z, (xr[u].w - mean) * rstd * gg.w + bb.w);
+            }
         }
     }
     TKTL(2);
@@ -84,32 +103,32 @@ __global__ __launch_bounds__(64) void toklin_kernel(const TokLin p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < NK16; ++u) {
+    for (int u = 0; u < NQ; ++u) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].x, wr[u].x, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].y, wr[u].y, acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].z, wr[u].z, acc[2], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[u].w, wr[u].w, acc[3], 0, 0, 0);
     }
     TKTL(3);
-    float mt[4] = {0.f, 0.f, 0.f, 0.f}, rt[4] = {1.f, 1.f, 1.f, 1.f};
-    if (p.use_ln == 2) {                                         // uniform: the statistics of token 4 g + r live in lane 4 g + r
+    *reinterpret_cast<float4*>(&part[wave][lane][0]) = make_float4((acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]), (acc[0][1] + acc[1][1]) + (acc[2][1] + acc[3][1]),
+                                                                   (acc[0][2] + acc[1][2]) + (acc[2][2] + acc[3][2]), (acc[0][3] + acc[1][3]) + (acc[2][3] + acc[3][3]));
+    __syncthreads();
+    // lane (output p16, token group g) of wave w finishes token 4 g + w: the K quarters in wave order
+    float v = (part[0][lane][wave] + part[1][lane][wave]) + (part[2][lane][wave] + part[3][lane][wave]);
+    if (p.use_ln == 2) {                                         // uniform: folded LayerNorm, statistics of token 4 g + wave
+        const int t16 = 4 * g + wave;
+        const float mean = ((stat[0][t16][0] + stat[1][t16][0]) + (stat[2][t16][0] + stat[3][t16][0])) * 0.25f;
+        float m2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { mt[r] = __shfl(ln_mean, 4 * g + r); rt[r] = __shfl(ln_rstd, 4 * g + r); }
+        for (int w = 0; w < 4; ++w) { const float d = stat[w][t16][0] - mean; m2 += stat[w][t16][1] + (float)(16 * NQ) * (d * d); }
+        const float rstd = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);
+        v = rstd * (v - mean * gs);
     }
-    if (ovalid) {                                                // lane (output p16; tokens 4 g + r of the tile)
-        const float bias = p.b[part0] ? p.b[part0][oc0 + p16] : 0.f;
-        const float gs = p.use_ln == 2 ? p.gsum[part0][oc0 + p16] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tok = tb + 4 * g + r;
-            float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-            if (p.use_ln == 2) v = rt[r] * (v - mt[r] * gs);
-            if (tok >= p.ntok) continue;
-            v += bias;
-            if (p.act) v = apply_act(v, p.act);
-            if (p.R) v += p.R[(int64_t)tok * p.ldr + o0 + p16];
-            p.Y[(int64_t)tok * p.ldy + o0 + p16] = v;
-        }
+    if (tvalid) {
+        v += bias;
+        if (p.act) v = apply_act(v, p.act);
+        if (p.R) v += res;
+        p.Y[(int64_t)tok * p.ldy + o0 + p16] = v;
     }
     TKTL(4);
 }
@@ -143,10 +162,10 @@ __global__ __launch_bounds__(256) void lat_selfattn_kernel(const float* __restri
 int launch_toklin(const TokLin& p, hipStream_t s) {
     const dim3 grid((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK);
     switch (p.K) {                                // widths of the Perceiver's latents / point features (validate: dkv == 256, dq a multiple of 128)
-        case 128: hipLaunchKernelGGL(toklin_kernel<8>, grid, dim3(64), 0, s, p); break;
-        case 256: hipLaunchKernelGGL(toklin_kernel<16>, grid, dim3(64), 0, s, p); break;
-        case 384: hipLaunchKernelGGL(toklin_kernel<24>, grid, dim3(64), 0, s, p); break;
-        case 512: hipLaunchKernelGGL(toklin_kernel<32>, grid, dim3(64), 0, s, p); break;
+        case 128: hipLaunchKernelGGL(toklin_kernel<8>, grid, dim3(256), 0, s, p); break;
+        case 256: hipLaunchKernelGGL(toklin_kernel<16>, grid, dim3(256), 0, s, p); break;
+        case 384: hipLaunchKernelGGL(toklin_kernel<24>, grid, dim3(256), 0, s, p); break;
+        case 512: hipLaunchKernelGGL(toklin_kernel<32>, grid, dim3(256), 0, s, p); break;
         default: return AFM_E_UNSUPPORTED;
     }
     AFM_CHECK_LAUNCH();
