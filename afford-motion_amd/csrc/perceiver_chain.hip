@@ -26,6 +26,7 @@ struct TokLin {
     afm_ln ln; int use_ln;                   // 1: LayerNorm (eps 1e-5) of the input rows; 2: the same FOLDED - W carries gamma, b carries W beta,
     const float* gsum[3];                    //    gsum[part][o] = sum_k W[o][k]: Y = rstd (W x - mean gsum) + b, the products do not wait for the statistics
     int act;                                 // AFM_ACT_*
+    int attn_hd;                             // > 0: X is [q | k | v] rows (ldx = 3 K) of token PAIRS and the input row is the self-attention of the pair (head size attn_hd)
     const float* R; int ldr;                 // residual rows or NULL (may be Y: every element is read and written by the same lane)
     float* Y; int ldy;
     int ntok, N, K;                          // K % 16 == 0, K <= MAXD
@@ -45,7 +46,7 @@ __device__ int afm_tk_slot = 0;
 // residual) were requested after the product (profiles/r03_toklin_timeline.txt).  Now every wave issues a quarter of the loads and of the
 // MFMAs, the epilogue's inputs are requested at kernel entry, the partial tiles and the per-quarter LayerNorm statistics (mean, M2 about that
 // mean: combined with Chan's formula in wave order) meet in LDS behind ONE barrier and wave w finishes token 4 g + w of every lane's four.
-template <int NK16>
+template <int NK16, bool ATTN = false>
 __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     TKTL(0);
     static_assert(NK16 % 4 == 0, "K is split over the four waves in whole K16 steps");
@@ -63,6 +64,38 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     for (int u = 0; u < NQ; ++u) {
         xr[u] = *reinterpret_cast<const float4*>(xrow + 16 * u);
         wr[u] = *reinterpret_cast<const float4*>(wrow + 16 * u);
+    }
+    if constexpr (ATTN) {
+        // Self-attention of the two latent tokens of a sample (modules.py:544-648) as the prologue of its o_proj: the input row of token 2 b + i is
+        // sum_j softmax_j(q_i . k_j / sqrt(hd)) v_j per head, the K quarter of a wave is whole heads (K / 4 = 2 heads of the reference's 8), and a
+        // token's channels of a head sit in the four lanes of its row: xr holds q_i here; k and v of both tokens of the pair come the same way.
+        constexpr int SH = NQ / 2;                                // K16 steps per head: NQ steps = two heads
+        const float* kb = xrow - (int64_t)(min(tb + p16, p.ntok - 1) & 1) * p.ldx + p.K;      // k of token 2 b (same channels); + ldx: token 2 b + 1; + K: v
+        float4 k0[NQ], k1[NQ], v0[NQ], v1[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            k0[u] = *reinterpret_cast<const float4*>(kb + 16 * u);
+            k1[u] = *reinterpret_cast<const float4*>(kb + p.ldx + 16 * u);
+            v0[u] = *reinterpret_cast<const float4*>(kb + p.K + 16 * u);
+            v1[u] = *reinterpret_cast<const float4*>(kb + p.ldx + p.K + 16 * u);
+        }
+        const float scale = 1.0f / sqrtf((float)p.attn_hd);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int u = h * SH; u < (h + 1) * SH; ++u) {
+                const float4 q = make_float4(xr[u].x * scale, xr[u].y * scale, xr[u].z * scale, xr[u].w * scale);      // q * dp_scale (modules.py:330)
+                s0 += (q.x * k0[u].x + q.y * k0[u].y) + (q.z * k0[u].z + q.w * k0[u].w);
+                s1 += (q.x * k1[u].x + q.y * k1[u].y) + (q.z * k1[u].z + q.w * k1[u].w);
+            }
+            s0 += xor16(s0); s0 += xor32(s0);
+            s1 += xor16(s1); s1 += xor32(s1);
+            const float mx = fmaxf(s0, s1), e0 = __expf(s0 - mx), e1 = __expf(s1 - mx), inv = 1.0f / (e0 + e1), a0 = e0 * inv, a1 = e1 * inv;
+#pragma unroll
+            for (int u = h * SH; u < (h + 1) * SH; ++u)
+                xr[u] = make_float4(a0 * v0[u].x + a1 * v1[u].x, a0 * v0[u].y + a1 * v1[u].y, a0 * v0[u].z + a1 * v1[u].z, a0 * v0[u].w + a1 * v1[u].w);
+        }
     }
     // the epilogue's side inputs of this lane's element (output o0 + p16 of token tb + 4 g + wave), requested with the operands
     const int tok = tb + 4 * g + wave, ocol = ovalid ? oc0 + p16 : 0;
@@ -133,34 +166,20 @@ __global__ __launch_bounds__(256) void toklin_kernel(const TokLin p) {
     TKTL(4);
 }
 
-// self-attention of the two latent tokens of a sample (modules.py:544-648): qkv [ntok][3 dq] -> out [ntok][dq].  grid B, block 256.
-__global__ __launch_bounds__(256) void lat_selfattn_kernel(const float* __restrict__ qkv, int dq, int He, float* __restrict__ out) {
-    __shared__ float sc[64], aw[64];
-    const int b = blockIdx.x, hd = dq / He;
-    const float* q = qkv + (int64_t)b * 2 * 3 * dq;               // token rows 2 b, 2 b + 1: [q | k | v]
-    const float scale = 1.0f / sqrtf((float)hd);
-    if (threadIdx.x < He * 4) {                                   // (h, i, j) scores
-        const int h = threadIdx.x >> 2, i = (threadIdx.x >> 1) & 1, j = threadIdx.x & 1;
-        float a = 0.f;
-        for (int r = 0; r < hd; ++r) a += (q[i * 3 * dq + h * hd + r] * scale) * q[j * 3 * dq + dq + h * hd + r];
-        sc[threadIdx.x] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x < He * 2) {                                   // softmax over the 2 keys
-        const int base = threadIdx.x * 2;
-        const float a0 = sc[base], a1 = sc[base + 1], mx = fmaxf(a0, a1);
-        const float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), inv = 1.0f / (e0 + e1);
-        aw[base] = e0 * inv; aw[base + 1] = e1 * inv;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * dq; e += blockDim.x) {
-        const int i = e / dq, c = e % dq, h = c / hd;
-        out[((int64_t)b * 2 + i) * dq + c] = aw[(h * 2 + i) * 2 + 0] * q[2 * dq + c] + aw[(h * 2 + i) * 2 + 1] * q[3 * dq + 2 * dq + c];
-    }
-}
-
 int launch_toklin(const TokLin& p, hipStream_t s) {
     const dim3 grid((p.N + TL_OB - 1) / TL_OB, (p.ntok + TL_TOK - 1) / TL_TOK);
+    if (p.attn_hd) {                              // self-attention prologue: a wave's K quarter is two whole heads
+        if (p.K != 8 * p.attn_hd || p.use_ln || p.head_out || p.ldx != 3 * p.K || (p.ntok & 1)) return AFM_E_UNSUPPORTED;
+        switch (p.K) {
+            case 128: hipLaunchKernelGGL((toklin_kernel<8, true>), grid, dim3(256), 0, s, p); break;
+            case 256: hipLaunchKernelGGL((toklin_kernel<16, true>), grid, dim3(256), 0, s, p); break;
+            case 384: hipLaunchKernelGGL((toklin_kernel<24, true>), grid, dim3(256), 0, s, p); break;
+            case 512: hipLaunchKernelGGL((toklin_kernel<32, true>), grid, dim3(256), 0, s, p); break;
+            default: return AFM_E_UNSUPPORTED;
+        }
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
     switch (p.K) {                                // widths of the Perceiver's latents / point features (validate: dkv == 256, dq a multiple of 128)
         case 128: hipLaunchKernelGGL(toklin_kernel<8>, grid, dim3(256), 0, s, p); break;
         case 256: hipLaunchKernelGGL(toklin_kernel<16>, grid, dim3(256), 0, s, p); break;
@@ -222,9 +241,8 @@ int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64
         p.ln = w.self_norm[li]; p.use_ln = 1;
         if (lnf) { folded(p, 0, 1 + 4 * li); folded(p, 1, 2 + 4 * li); folded(p, 2, 3 + 4 * li); }
         AFM_TRY(launch_toklin(p, s));
-        hipLaunchKernelGGL(lat_selfattn_kernel, dim3(B), dim3(256), 0, s, ws.lat_qkv, dq, He, ws.lat_t1);
-        AFM_CHECK_LAUNCH();
-        p = lin(ws.lat_t1, dq, dq, w.self_attn[li].o, dq, ws.lat_x, dq);
+        p = lin(ws.lat_qkv, 3 * dq, dq, w.self_attn[li].o, dq, ws.lat_x, dq);      // the attention of the pair is the prologue of its o_proj (toklin_kernel<., true>)
+        p.attn_hd = dq / He;
         p.R = ws.lat_x; p.ldr = dq;
         AFM_TRY(launch_toklin(p, s));
         AFM_TRY(mlp(w.self_mlp[li], 4 + 4 * li));
