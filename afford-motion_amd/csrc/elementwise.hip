@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
     }
 }
 
+// grid (x, B, steps): blockIdx.z = a further step of the same keying, its [B][per_sample] block behind the previous one
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t per_sample, uint64_t seed,
                                                     int64_t sample0, int step) {
     const int b = blockIdx.y;
+    out += (int64_t)blockIdx.z * gridDim.y * per_sample;
+    step += (int)blockIdx.z;
     const int64_t base = (int64_t)b * per_sample;
     const int64_t nquad = (per_sample + 3) >> 2;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
@@ -211,6 +214,18 @@ extern "C" int afm_ddpm_step(const float* x0, const float* x_t, const float* noi
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(ddpm_step_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x0, x_t, noise, x_next, c1, c2, sigma,
                        per_sample, seed, sample_index0, step);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// the noise of `nsteps` consecutive steps in one launch: out [nsteps][B][per_sample], step index step0 + i (same values as nsteps calls of afm_randn)
+__attribute__((visibility("hidden"))) int afm_randn_steps(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0, int32_t step0, int32_t nsteps, void* stream) {
+    if (!out || B < 0 || per_sample <= 0 || nsteps < 0 || nsteps > 65535) return AFM_E_BADARG;
+    if (B == 0 || nsteps == 0) return 0;
+    const int64_t nquad = (per_sample + 3) >> 2;
+    unsigned gx = (unsigned)((nquad + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(randn_kernel, dim3(gx, B, nsteps), dim3(256), 0, (hipStream_t)stream, out, per_sample, seed, sample_index0, step0);
     AFM_CHECK_LAUNCH();
     return 0;
 }

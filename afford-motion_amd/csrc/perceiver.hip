@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x
     }
 }
 
+constexpr int NOISE_STEPS = 16;               // steps of Philox noise generated per launch of the native loop (workspace: NOISE_STEPS x B x N x contact_dim floats)
+
 inline void cdm_sub_range(int B, int nsub, int s, int* start, int* count) {
     const int base = B / nsub, extra = B % nsub;
     *start = s * base + (s < extra ? s : extra);
@@ -343,7 +345,7 @@ extern "C" int64_t afm_cdm_loop_workspace_bytes(const afm_cdm_weights* w, int32_
     for (int s = 0; s < nsub; ++s) {
         int st, cnt;
         cdm_sub_range(B, nsub, s, &st, &cnt);
-        total += carve(*w, cnt, N, nullptr).bytes + align256((int64_t)cnt * N * w->contact_dim * 4);
+        total += carve(*w, cnt, N, nullptr).bytes + align256((int64_t)NOISE_STEPS * cnt * N * w->contact_dim * 4);
     }
     return total;
 }
@@ -389,7 +391,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             cdm_sub_range(B, nsub, s, &start[s], &count[s]);
             wsb[s] = carve(*w, count[s], N, nullptr).bytes;
             wsp[s] = base + off; off += wsb[s];
-            noise[s] = (float*)(base + off); off += align256((int64_t)count[s] * N * cd * 4);
+            noise[s] = (float*)(base + off); off += align256((int64_t)NOISE_STEPS * count[s] * N * cd * 4);
             if (nsub > 1) { mainst[s] = (hipStream_t)streams[2 * s]; sidest[s] = (hipStream_t)streams[2 * s + 1]; }
             else { mainst[s] = s0; sidest[s] = streams ? (hipStream_t)streams[0] : nullptr; }
         }
@@ -423,9 +425,11 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             afm_ddpm_args dd = {};
             if (step_noise) dd.noise = step_noise + ((int64_t)j * B + start[s]) * per;
             else {
-                rc = afm_randn(noise[s], count[s], per, seed, sample_index0 + start[s], first_step + j, mainst[s]);
-                if (rc) break;
-                dd.noise = noise[s];
+                if (j % NOISE_STEPS == 0) {               // the noise of the next NOISE_STEPS steps in one launch (6 us of launch per step otherwise)
+                    rc = afm_randn_steps(noise[s], count[s], per, seed, sample_index0 + start[s], first_step + j, n_steps - j < NOISE_STEPS ? n_steps - j : NOISE_STEPS, mainst[s]);
+                    if (rc) break;
+                }
+                dd.noise = noise[s] + (int64_t)(j % NOISE_STEPS) * count[s] * per;
             }
             dd.x_next = xs;                               // in place: each element is read then written by the same lane
             dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s]; dd.sigma = sg_all + (int64_t)j * B + start[s];

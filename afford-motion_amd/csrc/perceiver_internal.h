@@ -5,6 +5,10 @@
 #include "common.h"
 #include "profile.h"
 
+// elementwise.hip: the Philox noise of consecutive steps in one launch, out [nsteps][B][per_sample] (same values as nsteps calls of afm_randn)
+__attribute__((visibility("hidden"))) int afm_randn_steps(float* out, int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0, int32_t step0, int32_t nsteps,
+                                                          void* stream);
+
 namespace afm_cdm {
 
 constexpr int NSPLIT = 16;          // workgroups per sample in enc_reduce (x4 waves = 64 partials per sample)
