@@ -122,22 +122,34 @@ def config0(quick):
 
 
 def config2(quick):
-    """CDM Perceiver over N = 8192 points + text token, B = 32 (H3D variant: 9 input channels, 500-step schedule)."""
+    """CDM Perceiver over N = 8192 points + text token, B = 32 (H3D variant: 9 input channels, 500-step schedule), and the HUMANISE variant
+    (41 input channels: 32 scene features per point of the frozen backbone, hoisted out of the loop - SURVEY 8d[2] secondary)."""
     steps = 20 if quick else 100
     adm, d_adm, _, _ = cdm_models(str(steps), "2")
-    kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev))
-    run = lambda: d_adm.p_sample_loop(adm, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=1)
-    dt = timed(run, 1) / steps
-    ffi.profile_enable(True); ffi.profile_read(); run(); prof = ffi.profile_read(); ffi.profile_enable(False)
-    return {"config": "configs[2] CDM Perceiver, B=32, N=8192, text token, 1 MI355X", "metric": "denoising steps/sec", "value": round(1 / dt, 2),
-            "ms_per_step": round(1e3 * dt, 4), "dtype": "f32",
-            "as_written_tflops": round(313.4e9 / dt / 1e12, 1), "executed_gflop_per_step": 43.0,
-            "formulation": ("2-latent cross-attentions evaluated folded (no K/V over the points); sampling form of the per-point chain: the rows of "
-                            "encoder_adapter / decoder_adapter are generated on the matrix pipe from [x_t | xyz | 1] inside enc_reduce / dec_attend (never "
-                            "materialised), linear2 + residual + contact_layer collapsed into row-dots fused into linear1's epilogue (afm_cdm_weights.fold_* / "
-                            "gen_*); executed per step: linear1 34.4 GF (nine bf16 products per f32 product, weight-stationary form) + ~10 GF of f32 MFMA in "
-                            "enc_reduce / dec_attend (16x16x4); CDM.no_fold = True runs the layer-by-layer form (115 GF per step)"),
-            "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items()}}
+    lines = []
+    for tag, model, diff, extra in (("H3D variant (9 input channels)", adm, d_adm, {}), ("HUMANISE variant (41 input channels, scene features hoisted)", None, None, None)):
+        if model is None:
+            cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.arch=Perceiver", "model.input_feats=6", "model.text_model.max_length=20", "diffusion.steps=500",
+                                                                   f"diffusion.timestep_respacing='{steps}'", "model.scene_model.use_scene_model=True",
+                                                                   "model.scene_model.use_openscene=True", "model.scene_model.point_feat_dim=32",
+                                                                   "model.scene_model.pretrained_weight=''", "task.dataset.use_openscene=True"])
+            model = create_model(cfg, device=dev); synth.fill_module_(model); model = model.to(dev).eval()
+            diff = create_gaussian_diffusion(cfg)
+            extra = dict(c_pc_feat=synth.gaussian("cfg2_feat", (B, N, 32)).to(dev))
+        kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev), **extra)
+        run = lambda: diff.p_sample_loop(model, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=1)
+        dt = timed(run, 1) / steps
+        ffi.profile_enable(True); ffi.profile_read(); run(); prof = ffi.profile_read(); ffi.profile_enable(False)
+        lines.append({"config": f"configs[2] CDM Perceiver, B=32, N=8192, text token, 1 MI355X: {tag}", "metric": "denoising steps/sec", "value": round(1 / dt, 2),
+                      "ms_per_step": round(1e3 * dt, 4), "dtype": "f32", "as_written_tflops": round(313.4e9 / dt / 1e12, 1),
+                      "formulation": ("row-less sampling form (csrc/perceiver_points.hip): a point is its K = 12 / 44 inputs [x_t | features | 1] and 16 decoder attention "
+                                      "weights; the 256-wide rows of the reference (adapters, LayerNorms, attention output, the MLP's input and hidden row) are never "
+                                      "generated - enc_point / lat_head / 11 toklin launches / lat_dectables / dec_point per step; executed per step ~3 GF on the f32 "
+                                      "matrix pipe + 2.4 GF x 9 bf16 products (linear1 as a K = 28 / 60 product); CDM.no_gen = round 2's folded rows, CDM.no_fold = "
+                                      "layer by layer (115 GF per step)"),
+                      "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items()}})
+        del model
+    return lines
 
 
 def config3(quick):

@@ -14,6 +14,9 @@ for b in 32 16 8 4 1; do
 done
 ( timeout 600 bash tools/collect_profiles.sh ${R/r0/r} ) > $O/collect.log 2>&1
 ( timeout 500 bash tools/collect_profiles.sh ${R/r0/r} cdm ) > $O/collect_cdm.log 2>&1
+# kernel stats of the HUMANISE variant of the CDM loop (41 input channels)
+( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_cdm_h -- python $GRAFT_REPO_ROOT/tools/pmc_target.py cdm_h > /dev/null 2>&1 )
+find $O/stats_cdm_h -name "*kernel_trace.csv" -delete
 ( timeout 900 python tools/bench_configs.py ) > $O/configs.jsonl 2> $O/configs.err
 ( timeout 600 python tools/cdm_ab.py 100 ) > $O/cdm_ab.jsonl 2> $O/cdm_ab.err
 tail -4 $O/pytest_gpu.log; tail -3 $O/smoke.log
