@@ -561,26 +561,27 @@ typedef struct {
     int32_t flags;             /* AFM_CDM_* bits (ABI v4)                                                       */
     const float* fold_q;       /* [contact_dim, contact_dim]  contact_layer.w @ fold_xv^T                     */
     const float* fold_c0;      /* [contact_dim]  contact_layer.w @ (dec_mlp.fc2.b + dec_attn.o.b) + contact_layer.b */
-    /* ABI v5 (all or none; built by the host next to fold_* when feat_dim + 1 <= 12, i.e. the H3D variant's 9 input channels): the sampling form
-     * without per-point rows.  A point is x = [x_t | point features, xyz | 1] (12 numbers, zero-padded) and everything between the nonlinearities is
-     * linear in x and in the 16 attention weights a[jh] of the decoder:
+    /* ABI v5 (all or none; built by the host next to fold_* when feat_dim + 1 <= 44): the sampling form without per-point rows.  A point is
+     * x = [x_t | point features, xyz | 1 | 0 ...], K numbers: K = 12 when feat_dim + 1 <= 12 (the H3D variant's 9 input channels), else K = 44 (the
+     * HUMANISE variant's 41), NT = ceil(K / 16).  Everything between the nonlinearities is linear in x and in the 16 attention weights a[jh] of the
+     * decoder:
      *   encoder side   the rows the two latents attend over are LayerNorm_kv(x G_enc): var = x Qe x^T, any dot with a vector u is rstd (x . (Ec u)),
-     *                  the attention-weighted row sum is linear in sum_n a_n rstd_n x_n (enc_point_kernel accumulates 16 x 12 numbers per wave):
-     *     enc_ec  [12, dkv]  G_enc = [encoder_adapter.w^T ; encoder_adapter.b ; 0] minus its row means
-     *     enc_qee [16, 16]   enc_ec enc_ec^T / dkv in MFMA operand order: entry (k, i) = Q[4 (i & 3) + (i >> 2)][k], 0 where an index is >= 12
-     *     enc_wove [8 * 12, dq], enc_c1 [dq]   head of the latent chain: x1 = q0 + o_proj(v_proj(.)) as one product with the 8 x 12 accumulated numbers
-     *                  (row 12 h + k = o_proj.w[:, head h] v_proj.w[head h] (enc_kv_norm.w * enc_ec[k]); enc_c1 = o_proj.b + o_proj.w (v_proj.w enc_kv_norm.b + v_proj.b))
+     *                  the attention-weighted row sum is linear in sum_n a_n rstd_n x_n (enc_point_kernel accumulates 16 x K numbers per wave):
+     *     enc_ec  [K, dkv]   G_enc = [encoder_adapter.w^T ; encoder_adapter.b ; 0] minus its row means
+     *     enc_qee [K, 16 NT] enc_ec enc_ec^T / dkv in MFMA operand order: entry (k, 16 t + i) = Q[4 (4 t + (i & 3)) + (i >> 2)][k], 0 where that index is >= K
+     *     enc_wove [8 K, dq], enc_c1 [dq]   head of the latent chain: x1 = q0 + o_proj(v_proj(.)) as one product with the 8 x K accumulated numbers
+     *                  (row K h + k = o_proj.w[:, head h] v_proj.w[head h] (enc_kv_norm.w * enc_ec[k]); enc_c1 = o_proj.b + o_proj.w (v_proj.w enc_kv_norm.b + v_proj.b))
      *   decoder side   with G_dec = [(decoder_adapter.w encoder_adapter.w)^T ; decoder_adapter.w encoder_adapter.b + decoder_adapter.b ; 0]:
      *                  scores = rstd_q (x . EG) + const, var_q = x Qd x^T;  h1 = [a | x] T with T = [P ; G_dec + dec_attn.o.b on the constant's row];
-     *                  LayerNorm_mlp(h1) W1^T = rstd ([a | x] TWc) + C, var = [a | x] Qc [a | x]^T: linear1 is a K = 28 product.  Step-invariant parts:
-     *     dec_qdd [16, 16]   (G_dec - row means)(...)^T / dkv in operand order        dec_c   [dkv]      dec_mlp.fc1.b + dec_mlp.fc1.w dec_mlp.norm.b
-     *     dec_twx [12, dkv]  Xc (dec_mlp.fc1.w * dec_mlp.norm.w)^T, Xc = centred input rows of T     dec_qxx [12, 12]   Xc Xc^T / dkv
-     *     gen_qe  [contact_dim, 12]  contact_layer.w G_dec^T
+     *                  LayerNorm_mlp(h1) W1^T = rstd ([a | x] TWc) + C, var = [a | x] Qc [a | x]^T: linear1 is a K + 16 product.  Step-invariant parts:
+     *     dec_qdd [K, 16 NT] (G_dec - row means)(...)^T / dkv in operand order (as enc_qee)    dec_c   [dkv]      dec_mlp.fc1.b + dec_mlp.fc1.w dec_mlp.norm.b
+     *     dec_twx [K, dkv]   Xc (dec_mlp.fc1.w * dec_mlp.norm.w)^T, Xc = centred input rows of T     dec_qxx [K, K]     Xc Xc^T / dkv
+     *     gen_qe  [contact_dim, K]  contact_layer.w G_dec^T
      *                  and the parts that depend on the sample's latents come from their decoder keys / values (o = 32 h + r over a head's entries,
      *                  Woc = dec_attn.o.w minus its column means) through
-     *     dec_dwq [12, dkv] = ((G_dec - row means) * dec_q_norm.w) dec_attn.q.w^T      dec_wqb [dkv] = dec_attn.q.w dec_q_norm.b + dec_attn.q.b
+     *     dec_dwq [K, dkv]  = ((G_dec - row means) * dec_q_norm.w) dec_attn.q.w^T      dec_wqb [dkv] = dec_attn.q.w dec_q_norm.b + dec_attn.q.b
      *     dec_wco [8, dkv]  = contact_layer.w dec_attn.o.w (zero rows >= contact_dim)   dec_wow [dkv, dkv] = Woc^T (dec_mlp.fc1.w * dec_mlp.norm.w)^T
-     *     dec_wog [dkv, dkv] = Woc^T Woc / dkv                                          dec_xwo [12, dkv] = Xc Woc / dkv */
+     *     dec_wog [dkv, dkv] = Woc^T Woc / dkv                                          dec_xwo [K, dkv] = Xc Woc / dkv */
     const float* gen_qe;
     const float* dec_c; const float* dec_twx; const float* dec_qxx; const float* dec_qdd;
     const float* enc_ec; const float* enc_qee; const float* enc_wove; const float* enc_c1;
