@@ -13,9 +13,9 @@ from gpu_util import dev, load_named_weights, report
 pytestmark = pytest.mark.gpu
 
 
-def cdm_cfg(num_points=256, point_feats=False, steps=500, respacing=""):
+def cdm_cfg(num_points=256, point_feats=False, steps=500, respacing="", point_feat_dim=32):
     sm = dict(name="PointTransformerSeg", use_scene_model=point_feats, use_color=False, use_openscene=point_feats,
-              num_points=num_points, point_feat_dim=32, pretrained_weight="", freeze=True)
+              num_points=num_points, point_feat_dim=point_feat_dim, pretrained_weight="", freeze=True)
     return to_config(dict(
         model=dict(name="CDM", input_feats=6, data_repr="contact_cont_joints", time_emb_dim=128,
                    text_model=dict(version="ViT-B/32", max_length=20), scene_model=sm, arch="Perceiver",
@@ -280,6 +280,28 @@ def test_row_less_form_on_ragged_shapes(cdm, cdm_feat, B, N, feats):
     assert torch.isfinite(out["default"][0]).all() and torch.isfinite(out["default"][1]).all()
     report(f"CDM forward B={B} N={N}: row-less vs layered", out["default"][0], out["layered"][0].cpu(), 2e-5)
     report(f"CDM 4-step loop B={B} N={N}: row-less vs layered", out["default"][1], out["layered"][1].cpu(), 1e-4)
+
+
+@pytest.mark.parametrize("pfd", [3, 8, 34])
+def test_row_less_form_with_partly_filled_input_tiles(pfd):
+    """Feature widths between the two instantiations of the row-less kernels: feat_dim + 1 = 13 (the first width that needs K = 44), 18, and 44
+    (every input used) - the unused inputs are zero columns of the host's tables, the loads of a tile are clamped to the sample's last float."""
+    m = create_model(cdm_cfg(point_feats=True, point_feat_dim=pfd), device=dev())
+    load_named_weights(m)
+    m = m.to(dev()).eval()
+    assert m.contact_model.feat_dim + 1 == 6 + pfd + 3 + 1
+    B, N = 3, 333
+    kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_pc_xyz=synth.scene_cloud(B, N, seed=pfd).to(dev()),
+              c_pc_feat=synth.gaussian(f"partly_feat_{pfd}", (B, N, pfd)).to(dev()))
+    x, t = synth.gaussian(f"partly_x_{pfd}", (B, N, 6)).to(dev()), (torch.arange(B) * 97 % 500).to(dev())
+    d4 = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="4"))
+    out = {}
+    for tag, no_fold in (("default", False), ("layered", True)):
+        m.no_fold = no_fold
+        with torch.no_grad():
+            out[tag] = (m(x, t, **kw), d4.p_sample_loop(m, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=11))
+    report(f"CDM forward, {pfd} point features: row-less vs layered", out["default"][0], out["layered"][0].cpu(), 2e-5)
+    report(f"CDM 4-step loop, {pfd} point features: row-less vs layered", out["default"][1], out["layered"][1].cpu(), 1e-4)
 
 
 def test_sampling_forms_agree_with_each_other_and_the_oracle(cdm):
