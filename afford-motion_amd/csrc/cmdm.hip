@@ -17,11 +17,13 @@ extern "C" int afm_mha_fwd_grouped(const float*, const uint8_t*, float*, int32_t
 extern "C" int afm_layernorm(const float*, const float*, const float*, float*, int64_t, int32_t, float, void*);
 extern "C" int afm_layernorm_rows(const float*, const float*, const float*, float*, int64_t, int32_t, float, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_randn(float*, int32_t, int64_t, uint64_t, int64_t, int32_t, void*);
+__attribute__((visibility("hidden"))) int afm_randn_steps(float*, int32_t, int64_t, uint64_t, int64_t, int32_t, int32_t, void*);      // elementwise.hip: [nsteps][B][per_sample]
 
 namespace {
 
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
+constexpr int NOISE_STEPS = 16;
 struct Workspace {
     float *seq0, *y, *x1, *tmp, *qkv, *qkv0, *att, *hid, *noise, *xpad;
     uint8_t* keymask;
@@ -44,7 +46,7 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.qkv0 = (float*)take(M * 3 * d * 4);            // layer 0's in_proj output: its condition-token rows persist across the steps of a loop
     ws.att = (float*)take(M * d * 4);
     ws.hid = (float*)take(M * (int64_t)w.ff * 4);
-    ws.noise = (float*)take((int64_t)B * L * w.motion_dim * 4);
+    ws.noise = (float*)take((int64_t)NOISE_STEPS * B * L * w.motion_dim * 4);      // the native loop draws the Philox noise of NOISE_STEPS steps per launch
     ws.keymask = (uint8_t*)take(M);
     ws.lncnt = (uint32_t*)take(((M + 31) / 32) * 4);
     ws.stat1 = (float*)take(M * (d / 64 + 1) * 2 * 4); ws.stat2 = (float*)take(M * (d / 64 + 1) * 2 * 4);
@@ -359,7 +361,14 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
         for (int s = 0; s < nsub && rc == 0; ++s) {
             if (count[s] == 0) continue;
             afm_ddpm_args dd = {};
-            dd.noise = step_noise ? step_noise + ((int64_t)j * B + start[s]) * row : nullptr;
+            if (step_noise) dd.noise = step_noise + ((int64_t)j * B + start[s]) * row;
+            else {
+                if (j % NOISE_STEPS == 0) {               // one launch per NOISE_STEPS steps instead of one per step (a launch is ~5 us of a small-batch step)
+                    rc = afm_randn_steps(ws[s].noise, count[s], row, seed, sample_index0 + start[s], first_step + j, n_steps - j < NOISE_STEPS ? n_steps - j : NOISE_STEPS, st[s]);
+                    if (rc) break;
+                }
+                dd.noise = ws[s].noise + (int64_t)(j % NOISE_STEPS) * count[s] * row;
+            }
             dd.x_next = x + (int64_t)start[s] * row;      // in place: each element is read then written by the same lane
             dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s];
             dd.sigma = sg_all + (int64_t)j * B + start[s];
