@@ -48,11 +48,20 @@ def _strong_worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
+def _free_port():
+    """A port nobody listens on right now (a fixed number collides with a socket of the previous run still in TIME_WAIT, or with another job)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_strong_scaling_two_ranks_equal_one_process():
     total = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_strong_worker, args=(r, 2, 29655, total, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(2))
@@ -89,7 +98,7 @@ def _worker(rank, world, port, total, q):
 def test_two_rank_gather_matches_single_process(total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29611 + total
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
