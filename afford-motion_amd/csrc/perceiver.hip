@@ -162,7 +162,7 @@ extern "C" int afm_cdm_latent_tokens(const afm_cdm_weights* wp, int32_t which, c
 namespace {
 
 // sampling form of the per-point kernels: 3 = no rows (enc_point_kernel, lat_head_kernel, lat_dectables_kernel, dec_point_kernel: every fused
-// table present and feat_dim + 1 <= GEN_K), 1 = FOLD (round 2: step-invariant adapter parts materialised once per loop), 0 = layer by layer
+// table present and rowless_nks(feat_dim) != 0: at most 43 input channels), 1 = FOLD (round 2: step-invariant adapter parts materialised once per loop), 0 = layer by layer
 inline int cdm_mode(const afm_cdm_weights& w) {
     const bool folded = w.fold_xu && w.fold_xv && w.fold_w2 && w.fold_q && w.fold_c0 && w.contact_dim <= 8 && w.feat_dim > w.contact_dim && (w.dkv % 64) == 0;
     if (!folded) return 0;

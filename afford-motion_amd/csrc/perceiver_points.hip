@@ -11,10 +11,10 @@ using namespace afm_cdm;
 
 namespace {
 
-// ---------------------------------------------------------------- enc_reduce without rows (round 3; GEN inputs)
+// ---------------------------------------------------------------- the encoder's reduction over the points without rows
 // The rows the two latents attend over are LayerNorm_kv of a linear map of the point's K inputs x = [x_t | features | 1 | 0..] (K = 12: the
 // H3D variant, K = 44: 32 scene features per point, the HUMANISE variant), so, exactly as in the decoder (dec_point_kernel): var = x Qe x^T
-// (step-invariant K x K form), score[q] = rstd (x . EU[:, q]) + const with EU = Ec U'^T (Ec = gen_enc minus its row means; K x 16 per
+// (step-invariant K x K form), score[q] = rstd (x . EU[:, q]) + const with EU = Ec U'^T (Ec = the adapter map G_enc minus its row means: afm_cdm_weights.enc_ec; K x 16 per
 // sample and step, built in the prologue), and the attention-weighted sum of the normalised rows is linear in sum_n p[n, q] rstd[n] x[n]: a
 // wave accumulates 16 x K numbers instead of 16 x 256 and never generates a row.  Per 16 points at K = 12: 10 MFMAs (16x16x4) instead of
 // 176; the partial (max, sum, K-vector) records are merged and taken through v-proj and o-proj by lat_head_kernel.
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(64 * EP_WAVES) void enc_point_kernel(afm_ln kvn, co
 }
 
 // The head of the chain in one launch (fused sampling form): merge enc_point_kernel's partials of the 8 heads of a latent token into the
-// 8 x 12 numbers a12[h][k] = sum_n a[n] rstd[n] x[n][k], then apply everything that is linear behind them at once -
-//   x1 = q0 + o_proj(v_proj(gamma_kv * (a12 Ec) + beta_kv)) = q0 + c1 + sum_{h, k} a12[h][k] WOVE[12 h + k]
-// with WOVE [96][dq] = W_o (per-head blocks) W_v (gamma_kv * Ec)^T and c1 = b_o + W_o (W_v beta_kv + b_v) from the host (float64).
+// 8 x K numbers a12[h][k] = sum_n a[n] rstd[n] x[n][k], then apply everything that is linear behind them at once -
+//   x1 = q0 + o_proj(v_proj(gamma_kv * (a12 Ec) + beta_kv)) = q0 + c1 + sum_{h, k} a12[h][k] WOVE[K h + k]
+// with WOVE [8 K][dq] = W_o (per-head blocks) W_v (gamma_kv * Ec)^T and c1 = b_o + W_o (W_v beta_kv + b_v) from the host (float64).
 // Replaces lat_combine + the v-proj and o-proj toklin launches.  grid (B, 2 latents, dq / 256), block 256.
 template <int NKS>
 __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__ pm, const float* __restrict__ pl, const float* __restrict__ pacc12,
@@ -224,21 +224,21 @@ __global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------- the whole decoder of a point in ONE kernel (round 3; GEN inputs)
+// ---------------------------------------------------------------- the whole decoder of a point in ONE kernel (written for K = 12 inputs; K = 44: the same with NT = 3 input tiles)
 // After the attention weights a[p, jh] of a point are known, everything up to linear1 is LINEAR in u[p] = [a[p, 0..15] | x_t | features | 1]:
-//   h1[p, c] = sum_jh P[jh, c] a[p, jh] + b_o[c] + e[p, c],  e = the generated query row       = sum_m u[p, m] T[m, c]   (T = [P ; gen_dec (+ b_o)])
+//   h1[p, c] = sum_jh P[jh, c] a[p, jh] + b_o[c] + e[p, c],  e = the generated query row       = sum_m u[p, m] T[m, c]   (T = [P ; G_dec (+ b_o)], G_dec = both adapters as one map of the inputs)
 //   z = LayerNorm_mlp(h1): h1 - mean_c(h1) = sum_m u[p, m] Tc[m, c]  (Tc = T minus its row means),  var_c(h1) = u Qc u^T,  Qc = Tc Tc^T / 256
 //   linear1(z)[n] = rstd[p] * sum_m u[p, m] TWc[m, n] + C[n],   TWc = Tc (W1 * gamma_mlp)^T,  C = b1 + W1 beta_mlp
 // so the 256-wide rows h1 and z never exist and linear1 is a K = 28 product instead of K = 256 (x 9 bf16 products): per 16 points
 // 112 + 14 f32 MFMAs against 64 (P V) + 576 (linear1 on the bf16 pipe).  The hidden row GELU(linear1) lives one 16-channel tile at a time
 // and goes straight into the row-dots with w2 = contact_layer.w fc2.w (64 MFMAs, the contact channel as the output row), to which the
 // attention part (WP a) and the query part (gen_qe . inputs) of contact_layer.w . h1 are added in the same accumulator: the kernel reads
-// 9 floats per point and writes the 6 of x_0 / x_{t-1}.  Per sample and step the rows of P enter through two small launches in front:
-// lat_dectab_kernel (centred rows Pc, the [28 x 28] quadratic form in operand order) and one toklin launch (TWc rows of P = Pc W1g^T);
+// 9 floats per point and writes the 6 of x_0 / x_{t-1}.  Per sample and step the rows of P enter through one small launch in front,
+// lat_dectables_kernel (the TWc rows of the attention weights, the [28 x 28] quadratic form in operand order, EG, the score constants, WP);
 // the rows of the inputs are step-invariant and come from the host (afm_cdm_weights.dec_*).  Same function as the layer-by-layer form up
 // to f32 re-association (tests/test_gpu_cdm.py).
 // The attention scores fold the same way: LayerNorm_q(e) . G'[jh] = rstd_q (x . EG[:, jh]) + const with x = the 12 inputs, EG = Dc G'^T
-// (Dc = gen_dec minus its row means, per sample and step: lat_dectab_kernel) and var_q = x Qd x^T (step-invariant): the query row e is
+// (Dc = G_dec minus its row means, per sample and step: lat_dectables_kernel) and var_q = x Qd x^T (step-invariant): the query row e is
 // never generated either.
 constexpr int DP_LDW = 260;
 
