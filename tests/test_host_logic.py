@@ -180,6 +180,33 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert ffi.load().afm_version() == ffi.ABI_VERSION == 5     # pure host call, no GPU needed
 
 
+def test_ctypes_mirrors_match_the_c_structs(tmp_path):
+    """Every ctypes.Structure of afm/ffi.py against the struct it mirrors in include/afm_hip.h: total size and the offset of every field, as gcc
+    lays them out (a field added on one side only shifts everything behind it silently - the library would read garbage pointers)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    pairs = {"afm_linear_args": ffi.LinearArgs, "afm_linear_wgrad_args": ffi.WgradArgs, "afm_pt_attention_args": ffi.PtAttentionArgs,
+             "afm_lin": ffi.Lin, "afm_ln": ffi.Ln, "afm_mha_w": ffi.MhaW, "afm_mlp_w": ffi.MlpW, "afm_cdm_weights": ffi.CdmWeights,
+             "afm_profile_entry": ffi.ProfileEntry, "afm_encoder_layer_weights": ffi.EncoderLayerWeights, "afm_cmdm_weights": ffi.CmdmWeights,
+             "afm_ddpm_args": ffi.DdpmArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "afm_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), (cname, out[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_gemm_arithmetic_switches_are_host_state():
     """ABI v3: the GEMM arithmetic is a field of afm_linear_args / the weight packs; the switch lives in the Python host (afm.ops),
     initialised from AFM_GEMM_SPLIT* in the host's environment.  The library exports no setter and reads no environment."""
