@@ -256,76 +256,84 @@ __global__ __launch_bounds__(1024) void lat_dectables_kernel(const float* __rest
                                                             const float* __restrict__ wco, const float* __restrict__ wow, const float* __restrict__ wog,
                                                             const float* __restrict__ xwo, const float* __restrict__ qxx, int cd,
                                                             float* __restrict__ twp, float* __restrict__ tab) {
+    // grid (B, 4): workgroup w of a sample owns the columns [64 w, 64 w + 64) of the two [256][256] products (a quarter of the 512 KB of weights
+    // each: one workgroup per sample pulled all of it through ONE CU's vector-load path, 10.9 us), the attention-weight block of Qc whose second
+    // index lies in heads 2 w, 2 w + 1, and every fourth entry of EG / the mixed block; workgroup 0 also owns the constants.  Every table entry is
+    // written by exactly one workgroup.
     using RL = RowLess<NKS>;
     constexpr int K = RL::K, NQ = 16 + K;
     __shared__ float kd[2][256], vd[2][256];
-    __shared__ float tv[16][257];
+    __shared__ float tv[16][65];
     __shared__ float Q[NQ][NQ + 1];
-    const int b = blockIdx.x, c = threadIdx.x & 255, gq4 = threadIdx.x >> 8;
+    const int b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const float scd = 0.17677669529663687f;                       // 1 / sqrt(32)
-    if (gq4 < 2) {
-        kd[gq4][c] = lat_kv[((int64_t)b * 2 + gq4) * 512 + c];
-        vd[gq4][c] = lat_kv[((int64_t)b * 2 + gq4) * 512 + 256 + c];
+    if (tid < 512) {
+        const int j = tid >> 8, c = tid & 255;
+        kd[j][c] = lat_kv[((int64_t)b * 2 + j) * 512 + c];
+        vd[j][c] = lat_kv[((int64_t)b * 2 + j) * 512 + 256 + c];
     }
     __syncthreads();
-    {   // column c of the two [256][256] matrices against the value vectors of heads 2 gq4, 2 gq4 + 1: TWc rows (to memory), tv = vd WoG (to LDS)
+    float* T = tab + (int64_t)b * RL::TAB;
+    if (tid < 512) {   // column 64 w + cl of the two matrices against the value vectors of head h: TWc rows (to memory), tv = vd WoG (to LDS)
+        const int cl = tid & 63, h = tid >> 6, c = 64 * w + cl;
+        float t0 = 0.f, t1 = 0.f, g0 = 0.f, g1 = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int h = 2 * gq4 + hh;
-            float t0 = 0.f, t1 = 0.f, g0 = 0.f, g1 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int o = 32 * h + r;
-                const float w1 = wow[o * 256 + c], w2 = wog[o * 256 + c], v0 = vd[0][o], v1 = vd[1][o];
-                t0 += v0 * w1; t1 += v1 * w1;
-                g0 += v0 * w2; g1 += v1 * w2;
+        for (int r = 0; r < 32; ++r) {
+            const int o = 32 * h + r;
+            const float w1 = wow[o * 256 + c], w2 = wog[o * 256 + c], v0 = vd[0][o], v1 = vd[1][o];
+            t0 += v0 * w1; t1 += v1 * w1;
+            g0 += v0 * w2; g1 += v1 * w2;
+        }
+        twp[((int64_t)b * 16 + h) * 256 + c] = t0; twp[((int64_t)b * 16 + 8 + h) * 256 + c] = t1;
+        tv[h][cl] = g0; tv[8 + h][cl] = g1;
+    } else {           // meanwhile: this workgroup's quarter of EG [K][16] and of the attention-weight x input block of Qc (entries e = 4 i + w)
+        for (int e = 4 * (tid - 512) + w; e < K * 16; e += 4 * 512) {
+            const int k = e >> 4, jh = e & 15, j = jh >> 3, h = jh & 7;
+            float eg = 0.f, q = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) { eg += kd[j][32 * h + r] * dwq[k * 256 + 32 * h + r]; q += vd[j][32 * h + r] * xwo[k * 256 + 32 * h + r]; }
+            T[RL::QTAB + e] = eg * scd;
+            Q[jh][16 + k] = q; Q[16 + k][jh] = q;
+        }
+        if (w == 0) {
+            if (tid >= 1024 - 16) {
+                const int jh = tid - (1024 - 16), j = jh >> 3, h = jh & 7;
+                float gq = 0.f;
+                for (int r = 0; r < 32; ++r) gq += kd[j][32 * h + r] * wqb[32 * h + r];
+                T[RL::QTAB + K * 16 + jh] = gq * scd;
             }
-            twp[((int64_t)b * 16 + h) * 256 + c] = t0; twp[((int64_t)b * 16 + 8 + h) * 256 + c] = t1;
-            tv[h][c] = g0; tv[8 + h][c] = g1;
+            if (tid >= 512 + 256 && tid < 512 + 256 + 128) {      // WP [8][16]
+                const int e = tid - (512 + 256), rr = e >> 4, jh = e & 15, j = jh >> 3, h = jh & 7;
+                float wp = 0.f;
+                if (rr < cd)
+                    for (int r = 0; r < 32; ++r) wp += vd[j][32 * h + r] * wco[rr * 256 + 32 * h + r];
+                T[RL::QTAB + K * 16 + 16 + e] = wp;
+            }
+            for (int e = tid - 512; e < K * K; e += 512) Q[16 + e / K][16 + e % K] = qxx[e];
         }
     }
-    float* T = tab + (int64_t)b * RL::TAB;
-    for (int e = threadIdx.x; e < K * 16; e += 1024) {            // EG [K][16] and the attention-weight x input block of Qc
-        const int k = e >> 4, jh = e & 15, j = jh >> 3, h = jh & 7;
-        float eg = 0.f, q = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < 32; ++r) { eg += kd[j][32 * h + r] * dwq[k * 256 + 32 * h + r]; q += vd[j][32 * h + r] * xwo[k * 256 + 32 * h + r]; }
-        T[RL::QTAB + e] = eg * scd;
-        Q[jh][16 + k] = q; Q[16 + k][jh] = q;
-    }
-    if (threadIdx.x < 16) {
-        const int j = threadIdx.x >> 3, h = threadIdx.x & 7;
-        float gq = 0.f;
-        for (int r = 0; r < 32; ++r) gq += kd[j][32 * h + r] * wqb[32 * h + r];
-        T[RL::QTAB + K * 16 + threadIdx.x] = gq * scd;
-    }
-    if (threadIdx.x >= 256 && threadIdx.x < 256 + 128) {          // WP [8][16]
-        const int e = threadIdx.x - 256, rr = e >> 4, jh = e & 15, j = jh >> 3, h = jh & 7;
-        float wp = 0.f;
-        if (rr < cd)
-            for (int r = 0; r < 32; ++r) wp += vd[j][32 * h + r] * wco[rr * 256 + 32 * h + r];
-        T[RL::QTAB + K * 16 + 16 + e] = wp;
-    }
-    for (int e = threadIdx.x; e < K * K; e += 1024) Q[16 + e / K][16 + e % K] = qxx[e];
     __syncthreads();
-    if (threadIdx.x < 256) {   // Qc[jh][jh'] = tv[jh] (head block of jh') . vd_j'
-        const int jh = c >> 4, jh2 = c & 15, j2 = jh2 >> 3, h2 = jh2 & 7;
+    if (tid < 64) {    // Qc[jh][jh2] = tv[jh] (head block of jh2) . vd_j2 for the four jh2 of this workgroup's heads
+        const int jh = tid >> 2, j2 = (tid >> 1) & 1, hl = tid & 1, h2 = 2 * w + hl;
         float q = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) q += tv[jh][32 * h2 + r] * vd[j2][32 * h2 + r];
-        Q[jh][jh2] = q;
+        for (int r = 0; r < 32; ++r) q += tv[jh][32 * hl + r] * vd[j2][32 * h2 + r];
+        Q[jh][8 * j2 + h2] = q;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < RL::QTAB; e += 1024) {
+    for (int e = tid; e < RL::QTAB; e += 1024) {                  // operand order; an entry is written by the workgroup that holds its source
         const int cs = e / RL::LDQ, col = e - cs * RL::LDQ;
-        float v = 0.f;
+        int m = -1, m2 = -1;
         if (col < 16 + 16 * RL::NT) {
             const int i = col & 15, tt = (col >> 4) - 1, x = cs - 16, xg = x / RL::XS, xk = x - xg * RL::XS;
-            const int m2 = col < 16 ? i : (4 * tt + (i & 3) < NKS ? 16 + 4 * (4 * tt + (i & 3)) + (i >> 2) : -1);
-            const int m = cs < 16 ? cs : (xk < NKS ? 16 + 4 * xk + xg : -1);
-            if (m >= 0 && m2 >= 0) v = Q[m2][m];
+            m2 = col < 16 ? i : (4 * tt + (i & 3) < NKS ? 16 + 4 * (4 * tt + (i & 3)) + (i >> 2) : -1);
+            m = cs < 16 ? cs : (xk < NKS ? 16 + 4 * xk + xg : -1);
         }
-        T[e] = v;
+        const bool live = m >= 0 && m2 >= 0;
+        int owner = 0;                                            // zeros and the input x input block (qxx): workgroup 0
+        if (live && m < 16 && m2 < 16) owner = (m & 7) >> 1;      // Qc[jh = m2][jh2 = m]: the heads of jh2
+        else if (live && (m < 16) != (m2 < 16)) owner = (m < 16 ? m : m2) & 3;      // mixed block, entry e = 16 k + jh: e & 3 = jh & 3
+        if (owner == w) T[e] = live ? Q[m2][m] : 0.f;
     }
 }
 
@@ -581,7 +589,7 @@ int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, 
     static_assert(LDS <= 160 * 1024, "dec_point_kernel's tables fit the LDS");
     static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
-    hipLaunchKernelGGL(lat_dectables_kernel<NKS>, dim3(B), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
+    hipLaunchKernelGGL(lat_dectables_kernel<NKS>, dim3(B, 4), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
                        w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
     AFM_CHECK_LAUNCH();
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
