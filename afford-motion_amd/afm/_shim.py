@@ -4,17 +4,22 @@ A shim module shadows the reference's file of the same dotted name so that the h
 classes; the reference's own scripts, however, import OTHER names from those files as well
 (`utils/evaluate.py:15` wants `smplx_neutral_model, get_meshes_from_smplx` from `utils.misc`; `utils/joints_to_smplx.py:15-16`
 wants `optimize_params_with_joints, get_joints_from_smplx, ...`).  `reference_fallback()` gives the shim a PEP-562 module
-`__getattr__`: a name the shim does not define is looked up in the same-named file of the reference checkout that follows on
-`sys.path` (found through the parent package's extended `__path__`), loaded lazily, once, under a private module name.
-Names the shim defines always win; nothing is loaded unless a missing name is asked for, so a box without a checkout (or
-without the checkout's third-party deps, e.g. `smplkit`) can still import every shim.
+`__getattr__`: a name the shim does not define AND that is on the shim's explicit allow-list is looked up in the same-named file
+of the reference checkout that follows on `sys.path` (found through the parent package's extended `__path__`), loaded lazily, once,
+under a private module name.  Names the shim defines always win; nothing is loaded unless an allowed missing name is asked for, so a
+box without a checkout (or without the checkout's third-party deps, e.g. `smplkit`) can still import every shim.
+
+The allow-list is per shim and holds only names that are NOT on the denoising path (the SMPL-X helpers of `utils.misc`, the Perceiver
+building blocks the reference's own `models/cdm.py` imports from `models.modules`).  Every other missing name raises `AttributeError`
+naming the shim: a typo or a hot-path name the shim forgot (`diffusion.gaussian_diffusion._extract_into_tensor`, `respace._WrappedModel`)
+must fail loudly instead of silently executing the reference's code.
 """
 from __future__ import annotations
 
 import importlib.util
 import os
 import sys
-from typing import Callable, Optional
+from typing import Callable, Iterable, Optional
 
 
 def _reference_file(shim_name: str, shim_file: str) -> Optional[str]:
@@ -29,9 +34,11 @@ def _reference_file(shim_name: str, shim_file: str) -> Optional[str]:
     return None
 
 
-def reference_fallback(shim_name: str, shim_file: str) -> Callable[[str], object]:
-    """Returns a module-level `__getattr__` for the shim module `shim_name` (its `__name__`) at `shim_file`."""
+def reference_fallback(shim_name: str, shim_file: str, allow: Iterable[str] = ()) -> Callable[[str], object]:
+    """Returns a module-level `__getattr__` for the shim module `shim_name` (its `__name__`) at `shim_file`; only the names in
+    `allow` may resolve to the reference checkout's file."""
     state = {}
+    allowed = frozenset(allow)
 
     def _load():
         if "mod" in state:
@@ -55,6 +62,10 @@ def reference_fallback(shim_name: str, shim_file: str) -> Callable[[str], object
     def __getattr__(name: str):
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
+        if name not in allowed:
+            raise AttributeError(
+                f"module '{shim_name}' (afford-motion_amd drop-in shim) has no attribute '{name}': the shim does not define it and it is "
+                f"not on the shim's allow-list of non-hot-path names served from a reference checkout ({sorted(allowed) or 'none'})")
         mod = _load()
         if mod is None:
             raise AttributeError(

@@ -19,6 +19,17 @@ def _ws(nbytes: int, dev) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
 
 
+_ONES = {}
+
+
+def _ones(n: int, dev) -> torch.Tensor:
+    """Cached [n] tensor of ones per device (a fill, once): the gamma that makes afm_bn_fold return rstd."""
+    key = (n, str(dev))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, device=dev, dtype=torch.float32)
+    return _ONES[key]
+
+
 def _sync_group():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -65,10 +76,17 @@ class _BatchNormFn(torch.autograd.Function):
             if track and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
         else:                                                            # frozen BatchNorm (eval): running statistics
-            mean = bn.running_mean.detach().float().contiguous()
-            rstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
-            scale = (g * rstd).contiguous()
-            shift = (b - mean * scale).contiguous()
+            # afm_bn_fold (HIP): scale = gamma rstd, shift = beta - mean scale; with gamma = 1 the same kernel yields rstd itself -
+            # no eager ATen arithmetic on this path either
+            mean = ffi.f32c(bn.running_mean.detach())
+            var = ffi.f32c(bn.running_var.detach())
+            ones = _ones(Cn, dev)
+            st = _st(xc)
+            ffi.check(lib.afm_bn_fold(g.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(), float(bn.eps), None, scale.data_ptr(),
+                                      shift.data_ptr(), Cn, st), "afm_bn_fold")
+            unused_shift = torch.empty_like(rstd)
+            ffi.check(lib.afm_bn_fold(ones.data_ptr(), ones.data_ptr(), mean.data_ptr(), var.data_ptr(), float(bn.eps), None, rstd.data_ptr(),
+                                      unused_shift.data_ptr(), Cn, st), "afm_bn_fold")
         y = torch.empty_like(xc)
         ffi.check(lib.afm_colaffine(xc.data_ptr(), scale.data_ptr(), shift.data_ptr(), ffi.ptr(res), 1 if relu else 0, y.data_ptr(), rows, Cn,
                                     _st(xc)), "afm_colaffine")

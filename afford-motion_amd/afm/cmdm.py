@@ -246,11 +246,16 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             lw.norm1_w, lw.norm1_b, lw.norm2_w, lw.norm2_b = P(l.norm1.weight), P(l.norm1.bias), P(l.norm2.weight), P(l.norm2.bias)
         if not self.training:
             # eval: LayerNorm folded into the linears it feeds (afm_encoder_layer_weights.lin1_wg ...): W' = W * gamma, g = row sums of W',
-            # c = b + W beta - float64 products rounded once, on the device (a few 512 x 1536 products per weight version)
+            # c = b + W beta - float64 products rounded once, on the HOST in numpy (as afm/cdm.py builds the CDM's tables; once per weight
+            # version: ~12 MB down, the same up - no eager ATen arithmetic and no vendor BLAS call in a sampling job)
+            import numpy as np
+
             def fold(lin_w, lin_b, norm):
-                wd, gam, bet = lin_w.detach().double(), norm.weight.detach().double(), norm.bias.detach().double()
+                wd = lin_w.detach().cpu().numpy().astype(np.float64)
+                gam, bet = norm.weight.detach().cpu().numpy().astype(np.float64), norm.bias.detach().cpu().numpy().astype(np.float64)
                 wg = wd * gam[None, :]
-                return P(wg.float()), P(wg.sum(1).float()), P((lin_b.detach().double() + wd @ bet).float())
+                up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(dev)
+                return P(up(wg)), P(up(wg.sum(1))), P(up(lin_b.detach().cpu().numpy().astype(np.float64) + wd @ bet))
             for i, l in enumerate(layers):
                 lw = w.layer[i]
                 lw.lin1_wg, lw.lin1_g, lw.lin1_c = fold(l.linear1.weight, l.linear1.bias, l.norm1)
@@ -285,6 +290,10 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         extra = (tuple(kwargs["c_text"]) if "c_text" in kwargs and "c_text_feat" not in kwargs else None, _param_version(self))
         if self.hoist_conditions and self._cond_cache is not None and self._cond_cache[0].matches(tensors, extra):
             return self._cond_cache[1]
+        with torch.no_grad():           # sampling-side entry point (the training composition never calls it): always the fused inference kernels,
+            return self._condition_tokens(tensors, extra, kwargs)      # also when the caller has not disabled autograd itself
+
+    def _condition_tokens(self, tensors, extra, kwargs) -> torch.Tensor:
         text_feat = self.encode_text(kwargs)                                          # [B, text_dim]
         cont_emb = kwargs["c_cont_emb"] if "c_cont_emb" in kwargs else \
             self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])           # [B, G, planes[-1]]

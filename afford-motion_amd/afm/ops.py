@@ -108,6 +108,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         a.res_stat, a.res_gamma, a.res_beta = st.data_ptr(), g.data_ptr(), b.data_ptr()
     if stat_out is not None or a_stat is not None or res_stat is not None:
         a.ln_eps2 = float(ln_eps)
+        # the folded-LayerNorm epilogue reads its side inputs 16 bytes at a time and writes stat_out only from that branch: a
+        # contiguous-but-offset view (bias[1:]) is refused here as afm_linear refuses it (AFM_E_BADARG), never silently mis-normalised
+        for nm in ("C", "residual", "bias", "a_fold_g", "res_gamma", "res_beta"):
+            ptr = getattr(a, nm)
+            if ptr and ptr % 16:
+                raise ffi.AfmError(f"afm_linear with folded LayerNorm statistics: `{nm}` is not 16-byte aligned")
     fill_arith(a)
     ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
     return out

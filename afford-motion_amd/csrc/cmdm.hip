@@ -32,7 +32,7 @@ struct Workspace {
     int64_t bytes;
 };
 
-Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
+Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base, int noise_steps = 1) {
     const int64_t T = 1 + w.n_cond + L, M = (int64_t)B * T, d = w.d;
     char* p = (char*)base;
     int64_t off = 0;
@@ -46,7 +46,7 @@ Workspace carve(const afm_cmdm_weights& w, int B, int L, void* base) {
     ws.qkv0 = (float*)take(M * 3 * d * 4);            // layer 0's in_proj output: its condition-token rows persist across the steps of a loop
     ws.att = (float*)take(M * d * 4);
     ws.hid = (float*)take(M * (int64_t)w.ff * 4);
-    ws.noise = (float*)take((int64_t)NOISE_STEPS * B * L * w.motion_dim * 4);      // the native loop draws the Philox noise of NOISE_STEPS steps per launch
+    ws.noise = (float*)take((int64_t)noise_steps * B * L * w.motion_dim * 4);      // the native loop draws the Philox noise of NOISE_STEPS steps per launch (single-step forward: 1)
     ws.keymask = (uint8_t*)take(M);
     ws.lncnt = (uint32_t*)take(((M + 31) / 32) * 4);
     ws.stat1 = (float*)take(M * (d / 64 + 1) * 2 * 4); ws.stat2 = (float*)take(M * (d / 64 + 1) * 2 * 4);
@@ -141,8 +141,13 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
     // sums plus (mean, M2) per row and 64-column group, linear1 / the next in_proj / motion_layer run on the raw rows with gamma folded
     // into their weights and apply (mean, rstd) in the epilogue, the residual adds normalise their (raw) input on the fly
     // (afm_linear_args.stat_out / a_stat / res_stat).  10 launches and ~170 MB of traffic less per step at B = 32.
+    // Every folded GEMM must run on the bf16-split kernels (the native ones do not carry the row statistics): K = d or ff >= 128 and a
+    // multiple of 16, N >= the arithmetic's minimum width for all five shapes (N = 3d, d, ff, d, motion_dim) - otherwise the layers fall
+    // back to the separate LayerNorm launches instead of failing with AFM_E_UNSUPPORTED.
+    const int split_min_n = w.gemm_arith == AFM_ARITH_DEFAULT ? 32 : w.gemm_arith_min_n;
     bool fold = !(w.flags & (AFM_CMDM_NO_LN_FOLD | AFM_CMDM_FUSED_LN)) && w.motion_layer_wg && w.motion_layer_g && w.motion_layer_c && (d % 64) == 0 &&
-                w.gemm_arith != AFM_ARITH_F32 && (w.gemm_arith == AFM_ARITH_DEFAULT || w.gemm_arith_min_n <= 32);
+                w.gemm_arith != AFM_ARITH_F32 && d >= 128 && w.ff >= 128 && (w.ff % 16) == 0 && d >= split_min_n && w.ff >= split_min_n &&
+                w.motion_dim >= split_min_n;
     for (int li = 0; li < w.n_layers && fold; ++li)
         fold = w.layer[li].lin1_wg && w.layer[li].lin1_g && w.layer[li].lin1_c && (li == 0 || (w.layer[li].in_proj_wg && w.layer[li].in_proj_g && w.layer[li].in_proj_c));
     const int sg = d / 64;                            // statistic groups per row
@@ -277,7 +282,8 @@ extern "C" int afm_cmdm_forward(const afm_cmdm_weights* w, const float* x_t, con
     if (B == 0) return 0;
     const Workspace ws = carve(*w, B, L, workspace);
     if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
-    if (hipMemsetAsync(ws.lncnt, 0, (size_t)(((int64_t)B * (1 + w->n_cond + L) + 31) / 32) * 4, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+    if ((w->flags & AFM_CMDM_FUSED_LN) &&           // ticket words of the opt-in fused LayerNorm only
+        hipMemsetAsync(ws.lncnt, 0, (size_t)(((int64_t)B * (1 + w->n_cond + L) + 31) / 32) * 4, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     return forward_impl(*w, x_t, t, cond_tokens, frame_mask, x0_out, ddpm, B, L, ws, true, (hipStream_t)stream);
 }
 
@@ -301,7 +307,7 @@ extern "C" int64_t afm_cmdm_loop_workspace_bytes(const afm_cmdm_weights* w, int3
     for (int s = 0; s < n; ++s) {
         int st, cnt;
         sub_range(B, n, s, &st, &cnt);
-        total += carve(*w, cnt, L, nullptr).bytes;
+        total += carve(*w, cnt, L, nullptr, NOISE_STEPS).bytes;
     }
     return total;
 }
@@ -339,7 +345,7 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
         int64_t off = 0;
         for (int s = 0; s < nsub; ++s) {
             sub_range(B, nsub, s, &start[s], &count[s]);
-            ws[s] = carve(*w, count[s], L, base + off);
+            ws[s] = carve(*w, count[s], L, base + off, NOISE_STEPS);
             off += ws[s].bytes;
             st[s] = nsub > 1 ? (hipStream_t)side_streams[s] : s0;
         }
@@ -354,7 +360,7 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
 
     const int T = 1 + w->n_cond + L;
     for (int s = 0; s < nsub; ++s)        // ticket words of the fused LayerNorm: zero once, every launch leaves them zero
-        if (count[s] > 0 && hipMemsetAsync(ws[s].lncnt, 0, (size_t)(((int64_t)count[s] * T + 31) / 32) * 4, st[s]) != hipSuccess) return (int)hipGetLastError();
+        if (count[s] > 0 && (w->flags & AFM_CMDM_FUSED_LN) && hipMemsetAsync(ws[s].lncnt, 0, (size_t)(((int64_t)count[s] * T + 31) / 32) * 4, st[s]) != hipSuccess) return (int)hipGetLastError();
     const int64_t row = (int64_t)L * w->motion_dim;
     int rc = 0;
     for (int j = 0; j < n_steps && rc == 0; ++j) {

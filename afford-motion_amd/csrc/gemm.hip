@@ -423,6 +423,13 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
             !(a.ln_eps2 > 0.0f) || a.scale || a.rowtab || a.preact || a.dact_z || a.drop_p > 0.0f || a.act_post || a.rowdot_w || a.ln_out)
             return AFM_E_BADARG;
         if (a.stat_out && (!a.C || (a.N & 3) || (a.ldc & 3) || (a.ldr & 3) || a.ddpm_out)) return AFM_E_BADARG;
+        // stat_out is written by the 16-byte-row branch of the shared epilogue only: a side input that is not 16-byte aligned would send
+        // the launch down the scalar branch (which applies a_stat / res_stat but never writes stat_out) and the next consumer would
+        // normalise with uninitialised statistics - refuse it instead of returning success
+        if (a.stat_out && ((((uintptr_t)a.C | (uintptr_t)a.residual | (uintptr_t)a.bias) & 15) || (a.ldp & 3) || (a.ldz & 3))) return AFM_E_BADARG;
+        // the per-column fold vectors are read 16 bytes at a time, the statistic records 8
+        if ((((uintptr_t)a.a_fold_g | (uintptr_t)a.res_gamma | (uintptr_t)a.res_beta) & 15) ||
+            (((uintptr_t)a.stat_out | (uintptr_t)a.a_stat | (uintptr_t)a.res_stat) & 7)) return AFM_E_BADARG;
     }
     if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9 &&
         a.arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;

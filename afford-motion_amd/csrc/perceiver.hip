@@ -108,19 +108,22 @@ __global__ __launch_bounds__(1024) void latent_token_kernel(const afm_cdm_weight
     }
 }
 
-CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base) {
+// rows = false (the native loop in the row-less sampling form): the four [B N, dkv] row buffers and the folded form's per-point scratch are
+// never touched and are not carved (about 1 GB at B = 32, N = 8192)
+CdmWs carve(const afm_cdm_weights& w, int B, int N, void* base, bool rows = true) {
     char* p = (char*)base;
     int64_t off = 0;
     auto take = [&](int64_t n) { char* r = p ? p + off : nullptr; off += align256(n); return (float*)r; };
     const int64_t M = (int64_t)B * N, nih = 2 * w.enc_heads, njh = 2 * w.dec_heads;
     CdmWs s;
-    s.enc_kv = take(M * w.dkv * 4); s.bufB = take(M * w.dkv * 4); s.h1 = take(M * w.dkv * 4); s.z = take(M * w.dkv * 4);
+    const int64_t Mr = rows ? M : 0;
+    s.enc_kv = take(Mr * w.dkv * 4); s.bufB = take(Mr * w.dkv * 4); s.h1 = take(Mr * w.dkv * 4); s.z = take(Mr * w.dkv * 4);
     s.pm = take((int64_t)B * NPART * nih * 4); s.pl = take((int64_t)B * NPART * nih * 4);
     s.pacc = take((int64_t)B * NPART * nih * w.dkv * 4);
     s.dec_lat = take((int64_t)B * DEC_LAT_STRIDE(njh) * 4);
-    s.s1 = take(M * 8 * 4);                                  // folded path: contact_layer . h1 per point (<= 8 channels)
-    s.rdot = take(M * (w.dkv / 64) * 8 * 4);                 // folded path: row-dot partials of the fc1 GEMM
-    s.qe = take(M * 8 * 4);                                  // folded path: contact_layer . (step-invariant part of the decoder query)
+    s.s1 = take(Mr * 8 * 4);                                 // folded path: contact_layer . h1 per point (<= 8 channels)
+    s.rdot = take(Mr * (w.dkv / 64) * 8 * 4);                // folded path: row-dot partials of the fc1 GEMM
+    s.qe = take(Mr * 8 * 4);                                 // folded path: contact_layer . (step-invariant part of the decoder query)
     const int64_t ntok = 2 * (int64_t)B;
     s.lat_s = take(ntok * w.enc_heads * w.dkv * 4); s.lat_x = take(ntok * w.dq * 4); s.lat_t1 = take(ntok * w.dq * 4);
     s.lat_t2 = take(ntok * w.dq * 4); s.lat_qkv = take(ntok * 3 * w.dq * 4); s.lat_kv = take(ntok * 2 * w.dkv * 4);
@@ -218,7 +221,7 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
 static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
                             const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
                             const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
-                            void* side_stream, void* stream, bool prepared = false) {
+                            void* side_stream, void* stream, bool prepared = false, bool rowless_ws = false) {
     AFM_TRY(validate(wp, B, N));
     if (!feat || !t || !text_q0 || !text_u || !text_cu || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
     if (!wp->time_q0 || !wp->time_u || !wp->time_cu) return AFM_E_BADARG;
@@ -226,7 +229,8 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     if (B == 0) return 0;
     const afm_cdm_weights& w = *wp;
     hipStream_t s = (hipStream_t)stream;
-    const CdmWs ws = carve(w, B, N, workspace);
+    if (rowless_ws && !(cdm_mode(w) == 3 && x_t)) return AFM_E_BADARG;          // a workspace without row buffers serves the row-less form only
+    const CdmWs ws = carve(w, B, N, workspace, !rowless_ws);
     if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
     const int M = B * N, dkv = w.dkv;
     if (cdm_folded(w) && x_t) return cdm_forward_folded(w, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, ws, prepared, s);
@@ -345,7 +349,7 @@ extern "C" int64_t afm_cdm_loop_workspace_bytes(const afm_cdm_weights* w, int32_
     for (int s = 0; s < nsub; ++s) {
         int st, cnt;
         cdm_sub_range(B, nsub, s, &st, &cnt);
-        total += carve(*w, cnt, N, nullptr).bytes + align256((int64_t)NOISE_STEPS * cnt * N * w->contact_dim * 4);
+        total += carve(*w, cnt, N, nullptr, cdm_mode(*w) != 3).bytes + align256((int64_t)NOISE_STEPS * cnt * N * w->contact_dim * 4);
     }
     return total;
 }
@@ -379,6 +383,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
                        t_all, c1_all, c2_all, sg_all);
     AFM_CHECK_LAUNCH();
 
+    const bool rowless = cdm_mode(*w) == 3;
     int start[8], count[8];
     char* wsp[8];
     int64_t wsb[8];
@@ -389,7 +394,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
         int64_t off = 0;
         for (int s = 0; s < nsub; ++s) {
             cdm_sub_range(B, nsub, s, &start[s], &count[s]);
-            wsb[s] = carve(*w, count[s], N, nullptr).bytes;
+            wsb[s] = carve(*w, count[s], N, nullptr, !rowless).bytes;
             wsp[s] = base + off; off += wsb[s];
             noise[s] = (float*)(base + off); off += align256((int64_t)NOISE_STEPS * count[s] * N * cd * 4);
             if (nsub > 1) { mainst[s] = (hipStream_t)streams[2 * s]; sidest[s] = (hipStream_t)streams[2 * s + 1]; }
@@ -436,7 +441,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = first_step + j;
             rc = cdm_forward_impl(w, fs, xs, t_all + (int64_t)j * B + start[s], text_q0 + (int64_t)start[s] * dq,
                                   text_u + (int64_t)start[s] * He * dkv, text_cu + (int64_t)start[s] * He, nullptr, &dd, count[s], N, wsp[s], wsb[s],
-                                  sidest[s], mainst[s], folded);
+                                  sidest[s], mainst[s], folded, rowless);
         }
     }
     if (nsub > 1) {

@@ -19,5 +19,14 @@ class PositionalEncoding(_PositionalEncodingBuffers):
         return self.dropout(x + self.pe[: x.shape[0], :].to(x))
 
 
-# any other name (CrossAttentionLayer, SelfAttentionBlock ... used only by the reference's own models/cdm.py) -> the checkout's file
-__getattr__ = reference_fallback(__name__, __file__)
+def get_positional_encoding(max_len: int, time_emb_dim: int) -> torch.Tensor:
+    """[max_len, 1, d] sinusoid table (reference models/modules.py:10-25)."""
+    from afm.cmdm import sinusoid_table
+    return sinusoid_table(max_len, time_emb_dim)
+
+
+# the Perceiver building blocks that only the reference's own models/cdm.py imports (ours is afm.cdm) -> the checkout's file; every other
+# missing name raises
+__getattr__ = reference_fallback(__name__, __file__, allow=("CrossAttentionLayer", "SelfAttentionBlock", "SelfAttentionLayer", "CrossAttention",
+                                                            "SelfAttention", "MultiHeadAttention", "AbstractAttentionLayer", "Residual",
+                                                            "MLP", "ModuleOutput", "RotaryPositionEmbedding", "KVCache"))

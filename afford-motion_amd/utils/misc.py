@@ -5,4 +5,7 @@
 from afm._shim import reference_fallback
 from afm.cmdm import compute_repr_dimesion  # noqa: F401
 
-__getattr__ = reference_fallback(__name__, __file__)
+# the SMPL-X helpers (evaluation / visualisation only; none is on the denoising path) - nothing else falls through
+__getattr__ = reference_fallback(__name__, __file__, allow=("smplx_neutral_model", "get_meshes_from_smplx", "get_joints_from_smplx",
+                                                            "get_joints_and_meshes_from_smplx", "optimize_params_with_joints",
+                                                            "compute_optimization_loss"))

@@ -338,13 +338,25 @@ def test_shim_packages_fall_through_to_a_reference_checkout(tmp_path):
     fake = tmp_path / "ref"
     for pkg, mod, body in (("utils", "io", "MARK = 'ref-utils-io'"), ("diffusion", "resample", "MARK = 'ref-resample'"),
                            ("utils", "misc", "MARK = 'ref-misc'\ncompute_repr_dimesion = 'must-not-win'\n"
-                                             "def get_meshes_from_smplx():\n    return 'ref-meshes'")):
+                                             "def get_meshes_from_smplx():\n    return 'ref-meshes'"),
+                           ("diffusion", "gaussian_diffusion", "def _extract_into_tensor(*a):\n    return 'reference code ran'\nMARK = 'ref-gd'"),
+                           ("diffusion", "respace", "class _WrappedModel:\n    pass"),
+                           ("utils", "registry", "OTHER = 1"),
+                           ("models", "modules", "class CrossAttentionLayer:\n    pass\nclass NotAThing:\n    pass")):
         (fake / pkg).mkdir(parents=True, exist_ok=True)
         (fake / pkg / f"{mod}.py").write_text(body + "\n")
     code = ("import utils.io, diffusion.resample, utils.misc, models.base, diffusion.gaussian_diffusion as gd;"
             "assert utils.io.MARK == 'ref-utils-io' and diffusion.resample.MARK == 'ref-resample';"
             "assert callable(utils.misc.compute_repr_dimesion) and utils.misc.compute_repr_dimesion('h3d') == 263;"
-            "from utils.misc import get_meshes_from_smplx, MARK; assert MARK == 'ref-misc' and get_meshes_from_smplx() == 'ref-meshes';"
+            "from utils.misc import get_meshes_from_smplx; assert get_meshes_from_smplx() == 'ref-meshes';"
+            "from models.modules import CrossAttentionLayer; assert CrossAttentionLayer.__module__ == 'models._reference_modules';"
+            # negative cases: only the allow-listed, non-hot-path names may resolve to the checkout - a hot-path name the shim does not
+            # define (or a typo) raises instead of silently running the reference's code
+            "import diffusion.respace, utils.registry, models.modules\n"
+            "for mod, name in ((gd, '_extract_into_tensor'), (gd, 'MARK'), (diffusion.respace, '_WrappedModel'), (utils.misc, 'MARK'),"
+            " (utils.registry, 'OTHER'), (models.modules, 'NotAThing'), (models.modules, 'SceneMapEncoderX')):\n"
+            "    try:\n        getattr(mod, name); raise SystemExit(f'{mod.__name__}.{name} resolved')\n"
+            "    except AttributeError as e:\n        assert 'allow-list' in str(e), e\n"
             "assert 'afford-motion_amd' in models.base.__file__ and 'afford-motion_amd' in gd.__file__ and 'afford-motion_amd' in utils.misc.__file__;"
             "from models.modules import PositionalEncoding, TimestepEmbedder; print('fall-through ok')")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "afford-motion_amd"), str(fake)]))
