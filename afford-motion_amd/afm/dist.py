@@ -68,6 +68,21 @@ def shard_kwargs(kwargs: Dict[str, Any], start: int, count: int, total: int) -> 
     return out
 
 
+def all_gather_rows(local: torch.Tensor, world: int = None) -> list:
+    """all_gather of equally-shaped shards -> list in rank order.  RCCL ("nccl") gathers device tensors in place over xGMI; the gloo
+    backend (CPU tests, and the shared-GPU functional tests of the N > 1 control flow) has no device all_gather, so device shards take
+    one round trip through host memory there - never on the measured path."""
+    world = dist.get_world_size() if world is None else world
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        host = local.detach().cpu().contiguous()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host)
+        return [b.to(local.device) for b in bufs]
+    bufs = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(bufs, local.contiguous())
+    return bufs
+
+
 def sharded_sample(sample_fn: Callable[[Dict[str, Any], int, int], torch.Tensor], total: int, model_kwargs: Dict[str, Any],
                    rank: int = None, world: int = None, gather: bool = True) -> torch.Tensor:
     """Run ``sample_fn(shard_kwargs, count, sample_index0) -> [count, ...]`` on this rank's shard and
@@ -81,8 +96,7 @@ def sharded_sample(sample_fn: Callable[[Dict[str, Any], int, int], torch.Tensor]
     counts = [shard_range(total, r, world)[1] for r in range(world)]
     mx = max(counts)
     pad = local if count == mx else torch.cat([local, local.new_zeros((mx - count,) + tuple(local.shape[1:]))], 0)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous())
+    bufs = all_gather_rows(pad.contiguous(), world)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
 
 

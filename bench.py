@@ -8,10 +8,13 @@
 One "step" = one `p_sample` (CMDM denoiser forward over the rank's batch + DDPM posterior update) of
 BASELINE.json configs[1]: B = 32 samples per GPU, L = 196 frames, D = 263, N = 8192 scene points
 (128 contact-group tokens), hoisted step-invariant conditions, synthetic inputs, name-keyed random weights.
-Weak scaling (default): every rank runs its own 32 samples (global sample indices rank*32 ...), one all_gather at
-the end; value = (ranks x K steps) / max-over-ranks wall time.  `--scaling strong`: ONE 32-sample job (k_sample = 32,
-reference test.py:88-101) is sharded over the ranks (32 / N samples per GPU), value = K / max-over-ranks wall time; with
-N > 1 the line carries the OTHER mode as well (`other_scaling_mode`).  Rank 0 prints ONE JSON line.
+`--scaling strong` (the default for N > 1: BASELINE configs[4] is "k_sample = 32 sharded 8x"): ONE 32-sample job (k_sample = 32,
+reference test.py:88-101) is sharded over the ranks (32 / N samples per GPU), one all_gather at the end, value = K / max-over-ranks
+wall time.  `--scaling weak`: every rank runs its own 32 samples (global sample indices rank*32 ...), value = (ranks x K steps) /
+max-over-ranks wall time.  At N = 1 the two are the same job; with N > 1 the line carries the OTHER mode as well
+(`other_scaling_mode`).  Rank 0 prints ONE JSON line.  At N = 1 the line also carries `secondary`: the other BASELINE configs
+([0], [2], [3], [4]), the headline shape with the conditions recomputed every step ("faithful") and the per-GPU batch sizes of the
+strong-scaling job (B = 16 / 8 / 4 / 1), all measured after the headline and outside its timed region.
 """
 import argparse
 import json
@@ -145,9 +148,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="samples per GPU (weak) / in the whole job (strong); the headline is 32")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("AFM_BENCH_SCALING", "weak"),
-                    help="weak: --batch samples on EVERY GPU (the metric's B=32 per GPU); strong: ONE --batch-sample job (k_sample = 32 of "
-                         "test.py:88-101) sharded over the GPUs, value = steps/s of that job")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default=os.environ.get("AFM_BENCH_SCALING", "auto"),
+                    help="strong: ONE --batch-sample job (k_sample = 32 of test.py:88-101, BASELINE configs[4]) sharded over the GPUs, value = "
+                         "steps/s of that job; weak: --batch samples on EVERY GPU; auto (default): strong when N > 1 (at N = 1 both are the same job)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (other BASELINE configs, faithful headline, small-batch table; N = 1 only)")
     ap.add_argument("--latency-runs", type=int, default=5, help="full 1000-step loops at B=32 for the p50 sample latency (N=1 only)")
     ap.add_argument("--latency-runs-b1", type=int, default=20, help="full 1000-step loops at B=1 for the p50 sample latency (N=1 only)")
     ap.add_argument("--cpu-steps", type=int, default=20, help="p_sample steps per repetition of the CPU baseline")
@@ -164,6 +168,8 @@ def main():
     from afm import dist as adist, ffi, synth
     rank, world, local = adist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.scaling == "auto":
+        args.scaling = "strong" if world > 1 else "weak"
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
     # AFM_BENCH_SHARE_GPU=1 (testing only, with AFM_DIST_BACKEND=gloo): every rank uses cuda:0, to exercise the N > 1 control flow
     dev = torch.device("cuda:0" if os.environ.get("AFM_BENCH_SHARE_GPU") else f"cuda:{local}")
@@ -215,9 +221,8 @@ def main():
     def run(diffusion, seed, kwargs=None, nb=None, index0=None, gather=True):
         kwargs, nb, index0 = kwargs or kw, B if nb is None else nb, i0 if index0 is None else index0
         x = diffusion.p_sample_loop(model, (nb, L, D), clip_denoised=False, model_kwargs=kwargs, seed=seed, sample_index0=index0)
-        if world > 1 and gather:                       # the path's only collective: gather the shards at the end
-            out = [torch.empty_like(x) for _ in range(world)]
-            dist.all_gather(out, x)
+        if world > 1 and gather:                       # the path's only collective: gather the shards at the end (RCCL over xGMI)
+            adist.all_gather_rows(x, world)
         return x
 
     def timed(kwargs=None, nb=None, index0=None):
@@ -366,6 +371,71 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_steps, args.cpu_reps)
 
+    sub_streams = max(1, min(model.loop_streams, B // 8 if model.loop_streams_auto else B))       # of the timed headline run
+    # ---- `secondary` (N = 1 only; after the headline, outside its timed region): everything else BASELINE.json names, driver-visible
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = {}
+        K2, W2 = 100, 10
+        cfg.diffusion.timestep_respacing = str(K2)
+        diff_k2 = create_gaussian_diffusion(cfg); diff_k2.tables(dev)
+
+        def rate(kwargs, nb, diffusion=diff_k2, steps=K2):
+            run(diff_w, 1, kwargs, nb, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(diffusion, 2, kwargs, nb, 0)
+            torch.cuda.synchronize()
+            return steps / (time.perf_counter() - t0)
+        try:
+            # what each GPU runs when the 32-sample job is sharded over G GPUs (strong scaling): B = 32 / G samples; per-sample efficiency
+            # against B = 32 bounds the speed-up at G GPUs (no collective inside the loop; the final all_gather is 0.8 MB per rank)
+            base = rate(kw, B)
+            tab = {}
+            for nb in (16, 8, 4, 1):
+                kwb = {k: v[:nb].contiguous() for k, v in kw.items()}
+                r = rate(kwb, nb)
+                tab[f"B{nb}"] = {"steps_per_s": round(r, 1), "ms_per_step": round(1e3 / r, 4), "gpus_at_32_samples": 32 // nb,
+                                 "per_sample_efficiency_vs_B32": round((r * nb) / (base * B), 4), "predicted_speedup_at_that_gpu_count": round(r / base, 2)}
+            secondary["strong_scaling_batch_per_gpu"] = {"steps": K2, "B32_steps_per_s": round(base, 1), **tab}
+            model.condition_tokens(**kw)
+        except Exception as e:                          # noqa: BLE001
+            secondary["strong_scaling_batch_per_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            # the headline shape as the reference runs it: conditions (text adapter, SceneMapEncoder over 32 x 8192 points, contact adapter)
+            # recomputed inside EVERY step (models/cmdm.py:134-156), p_sample by p_sample
+            Kf = 10
+            model.hoist_conditions = False
+            tvec = diff_k.tables(dev).timesteps(B)
+
+            def faithful():
+                x = torch.zeros(B, L, D, device=dev)
+                for j in range(Kf):
+                    x = diff_k.p_sample(model, x, tvec[K - 1 - j], clip_denoised=False, model_kwargs=kw, seed=1, step=j)["sample"]
+                return x
+            faithful()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            faithful()
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t0) / Kf
+            secondary["configs[1] faithful"] = {"steps_per_s": round(1 / dtf, 2), "ms_per_step": round(1e3 * dtf, 3), "steps": Kf,
+                                                "note": "B=32, L=196, N=8192, conditions recomputed every step (hoist_conditions=False), one p_sample call per step"}
+        except Exception as e:                          # noqa: BLE001
+            secondary["configs[1] faithful"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            model.hoist_conditions = True
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("afm_bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+            bc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bc)
+            del model                                    # the headline model's workspaces are not needed any more
+            torch.cuda.empty_cache()
+            secondary.update(bc.secondary_block(quick=True))
+        except Exception as e:                          # noqa: BLE001
+            secondary["error"] = f"{type(e).__name__}: {e}"
+
     if rank == 0:
         ms = 1e3 * dt / K
         job_steps = (world if args.scaling == "weak" else 1) * K
@@ -380,7 +450,7 @@ def main():
                                           "(exact in f32) on the bf16 MFMA pipe, f32 accumulation; motion adapter (K = 263): f32 MFMA",
                        "batch_per_gpu": B, "job_samples": total, "frames": L, "motion_dim": D, "scene_points": NPTS, "tokens": 2 + NPTS // 64 + L,
                        "conditions": "hoisted (step-invariant, computed once: setup_ms)",
-                       "parallelism": f"batch-shard x{world} ({args.scaling})", "sub_batch_streams": max(1, min(model.loop_streams, B // 8 if model.loop_streams_auto else B))},
+                       "parallelism": f"batch-shard x{world} ({args.scaling})", "sub_batch_streams": sub_streams},
             "algorithmic_tflops": round(flops * K / dt / 1e12, 2),
             "executed_tflops": round((flops - elided) * K / dt / 1e12, 2),
             "elided_gflop_per_step": round(elided / 1e9, 2),
@@ -390,6 +460,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * t_enq / K, 4),
             "setup_ms": round(setup_ms, 2), "setup_ms_steady": round(setup_ms_steady, 2),
             "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat, "alt_gemm_modes": alt, "other_scaling_mode": other,
+            "secondary": secondary,
         }
         print(json.dumps(line))
     if world > 1:
