@@ -19,9 +19,9 @@ _lib = None
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
-CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD = 0x1, 0x2, 0x4
+CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES = 0x1, 0x2, 0x4, 0x8
 CDM_NO_GEN = 0x2
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 16
 
 c_f32p = C.c_void_p
@@ -146,6 +146,7 @@ EXPORTS = {
     "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_fwd_grouped": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
+    "afm_mha_fwd_rows": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_cross_fwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, C.c_void_p]),
     "afm_layernorm_rows": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, i32, i32, i32, C.c_void_p]),

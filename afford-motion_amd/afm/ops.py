@@ -177,19 +177,25 @@ def fill_arith(a) -> None:
     a.tune = _gemm_tune
 
 
-def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int, group_waves: int = 0) -> torch.Tensor:
+def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int, group_waves: int = 0, q_first: int = 0) -> torch.Tensor:
     """qkv [B, T, 3*d] (packed in_proj output) -> softmax(QK^T/sqrt(dh) + mask) V, [B, T, d].  ``group_waves``: workgroup shape of
-    afm_mha_fwd_grouped (0 = the library's choice); results do not depend on it."""
+    afm_mha_fwd_grouped (0 = the library's choice); results do not depend on it.  ``q_first`` > 0 (afm_mha_fwd_rows): only the query
+    rows q_first .. T - 1 are computed, the leading rows of the result are zeros."""
     lib = ffi.load()
     ffi.require_gpu(qkv)
     qkv = ffi.f32c(qkv)
     B, T, d3 = qkv.shape
     d = d3 // 3
-    out = torch.empty(B, T, d, device=qkv.device, dtype=torch.float32)
     km = None
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
         assert km.shape == (B, T)
+    if q_first:
+        out = torch.zeros(B, T, d, device=qkv.device, dtype=torch.float32)
+        ffi.check(lib.afm_mha_fwd_rows(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, int(q_first), int(group_waves),
+                                       ffi.stream_of(qkv)), "afm_mha_fwd_rows")
+        return out
+    out = torch.empty(B, T, d, device=qkv.device, dtype=torch.float32)
     ffi.check(lib.afm_mha_fwd_grouped(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, int(group_waves),
                                       ffi.stream_of(qkv)), "afm_mha_fwd_grouped")
     return out

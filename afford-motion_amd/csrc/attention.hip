@@ -253,8 +253,9 @@ constexpr int KVSTAGE = 3 * KPLANE + 3 * VPLANE;       // 29184 bytes per stage
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW == 12 ? 3 : 1)) void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
                                                                 const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
-                                                                float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk) {
+                                                                float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk, int q_first) {
     // `scale` = log2(e) / sqrt(dh): the logits are kept in base-2 units, so the softmax is exp2(s - m) = one v_exp_f32 per element
+    // q_first: only the query rows q_first .. Tq - 1 are computed (query blocks start at q_first; the rows in front keep whatever `out` held)
     constexpr int NT = 64 * NW;
     constexpr int NIT = (256 + NT - 1) / NT;            // staging items per thread (256 items per block: 128 of K, 128 of V)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -274,20 +275,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
     const int D = H * DH;
-    const int nkb = (T + KB - 1) / KB, nqb = (Tq + 31) / 32;
+    const int nkb = (T + KB - 1) / KB, nqb = (Tq - q_first + 31) / 32;
     const float* qbase = qp_ + (int64_t)b * Tq * ldq + h * DH;
     const float* kbase = kp_ + (int64_t)b * T * ldkv + h * DH;
     const float* vbase = vp_ + (int64_t)b * T * ldkv + h * DH;
     const float NEG_INF = -INFINITY;
 
-    // blk_valid[kb]: bit 0 = the block has a valid key, bit 1 = it has a masked key (blocks without bit 0 are skipped, blocks without bit 1
-    // skip the mask addition); both written with atomic ORs by whichever threads see such a key
+    // blk_valid[kb]: bit 0 = the block has a valid key, bit 1 = it has a masked key, bit 2 = it has a valid key among its keys 16 .. 31
+    // (blocks without bit 0 are skipped, blocks without bit 1 skip the mask addition, blocks without bit 2 - the ragged tail of T = 326:
+    // 6 keys - skip the second K16 step of P V, whose probabilities are exact zeros); written with atomic ORs by whichever threads see such a key
     for (int i = tid; i < nkb; i += NT) blk_valid[i] = 0;
     __syncthreads();
     for (int i = tid; i < nkb * KB; i += NT) {
         const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
         madd[i] = ok ? 0.0f : NEG_INF;
-        atomicOr(&blk_valid[i / KB], ok ? 1 : 2);
+        atomicOr(&blk_valid[i / KB], ok ? (1 | ((i & 16) ? 4 : 0)) : 2);
     }
 
     // Staging items (all loads unconditional, rows past the last key clamped to key T-1: those keys carry an additive -inf):
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
         // Q planes: query row (clamped), K16 step s covers head dims 16 s + 8 hh .. + 7, pre-scaled (1 / sqrt(64) is a power of two)
         u32x4 qpl[4][3];
         {
-            const int qrow = min(qb * 32 + r32, Tq - 1);
+            const int qrow = min(q_first + qb * 32 + r32, Tq - 1);
             const float* qp = qbase + (int64_t)(active ? qrow : 0) * ldq + hh * 8;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
                 // ---- O^T += V^T P^T: K16 step t takes the P registers 8 t .. 8 t + 7 of this lane (k-slot 8 hh + e <-> register 8 t + e)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+                    if (t == 1 && !(bflag & 4)) continue;          // wave-uniform: no valid key in slots 16 .. 31 - every P there is +0, the step adds nothing
                     uint32_t w1[4], w2[4], w3[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) split2(s[8 * t + 2 * i], s[8 * t + 2 * i + 1], w1[i], w2[i], w3[i]);
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
         }
 
         if (active) {
-            const int qrow = qb * 32 + r32;
+            const int qrow = q_first + qb * 32 + r32;
             if (qrow < Tq) {
                 const float inv = 1.0f / l_run;
                 float* op = out + ((int64_t)b * Tq + qrow) * D + h * DH + 4 * hh;
@@ -485,24 +488,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
 // (lse output, attention dropout) the f32-MFMA kernel.
 template <int NW>
 int launch_split_mha(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, int B, int Tq, int T, int H,
-                     float scale, int nchunk, size_t lds, hipStream_t s) {
+                     float scale, int nchunk, size_t lds, hipStream_t s, int q_first) {
     static const int attr = (int)hipFuncSetAttribute((const void*)mha_fwd_split_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != 0) return attr;
-    hipLaunchKernelGGL((mha_fwd_split_kernel<NW>), dim3(B * H * nchunk), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, nchunk);
+    hipLaunchKernelGGL((mha_fwd_split_kernel<NW>), dim3(B * H * nchunk), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, nchunk, q_first);
     AFM_CHECK_LAUNCH();
     return 0;
 }
 
 int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, float* lse, int32_t B,
                    int32_t Tq, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, int group_waves,
-                   void* stream) {
+                   void* stream, int q_first = 0) {
     if (dh != DH) return AFM_E_UNSUPPORTED;
     if (B == 0) return 0;                                     // empty batch (pointers may be null)
     if (!q || !k || !v || !out || B < 0 || T <= 0 || Tq <= 0 || H <= 0) return AFM_E_BADARG;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return AFM_E_BADARG;
     if ((ldq & 3) || (ldkv & 3)) return AFM_E_BADARG;
     if (train && (!lse || drop_p < 0.0f || drop_p >= 1.0f)) return AFM_E_BADARG;
-    const int nqb = (Tq + 31) / 32, nkb = (T + 31) / 32;
+    if (q_first < 0 || q_first >= Tq || (train && q_first)) return AFM_E_BADARG;
+    const int nqb = (Tq - q_first + 31) / 32, nkb = (T + 31) / 32;
     const float scale = 1.0f / sqrtf((float)dh);
     const float scale2 = 1.4426950408889634f * scale;         // log2(e) / sqrt(dh): the inference kernel's logits are in base-2 units
     hipStream_t s = (hipStream_t)stream;
@@ -543,12 +547,12 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~25000 keys
     AfmProf prof(AFM_PROF_MHA_SPLIT, 4.0 * B * H * (double)Tq * T * dh, s);
     switch (nw) {
-        case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
-        case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
-        case 4: return launch_split_mha<4>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
-        case 6: return launch_split_mha<6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
-        case 8: return launch_split_mha<8>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
-        default: return launch_split_mha<12>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s);
+        case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
+        case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
+        case 4: return launch_split_mha<4>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
+        case 6: return launch_split_mha<6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
+        case 8: return launch_split_mha<8>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
+        default: return launch_split_mha<12>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
     }
 }
 
@@ -560,6 +564,14 @@ extern "C" int afm_mha_fwd_grouped(const float* qkv, const uint8_t* key_mask, fl
     const int D = H * dh;
     return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, nullptr, B, T, T, H, dh, 0.0f, 0, 0, false,
                           group_waves, stream);
+}
+
+extern "C" int afm_mha_fwd_rows(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H, int32_t dh, int32_t q_first,
+                                int32_t group_waves, void* stream) {
+    if (group_waves < 0) return AFM_E_BADARG;
+    const int D = H * dh;
+    return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, nullptr, B, T, T, H, dh, 0.0f, 0, 0, false,
+                          group_waves, stream, q_first);
 }
 
 extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,

@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{a3, b3};
     }
     __syncthreads();
+#ifdef AFM_TIMELINE
+    const unsigned long long tl_pro = __builtin_amdgcn_s_memrealtime();          // prologue done: first K-tile split and published
+#endif
 
     const int a_off = (wm * (BM / 2) + r32) * ROWB + hh * 16;
     const int w_off = (BM + wn * (BN / 2) + r32) * ROWB + hh * 16;
@@ -220,6 +223,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         if (kt + 1 < nk) body(Set1{}, kt + 1);
     }
 
+#ifdef AFM_TIMELINE
+    const unsigned long long tl_kloop = __builtin_amdgcn_s_memrealtime();        // K loop done
+#endif
     if (KG == 1 && have_tot) {                        // ((s0 + s1) + ...) + s_last
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -258,6 +264,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
                     ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
     }
     __syncthreads();
+#ifdef AFM_TIMELINE
+    const unsigned long long tl_staged = __builtin_amdgcn_s_memrealtime();       // K groups merged, accumulators staged in LDS
+#endif
     if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid, rowst);
     gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(ldsf));
 #ifdef AFM_TIMELINE
@@ -265,7 +274,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), hw, xcc, tl_c0, afm_cycles(), 0, 0, 0, 0};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores have left the wave
+        const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime();
+        // phase spans in s_memrealtime ticks (10 ns): prologue | K loop | merge + staging | epilogue
+        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, tl_end, hw, xcc, tl_c0, afm_cycles(), tl_pro - tl_t0, tl_kloop - tl_pro, tl_staged - tl_kloop, tl_end - tl_staged};
     }
 #endif
 }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 5
+#define AFM_ABI_VERSION 6
 
 #define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
 #define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
@@ -159,6 +159,12 @@ int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out,
  * launch still fills 256 CUs).  A query row's arithmetic does not depend on the grouping: results are bit-identical. */
 int afm_mha_fwd_grouped(const float* qkv, const uint8_t* key_mask, float* out,
                         int32_t B, int32_t T, int32_t H, int32_t dh, int32_t group_waves, void* stream);
+/* Same, for the query rows q_first .. T - 1 of every sample only (all T keys): rows 0 .. q_first - 1 of `out` are not written.  The CMDM's
+ * last encoder layer is read on its L motion tokens only (cmdm.py:169,195), so its attention skips the 2 + n_groups condition-token
+ * queries (q_first = 130 of T = 326: 7 query blocks instead of 11).  A query row's arithmetic does not depend on q_first (bit-identical
+ * to afm_mha_fwd_grouped on the rows it computes).  ABI v6. */
+int afm_mha_fwd_rows(const float* qkv, const uint8_t* key_mask, float* out,
+                     int32_t B, int32_t T, int32_t H, int32_t dh, int32_t q_first, int32_t group_waves, void* stream);
 
 /* Cross-attention core of nn.TransformerDecoderLayer (CMDM `trans_dec`, cmdm.py:78-113,171-191): Tq queries q [B*Tq, H*dh] over a
  * packed memory kv [B*Tk, 2*H*dh] (k | v), key_mask [B,Tk] or NULL.  Same kernel as afm_mha_fwd (dh = 64). */
@@ -449,6 +455,7 @@ typedef struct {
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
 #define AFM_CMDM_NO_LN_FOLD  0x4           /* measurement: separate afm_layernorm launches although the folded tensors are present */
 #define AFM_CMDM_WIDE_TILE_SHIFT 8        /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the encoder GEMMs with N >= 512 and M >= 2048 (bit-neutral) */
+#define AFM_CMDM_ALL_QUERIES 0x8           /* measurement: the last layer's attention computes all T query rows (bit-identical on the rows that are read) */
 #define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */
 
 /* bytes of workspace afm_cmdm_forward needs for (B, L). */

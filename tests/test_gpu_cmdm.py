@@ -442,6 +442,28 @@ def test_small_batch_loop_is_bit_identical_to_the_large_batch():
         assert torch.equal(got, whole[: got.shape[0]]), f"shards of {nb} samples differ from the batch of {B}"
 
 
+def test_last_layer_attention_on_the_motion_queries_only_is_bit_neutral():
+    """Round 4: the last encoder layer's attention computes the L motion tokens' query rows only (afm_mha_fwd_rows, q_first = 2 + n_groups;
+    nothing reads the other rows).  `model.all_queries` restores the full launch: a sampling loop and a single forward must not change by a
+    bit, with ragged frame masks, at a large and at a small batch."""
+    cfg = cmdm_cfg(num_points=8192, steps=1000, respacing="8")
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    for B, L in ((16, 196), (4, 196), (3, 60)):
+        kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("aq_cont", (B, 128, 256)).to(dev()),
+                  x_mask=synth.frame_mask(B, L, seed=7).to(dev()))
+        x = synth.gaussian("aq_x", (B, L, 263)).to(dev())
+        t = torch.arange(B, device=dev()) * 37 % 1000
+        outs = {}
+        for allq in (False, True):
+            model.all_queries = allq
+            outs[allq] = (diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=44).clone(), model(x, t, **kw).clone())
+        model.all_queries = False
+        assert torch.isfinite(outs[False][0]).all()
+        assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1]), f"B={B}, L={L}"
+
+
 def test_two_stream_loop_soak():
     """Round 3: 50 two-stream 100-step loops of the headline CMDM shape (B = 32, L = 196, N = 8192) against the
     single-stream result, bit for bit - the harness that caught round 2's lat_decfold defect (profiles/r02_decfold_nondeterminism.md)."""

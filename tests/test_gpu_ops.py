@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loaded_and_versioned():
     lib = ffi.load()
-    assert lib.afm_version() == ffi.ABI_VERSION == 5
+    assert lib.afm_version() == ffi.ABI_VERSION == 6
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (326, 512, 512), (1000, 1536, 512), (777, 263, 512),
@@ -364,6 +364,30 @@ def test_mha_workgroup_groupings_are_bit_identical(B, T):
             assert torch.equal(o, outs[0]), f"group_waves={g} differs (B={B}, T={T}, masked={km is not None})"
     with pytest.raises(ffi.AfmError):
         ops.mha(qkv, None, H, group_waves=3)
+
+
+@pytest.mark.parametrize("B,T,q_first", [(4, 326, 130), (1, 326, 130), (2, 196, 7), (3, 61, 60), (2, 326, 320)])
+def test_mha_query_rows_subset_is_bit_identical(B, T, q_first):
+    """afm_mha_fwd_rows (ABI v6): the query rows q_first .. T - 1 only (the CMDM's last layer is read on its motion tokens only).  The query
+    blocks start at q_first, i.e. rows land in other lanes / waves / workgroups than in the full launch - the rows that are computed must
+    carry the same bits for every grouping, and the rows in front must stay untouched.  The ragged key tail (T = 326: 6 keys in the last
+    32-key block, second K16 step of P V skipped) and masks that empty the upper half of other blocks ride along."""
+    H, dh = 8, 64
+    qkv = synth.gaussian("mha_rows", (B, T, 3 * H * dh)).to(dev())
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for b in range(B):
+        mask[b, T - 1 - 13 * b:] = True
+        mask[b, 48:64] = True                                 # block 1 keeps valid keys in its lower half only
+    mask[0, 5] = True
+    mask = mask.to(dev())
+    for km in (None, mask):
+        full = ops.mha(qkv, km, H)
+        for g in (0, 1, 2, 4, 6, 8, 12):
+            part = ops.mha(qkv, km, H, group_waves=g, q_first=q_first)
+            assert torch.equal(part[:, q_first:], full[:, q_first:]), f"q_first={q_first} group_waves={g} masked={km is not None}"
+            assert not part[:, :q_first].any()
+    with pytest.raises(ffi.AfmError):
+        ops.mha(qkv, None, H, q_first=T)
 
 
 def test_mha_softmax_rescale_branch():

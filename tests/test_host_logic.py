@@ -177,7 +177,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(ffi.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"missing export {name}"
-    assert ffi.load().afm_version() == ffi.ABI_VERSION == 5     # pure host call, no GPU needed
+    assert ffi.load().afm_version() == ffi.ABI_VERSION == 6     # pure host call, no GPU needed
 
 
 def test_ctypes_mirrors_match_the_c_structs(tmp_path):
@@ -234,7 +234,7 @@ def test_gemm_arithmetic_switches_are_host_state():
         assert "afm_linear_set_split" not in syms                      # no process-wide switch left in the library
         imports = subprocess.run(["nm", "-D", "--undefined-only", ffi.lib_path()], capture_output=True, text=True).stdout
         assert " getenv" not in imports and "secure_getenv" not in imports, "libafm_hip.so must not read the environment"
-        assert ffi.load().afm_version() == ffi.ABI_VERSION == 5
+        assert ffi.load().afm_version() == ffi.ABI_VERSION == 6
 
 
 def _build_hip_module():

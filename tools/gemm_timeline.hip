@@ -9,12 +9,13 @@
 #include "../afford-motion_amd/csrc/gemm_split.hip"
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pad = 0, int flags = 0) {
+static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pad = 0, int flags = 0, int lnfold = 0) {
     const int lda = K + pad, ldw = K + pad;           // pad != 0: row strides that are not a power of two (L2 channel spread)
     float *dA, *dW, *dC, *dR;
     CK(hipMalloc(&dA, (size_t)M * lda * 4)); CK(hipMalloc(&dW, (size_t)N * ldw * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dR, (size_t)M * N * 4));
@@ -27,6 +28,14 @@ static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pa
     afm_linear_args a = {};
     a.A = dA; a.lda = lda; a.W = dW; a.ldw = ldw; a.C = dC; a.ldc = N; a.residual = dR; a.ldr = N; a.M = M; a.N = N; a.K = K;
     a.arith = arith; a.tune = (tile << AFM_TUNE_TILE_SHIFT) | flags;
+    float *dS1 = nullptr, *dS2 = nullptr, *dG = nullptr;
+    if (lnfold) {       // the sampling loop's epilogues: 1 = out_proj / linear2 (raw residual normalised on the fly, statistics out), 2 = linear1 / in_proj (folded LayerNorm of A)
+        CK(hipMalloc(&dS1, (size_t)M * 16 * 2 * 4)); CK(hipMalloc(&dS2, (size_t)M * 16 * 2 * 4)); CK(hipMalloc(&dG, (size_t)(N + K) * 4 * 2));
+        CK(hipMemset(dS1, 0, (size_t)M * 16 * 2 * 4)); CK(hipMemset(dS2, 0, (size_t)M * 16 * 2 * 4)); CK(hipMemset(dG, 0, (size_t)(N + K) * 4 * 2));
+        a.bias = dG; a.ln_eps2 = 1e-5f;
+        if (lnfold == 1) { a.stat_out = dS1; a.res_stat = dS2; a.res_gamma = dG; a.res_beta = dG + N; }
+        else { a.a_stat = dS2; a.a_stat_groups = K / 64; a.a_fold_g = dG; a.residual = nullptr; a.act = AFM_ACT_GELU; }
+    }
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -48,7 +57,7 @@ static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pa
     unsigned long long tmin = ~0ull, tmax = 0;
     for (auto& x : r) { tmin = std::min(tmin, x.t0); tmax = std::max(tmax, x.t1); }
     const double tick_us = 0.01;                       // s_memrealtime: 100 MHz
-    printf("== arith=%d flags=%d pad=%d M=%d N=%d K=%d tile=%d: %d workgroups, event time %.1f us, first entry -> last exit %.1f us, %.1f TF\n", arith, flags, pad, M, N, K, tile, n, ms * 1e3,
+    printf("== arith=%d flags=%d pad=%d lnfold=%d M=%d N=%d K=%d tile=%d: %d workgroups, event time %.1f us, first entry -> last exit %.1f us, %.1f TF\n", arith, flags, pad, lnfold, M, N, K, tile, n, ms * 1e3,
            (tmax - tmin) * tick_us, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
     std::map<unsigned, int> cus;
     for (auto& x : r) cus[(x.xcc_id & 0xF) << 16 | (x.hw_id & 0xFF00)]++;           // (xcc, se, sh, cu)
@@ -81,6 +90,12 @@ static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pa
         printf("   %-22s shader clock %.2f GHz; per workgroup: %.0f cycles = vmcnt wait %.0f + barrier %.0f + DMA issue %.0f + ds_read/MFMA section %.0f + prologue/epilogue %.0f  (MFMA-only floor per wave: %d)\n",
                name, cyc / us / 1e3, cyc / m, w / m, b / m, is / m, mf / m, (cyc - w - b - is - mf) / m, 64 * (K / 2) * (tile == 5 ? 4 : tile == 4 ? 2 : 1));
     };
+    if (arith != AFM_ARITH_F32) {          // bf16-split kernels: the four trailing fields are phase spans in 10 ns ticks (gemm_split.hip)
+        double a = 0, b = 0, c = 0, d = 0;
+        for (auto& x : r) { a += x.wait_c; b += x.barrier_c; c += x.issue_c; d += x.mfma_c; }
+        printf("   phases of thread 0, mean over workgroups (us): prologue (operand + statistic loads, first split) %.2f | K loop %.2f | K-group merge + staging %.2f | epilogue %.2f;  launch overhead = event time - (first entry -> last exit) = %.1f us\n",
+               a / n * tick_us, b / n * tick_us, c / n * tick_us, d / n * tick_us, ms * 1e3 - (tmax - tmin) * tick_us);
+    } else
     phases(0, first_round, "started in first 3 us");
     phases(first_round, n, "started later");
     const double span = (tmax - tmin) * tick_us, bucket = span / 24;
@@ -93,10 +108,21 @@ static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pa
     }
     printf("\n");
     CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(drec));
+    if (dS1) { CK(hipFree(dS1)); CK(hipFree(dS2)); CK(hipFree(dG)); }
 }
 
 int main(int argc, char** argv) {
-    if (argc >= 4) { one(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 0, argc > 5 ? atoi(argv[5]) : AFM_ARITH_F32, argc > 6 ? atoi(argv[6]) : 0); return 0; }
+    if (argc >= 4) { one(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 0, argc > 5 ? atoi(argv[5]) : AFM_ARITH_F32, argc > 6 ? atoi(argv[6]) : 0, 0, argc > 7 ? atoi(argv[7]) : 0); return 0; }
+    if (argc == 2 && !strcmp(argv[1], "small")) {       // round 4: the small-launch regime (what each GPU runs under strong scaling), phase spans
+        for (int M : {1304, 326})
+            for (int lf : {0, 1, 2}) {
+                one(M, 512, 512, 0, AFM_ARITH_BF16X9, 0, 0, lf);
+                if (lf != 1) one(M, 1024, 512, 0, AFM_ARITH_BF16X9, 0, 0, lf);
+                if (lf != 1) one(M, 1536, 512, 0, AFM_ARITH_BF16X9, 0, 0, lf);
+                if (lf != 2) one(M, 512, 1024, 0, AFM_ARITH_BF16X9, 0, 0, lf);
+            }
+        return 0;
+    }
     for (int tile : {3, 5}) one(10432, 512, 512, tile);
     one(10432, 512, 1024, 3);
     one(10432, 1536, 512, 3);
