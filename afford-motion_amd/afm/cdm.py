@@ -295,6 +295,10 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.no_fold = False            # measurement: the layer-by-layer sampling form (what training-mode forward also runs)
         self.gemm_tile = 0              # measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral)
         self.no_gen = False             # measurement: round 2's folded form (per-point rows) instead of the row-less sampling form
+        self.chain_side = False         # sub-batch streams: the latent chain of a sub-batch on its side stream (afm_cdm_weights.flags: AFM_CDM_CHAIN_SIDE)
+        self.dec_chunks = 0             # dec_point workgroups per sample (0 = 16); bit-neutral tuning
+        self.chain_cu_mask = None       # CU masks (lists of uint32 words) of the side / main streams of the native loop; None = ordinary streams
+        self.point_cu_mask = None
 
     # ------------------------------------------------------------------ weight pack
     def _weights(self) -> ffi.CdmWeights:
@@ -302,7 +306,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         if self._pack is not None and self._pack[0] == ver:
             w = self._pack[1]
             w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()       # host arithmetic setting, per call (afm.ops.set_gemm_split)
-            w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+            w.flags = self._flags()
             return w
         if self.contact_layer.weight.device.type != "cuda":
             raise ffi.AfmError("CDM parameters are on the CPU; move the model to the MI355X (`model.to('cuda')`)")
@@ -439,8 +443,25 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._pack = (ver, w, keep)
         self._text_cache = None
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
-        w.flags = (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+        w.flags = self._flags()
         return w
+
+    def _flags(self) -> int:
+        return (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8) | (ffi.CDM_CHAIN_SIDE if self.chain_side else 0) | \
+            ((int(self.dec_chunks) & 0x3F) << ffi.CDM_DEC_CHUNKS_SHIFT)
+
+    def _loop_streams(self, need: int, dev):
+        """Streams of the native loop: [main_0, side_0, main_1, side_1, ...].  With `chain_cu_mask` / `point_cu_mask` (lists of 32-bit words,
+        one bit per CU) the side / main streams are created with hipExtStreamCreateWithCUMask, so that the latent chain of one sub-batch owns
+        a few CUs while the point kernels of the other sub-batch fill the rest (round 4 experiment; results do not depend on it)."""
+        key = (tuple(self.chain_cu_mask or ()), tuple(self.point_cu_mask or ()), str(dev))
+        if getattr(self, "_streams_key", None) != key:
+            self._streams, self._streams_key = [], key
+        while len(self._streams) < need:
+            i = len(self._streams)
+            mask = self.chain_cu_mask if (i & 1) else self.point_cu_mask
+            self._streams.append(ffi.cu_masked_stream(dev, mask) if mask else torch.cuda.Stream(device=dev))
+        return self._streams[:need]
 
     def _latent_tokens(self, w, which: int, rows: torch.Tensor):
         """afm_cdm_latent_tokens: rows [n, in_dim] -> (q0 [n,dq], u [n,He,dkv], cu [n,He])."""
@@ -563,9 +584,8 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             nsub = int(self.loop_sub_batches) or 1
             nsub = max(1, min(nsub, B))
             need = 2 * nsub if nsub > 1 else (1 if self.overlap_streams else 0)
-            while len(self._streams) < need:
-                self._streams.append(torch.cuda.Stream(device=dev))
-            handles = (C.c_void_p * max(need, 1))(*[s_.cuda_stream for s_ in self._streams[:need]]) if need else None
+            streams = self._loop_streams(need, dev)
+            handles = (C.c_void_p * max(need, 1))(*[s_.cuda_stream for s_ in streams]) if need else None
             nbytes = lib.afm_cdm_loop_workspace_bytes(C.byref(w), B, N, nsub)
             if nbytes < 0:
                 ffi.check(int(nbytes), "afm_cdm_loop_workspace_bytes")

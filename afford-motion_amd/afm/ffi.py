@@ -20,7 +20,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
 CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES = 0x1, 0x2, 0x4, 0x8
-CDM_NO_GEN = 0x2
+CDM_NO_GEN, CDM_CHAIN_SIDE, CDM_DEC_CHUNKS_SHIFT = 0x2, 0x4, 12
 ABI_VERSION = 6
 MAX_LAYERS = 16
 
@@ -260,6 +260,28 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream_of(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_HIP_RT = None
+
+
+def cu_masked_stream(device, mask_words):
+    """A HIP stream restricted to the compute units whose bits are set in `mask_words` (uint32 words, bit i = CU i as the runtime numbers
+    them), wrapped so that torch sees it (`.cuda_stream`, events).  hipExtStreamCreateWithCUMask lives in the HIP runtime the process has
+    already loaded (libamdhip64): the library of this package neither creates nor owns streams."""
+    global _HIP_RT
+    if _HIP_RT is None:
+        _HIP_RT = C.CDLL("libamdhip64.so")
+        _HIP_RT.hipExtStreamCreateWithCUMask.restype = C.c_int
+        _HIP_RT.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    words = [int(w) & 0xFFFFFFFF for w in mask_words]
+    arr = (C.c_uint32 * len(words))(*words)
+    handle = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIP_RT.hipExtStreamCreateWithCUMask(C.byref(handle), len(words), arr)
+    if rc != 0 or not handle.value:
+        raise AfmError(f"hipExtStreamCreateWithCUMask failed (hipError {rc})")
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 def require_gpu(*tensors: torch.Tensor) -> None:

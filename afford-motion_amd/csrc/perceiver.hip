@@ -199,11 +199,21 @@ int cdm_prepare_invariants(const afm_cdm_weights& w, const float* feat, int B, i
 // one denoiser evaluation in the folded (mode 1) or generated (mode 2) form; `prepared` (mode 1): ws.enc_kv / ws.bufB already hold C / D
 int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float* x_t, const int64_t* t, const float* text_q0,
                        const float* text_u, const float* text_cu, float* x0_out, const afm_ddpm_args* ddpm, int B, int N, const CdmWs& ws,
-                       bool prepared, hipStream_t s) {
+                       bool prepared, hipStream_t s, const CdmChainSide* cs = nullptr) {
     const int M = B * N, dkv = w.dkv, cd = w.contact_dim, mode = cdm_mode(w);
     if (mode == 1 && !prepared) AFM_TRY(cdm_prepare_invariants(w, feat, B, N, ws, s));
     if (mode == 3) AFM_TRY(launch_enc_point(w, text_u, text_cu, t, B, N, ws, x_t, feat, s));
     else AFM_TRY(launch_enc_reduce(w, ws.enc_kv, text_u, text_cu, t, B, N, ws, x_t, mode, s));
+    if (mode == 3 && cs && cs->chain) {
+        // the chain (13 small launches for 2 B tokens) on the sub-batch's side stream: enc_point -> [event] -> chain + tables -> [event] -> dec_point
+        (void)hipEventRecord(cs->forked, s);
+        (void)hipStreamWaitEvent(cs->chain, cs->forked, 0);
+        AFM_TRY(cdm_latent_chain(w, text_q0, t, ws, B, cs->chain, true));
+        AFM_TRY(launch_dec_tables(w, B, ws, cs->chain));
+        (void)hipEventRecord(cs->joined, cs->chain);
+        (void)hipStreamWaitEvent(s, cs->joined, 0);
+        return launch_dec_point(w, B, N, ws, x_t, feat, x0_out, ddpm, s, false);
+    }
     AFM_TRY(cdm_latent_chain(w, text_q0, t, ws, B, s, mode == 3));
     if (mode == 3) return launch_dec_point(w, B, N, ws, x_t, feat, x0_out, ddpm, s);
     AFM_TRY(launch_dec_attend(w, B, N, ws, x_t, mode, s));
@@ -221,7 +231,7 @@ int cdm_forward_folded(const afm_cdm_weights& w, const float* feat, const float*
 static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const float* x_t, const int64_t* t,
                             const float* text_q0, const float* text_u, const float* text_cu, float* x0_out,
                             const afm_ddpm_args* ddpm, int32_t B, int32_t N, void* workspace, int64_t workspace_bytes,
-                            void* side_stream, void* stream, bool prepared = false, bool rowless_ws = false) {
+                            void* side_stream, void* stream, bool prepared = false, bool rowless_ws = false, const CdmChainSide* cs = nullptr) {
     AFM_TRY(validate(wp, B, N));
     if (!feat || !t || !text_q0 || !text_u || !text_cu || !workspace || (!x0_out && !ddpm)) return AFM_E_BADARG;
     if (!wp->time_q0 || !wp->time_u || !wp->time_cu) return AFM_E_BADARG;
@@ -233,7 +243,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     const CdmWs ws = carve(w, B, N, workspace, !rowless_ws);
     if (ws.bytes > workspace_bytes) return AFM_E_WORKSPACE;
     const int M = B * N, dkv = w.dkv;
-    if (cdm_folded(w) && x_t) return cdm_forward_folded(w, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, ws, prepared, s);
+    if (cdm_folded(w) && x_t) return cdm_forward_folded(w, feat, x_t, t, text_q0, text_u, text_cu, x0_out, ddpm, B, N, ws, prepared, s, cs);
 
     afm_linear_args a = {};
     a.A = feat; a.lda = w.feat_dim; a.W = w.encoder_adapter.w; a.ldw = w.feat_dim; a.C = ws.enc_kv; a.ldc = dkv;
@@ -408,6 +418,16 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
         (void)hipEventRecord(fork, s0);
         for (int s = 0; s < nsub; ++s) (void)hipStreamWaitEvent(mainst[s], fork, 0);
     }
+    // AFM_CDM_CHAIN_SIDE: the latent chain of sub-batch s on sidest[s] (one event pair per sub-batch, reused by every step: an event
+    // re-recorded on a stream orders behind the waits already enqueued on its previous record)
+    CdmChainSide side[8] = {};
+    const bool chain_side = rowless && nsub > 1 && (w->flags & AFM_CDM_CHAIN_SIDE);
+    for (int s = 0; chain_side && s < nsub; ++s) {
+        side[s].chain = sidest[s];
+        if (hipEventCreateWithFlags(&side[s].forked, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&side[s].joined, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        (void)hipStreamWaitEvent(sidest[s], fork, 0);
+    }
     const int64_t per = (int64_t)N * cd;
     int rc = 0;
     // folded form: the step-invariant parts of the two adapters are computed once for the whole range of steps and x_t is read where
@@ -441,7 +461,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = first_step + j;
             rc = cdm_forward_impl(w, fs, xs, t_all + (int64_t)j * B + start[s], text_q0 + (int64_t)start[s] * dq,
                                   text_u + (int64_t)start[s] * He * dkv, text_cu + (int64_t)start[s] * He, nullptr, &dd, count[s], N, wsp[s], wsb[s],
-                                  sidest[s], mainst[s], folded, rowless);
+                                  sidest[s], mainst[s], folded, rowless, chain_side ? &side[s] : nullptr);
         }
     }
     if (nsub > 1) {
@@ -455,6 +475,7 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
         }
         (void)hipEventDestroy(fork);
     }
+    for (int s = 0; chain_side && s < nsub; ++s) { (void)hipEventDestroy(side[s].forked); (void)hipEventDestroy(side[s].joined); }
     return rc;
 }
 

@@ -44,6 +44,9 @@ struct CdmWs {
     int64_t bytes;
 };
 
+// AFM_CDM_CHAIN_SIDE: the sub-batch's chain stream and its fork / join events (created once per loop)
+struct CdmChainSide { hipStream_t chain; hipEvent_t forked, joined; };
+
 #pragma GCC visibility push(hidden)
 // perceiver_rows.hip - per-point kernels that read rows: mode 0 = rows from memory (layer-by-layer form), 1 = FOLD (step-invariant part
 // materialised once per loop + contact columns)
@@ -58,7 +61,8 @@ int launch_enc_point(const afm_cdm_weights& w, const float* text_u, const float*
                      const float* x_t, const float* feat, hipStream_t s);
 int launch_lat_head(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s);
 int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
-                     const afm_ddpm_args* ddpm, hipStream_t s);
+                     const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables = true);
+int launch_dec_tables(const afm_cdm_weights& w, int B, const CdmWs& ws, hipStream_t s);      // lat_dectables_kernel alone (chain stream)
 // perceiver_chain.hip - enc_reduce / enc_point partials -> the decoder's view of the two latents (dec_lat records / lat_kv for the row-less form)
 int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool rowless);
 #pragma GCC visibility pop

@@ -541,7 +541,14 @@ void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ q
 
 template <int NKS>
 int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
-                       const afm_ddpm_args* ddpm, hipStream_t s);
+                       const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables);
+template <int NKS>
+int launch_dec_tables_t(const afm_cdm_weights& w, int B, const CdmWs& ws, hipStream_t s) {
+    hipLaunchKernelGGL(lat_dectables_kernel<NKS>, dim3(B, 4), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
+                       w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
 
 }  // namespace
 
@@ -573,9 +580,15 @@ int launch_lat_head(const afm_cdm_weights& w, const float* text_q0, const int64_
 
 // the fused decoder (mode 3): the per-sample tables of the step (one launch), then one kernel over the points
 int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
-                     const afm_ddpm_args* ddpm, hipStream_t s) {
+                     const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables) {
     AfmProf prof(AFM_PROF_CDM, 0.0, s);
-    return rowless_nks(w.feat_dim) == 3 ? launch_dec_point_t<3>(w, B, N, ws, x_t, feat, x0_out, ddpm, s) : launch_dec_point_t<11>(w, B, N, ws, x_t, feat, x0_out, ddpm, s);
+    return rowless_nks(w.feat_dim) == 3 ? launch_dec_point_t<3>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, with_tables)
+                                        : launch_dec_point_t<11>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, with_tables);
+}
+
+int launch_dec_tables(const afm_cdm_weights& w, int B, const CdmWs& ws, hipStream_t s) {
+    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    return rowless_nks(w.feat_dim) == 3 ? launch_dec_tables_t<3>(w, B, ws, s) : launch_dec_tables_t<11>(w, B, ws, s);
 }
 
 }  // namespace afm_cdm
@@ -584,16 +597,17 @@ namespace {
 
 template <int NKS>
 int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
-                       const afm_ddpm_args* ddpm, hipStream_t s) {
+                       const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables) {
     constexpr int LDS = dp_lds_floats<NKS>() * (int)sizeof(float);
     static_assert(LDS <= 160 * 1024, "dec_point_kernel's tables fit the LDS");
     static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
-    hipLaunchKernelGGL(lat_dectables_kernel<NKS>, dim3(B, 4), dim3(1024), 0, s, ws.lat_kv, w.dec_dwq, w.dec_wqb, w.dec_wco, w.dec_wow, w.dec_wog, w.dec_xwo,
-                       w.dec_qxx, w.contact_dim, ws.twp, ws.qtab);
-    AFM_CHECK_LAUNCH();
+    if (with_tables) AFM_TRY(launch_dec_tables_t<NKS>(w, B, ws, s));
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
-    if (chunks > 16) chunks = 16;                     // (three workgroups per CU measured slower: the kernel is bound by VALU + f32 MFMA issue, not by latency)
+    const int cap = (w.flags >> AFM_CDM_DEC_CHUNKS_SHIFT) & 0x3F;      // tuning knob (sub-batch streams: half a batch wants twice the chunks to keep two workgroups per CU)
+    if (cap) chunks = cap;
+    else if (chunks > 16) chunks = 16;                // (three workgroups per CU measured slower: the kernel is bound by VALU + f32 MFMA issue, not by latency)
+    if (chunks > (N + 15) / 16) chunks = (N + 15) / 16;
     hipLaunchKernelGGL(dec_point_kernel<NKS>, dim3(chunks, B), dim3(64 * RowLess<NKS>::NW), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
                        ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);

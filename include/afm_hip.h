@@ -601,6 +601,8 @@ typedef struct {
 } afm_cdm_weights;
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
+#define AFM_CDM_CHAIN_SIDE     0x4     /* row-less form with sub-batch streams: the 2-latent chain (lat_head .. lat_dectables) of a sub-batch runs on its SIDE stream (fork / join by events), so that it can sit on CUs of its own (a CU-masked stream) under the other sub-batch's point kernels; bit-identical */
+#define AFM_CDM_DEC_CHUNKS_SHIFT 12    /* bits 12..17: workgroups per sample of enc_point's successor dec_point_kernel (0 = 16); a tuning knob, bit-identical (a point's arithmetic does not depend on its chunk) */
 #define AFM_CDM_NO_GEN         0x2     /* measurement: round 2's folded form (step-invariant adapter parts materialised, per-point rows) although the row-less tables are present */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);
