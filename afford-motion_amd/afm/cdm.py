@@ -590,7 +590,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             if nbytes < 0:
                 ffi.check(int(nbytes), "afm_cdm_loop_workspace_bytes")
             key = ("loop", B, N, nsub, str(dev))
-            if key not in self._ws:
+            if key not in self._ws or self._ws[key].numel() < nbytes:        # (the row-less form's workspace is smaller than the other forms')
                 self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             ws = self._ws[key]
             if step_noise is not None:

@@ -201,7 +201,7 @@ namespace afm_cdm {
 
 // enc_reduce partials -> dec_lat records, as 17 small launches over all 2 B latent tokens (see toklin_kernel; 14-18 us each, ~2 us apart)
 int cdm_latent_chain(const afm_cdm_weights& w, const float* text_q0, const int64_t* t, const CdmWs& ws, int B, hipStream_t s, bool enc12) {
-    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    AfmProf prof(enc12 ? AFM_PROF_CDM_CHAIN : AFM_PROF_CDM, 0.0, s);
     const int ntok = 2 * B, dq = w.dq, dkv = w.dkv, He = w.enc_heads;
     const bool head = enc12;                          // fused form: combine + v-proj + o-proj as one launch (lat_head_kernel)
     if (head) AFM_TRY(launch_lat_head(w, text_q0, t, ws, B, s));

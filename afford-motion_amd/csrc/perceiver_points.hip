@@ -556,7 +556,7 @@ namespace afm_cdm {
 
 int launch_enc_point(const afm_cdm_weights& w, const float* text_u, const float* text_cu, const int64_t* t, int B, int N, const CdmWs& ws,
                      const float* x_t, const float* feat, hipStream_t s) {
-    AfmProf prof(AFM_PROF_CDM, 0.0, s);               // K-vector partials in ws.pacc (stride 16 NT)
+    AfmProf prof(AFM_PROF_CDM_ENC, 0.0, s);           // K-vector partials in ws.pacc (stride 16 NT)
     if (rowless_nks(w.feat_dim) == 3)
         hipLaunchKernelGGL(enc_point_kernel<3>, dim3(EP_SPLIT, B), dim3(64 * EP_WAVES), 0, s, w.enc_kv_norm, text_u, text_cu, w.time_u, w.time_cu, t, w.n_timesteps, N,
                            ws.pm, ws.pl, ws.pacc, x_t, w.contact_dim, feat, w.feat_dim, w.enc_ec, w.enc_qee);
@@ -581,13 +581,14 @@ int launch_lat_head(const afm_cdm_weights& w, const float* text_q0, const int64_
 // the fused decoder (mode 3): the per-sample tables of the step (one launch), then one kernel over the points
 int launch_dec_point(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
                      const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables) {
-    AfmProf prof(AFM_PROF_CDM, 0.0, s);
-    return rowless_nks(w.feat_dim) == 3 ? launch_dec_point_t<3>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, with_tables)
-                                        : launch_dec_point_t<11>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, with_tables);
+    if (with_tables) AFM_TRY(launch_dec_tables(w, B, ws, s));        // (its own profile bracket: the tables belong to the chain's time)
+    AfmProf prof(AFM_PROF_CDM_DEC, 0.0, s);
+    return rowless_nks(w.feat_dim) == 3 ? launch_dec_point_t<3>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, false)
+                                        : launch_dec_point_t<11>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, false);
 }
 
 int launch_dec_tables(const afm_cdm_weights& w, int B, const CdmWs& ws, hipStream_t s) {
-    AfmProf prof(AFM_PROF_CDM, 0.0, s);
+    AfmProf prof(AFM_PROF_CDM_CHAIN, 0.0, s);
     return rowless_nks(w.feat_dim) == 3 ? launch_dec_tables_t<3>(w, B, ws, s) : launch_dec_tables_t<11>(w, B, ws, s);
 }
 

@@ -5,6 +5,7 @@ enum {
     AFM_PROF_KNN, AFM_PROF_TD, AFM_PROF_PTATTN, AFM_PROF_CDM, AFM_PROF_GEMM128_DMA, AFM_PROF_GEMM64x128_DMA, AFM_PROF_GEMM64_DMA,
     AFM_PROF_WGRAD, AFM_PROF_LN_BWD, AFM_PROF_MHA_BWD_DQ, AFM_PROF_MHA_BWD_DKV, AFM_PROF_TRAIN_MISC, AFM_PROF_POINT_TRAIN, AFM_PROF_WGRAD_SKINNY, AFM_PROF_CDM_TRAIN,
     AFM_PROF_GEMM_SPLIT128, AFM_PROF_GEMM_SPLIT64, AFM_PROF_GEMM32_DMA, AFM_PROF_GEMM32x64_DMA, AFM_PROF_GEMM_SPLIT64_KG, AFM_PROF_GEMM_SLAB, AFM_PROF_MHA_SPLIT,
+    AFM_PROF_CDM_ENC, AFM_PROF_CDM_DEC, AFM_PROF_CDM_CHAIN,
     AFM_PROF_NTAGS
 };
 bool afm_prof_on();

@@ -17,7 +17,8 @@ const char* kNames[AFM_PROF_NTAGS] = {"gemm_f32_mfma<128,128>", "gemm_f32_mfma<6
                                       "layernorm_kernel", "ddpm_randn_misc", "fps_kernel", "knn_kernel",
                                       "transition_down_kernel", "pt_attention_kernel", "cdm_perceiver", "gemm_f32_mfma_dma<128,128>",
                                       "gemm_f32_mfma_dma<64,128>", "gemm_f32_mfma_dma<64,64>", "wgrad_kernel", "layernorm_bwd_kernel",
-                                      "mha_bwd_dq_kernel", "mha_bwd_dkv_kernel", "train_misc", "point_train_passes", "wgrad_skinny_kernel", "cdm_train_attention", "gemm_f32_split_bf16<128, 128>", "gemm_f32_split_bf16<64, 64>", "gemm_f32_mfma_dma<32,32>", "gemm_f32_mfma_dma<32,64>", "gemm_f32_split_bf16<64, 64, split-K>", "gemm_f32_split_rowdot_slab", "mha_fwd_split_kernel"};
+                                      "mha_bwd_dq_kernel", "mha_bwd_dkv_kernel", "train_misc", "point_train_passes", "wgrad_skinny_kernel", "cdm_train_attention", "gemm_f32_split_bf16<128, 128>", "gemm_f32_split_bf16<64, 64>", "gemm_f32_mfma_dma<32,32>", "gemm_f32_mfma_dma<32,64>", "gemm_f32_split_bf16<64, 64, split-K>", "gemm_f32_split_rowdot_slab", "mha_fwd_split_kernel",
+                                      "enc_point_kernel", "dec_point_kernel", "cdm_latent_chain (lat_head + toklin x 11 + lat_dectables)"};
 }  // namespace
 
 bool afm_prof_on() { return g_on; }
