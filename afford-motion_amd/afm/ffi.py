@@ -54,6 +54,8 @@ class LinearArgs(C.Structure):
         # LayerNorm folded across kernel boundaries (ABI v5)
         ("stat_out", c_f32p), ("a_stat", c_f32p), ("a_stat_groups", i32), ("a_fold_g", c_f32p),
         ("res_stat", c_f32p), ("res_gamma", c_f32p), ("res_beta", c_f32p), ("ln_eps2", C.c_float),
+        # a hole inside every group of the row remaps (ABI v6)
+        ("a_skip_after", i32), ("a_skip", i32), ("c_skip_after", i32), ("c_skip", i32),
     ]
 
 

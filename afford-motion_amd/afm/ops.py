@@ -13,7 +13,7 @@ import torch
 
 from . import ffi
 
-RowMap = Tuple[int, int, int]   # (group, stride, offset): row r -> (r // group) * stride + offset + r % group
+RowMap = Tuple[int, ...]   # (group, stride, offset[, skip_after, skip]): row r -> (r // group) * stride + offset + j + (skip if j >= skip_after), j = r % group
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ffi.ACT_NONE,
@@ -68,9 +68,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         a.rowtab, a.rowtab_period = rowtab.data_ptr(), rowtab.shape[0]
     a.act, a.act_post = act, act_post
     if a_map:
-        a.a_grp, a.a_stride, a.a_off = a_map
+        a.a_grp, a.a_stride, a.a_off = a_map[:3]
+        if len(a_map) == 5:                       # (group, stride, offset, skip_after, skip): a hole of `skip` rows behind member skip_after - 1
+            a.a_skip_after, a.a_skip = a_map[3:]
     if c_map:
-        a.c_grp, a.c_stride, a.c_off = c_map
+        a.c_grp, a.c_stride, a.c_off = c_map[:3]
+        if len(c_map) == 5:
+            a.c_skip_after, a.c_skip = c_map[3:]
     if rowdot_w is not None:
         rowdot_w = ffi.f32c(rowdot_w)
         R = rowdot_w.shape[0]

@@ -167,9 +167,11 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         }
         const bool no_l0_cache = (w.flags & AFM_CMDM_NO_L0_CACHE) != 0;                  // measurement knob
         if (li == 0 && !copy_cond && w.n_cond > 0 && !no_l0_cache) {
-            a.M = B; a.a_grp = 1; a.a_stride = T; a.a_off = 0; a.c_grp = 1; a.c_stride = T; a.c_off = 0;                 // time tokens
-            AFM_TRY(run_linear(w, a, s));
-            a.M = B * L; a.a_grp = L; a.a_stride = T; a.a_off = 1 + w.n_cond; a.c_grp = L; a.c_stride = T; a.c_off = 1 + w.n_cond;   // motion tokens
+            // ONE launch over the time token and the L motion tokens of every sample: groups of 1 + L rows with a hole of n_cond rows
+            // behind the first (afm_linear_args.a_skip; round 3 ran two launches - a launch is ~17 us of a small-batch step)
+            a.M = B * (1 + L);
+            a.a_grp = 1 + L; a.a_stride = T; a.a_off = 0; a.a_skip_after = 1; a.a_skip = w.n_cond;
+            a.c_grp = 1 + L; a.c_stride = T; a.c_off = 0; a.c_skip_after = 1; a.c_skip = w.n_cond;
             AFM_TRY(run_linear(w, a, s));
         } else {
             a.M = M;

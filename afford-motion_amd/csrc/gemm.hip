@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const afm_linear_args p,
     const int r32 = lane & 31, hh = lane >> 5;
     const int c4 = tid & 7, r0 = tid >> 3;
 
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off};
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off, p.a_skip_after, p.a_skip};
     const float* arow[BM / 32];
     const float* wrow[BN / 32];
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_mfma_dma(const afm_line
     const int r32 = lane & 31, hh = lane >> 5;
     const int c8 = tid & 7, r0 = tid >> 3;           // this thread's (row-in-pass, 16-byte slot) of every DMA pass
 
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off};
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off, p.a_skip_after, p.a_skip};
     // per-pass source pointers with the swizzle folded in: slot c8 of row r receives logical chunk c8 ^ ((r >> 1) & 7)
     const float* asrc[PA];
     const float* wsrc[PW];
@@ -411,6 +411,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
+    if (a.a_skip < 0 || a.c_skip < 0 || a.a_skip_after < 0 || a.c_skip_after < 0 || (a.a_skip && !a.a_grp) || (a.c_skip && !a.c_grp)) return AFM_E_BADARG;
     if (a.ln_out) {                               // fused LayerNorm of the output rows (ABI v5)
         const uintptr_t lp = (uintptr_t)a.C | (uintptr_t)a.ln_out | (uintptr_t)a.ln_gamma | (uintptr_t)a.ln_beta;
         if (!a.C || !a.ln_gamma || !a.ln_beta || !a.ln_counters || (a.N & 3) || (a.ldc & 3) || (a.ldo & 3) || (lp & 15) || a.N > 1024 ||

@@ -7,9 +7,11 @@
 namespace {
 
 struct RowMap {
-    int grp, stride, off;
+    int grp, stride, off, skip_after = 0, skip = 0;      // skip: the members j >= skip_after of a group sit `skip` rows further on (afm_linear_args.a_skip)
     __device__ __forceinline__ int64_t operator()(int r) const {
-        return grp ? (int64_t)(r / grp) * stride + off + (r % grp) : (int64_t)r;
+        if (!grp) return (int64_t)r;
+        const int j = r % grp;
+        return (int64_t)(r / grp) * stride + off + j + (j >= skip_after ? skip : 0);
     }
 };
 
@@ -24,12 +26,31 @@ __device__ __forceinline__ void store_f4_sc1(float* ptr, const float4& v) {
 // ---- LayerNorm folded across kernel boundaries (afm_linear_args.stat_out / a_stat / res_stat, ABI v5).  A producer writes, per output
 // row and 64-column group, (mean, M2 = sum of squared deviations from that mean) of what it stores; consumers combine the groups of a row
 // in index order (Chan's parallel-variance formula): mean = avg(mean_t), M2 = sum_t M2_t + 64 sum_t (mean_t - mean)^2.
+// All records of the row are REQUESTED before the first is used: the loop over a run-time `groups` made hipcc wait for every load before it
+// issued the next - 8 (d = 512) or 16 (ff = 1024) dependent round trips to rows the previous kernel has just written on other XCDs, 1.3 us
+// at the head of every folded launch (profiles/r04_gemm_timeline_small.txt: prologue 1.1 -> 2.5 us).  Records past `groups` re-read the
+// last one (unconditional loads, no predicate); the sums still run over the first `groups` records in index order: same bits as before.
+constexpr int AFM_STAT_MAXG = 16;
 __device__ __forceinline__ void row_stat_combine(const float* __restrict__ st, int groups, float eps, float& mean, float& rstd) {
+    if (groups > AFM_STAT_MAXG) {                   // wider rows than the encoder's (not on the shipped path): the plain loop
+        float ms = 0.f;
+        for (int t = 0; t < groups; ++t) ms += st[2 * t];
+        mean = ms / (float)groups;
+        float m2 = 0.f;
+        for (int t = 0; t < groups; ++t) { const float d = st[2 * t] - mean; m2 += st[2 * t + 1] + 64.0f * (d * d); }
+        rstd = 1.0f / sqrtf(m2 / (64.0f * (float)groups) + eps);
+        return;
+    }
+    float2 rec[AFM_STAT_MAXG];
+#pragma unroll
+    for (int t = 0; t < AFM_STAT_MAXG; ++t) rec[t] = *reinterpret_cast<const float2*>(st + 2 * min(t, groups - 1));
     float ms = 0.f;
-    for (int t = 0; t < groups; ++t) ms += st[2 * t];
+#pragma unroll
+    for (int t = 0; t < AFM_STAT_MAXG; ++t) if (t < groups) ms += rec[t].x;
     mean = ms / (float)groups;
     float m2 = 0.f;
-    for (int t = 0; t < groups; ++t) { const float d = st[2 * t] - mean; m2 += st[2 * t + 1] + 64.0f * (d * d); }
+#pragma unroll
+    for (int t = 0; t < AFM_STAT_MAXG; ++t) if (t < groups) { const float d = rec[t].x - mean; m2 += rec[t].y + 64.0f * (d * d); }
     rstd = 1.0f / sqrtf(m2 / (64.0f * (float)groups) + eps);
 }
 
@@ -43,7 +64,7 @@ __device__ __forceinline__ void gemm_rowstats(const afm_linear_args& p, float* r
     if (!p.a_stat && !p.res_stat) return;                               // uniform
     const int r = threadIdx.x;
     if (r >= 2 * BM) return;
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off}, cmap{p.c_grp, p.c_stride, p.c_off};
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off, p.a_skip_after, p.a_skip}, cmap{p.c_grp, p.c_stride, p.c_off, p.c_skip_after, p.c_skip};
     const bool is_res = r >= BM;
     const int grow = bm * BM + (is_res ? r - BM : r);
     const float* st = is_res ? p.res_stat : p.a_stat;
@@ -78,7 +99,7 @@ __device__ __forceinline__ float epilogue(const afm_linear_args& p, float v, int
 // Shared epilogue: the accumulators were staged in `lds` as a [BM][BN + 4] tile; stream rows out with 16-byte accesses.
 template <int BM, int BN, int NT = 256, int LDC = BN + 4>
 __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const float* lds, int bm, int bn, int tid, const float* rowst = nullptr) {
-    const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
+    const RowMap cmap{p.c_grp, p.c_stride, p.c_off, p.c_skip_after, p.c_skip};
     const int col0 = bn * BN;
     const bool vec_out = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((p.ldr & 3) == 0) && ((p.ldp & 3) == 0) && ((p.ldz & 3) == 0) && !p.ddpm_out &&
                          ((((uintptr_t)p.C) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) | ((uintptr_t)p.scale) | ((uintptr_t)p.rowtab) |
@@ -226,7 +247,7 @@ __device__ __forceinline__ void gemm_ln_tail(const afm_linear_args& p, int bm, i
     }
     __syncthreads();
     if (!*flag) return;
-    const RowMap cmap{p.c_grp, p.c_stride, p.c_off};
+    const RowMap cmap{p.c_grp, p.c_stride, p.c_off, p.c_skip_after, p.c_skip};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int r = wave; r < BM; r += nw) {
         const int grow = bm * BM + r;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * SLAB_WAVES) void gemm_f32_split_rowdot_slab(co
 
     const int r32 = lane & 31, hh = lane >> 5;
     const unsigned char* bbase = sl_raw + r32 * 32 + ((hh ^ ((r32 >> 3) & 1)) * 16);      // this lane's 16 bytes of (step 0, plane 0, column half 0)
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off}, cmap{p.c_grp, p.c_stride, p.c_off};
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off, p.a_skip_after, p.a_skip}, cmap{p.c_grp, p.c_stride, p.c_off, p.c_skip_after, p.c_skip};
     const int ntile_all = (p.M + 31) / 32;
     const int tile0 = chunk * tiles_per_chunk;
     const int ntile = min(tiles_per_chunk, ntile_all - tile0);

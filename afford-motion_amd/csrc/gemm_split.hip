@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     // TCP_TOTAL_CACHE_ACCESSES 11.7 M -> 6.0 M per out_proj launch, 2-3 % faster), and every thread carries the same mix of A and W
     // work.  16 consecutive lanes (the unit ds_write_b64 is serviced in) take the four quarters of four rows of equal parity inside a
     // block of 8 rows: with rows 48 B apart those are four disjoint 32-byte windows of the 128-byte bank row.
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off};
+    const RowMap amap{p.a_grp, p.a_stride, p.a_off, p.a_skip_after, p.a_skip};
     const float* src[NI];
     int dst[NI];
 #pragma unroll
@@ -267,7 +267,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
 #ifdef AFM_TIMELINE
     const unsigned long long tl_staged = __builtin_amdgcn_s_memrealtime();       // K groups merged, accumulators staged in LDS
 #endif
-    if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid, rowst);
+    // The split-K form's epilogue runs on ALL its wave groups (512 / 1024 threads: two trips / one over the 64 x 64 tile instead of four -
+    // a small launch has nothing else to hide the trips' memory round trips behind; profiles/r04_gemm_timeline_small.txt: epilogue 3.5 of
+    // 14.8 us).  An output element's arithmetic does not depend on which thread handles it: bit-identical.
+    constexpr int ENT = (KG == 2 || KG == 4) ? 256 * KG : 256;
+    if (ENT > 256) gemm_epilogue<BM, BN, ENT>(p, ldsf, bm, bn, (int)threadIdx.x, rowst);
+    else if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid, rowst);
     gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(ldsf));
 #ifdef AFM_TIMELINE
     if (afm_timeline && threadIdx.x == 0) {

@@ -129,6 +129,11 @@ typedef struct {
      * kernels only (AFM_E_UNSUPPORTED when the arithmetic selects the native kernels). */
     float* stat_out; const float* a_stat; int32_t a_stat_groups; const float* a_fold_g;
     const float* res_stat; const float* res_gamma; const float* res_beta; float ln_eps2;
+    /* ---- a hole inside every group of the row remaps (ABI v6; 0 = none): with a_skip > 0 the members j >= a_skip_after of a group sit
+     * a_skip rows further on: A row = (r / a_grp) * a_stride + a_off + j + (j >= a_skip_after ? a_skip : 0), j = r % a_grp (c_* alike).
+     * One launch then covers the time token AND the L motion tokens of every sample while skipping the n_cond step-invariant condition
+     * tokens between them (layer 0's in_proj of the sampling loop: a_grp = 1 + L, a_stride = T, a_skip_after = 1, a_skip = n_cond). */
+    int32_t a_skip_after, a_skip, c_skip_after, c_skip;
 } afm_linear_args;
 
 #define AFM_ARITH_DEFAULT 0

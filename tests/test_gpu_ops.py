@@ -366,6 +366,26 @@ def test_mha_workgroup_groupings_are_bit_identical(B, T):
         ops.mha(qkv, None, H, group_waves=3)
 
 
+def test_linear_row_maps_with_a_hole():
+    """ABI v6 (afm_linear_args.a_skip / c_skip): one launch over the time token and the L motion tokens of every sample, skipping the
+    n_cond condition tokens between them - layer 0's in_proj of the sampling loop.  Rows are independent: bit-identical to the two
+    launches it replaces (M = B and M = B L), for the folded-statistics epilogue's row indexing too."""
+    B, L, nc, K, N = 3, 21, 7, 512, 1536
+    T = 1 + nc + L
+    x = synth.gaussian("hole_x", (B * T, K)).to(dev())
+    w, b = synth.gaussian("hole_w", (N, K)).to(dev()) * 0.05, synth.gaussian("hole_b", (N,)).to(dev())
+    want = torch.full((B * T, N), 7.0, device=dev())
+    ops.linear(x, w, b, out=want, rows=B, a_map=(1, T, 0), c_map=(1, T, 0))
+    ops.linear(x, w, b, out=want, rows=B * L, a_map=(L, T, 1 + nc), c_map=(L, T, 1 + nc))
+    got = torch.full((B * T, N), 7.0, device=dev())
+    ops.linear(x, w, b, out=got, rows=B * (1 + L), a_map=(1 + L, T, 0, 1, nc), c_map=(1 + L, T, 0, 1, nc))
+    assert torch.equal(got, want)
+    keep = got.view(B, T, N)[:, 1:1 + nc]
+    assert (keep == 7.0).all()                               # the condition tokens' rows are not touched
+    ref = x.view(B, T, K)[:, [0] + list(range(1 + nc, T))].cpu().double() @ w.cpu().double().T + b.cpu().double()
+    report("linear with a hole in the row map", got.view(B, T, N)[:, [0] + list(range(1 + nc, T))], ref.float(), 2e-4)
+
+
 @pytest.mark.parametrize("B,T,q_first", [(4, 326, 130), (1, 326, 130), (2, 196, 7), (3, 61, 60), (2, 326, 320)])
 def test_mha_query_rows_subset_is_bit_identical(B, T, q_first):
     """afm_mha_fwd_rows (ABI v6): the query rows q_first .. T - 1 only (the CMDM's last layer is read on its motion tokens only).  The query
