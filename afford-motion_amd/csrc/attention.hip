@@ -250,20 +250,44 @@ constexpr int KROWB = 144, VROWB = 80;                 // plane row bytes
 constexpr int KPLANE = KB * KROWB, VPLANE = DH * VROWB;
 constexpr int KVSTAGE = 3 * KPLANE + 3 * VPLANE;       // 29184 bytes per stage
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW == 12 ? 3 : 1)) void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
-                                                                const float* __restrict__ vp_, int ldkv, const uint8_t* __restrict__ key_mask,
-                                                                float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk, int q_first) {
+// ---- Two key segments (round 4).  The softmax of a query row is computed over TWO segments of the key blocks - segment 0 = blocks
+// [0, n0), segment 1 = [n0, nkb), n0 = ceil(nkb / 2) - each with its own online-softmax state (m, l, O) started from (-inf, 0, 0), and the two
+// states are merged once at the end:  m = max(m0, m1), a_s = exp2(m_s - m), l = l0 a0 + l1 a1, O = O0 a0 + O1 a1, out = O / l  (seg_merge
+// below pins the operation order).  What this buys: a small launch (B H < 128: strong scaling runs 4 samples per GPU) puts the two segments
+// of a query block on TWO waves (SEG2: a workgroup of 2 NW waves, waves NW .. 2 NW - 1 take segment 1 with K / V stages of their own) - the
+// serial chain of a wave drops from 11 to 6 key blocks at T = 326 (26.5 -> ~17 us per launch at B = 4), while a large launch walks the
+// segments one after the other in one wave (O0 parked in LDS in between).  Both forms execute the same float operations in the same
+// order for every query row: a batch and its shards stay bit-identical (tests/test_gpu_ops.py, test_gpu_cmdm.py).  One segment when nkb == 1.
+__device__ __forceinline__ float seg_merge(float x0, float a0, float x1, float a1) { return __fmaf_rn(x0, a0, __fmul_rn(x1, a1)); }
+// a wave's parked segment state in LDS: O as [32 registers][64 lanes] (conflict-free), then (m, l) per query [32][2] (written by the lanes of
+// the first half-wave, read by both): 8448 bytes - twelve of them fit next to the K / V stages of the 12-wave form (160 KB)
+constexpr int PARK_FLOATS = 32 * 64 + 64;
+
+// second launch bound = waves per SIMD the grid needs: the sequential forms as in round 3 (12 waves: one workgroup of three waves per SIMD =
+// 168 VGPRs; 4 / 8 waves: two; 6: three), SEG2: one workgroup per CU (its LDS) of 2 NW waves
+template <int NW, bool SEG2>
+__global__ __launch_bounds__(64 * NW * (SEG2 ? 2 : 1), SEG2 ? (NW >= 2 ? NW / 2 : 1) : (NW == 4 || NW == 8 ? 2 : (NW == 6 || NW == 12 ? 3 : 1)))
+void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_, const float* __restrict__ vp_, int ldkv,
+                          const uint8_t* __restrict__ key_mask, float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk, int q_first) {
     // `scale` = log2(e) / sqrt(dh): the logits are kept in base-2 units, so the softmax is exp2(s - m) = one v_exp_f32 per element
     // q_first: only the query rows q_first .. Tq - 1 are computed (query blocks start at q_first; the rows in front keep whatever `out` held)
-    constexpr int NT = 64 * NW;
-    constexpr int NIT = (256 + NT - 1) / NT;            // staging items per thread (256 items per block: 128 of K, 128 of V)
+    static_assert(!SEG2 || NW * PARK_FLOATS * 4 <= 2 * KVSTAGE, "SEG2: segment 1's parked state fits its own K / V stages");
+    constexpr int NSEGW = SEG2 ? 2 : 1;                 // key segments in flight per workgroup
+    constexpr int NTH = 64 * NW;                        // threads that stage one segment's blocks
+    constexpr int NT = NTH * NSEGW;
+    constexpr int NIT = (256 + NTH - 1) / NTH;          // staging items per thread (256 items per block: 128 of K, 128 of V)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TL(const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(); const unsigned long long tl_c0 = afm_cyc();
        unsigned long long tl_s = 0, tl_soft = 0, tl_pv = 0, tl_sync = 0;)
-    unsigned char* kv = smem_raw;                       // [2][KVSTAGE]
-    float* madd = reinterpret_cast<float*>(smem_raw + 2 * KVSTAGE);                 // [nkb * KB] additive mask (0 / -inf)
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+    const int seg = SEG2 ? __builtin_amdgcn_readfirstlane(wave_all / NW) : 0;      // SEG2: which segment this wave works on
+    const int wave = SEG2 ? wave_all - seg * NW : wave_all, htid = tid - seg * NTH;
+    unsigned char* kv = smem_raw + seg * (2 * KVSTAGE);  // [2][KVSTAGE] per segment in flight
+    float* madd = reinterpret_cast<float*>(smem_raw + NSEGW * 2 * KVSTAGE);         // [nkb * KB] additive mask (0 / -inf)
     int* blk_valid = reinterpret_cast<int*>(madd + ((T + KB - 1) / KB) * KB);       // [nkb]
+    // parked state: SEG2 - segment 1's final (O, m, l) on its way to the merging wave, in segment 1's (then idle) K / V stages;
+    //               sequential - O0 of every wave while it walks segment 1, behind the mask
+    float* park = SEG2 ? reinterpret_cast<float*>(smem_raw + 2 * KVSTAGE) : reinterpret_cast<float*>(blk_valid + ((T + KB - 1) / KB + 3) / 4 * 4);
 
     int bid = blockIdx.x;
     {
@@ -272,10 +296,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
     }
     const int bh = bid / nchunk, chunk = bid % nchunk;
     const int b = bh / H, h = bh % H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
     const int D = H * DH;
     const int nkb = (T + KB - 1) / KB, nqb = (Tq - q_first + 31) / 32;
+    const int n0 = (nkb + 1) / 2, n1 = nkb - n0;        // blocks of segment 0 / 1 (n0 >= n1; n1 == 0: one segment, no merge)
     const float* qbase = qp_ + (int64_t)b * Tq * ldq + h * DH;
     const float* kbase = kp_ + (int64_t)b * T * ldkv + h * DH;
     const float* vbase = vp_ + (int64_t)b * T * ldkv + h * DH;
@@ -299,8 +323,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
     auto load_block = [&](int kb) {
 #pragma unroll
         for (int n = 0; n < NIT; ++n) {
-            const int item = tid + n * NT;
-            if (NT * NIT > 256 && item >= 256) continue;
+            const int item = htid + n * NTH;
+            if (NTH * NIT > 256 && item >= 256) continue;
             if (item < 128) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -321,8 +345,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
         unsigned char* base = kv + buf * KVSTAGE;
 #pragma unroll
         for (int n = 0; n < NIT; ++n) {
-            const int item = tid + n * NT;
-            if (NT * NIT > 256 && item >= 256) continue;
+            const int item = htid + n * NTH;
+            if (NTH * NIT > 256 && item >= 256) continue;
             if (item < 128) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -352,10 +376,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
         }
     };
 
+    // the blocks this wave walks: SEG2 - its segment's (padded to n0 trips so that both halves meet at every barrier); sequential - all
+    const int kb_first = SEG2 ? seg * n0 : 0, ntrip = SEG2 ? n0 : nkb, kb_end = SEG2 ? (seg ? nkb : n0) : nkb;
+
     for (int q0 = chunk * NW; q0 < nqb; q0 += NW * nchunk) {
         const int qb = q0 + wave;
         const bool active = qb < nqb;
-        if (NW <= 4) load_block(0);      // in flight under the Q loads and the Q split (the 168-register variants cannot afford the live range)
+        if (NW <= 4) load_block(kb_first);      // in flight under the Q loads and the Q split (the 168-register variants cannot afford the live range)
         // Q planes: query row (clamped), K16 step s covers head dims 16 s + 8 hh .. + 7, pre-scaled (1 / sqrt(64) is a power of two)
         u32x4 qpl[4][3];
         {
@@ -379,16 +406,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 
-        __syncthreads();                 // previous pass done with LDS; madd / blk_valid visible
-        if (NW > 4) load_block(0);
+        __syncthreads();                 // previous pass done with LDS (stages and parked state); madd / blk_valid visible
+        if (NW > 4) load_block(kb_first);
         store_block(0);
         __syncthreads();
 
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int buf = kb & 1;
+        for (int it = 0; it < ntrip; ++it) {
+            const int kb = kb_first + it, buf = it & 1;
+            const bool have = kb < kb_end;                       // SEG2: segment 1 may have one block less (an idle trip, barriers only)
             TL(const unsigned long long tl_a = afm_cyc();)
-            if (kb + 1 < nkb) load_block(kb + 1);
-            const int bflag = blk_valid[kb];
+            if (kb + 1 < kb_end) load_block(kb + 1);
+            if (!SEG2 && n1 > 0 && kb == n0 && active) {
+                // sequential form, first block of segment 1: park (O0, m0, l0) (LDS), start over
+                float* pk = park + wave * PARK_FLOATS + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pk[r * 64] = o0[r]; pk[(16 + r) * 64] = o1[r]; o0[r] = 0.f; o1[r] = 0.f; }
+                if (hh == 0) *reinterpret_cast<float2*>(park + wave * PARK_FLOATS + 32 * 64 + 2 * r32) = make_float2(m_run, l_run);
+                m_run = NEG_INF; l_run = 0.0f;
+            }
+            const int bflag = have ? blk_valid[kb] : 0;
             if (active && (bflag & 1)) {
                 const unsigned char* kpl = kv + buf * KVSTAGE + r32 * KROWB + hh * 16;
                 const unsigned char* vpl = kv + buf * KVSTAGE + 3 * KPLANE + r32 * VROWB + hh * 16;
@@ -455,15 +491,46 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
                 TL(asm volatile("" : "+v"(o0), "+v"(o1)); const unsigned long long tl_d = afm_cyc(); tl_pv += tl_d - tl_c;)
             }
             TL(const unsigned long long tl_e = afm_cyc();)
-            if (kb + 1 < nkb) store_block(buf ^ 1);
+            if (kb + 1 < kb_end) store_block(buf ^ 1);
             __syncthreads();
             TL(tl_sync += afm_cyc() - tl_e;)
         }
 
-        if (active) {
+        // ---- merge the two segments' states (n1 > 0), normalise, store
+        if (SEG2 && n1 > 0) {
+            if (seg == 1 && active) {              // segment 1's state -> LDS (its own, now idle, stages)
+                float* pk = park + wave * PARK_FLOATS + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pk[r * 64] = o0[r]; pk[(16 + r) * 64] = o1[r]; }
+                if (hh == 0) *reinterpret_cast<float2*>(park + wave * PARK_FLOATS + 32 * 64 + 2 * r32) = make_float2(m_run, l_run);
+            }
+            __syncthreads();
+        }
+        if (active && seg == 0) {
             const int qrow = q_first + qb * 32 + r32;
+            float l_fin = l_run;
+            if (n1 > 0) {
+                // the parked state is read operand by operand (no second accumulator set in registers: the 168-register forms have none to spare)
+                const float* pk = park + wave * PARK_FLOATS + lane;
+                const float2 mlp = *reinterpret_cast<const float2*>(park + wave * PARK_FLOATS + 32 * 64 + 2 * r32);
+                const float mp = mlp.x, lp = mlp.y;
+                const float m0 = SEG2 ? m_run : mp, l0 = SEG2 ? l_run : lp, m1 = SEG2 ? mp : m_run, l1 = SEG2 ? lp : l_run;
+                const float m = fmaxf(m0, m1), ms = (m == NEG_INF) ? 0.0f : m;
+                const float a0 = __builtin_amdgcn_exp2f(m0 - ms), a1 = __builtin_amdgcn_exp2f(m1 - ms);
+                l_fin = seg_merge(l0, a0, l1, a1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (SEG2) {        // registers hold segment 0, LDS segment 1
+                        o0[r] = seg_merge(o0[r], a0, pk[r * 64], a1);
+                        o1[r] = seg_merge(o1[r], a0, pk[(16 + r) * 64], a1);
+                    } else {           // LDS holds segment 0, registers segment 1
+                        o0[r] = seg_merge(pk[r * 64], a0, o0[r], a1);
+                        o1[r] = seg_merge(pk[(16 + r) * 64], a0, o1[r], a1);
+                    }
+                }
+            }
             if (qrow < Tq) {
-                const float inv = 1.0f / l_run;
+                const float inv = 1.0f / l_fin;
                 float* op = out + ((int64_t)b * Tq + qrow) * D + h * DH + 4 * hh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -483,17 +550,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 || NW == 8 ? 2 : (NW == 6 || NW ==
     })
 }
 
-// group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 6 / 8 / 12; 0 = the library's choice; < 0 = one workgroup per
-// (sample, head) that walks all query blocks (long-query cross-attention, training).  Inference runs the bf16-split kernel, training
-// (lse output, attention dropout) the f32-MFMA kernel.
-template <int NW>
+// group_waves: waves (32-query blocks) per workgroup, one of 1 / 2 / 4 / 6 / 8 / 12 (one wave walks both key segments of its query block),
+// or 100 + {2, 4}: the two key segments of a query block on two waves (workgroups of 2 x that many waves); 0 = the library's choice;
+// < 0 = one workgroup per (sample, head) that walks all query blocks (long-query cross-attention, training).  Inference runs the
+// bf16-split kernel, training (lse output, attention dropout) the f32-MFMA kernel.
+template <int NW, bool SEG2>
 int launch_split_mha(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, int B, int Tq, int T, int H,
                      float scale, int nchunk, size_t lds, hipStream_t s, int q_first) {
-    static const int attr = (int)hipFuncSetAttribute((const void*)mha_fwd_split_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const int attr = (int)hipFuncSetAttribute((const void*)mha_fwd_split_kernel<NW, SEG2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != 0) return attr;
-    hipLaunchKernelGGL((mha_fwd_split_kernel<NW>), dim3(B * H * nchunk), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale, nchunk, q_first);
+    hipLaunchKernelGGL((mha_fwd_split_kernel<NW, SEG2>), dim3(B * H * nchunk), dim3(NW * 64 * (SEG2 ? 2 : 1)), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale,
+                       nchunk, q_first);
     AFM_CHECK_LAUNCH();
     return 0;
+}
+
+// dynamic LDS of the split kernel: stages + additive mask + block flags (+ the sequential form's parked segment-0 state: 8448 B per wave)
+inline size_t split_mha_lds(int nkb, int nw, bool seg2) {
+    const size_t mask = (size_t)nkb * KB * sizeof(float) + (size_t)((nkb + 3) / 4 * 4) * sizeof(int);
+    return seg2 ? (size_t)4 * KVSTAGE + mask : (size_t)2 * KVSTAGE + mask + (nkb > 1 ? (size_t)nw * PARK_FLOATS * sizeof(float) : 0);
 }
 
 int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, float* lse, int32_t B,
@@ -532,28 +607,47 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
         return 0;
     }
     int nw, nchunk = 1;
+    bool seg2 = false;
+    const size_t lds_cap = 160 * 1024;
     if (group_waves < 0) {
         nw = nqb <= 4 ? 4 : (nqb <= 6 ? 6 : (nqb <= 8 ? 8 : 12));
     } else {
-        if (group_waves != 0 && group_waves != 1 && group_waves != 2 && group_waves != 4 && group_waves != 6 && group_waves != 8 && group_waves != 12)
+        int gw = group_waves;
+        if (gw >= 100) {
+            seg2 = true; gw -= 100;
+            if (gw != 2 && gw != 4) return AFM_E_BADARG;
+        } else if (gw != 0 && gw != 1 && gw != 2 && gw != 4 && gw != 6 && gw != 8 && gw != 12)
             return AFM_E_BADARG;
         // one 12-wave workgroup per (sample, head) when those alone fill the chip (every K / V block is split and staged once, three waves per
-        // SIMD: profiles/r03_mha_timeline.txt), 4-wave groups (three workgroups per (sample, head)) for small launches.  Bit-identical either way.
-        nw = group_waves ? group_waves : ((int64_t)B * H >= 128 ? 12 : AFM_MHA_DEFAULT_GROUP);
+        // SIMD: profiles/r03_mha_timeline.txt); small launches (strong scaling: B = 4 per GPU): groups of four query blocks with the two key
+        // segments of a block on two waves (8-wave workgroups, one per CU) while they fit the chip in one round, plain 4-wave groups otherwise.
+        // Bit-identical either way.
+        nw = gw ? gw : ((int64_t)B * H >= 128 ? 12 : AFM_MHA_DEFAULT_GROUP);
         if (nw > nqb) nw = nqb > 8 ? 12 : (nqb > 6 ? 8 : (nqb > 4 ? 6 : (nqb > 2 ? 4 : nqb)));      // the smallest group that covers the query blocks
         nchunk = (nqb + nw - 1) / nw;
+        if (!gw && (int64_t)B * H < 128 && nkb >= 2 && (int64_t)B * H * nchunk <= 256 && (nw == 2 || nw == 4)) seg2 = true;
+        if (seg2 && nw != 2 && nw != 4) seg2 = false;                                              // (an explicit 100 + g clipped by nqb)
     }
-    const size_t lds = (size_t)2 * KVSTAGE + (size_t)nkb * KB * sizeof(float) + (size_t)nkb * sizeof(int);
-    if (lds > 160 * 1024) return AFM_E_UNSUPPORTED;           // T <= ~25000 keys
+    // the sequential form parks 8 KB per wave in LDS: long key sequences (cross-attention over N points) take fewer waves per workgroup
+    while (!seg2 && split_mha_lds(nkb, nw, false) > lds_cap && nw > 1) nw = nw > 8 ? 8 : (nw > 6 ? 6 : (nw > 4 ? 4 : nw / 2));
+    if (group_waves >= 0) nchunk = (nqb + nw - 1) / nw;
+    const size_t lds = split_mha_lds(nkb, nw, seg2);
+    if (lds > lds_cap) return AFM_E_UNSUPPORTED;
     AfmProf prof(AFM_PROF_MHA_SPLIT, 4.0 * B * H * (double)Tq * T * dh, s);
-    switch (nw) {
-        case 1: return launch_split_mha<1>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
-        case 2: return launch_split_mha<2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
-        case 4: return launch_split_mha<4>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
-        case 6: return launch_split_mha<6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
-        case 8: return launch_split_mha<8>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
-        default: return launch_split_mha<12>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first);
+#define AFM_MHA_GO(NWV, S2) return launch_split_mha<NWV, S2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first)
+    if (seg2) {
+        if (nw == 2) AFM_MHA_GO(2, true);
+        AFM_MHA_GO(4, true);
     }
+    switch (nw) {
+        case 1: AFM_MHA_GO(1, false);
+        case 2: AFM_MHA_GO(2, false);
+        case 4: AFM_MHA_GO(4, false);
+        case 6: AFM_MHA_GO(6, false);
+        case 8: AFM_MHA_GO(8, false);
+        default: AFM_MHA_GO(12, false);
+    }
+#undef AFM_MHA_GO
 }
 
 }  // namespace

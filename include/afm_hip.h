@@ -159,9 +159,11 @@ int afm_linear(const afm_linear_args* args, void* stream);
  */
 int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out,
                 int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
-/* Same with an explicit workgroup shape: group_waves in {1, 2, 4, 8, 12} 32-query waves per workgroup (the grid is
- * (sample, head, query group)); 0 = the library's choice from B*H and T (small batches get small groups so that the
- * launch still fills 256 CUs).  A query row's arithmetic does not depend on the grouping: results are bit-identical. */
+/* Same with an explicit workgroup shape: group_waves in {1, 2, 4, 6, 8, 12} 32-query waves per workgroup (the grid is
+ * (sample, head, query group)), or 100 + {2, 4}: the two key segments of every query block on two waves (workgroups of twice that many
+ * waves - what small launches take: the serial chain of a wave halves); 0 = the library's choice from B*H and T.  The softmax of a
+ * row is computed over two key segments (blocks [0, ceil(nkb / 2)) and the rest) whose states are merged in a fixed operation order, so
+ * a query row's arithmetic does not depend on the grouping: results are bit-identical. */
 int afm_mha_fwd_grouped(const float* qkv, const uint8_t* key_mask, float* out,
                         int32_t B, int32_t T, int32_t H, int32_t dh, int32_t group_waves, void* stream);
 /* Same, for the query rows q_first .. T - 1 of every sample only (all T keys): rows 0 .. q_first - 1 of `out` are not written.  The CMDM's

@@ -348,10 +348,11 @@ def test_mha(B, T, masked):
     report(f"mha B{B} T{T} masked={masked}", got, want, 2e-5)
 
 
-@pytest.mark.parametrize("B,T", [(4, 326), (1, 326), (2, 196), (3, 61)])
+@pytest.mark.parametrize("B,T", [(4, 326), (1, 326), (2, 196), (3, 61), (2, 32), (17, 326), (2, 33)])
 def test_mha_workgroup_groupings_are_bit_identical(B, T):
     """grid = (sample, head, query group): groups of 1 / 2 / 4 / 6 / 8 / 12 waves (and the automatic choice, which depends on B) must give the
-    same bits - a query row's arithmetic never depends on which workgroup it ran in."""
+    same bits - a query row's arithmetic never depends on which workgroup it ran in.  Round 4: nor on whether the two key segments of its
+    softmax ran on one wave (one after the other) or on two (codes 102 / 104: workgroups of 2 x 2 / 2 x 4 waves, the small-launch form)."""
     H, dh = 8, 64
     qkv = synth.gaussian("mha_grp", (B, T, 3 * H * dh)).to(dev())
     mask = torch.zeros(B, T, dtype=torch.bool)
@@ -359,8 +360,8 @@ def test_mha_workgroup_groupings_are_bit_identical(B, T):
         mask[b, T - 1 - 11 * b:] = True
     mask = mask.to(dev())
     for km in (None, mask):
-        outs = [ops.mha(qkv, km, H, group_waves=g) for g in (0, 1, 2, 4, 6, 8, 12)]
-        for g, o in zip((1, 2, 4, 6, 8, 12), outs[1:]):
+        outs = [ops.mha(qkv, km, H, group_waves=g) for g in (0, 1, 2, 4, 6, 8, 12, 102, 104)]
+        for g, o in zip((1, 2, 4, 6, 8, 12, 102, 104), outs[1:]):
             assert torch.equal(o, outs[0]), f"group_waves={g} differs (B={B}, T={T}, masked={km is not None})"
     with pytest.raises(ffi.AfmError):
         ops.mha(qkv, None, H, group_waves=3)
@@ -402,7 +403,7 @@ def test_mha_query_rows_subset_is_bit_identical(B, T, q_first):
     mask = mask.to(dev())
     for km in (None, mask):
         full = ops.mha(qkv, km, H)
-        for g in (0, 1, 2, 4, 6, 8, 12):
+        for g in (0, 1, 2, 4, 6, 8, 12, 102, 104):
             part = ops.mha(qkv, km, H, group_waves=g, q_first=q_first)
             assert torch.equal(part[:, q_first:], full[:, q_first:]), f"q_first={q_first} group_waves={g} masked={km is not None}"
             assert not part[:, :q_first].any()
