@@ -562,7 +562,8 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         return out
 
     # ------------------------------------------------------------------ native sampling loop
-    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False, snapshots=None):
+    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False, snapshots=None,
+                        clip_denoised=False):
         """Whole p_sample_loop of the ADM on the device (afm_cdm_sample_loop): x holds x_T on entry, returns the sample.  ``progress``
         slices the chain (afm_cdm_sample_loop_range) so a tqdm bar can advance, with bit-identical results.  The batch
         runs as `loop_sub_batches` sub-batches on their own stream pairs (see __init__; bit-identical results).  ``snapshots`` =
@@ -597,6 +598,8 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                 step_noise = ffi.f32c(step_noise.to(dev))
                 assert step_noise.shape == (n,) + tuple(x.shape), step_noise.shape
             stream = ffi.stream_of(x)
+            if clip_denoised:
+                w.flags |= ffi.CDM_CLIP_X0                   # per call: the next _weights() rewrites the flags
 
             def enqueue(j0, j1):        # executed steps j0..j1-1 = timestep indices n-j1 .. n-1-j0
                 lo, cnt = n - j1, j1 - j0

@@ -484,8 +484,10 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         return out.view(B, L, self.motion_dim)
 
     # ------------------------------------------------------------------ native sampling loop
-    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False, snapshots=None):
-        """Whole p_sample_loop on the device: x holds x_T on entry, returns the final sample.  ``progress`` (test.py:85 passes
+    def afm_native_loop(self, diffusion, x, model_kwargs, *, step_noise=None, seed=0, sample_index0=0, progress=False, snapshots=None,
+                        clip_denoised=False):
+        """Whole p_sample_loop on the device: x holds x_T on entry, returns the final sample.  ``clip_denoised``: pred_xstart clamped to
+        [-1, 1] inside the fused DDPM update (the reference's default argument; test.py passes False).  ``progress`` (test.py:85 passes
         True) splits the chain into ~50 native slices (afm_cmdm_sample_loop_range) and advances a tqdm bar between them; the
         result is bit-identical to the unsliced loop."""
         if any(k in model_kwargs for k in COND_SWITCHES):
@@ -497,6 +499,8 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             x = ffi.f32c(x)
             B, L, _ = x.shape
             w = self._weights()
+            if clip_denoised:
+                w.flags |= ffi.CMDM_CLIP_X0                  # per call: _stamp() rewrites the flags on the next _weights()
             cond = self.condition_tokens(**model_kwargs)
             fm = model_kwargs["x_mask"].to(device=x.device, dtype=torch.uint8).contiguous() if self.mask_motion else None
             tab = diffusion.tables(x.device)

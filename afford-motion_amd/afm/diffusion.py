@@ -171,7 +171,7 @@ class GaussianDiffusion:
             if denoised_fn is not None:
                 x0 = denoised_fn(x0)
             if clip_denoised:
-                x0 = x0.clamp(-1, 1)
+                x0 = ops.clamp_(x0.clone() if x0 is x else x0, -1.0, 1.0)       # afm_clamp (HIP), in place on the denoiser's own output
             sample = ops.ddpm_step(x0, x, noise, tab.coef1[t], tab.coef2[t], tab.sigma[t], seed=seed,
                                    sample_index0=sample_index0, step=step)
         return {"sample": sample, "pred_xstart": x0}
@@ -209,8 +209,7 @@ class GaussianDiffusion:
         clones of x after those steps (what iterating p_sample_loop_progressive would have shown)."""
         native = getattr(model, "afm_native_loop", None)
         switches = any(k in (model_kwargs or {}) for k in ("c_text_mask", "c_text_erase", "c_pc_mask", "c_pc_erase"))
-        if native is not None and not clip_denoised and denoised_fn is None and cond_fn is None \
-                and not self.rescale_timesteps and not switches:
+        if native is not None and denoised_fn is None and cond_fn is None and not self.rescale_timesteps and not switches:
             if device is None:
                 device = next(model.parameters()).device
             seed = self._fresh_seed("_sample_calls") if seed is None else seed
@@ -219,6 +218,8 @@ class GaussianDiffusion:
             if isinstance(step_noise, (list, tuple)):
                 step_noise = torch.stack(list(step_noise), 0)
             extra = {} if snapshots is None else {"snapshots": snapshots}
+            if clip_denoised:                      # the reference's default: pred_xstart clamped to [-1, 1] inside the fused DDPM update
+                extra["clip_denoised"] = True
             return native(self, x, model_kwargs or {}, step_noise=step_noise, seed=seed, sample_index0=sample_index0,
                           progress=bool(progress), **extra)
         final, done = None, 0

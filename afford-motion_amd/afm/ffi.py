@@ -19,8 +19,8 @@ _lib = None
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
-CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES = 0x1, 0x2, 0x4, 0x8
-CDM_NO_GEN, CDM_CHAIN_SIDE, CDM_DEC_CHUNKS_SHIFT = 0x2, 0x4, 12
+CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES, CMDM_CLIP_X0 = 0x1, 0x2, 0x4, 0x8, 0x10
+CDM_NO_GEN, CDM_CHAIN_SIDE, CDM_DEC_CHUNKS_SHIFT, CDM_CLIP_X0 = 0x2, 0x4, 12, 0x8
 ABI_VERSION = 6
 MAX_LAYERS = 16
 
@@ -56,6 +56,7 @@ class LinearArgs(C.Structure):
         ("res_stat", c_f32p), ("res_gamma", c_f32p), ("res_beta", c_f32p), ("ln_eps2", C.c_float),
         # a hole inside every group of the row remaps (ABI v6)
         ("a_skip_after", i32), ("a_skip", i32), ("c_skip_after", i32), ("c_skip", i32),
+        ("ddpm_clip", i32),
     ]
 
 
@@ -148,6 +149,7 @@ EXPORTS = {
     "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_fwd_grouped": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
+    "afm_clamp": (C.c_int, [c_f32p, i64, C.c_float, C.c_float, C.c_void_p]),
     "afm_mha_fwd_rows": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_cross_fwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, C.c_float, C.c_void_p]),

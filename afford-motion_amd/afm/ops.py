@@ -205,6 +205,14 @@ def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int, group_w
     return out
 
 
+def clamp_(x: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    """In-place clamp of a float32 GPU tensor (afm_clamp): `process_xstart` with clip_denoised=True (gaussian_diffusion.py:289-294)."""
+    ffi.require_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    ffi.check(ffi.load().afm_clamp(x.data_ptr(), x.numel(), float(lo), float(hi), ffi.stream_of(x)), "afm_clamp")
+    return x
+
+
 def mha_cross(q: torch.Tensor, kv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
     """q [B, Tq, d], kv [B, Tk, 2*d] (packed k | v), key_mask [B, Tk] (True = ignore) -> [B, Tq, d]."""
     lib = ffi.load()

@@ -308,13 +308,19 @@ void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* _
     // blk_valid[kb]: bit 0 = the block has a valid key, bit 1 = it has a masked key, bit 2 = it has a valid key among its keys 16 .. 31
     // (blocks without bit 0 are skipped, blocks without bit 1 skip the mask addition, blocks without bit 2 - the ragged tail of T = 326:
     // 6 keys - skip the second K16 step of P V, whose probabilities are exact zeros); written with atomic ORs by whichever threads see such a key
-    for (int i = tid; i < nkb; i += NT) blk_valid[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < nkb * KB; i += NT) {
-        const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
-        madd[i] = ok ? 0.0f : NEG_INF;
-        atomicOr(&blk_valid[i / KB], ok ? (1 | ((i & 16) ? 4 : 0)) : 2);
-    }
+    auto setup_mask = [&]() {
+        for (int i = tid; i < nkb; i += NT) blk_valid[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < nkb * KB; i += NT) {
+            const bool ok = (i < T) && !(key_mask && key_mask[(int64_t)b * T + i]);
+            madd[i] = ok ? 0.0f : NEG_INF;
+            atomicOr(&blk_valid[i / KB], ok ? (1 | ((i & 16) ? 4 : 0)) : 2);
+        }
+    };
+    // small groups request their first K / V block BEFORE the mask is built (the mask bytes are a memory round trip of their own - the
+    // key mask was written by the step's prologue on another XCD - and a small launch has nothing else in flight to hide it behind:
+    // ~1.5 us at the head of every launch, profiles/r04_mha_timeline_small.txt); the 168-register forms cannot afford the live range
+    if (NW > 4) setup_mask();
 
     // Staging items (all loads unconditional, rows past the last key clamped to key T-1: those keys carry an additive -inf):
     //   item i < 128  (K): float4 c4 = i & 15 of keys (i >> 4) + 8 q, q = 0..3  -> per load instruction 4 key rows x 256 contiguous bytes
@@ -379,10 +385,12 @@ void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* _
     // the blocks this wave walks: SEG2 - its segment's (padded to n0 trips so that both halves meet at every barrier); sequential - all
     const int kb_first = SEG2 ? seg * n0 : 0, ntrip = SEG2 ? n0 : nkb, kb_end = SEG2 ? (seg ? nkb : n0) : nkb;
 
+    bool first_pass = true;
     for (int q0 = chunk * NW; q0 < nqb; q0 += NW * nchunk) {
         const int qb = q0 + wave;
         const bool active = qb < nqb;
-        if (NW <= 4) load_block(kb_first);      // in flight under the Q loads and the Q split (the 168-register variants cannot afford the live range)
+        if (NW <= 4) load_block(kb_first);      // in flight under the mask setup, the Q loads and the Q split (the 168-register variants cannot afford the live range)
+        if (NW <= 4 && first_pass) { setup_mask(); first_pass = false; }
         // Q planes: query row (clamped), K16 step s covers head dims 16 s + 8 hh .. + 7, pre-scaled (1 / sqrt(64) is a power of two)
         u32x4 qpl[4][3];
         {
@@ -625,7 +633,14 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
         nw = gw ? gw : ((int64_t)B * H >= 128 ? 12 : AFM_MHA_DEFAULT_GROUP);
         if (nw > nqb) nw = nqb > 8 ? 12 : (nqb > 6 ? 8 : (nqb > 4 ? 6 : (nqb > 2 ? 4 : nqb)));      // the smallest group that covers the query blocks
         nchunk = (nqb + nw - 1) / nw;
-        if (!gw && (int64_t)B * H < 128 && nkb >= 2 && (int64_t)B * H * nchunk <= 256 && (nw == 2 || nw == 4)) seg2 = true;
+        if (!gw && (int64_t)B * H < 128 && nkb >= 2) {
+            // the two key segments of a query block on two waves: groups of two query blocks (4-wave workgroups, one wave per SIMD) while the
+            // launch still fits the 256 CUs in one round (B = 4: 192 workgroups, 21.9 us against 24.9 for groups of four and 29.2 for round 3's
+            // form in one call, profiles/r04_mha_timeline_small.txt), groups of four query blocks above that
+            const int n2 = (nqb + 1) / 2, n4 = (nqb + 3) / 4;
+            if (nqb >= 2 && (int64_t)B * H * n2 <= 256) { nw = 2; nchunk = n2; seg2 = true; }
+            else if (nqb >= 3 && (int64_t)B * H * n4 <= 256) { nw = 4; nchunk = n4; seg2 = true; }
+        }
         if (seg2 && nw != 2 && nw != 4) seg2 = false;                                              // (an explicit 100 + g clipped by nqb)
     }
     // the sequential form parks 8 KB per wave in LDS: long key sequences (cross-attention over N points) take fewer waves per workgroup

@@ -251,6 +251,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
             }
             a.ddpm_xt = x_t; a.ddpm_noise = nz; a.ddpm_out = ddpm->x_next; a.ldx = w.motion_dim;
             a.ddpm_c1 = ddpm->c1; a.ddpm_c2 = ddpm->c2; a.ddpm_sigma = ddpm->sigma; a.rows_per_sample = L;
+            a.ddpm_clip = (w.flags & AFM_CMDM_CLIP_X0) ? 1 : 0;
         }
         AFM_TRY(run_linear(w, a, s));
     }

@@ -144,6 +144,24 @@ __global__ __launch_bounds__(256) void contact_glue_kernel(const float* __restri
 
 }  // namespace
 
+namespace {
+__global__ void clamp_kernel(float* __restrict__ x, int64_t n, float lo, float hi) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        x[i] = v < lo ? lo : (v > hi ? hi : v);
+    }
+}
+}  // namespace
+
+extern "C" int afm_clamp(float* x, int64_t n, float lo, float hi, void* stream) {
+    if (n == 0) return 0;
+    if (!x || n < 0 || !(lo <= hi)) return AFM_E_BADARG;
+    int64_t g = (n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, lo, hi);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int afm_bn_fold(const float* w, const float* b, const float* mean, const float* var, float eps, const float* lin_bias, float* scale,
                            float* shift, int32_t C, void* stream) {
     if (C == 0) return 0;

@@ -408,6 +408,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
             a.ddpm_out || a.rowtab || a.preact || a.dact_z || a.drop_p > 0.0f)
             return AFM_E_BADARG;
     }
+    if (a.ddpm_clip && !a.ddpm_out) return AFM_E_BADARG;
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;

@@ -213,7 +213,8 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             const int grow = bm * BM + row, gcol = col0 + c;
             if (grow >= p.M || gcol >= p.N) continue;
             const int64_t orow = cmap(grow);
-            const float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol, rowst, row, BM);
+            float v = epilogue(p, lds[row * LDC + c], grow, orow, gcol, rowst, row, BM);
+            if (p.ddpm_clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);          // clip_denoised (NaN passes through, as torch.clamp)
             if (p.C && p.ln_out) __hip_atomic_store(p.C + orow * p.ldc + gcol, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1), scalar form
             else if (p.C) p.C[orow * p.ldc + gcol] = v;
             if (p.ddpm_out) {

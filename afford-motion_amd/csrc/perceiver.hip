@@ -299,6 +299,7 @@ static int cdm_forward_impl(const afm_cdm_weights* wp, const float* feat, const 
     if (ddpm) {
         a.ddpm_xt = x_t; a.ddpm_noise = ddpm->noise; a.ddpm_out = ddpm->x_next; a.ldx = w.contact_dim;
         a.ddpm_c1 = ddpm->c1; a.ddpm_c2 = ddpm->c2; a.ddpm_sigma = ddpm->sigma; a.rows_per_sample = N;
+        a.ddpm_clip = (w.flags & AFM_CDM_CLIP_X0) ? 1 : 0;
     }
     a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     AFM_TRY(afm_linear(&a, s));

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * RowLess<NKS>::NW, NKS <= 4 ? 2 : 1)
 void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab, const float* __restrict__ qdd, const float* __restrict__ twx,
                       const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe, const float* __restrict__ c0, int N, int cd,
                       const float* xt, const float* __restrict__ feat, int fd, float* __restrict__ x0_out, const float* __restrict__ noise, float* x_next,
-                      const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma) {
+                      const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ sigma, int clip) {
     using RL = RowLess<NKS>;
     constexpr int K = RL::K, NT = RL::NT, LDQ = RL::LDQ, XS = RL::XS, NSTEP = RL::NSTEP, NW = RL::NW, NTH = 64 * NW, QEW = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) float dp_sm[];
@@ -530,7 +530,8 @@ void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ q
                 const int j = 4 * g + r;
                 if (j < cd) {
                     const int64_t i = pt * cd + j;
-                    const float v = sat[r] + c0s[j];
+                    float v = sat[r] + c0s[j];
+                    if (clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);      // clip_denoised
                     if (x0_out) x0_out[i] = v;
                     if (x_next) x_next[i] = (c1[b] * v + c2[b] * xt[i]) + sigma[b] * noise[i];
                 }
@@ -611,7 +612,8 @@ int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, 
     if (chunks > (N + 15) / 16) chunks = (N + 15) / 16;
     hipLaunchKernelGGL(dec_point_kernel<NKS>, dim3(chunks, B), dim3(64 * RowLess<NKS>::NW), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
-                       ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr);
+                       ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr,
+                       (ddpm && (w.flags & AFM_CDM_CLIP_X0)) ? 1 : 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }

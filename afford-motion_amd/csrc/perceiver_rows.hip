@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
                                                          const float* __restrict__ c0, int cd, int64_t rows, int rows_per_sample,
                                                          float* __restrict__ x0_out, const float* xt, const float* __restrict__ noise,
                                                          float* x_next, const float* __restrict__ c1, const float* __restrict__ c2,
-                                                         const float* __restrict__ sigma) {
+                                                         const float* __restrict__ sigma, int clip) {
     const int rpb = 256 / cd;                                     // rows per block and trip
     const int lr = threadIdx.x / cd, j = threadIdx.x - lr * cd;
     const bool act = lr < rpb;
@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256) void cdm_output_kernel(const float* __restrict
         }
         __syncthreads();                                                            // every read of this block's rows of x_t is done
         if (ok) {
+            if (clip) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);               // clip_denoised
             if (x0_out) x0_out[i] = v;
             if (x_next) {
                 const int b = (int)(r / rows_per_sample);
@@ -548,7 +549,7 @@ int launch_cdm_output(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, c
     int64_t g = ((int64_t)M + rpb - 1) / rpb; if (g > 8192) g = 8192;
     hipLaunchKernelGGL(cdm_output_kernel, dim3((unsigned)g), dim3(256), 0, s, ws.rdot, w.dkv / 64, ws.s1, ws.qe, w.fold_q, w.fold_c0, cd, (int64_t)M, N, x0_out, x_t,
                        ddpm ? ddpm->noise : nullptr, ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr,
-                       ddpm ? ddpm->sigma : nullptr);
+                       ddpm ? ddpm->sigma : nullptr, (ddpm && (w.flags & AFM_CDM_CLIP_X0)) ? 1 : 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }

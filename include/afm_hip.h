@@ -134,6 +134,9 @@ typedef struct {
      * One launch then covers the time token AND the L motion tokens of every sample while skipping the n_cond step-invariant condition
      * tokens between them (layer 0's in_proj of the sampling loop: a_grp = 1 + L, a_stride = T, a_skip_after = 1, a_skip = n_cond). */
     int32_t a_skip_after, a_skip, c_skip_after, c_skip;
+    /* ---- clip_denoised (ABI v6; with ddpm_out only): the epilogue's value (pred_xstart) is clamped to [-1, 1] before it is stored to C
+     * and enters the DDPM update - `process_xstart` of gaussian_diffusion.py:289-294 with clip_denoised=True, the reference's default. */
+    int32_t ddpm_clip;
 } afm_linear_args;
 
 #define AFM_ARITH_DEFAULT 0
@@ -200,6 +203,10 @@ int afm_ddpm_step(const float* x0, const float* x_t, const float* noise, float* 
                   const float* c1, const float* c2, const float* sigma,
                   int32_t B, int64_t per_sample, uint64_t seed, int64_t sample_index0,
                   int32_t step, void* stream);
+
+/* afm_clamp: x <- min(max(x, lo), hi) in place (NaN propagates, as torch.clamp): `process_xstart` with clip_denoised=True on the
+ * step-by-step path (gaussian_diffusion.py:289-294).  ABI v6. */
+int afm_clamp(float* x, int64_t n, float lo, float hi, void* stream);
 
 /* afm_randn: standalone Philox normal generator with the same keying as afm_ddpm_step
  * (replaces th.randn / th.randn_like, gaussian_diffusion.py:431,514). */
@@ -462,6 +469,7 @@ typedef struct {
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
 #define AFM_CMDM_NO_LN_FOLD  0x4           /* measurement: separate afm_layernorm launches although the folded tensors are present */
 #define AFM_CMDM_WIDE_TILE_SHIFT 8        /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the encoder GEMMs with N >= 512 and M >= 2048 (bit-neutral) */
+#define AFM_CMDM_CLIP_X0     0x10          /* clip_denoised=True (gaussian_diffusion.py:289-294): pred_xstart clamped to [-1, 1] inside the fused DDPM update */
 #define AFM_CMDM_ALL_QUERIES 0x8           /* measurement: the last layer's attention computes all T query rows (bit-identical on the rows that are read) */
 #define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */
 
@@ -610,6 +618,7 @@ typedef struct {
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
 #define AFM_CDM_CHAIN_SIDE     0x4     /* row-less form with sub-batch streams: the 2-latent chain (lat_head .. lat_dectables) of a sub-batch runs on its SIDE stream (fork / join by events), so that it can sit on CUs of its own (a CU-masked stream) under the other sub-batch's point kernels; bit-identical */
 #define AFM_CDM_DEC_CHUNKS_SHIFT 12    /* bits 12..17: workgroups per sample of enc_point's successor dec_point_kernel (0 = 16); a tuning knob, bit-identical (a point's arithmetic does not depend on its chunk) */
+#define AFM_CDM_CLIP_X0        0x8     /* clip_denoised=True: pred_xstart clamped to [-1, 1] inside the fused DDPM update of every sampling form */
 #define AFM_CDM_NO_GEN         0x2     /* measurement: round 2's folded form (step-invariant adapter parts materialised, per-point rows) although the row-less tables are present */
 
 int64_t afm_cdm_workspace_bytes(const afm_cdm_weights* w, int32_t B, int32_t N);

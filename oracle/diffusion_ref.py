@@ -93,13 +93,15 @@ def q_sample(s: Schedule, x_start, t, noise):
             + _extract(s.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
 
 
-def p_sample(s: Schedule, model: Callable, x, t, noise, model_kwargs: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
-    """gaussian_diffusion.py:233-327 (FIXED_SMALL / START_X / no clip) + :396-440.
+def p_sample(s: Schedule, model: Callable, x, t, noise, model_kwargs: Optional[Dict] = None, clip_denoised: bool = False) -> Dict[str, torch.Tensor]:
+    """gaussian_diffusion.py:233-327 (FIXED_SMALL / START_X; clip_denoised = `process_xstart` :289-294) + :396-440.
 
     ``model(x, mapped_t, **kw)`` sees the ORIGINAL timestep (respace.py:124-129)."""
     model_kwargs = model_kwargs or {}
     tmap = torch.tensor(s.timestep_map, dtype=t.dtype)
     x0 = model(x, tmap[t], **model_kwargs)
+    if clip_denoised:
+        x0 = x0.clamp(-1, 1)
     mean = _extract(s.posterior_mean_coef1, t, x.shape) * x0 + _extract(s.posterior_mean_coef2, t, x.shape) * x
     logvar = _extract(s.posterior_log_variance_clipped, t, x.shape)
     nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
@@ -108,14 +110,14 @@ def p_sample(s: Schedule, model: Callable, x, t, noise, model_kwargs: Optional[D
 
 
 def p_sample_loop(s: Schedule, model: Callable, x_T, step_noise: Sequence[torch.Tensor],
-                  model_kwargs: Optional[Dict] = None):
+                  model_kwargs: Optional[Dict] = None, clip_denoised: bool = False):
     """gaussian_diffusion.py:442-536 with the per-step `randn_like` draws made explicit:
     ``step_noise[j]`` is the noise of the j-th executed step (t = T-1-j)."""
     img = x_T
     with torch.no_grad():
         for j, i in enumerate(range(s.num_timesteps - 1, -1, -1)):
             t = torch.tensor([i] * x_T.shape[0])
-            img = p_sample(s, model, img, t, step_noise[j], model_kwargs)["sample"]
+            img = p_sample(s, model, img, t, step_noise[j], model_kwargs, clip_denoised)["sample"]
     return img
 
 

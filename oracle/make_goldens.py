@@ -199,6 +199,12 @@ def main():
         with recorded_randn_like(nz):
             s = d.p_sample_loop(model, (B, L, 263), noise=xT, clip_denoised=False, model_kwargs=kw, progress=False)
         save(f"cmdm_loop_{tag}", sample=s)     # inputs are regenerated by name; only the output is stored
+        if tag == "r5":
+            # the reference's DEFAULT argument clip_denoised=True (gaussian_diffusion.py:442-449, process_xstart :289-294): same noise, x_T
+            # doubled so that the clamp is live on most elements
+            with recorded_randn_like(nz):
+                s = d.p_sample_loop(model, (B, L, 263), noise=2.0 * xT, model_kwargs=kw, progress=False)
+            save("cmdm_loop_r5_clip", sample=s)
 
     # (iv) training losses (eval mode: dropout off)
     x0 = synth.gaussian("train_x0", (B, L, 263))

@@ -464,6 +464,29 @@ def test_last_layer_attention_on_the_motion_queries_only_is_bit_neutral():
         assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1]), f"B={B}, L={L}"
 
 
+def test_clip_denoised_native_loop_matches_the_step_by_step_path(cmdm):
+    """`clip_denoised=True` is the reference's DEFAULT argument of p_sample_loop (gaussian_diffusion.py:442-449; test.py passes False): the native
+    loop clamps pred_xstart to [-1, 1] inside the fused DDPM update (ABI v6).  Against the REFERENCE's own loop (golden `cmdm_loop_r5_clip`:
+    default arguments, recorded noise) and against the step-by-step composition (model -> afm_clamp -> DDPM update kernel)."""
+    model, _ = cmdm
+    g = golden("cmdm_forward_N1024_L16")
+    diff = create_gaussian_diffusion(cmdm_cfg(respacing="5"))
+    B, L = 2, 16
+    kw = _kw(g)
+    x_T = 2.0 * synth.gaussian("loop_r5_xT", (B, L, 263))
+    nz = [synth.gaussian(f"loop_r5_{j}", (B, L, 263)) for j in range(5)]
+    native = diff.p_sample_loop(model, (B, L, 263), noise=x_T.to(dev()), model_kwargs=kw, step_noise=torch.stack(nz).to(dev()))          # default: clip on
+    report("clip_denoised=True (default): native loop vs reference", native, golden("cmdm_loop_r5_clip")["sample"], 1e-3)
+    steps = None
+    for out in diff.p_sample_loop_progressive(model, (B, L, 263), noise=x_T.to(dev()), clip_denoised=True, model_kwargs=kw,
+                                              step_noise=[z.to(dev()) for z in nz]):
+        steps = out
+    report("clip_denoised: native loop vs step-by-step", native, steps["sample"], 2e-5)
+    assert steps["pred_xstart"].abs().max().item() <= 1.0
+    unclipped = diff.p_sample_loop(model, (B, L, 263), noise=x_T.to(dev()), clip_denoised=False, model_kwargs=kw, step_noise=torch.stack(nz).to(dev()))
+    assert (unclipped - native).abs().max().item() > 1e-2           # the clamp is live on this input
+
+
 def test_two_stream_loop_soak():
     """Round 3: 50 two-stream 100-step loops of the headline CMDM shape (B = 32, L = 196, N = 8192) against the
     single-stream result, bit for bit - the harness that caught round 2's lat_decfold defect (profiles/r02_decfold_nondeterminism.md)."""
