@@ -50,6 +50,34 @@ def test_loop_vs_reference_golden(cdm):
     report("CDM 4-step loop vs reference", out, golden("cdm_loop_r4")["sample"], 1e-3)
 
 
+def test_clip_denoised_in_every_sampling_form(cdm):
+    """clip_denoised=True (the reference's default argument): the clamp of pred_xstart rides inside the fused DDPM update of the row-less,
+    the folded-rows and the layer-by-layer form; each native loop against the step-by-step composition (model -> afm_clamp -> DDPM kernel)
+    on the same recorded noise, and the three forms against each other."""
+    g = golden("cdm_forward_N256")
+    diff = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="4"))
+    nz = torch.stack([synth.gaussian(f"cdm_loop_{j}", (2, 256, 6)) for j in range(diff.num_timesteps)]).to(dev())
+    xT = 2.0 * synth.gaussian("cdm_loop_xT", (2, 256, 6)).to(dev())
+    kw = dict(c_text_feat=g["text_feat"].to(dev()), c_pc_xyz=g["xyz"].to(dev()))
+    outs = {}
+    try:
+        for form, attrs in (("row-less", {}), ("folded rows", dict(no_gen=True)), ("layer by layer", dict(no_fold=True))):
+            for k, v in attrs.items():
+                setattr(cdm, k, v)
+            outs[form] = diff.p_sample_loop(cdm, (2, 256, 6), noise=xT, model_kwargs=kw, step_noise=nz).clone()        # default: clip on
+            cdm.no_gen = cdm.no_fold = False
+    finally:
+        cdm.no_gen = cdm.no_fold = False
+    step = None
+    for out in diff.p_sample_loop_progressive(cdm, (2, 256, 6), noise=xT, clip_denoised=True, model_kwargs=kw, step_noise=list(nz)):
+        step = out
+    assert step["pred_xstart"].abs().max().item() <= 1.0
+    for form, o in outs.items():
+        report(f"CDM clip_denoised, {form}: native loop vs step-by-step", o, step["sample"], 5e-5)
+    unclipped = diff.p_sample_loop(cdm, (2, 256, 6), noise=xT, clip_denoised=False, model_kwargs=kw, step_noise=nz)
+    assert (unclipped - outs["row-less"]).abs().max().item() > 1e-2
+
+
 def test_forward_with_point_features_vs_reference_golden():
     g, g2 = golden("cdm_forward_N256"), golden("cdm_forward_feat32")
     m = create_model(cdm_cfg(point_feats=True), device=dev())
