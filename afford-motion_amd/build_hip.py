@@ -22,6 +22,11 @@ OBJ = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-Werror=pass-failed",          # a failed `#pragma unroll` demotes register arrays to scratch
          "-Rpass-analysis=kernel-resource-usage"]
+# Round 4 narrowed the defect to ONE instruction property (tools/probes/pk_repro.hip, profiles/r04_packed_f32_repro.md): a v_pk_{mul,add,fma}_f32
+# whose op_sel routes a source's HIGH half into the LOW result computes that low result wrong in lanes 48..63 whenever another wave on the
+# chip interleaves MFMAs with v_accvgpr_read / v_accvgpr_write (what every GEMM kernel of this library does) - reproduced as a single
+# instruction in a loop; op_sel_hi variants and op_sel-free packed ops are exact.  hipcc picks the operand selection, so the WHOLE class
+# stays fenced:
 # Packed-f32 VALU instructions (v_pk_mul / v_pk_fma / v_pk_add _f32) are NOT selected: kernels using them gave wrong results in lanes
 # 48..63 of single waves whenever a second stream had kernels in flight on the chip - round 2's lat_decfold (hi half of an SGPR-pair
 # operand read as 0) and round 3's statistics-carrying GEMM epilogue (low halves of VGPR pairs wrong: rows 3 mod 4 x even columns), the
@@ -66,6 +71,10 @@ def scan_disassembly(text, window=ISA_SCAN_WINDOW):
                 mm = re.search(k + r":\[([0-9,]+)\]", rest)
                 if mm:
                     sel[k] = [int(x) for x in mm.group(1).split(",")]
+            if sel["op_sel"] and any(sel["op_sel"]):
+                # round 4 (profiles/r04_packed_f32_repro.md): THE failing form - a source's HIGH half feeding the LOW result - reproduced as one
+                # instruction in a loop: wrong low results in lanes 48..63 while a co-resident wave interleaves MFMAs with v_accvgpr moves
+                note = "(packed-f32 with op_sel: a source's high half feeds the low result - the form that fails in lanes 48..63, round 4)"
             srcs = re.split(r",\s*", _MOD.sub("", rest.strip()))[1:]
             hi_pairs = []
             for si, tok in enumerate(srcs):

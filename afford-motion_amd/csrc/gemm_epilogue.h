@@ -4,6 +4,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef AFM_PK_PROBE        // instrumentation of the packed-f32 defect hunt (tools/probes/build_packed.sh builds probe libraries; never in the product)
+#define AFM_PK_PROBE 0
+#endif
+
 namespace {
 
 struct RowMap {
@@ -170,11 +174,51 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
                     if (p.res_stat) {
                         const float mu = rowst[2 * (BM + row)], rs = rowst[2 * (BM + row) + 1];
                         const float4 g = *reinterpret_cast<const float4*>(p.res_gamma + gcol), b = *reinterpret_cast<const float4*>(p.res_beta + gcol);
+#if AFM_PK_PROBE & 1       // (tools/probes/build_packed.sh only) every load of the trip has landed, plus 16 idle cycles, before the packed arithmetic starts
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+#if AFM_PK_PROBE & 4       // the packed arithmetic's inputs pinned in registers of their own (no register reuse between the loads and the packed ops)
+                        asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+#endif
+#if AFM_PK_PROBE & (16 | 32 | 64 | 128)
+                        // the instruction forms themselves, written out (profiles/r04_packed_f32_repro.md): (r - mean) * rstd on the pair {mean, rstd}
+                        //   16  the form hipcc emits and that fails: v_pk_add (mean = low half of src1 for both results), then v_pk_mul with
+                        //       op_sel:[0,1] (rstd = HIGH half of src1 feeding the LOW result)
+                        //   32  the same with four idle cycles between the adds and the multiplies
+                        //   64  the commuted form of the passing build: the pair as src0, op_sel:[1,0]
+                        //  128  no op_sel at all: rstd replicated into a register pair of its own
+                        {
+                            typedef float pk2 __attribute__((ext_vector_type(2)));
+                            pk2 t01 = {t.x, t.y}, t23 = {t.z, t.w};
+                            const pk2 ms = {mu, rs}, rr = {rs, rs};
+#if AFM_PK_PROBE & 16
+                            asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                                         "v_pk_mul_f32 %0, %0, %2 op_sel:[0,1]\n\tv_pk_mul_f32 %1, %1, %2 op_sel:[0,1]" : "+v"(t01), "+v"(t23) : "v"(ms), "v"(rr));
+#elif AFM_PK_PROBE & 32
+                            asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 3\n\t"
+                                         "v_pk_mul_f32 %0, %0, %2 op_sel:[0,1]\n\tv_pk_mul_f32 %1, %1, %2 op_sel:[0,1]" : "+v"(t01), "+v"(t23) : "v"(ms), "v"(rr));
+#elif AFM_PK_PROBE & 64
+                            asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                                         "v_pk_mul_f32 %0, %2, %0 op_sel:[1,0]\n\tv_pk_mul_f32 %1, %2, %1 op_sel:[1,0]" : "+v"(t01), "+v"(t23) : "v"(ms), "v"(rr));
+#else
+                            asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                                         "v_pk_mul_f32 %0, %0, %3\n\tv_pk_mul_f32 %1, %1, %3" : "+v"(t01), "+v"(t23) : "v"(ms), "v"(rr));
+#endif
+                            t.x = t01.x * g.x + b.x; t.y = t01.y * g.y + b.y; t.z = t23.x * g.z + b.z; t.w = t23.y * g.w + b.w;
+                        }
+#else
                         t.x = (t.x - mu) * rs * g.x + b.x; t.y = (t.y - mu) * rs * g.y + b.y; t.z = (t.z - mu) * rs * g.z + b.z; t.w = (t.w - mu) * rs * g.w + b.w;
+#endif
+#if AFM_PK_PROBE & 8       // 16 idle cycles BEHIND the packed arithmetic: nothing may overwrite its source registers while it is still reading them
+                        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+#endif
                     }
                     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
                 }
                 *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
+#if AFM_PK_PROBE & 2       // the trip's stores drained and no load of the NEXT trip issued before this point
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             }
             if (p.stat_out) {                       // uniform
                 float sm = (v.x + v.y) + (v.z + v.w);
