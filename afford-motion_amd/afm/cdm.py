@@ -581,7 +581,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             tq0, tu, tcu = self._text_latent(w, model_kwargs, dev)
             tab = diffusion.tables(dev)
             n = diffusion.num_timesteps
-            sched = torch.empty(lib.afm_cmdm_sched_scratch_bytes(n, B), dtype=torch.uint8, device=dev)
+            sched = ffi.sched_scratch(self, n, B, dev)
             nsub = int(self.loop_sub_batches) or 1
             nsub = max(1, min(nsub, B))
             need = 2 * nsub if nsub > 1 else (1 if self.overlap_streams else 0)

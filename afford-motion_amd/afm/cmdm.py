@@ -505,7 +505,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             fm = model_kwargs["x_mask"].to(device=x.device, dtype=torch.uint8).contiguous() if self.mask_motion else None
             tab = diffusion.tables(x.device)
             n = diffusion.num_timesteps
-            sched = torch.empty(lib.afm_cmdm_sched_scratch_bytes(n, B), dtype=torch.uint8, device=x.device)
+            sched = ffi.sched_scratch(self, n, B, x.device)
             # sub-batch streams fill the wave-quantisation tails of B >= 16 launches; below that every launch is latency-bound and a
             # second stream only adds launches (B = 4: 1311 steps/s on one stream vs 1159 on two, profiles/r02_small_batch.md)
             nsub = max(1, min(int(self.loop_streams), B // 8 if self.loop_streams_auto else B))

@@ -266,6 +266,24 @@ def stream_of(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def sched_scratch(owner, n_steps: int, batch: int, device) -> torch.Tensor:
+    """The expanded-schedule scratch of a native sampling loop (afm_cmdm_sched_scratch_bytes), kept on `owner` (the model) across calls and
+    grown geometrically from 1 MiB (1000 steps x 32 samples need 0.64 MB): a loop call allocates NOTHING after the first one, whatever its
+    step count - a fresh device allocation inside a short loop call costs tens of milliseconds (tools/probe_k20_first.py: the first 20-step
+    call 100 ms instead of 46).  Calls are stream-ordered, so the next call's expand kernel cannot overtake the previous call's readers."""
+    need = int(load().afm_cmdm_sched_scratch_bytes(n_steps, batch))
+    if need < 0:
+        check(need, "afm_cmdm_sched_scratch_bytes")
+    cache = owner.__dict__.setdefault("_afm_sched", {})
+    buf = cache.get(str(device))
+    if buf is None or buf.numel() < need:
+        size = 1 << 20
+        while size < need:
+            size *= 2
+        buf = cache[str(device)] = torch.empty(size, dtype=torch.uint8, device=device)
+    return buf
+
+
 _HIP_RT = None
 
 
