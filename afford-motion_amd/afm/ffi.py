@@ -19,7 +19,7 @@ _lib = None
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
-CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES, CMDM_CLIP_X0 = 0x1, 0x2, 0x4, 0x8, 0x10
+CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES, CMDM_CLIP_X0, CMDM_NO_RIDERS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 CDM_NO_GEN, CDM_CHAIN_SIDE, CDM_DEC_CHUNKS_SHIFT, CDM_CLIP_X0 = 0x2, 0x4, 12, 0x8
 ABI_VERSION = 6
 MAX_LAYERS = 16
@@ -57,6 +57,9 @@ class LinearArgs(C.Structure):
         # a hole inside every group of the row remaps (ABI v6)
         ("a_skip_after", i32), ("a_skip", i32), ("c_skip_after", i32), ("c_skip", i32),
         ("ddpm_clip", i32),
+        ("ddpm_out2", c_f32p), ("ldx2", i64),
+        ("aux_src", c_f32p), ("aux_idx", C.c_void_p), ("aux_add", c_f32p), ("aux_dst", c_f32p), ("aux_dst_ld", i64),
+        ("aux_rows", i32), ("aux_cols", i32), ("aux_idx_max", i32),
     ]
 
 

@@ -409,6 +409,9 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
             return AFM_E_BADARG;
     }
     if (a.ddpm_clip && !a.ddpm_out) return AFM_E_BADARG;
+    if (a.ddpm_out2 && (!a.ddpm_out || a.ldx2 < a.N)) return AFM_E_BADARG;
+    if (a.aux_dst && (!a.aux_src || a.aux_rows <= 0 || a.aux_cols <= 0 || a.aux_idx_max <= 0 || a.aux_dst_ld < a.aux_cols ||
+                      a.aux_rows > (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128))) return AFM_E_BADARG;      // (one rider row per workgroup of the coarsest tiling)
     if (a.ddpm_out && (!a.ddpm_xt || !a.ddpm_noise || !a.ddpm_c1 || !a.ddpm_c2 || !a.ddpm_sigma || a.rows_per_sample <= 0))
         return AFM_E_BADARG;
     if (a.rowtab && a.rowtab_period <= 0) return AFM_E_BADARG;
@@ -440,7 +443,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                      (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
     if (const int mode = afm_linear_split_mode(a)) return afm_linear_split(a, mode, s);
-    if (lnfold) return AFM_E_UNSUPPORTED;         // the native kernels do not carry the row statistics
+    if (lnfold || a.aux_dst) return AFM_E_UNSUPPORTED;         // the native kernels carry neither the row statistics nor the riders
     // Native f32 MFMA.  Tile choice (measured on MI355X, profiles/r01_gemm_investigation.md): with the 64-cycle f32 MFMA neither LDS
     // nor L2 bandwidth limits; what limits is keeping every SIMD's matrix pipe busy across the barrier / load phases of its waves
     // and filling 256 CUs.  64x64 tiles (4 workgroups = 4 waves per SIMD, fine-grained tails) beat 64x128 and 128x128 on every

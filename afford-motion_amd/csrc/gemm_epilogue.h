@@ -264,7 +264,9 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             if (p.ddpm_out) {
                 const int b = grow / p.rows_per_sample;
                 const int64_t ix = orow * p.ldx + gcol;
-                p.ddpm_out[ix] = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
+                const float xn = (p.ddpm_c1[b] * v + p.ddpm_c2[b] * p.ddpm_xt[ix]) + p.ddpm_sigma[b] * p.ddpm_noise[ix];
+                p.ddpm_out[ix] = xn;
+                if (p.ddpm_out2) p.ddpm_out2[orow * p.ldx2 + gcol] = xn;          // the next step's K-padded copy of x_t
             }
         }
     }

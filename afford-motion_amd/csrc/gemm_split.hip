@@ -274,6 +274,13 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     if (ENT > 256) gemm_epilogue<BM, BN, ENT>(p, ldsf, bm, bn, (int)threadIdx.x, rowst);
     else if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid, rowst);
     gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(ldsf));
+    if (p.aux_dst && (int)blockIdx.x < p.aux_rows) {          // rider: one row copy (+ add) per workgroup, behind its own tile
+        const int r = blockIdx.x;
+        int64_t ix = p.aux_idx ? p.aux_idx[r] : r;
+        ix = ix < 0 ? 0 : (ix >= p.aux_idx_max ? p.aux_idx_max - 1 : ix);
+        for (int c = threadIdx.x; c < p.aux_cols; c += blockDim.x)
+            p.aux_dst[(int64_t)r * p.aux_dst_ld + c] = p.aux_src[ix * p.aux_cols + c] + (p.aux_add ? p.aux_add[c] : 0.0f);
+    }
 #ifdef AFM_TIMELINE
     if (afm_timeline && threadIdx.x == 0) {
         unsigned hw, xcc;

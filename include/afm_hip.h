@@ -137,6 +137,16 @@ typedef struct {
     /* ---- clip_denoised (ABI v6; with ddpm_out only): the epilogue's value (pred_xstart) is clamped to [-1, 1] before it is stored to C
      * and enters the DDPM update - `process_xstart` of gaussian_diffusion.py:289-294 with clip_denoised=True, the reference's default. */
     int32_t ddpm_clip;
+    /* ---- riders of the sampling loop's first and last launch of a step (ABI v6; NULL = off; bf16-split kernels only): what used to be a
+     * launch of its own per step (prologue_kernel: ~8 us of a 430 us step at one sample per GPU).
+     *   ddpm_out2 / ldx2   a second copy of the DDPM update's x_next with row stride ldx2 >= N (the K-padded copy of x_t the NEXT step's
+     *                      motion adapter reads; its padding columns are zeroed once per loop)
+     *   aux_*              aux_rows rows of aux_cols floats: aux_dst[r * aux_dst_ld + c] = aux_src[clamp(aux_idx[r], 0, aux_idx_max - 1) * aux_cols + c]
+     *                      + aux_add[c]  - the time token of every sample (TimestepEmbedder table row of t[r] + positional row 0), written by the
+     *                      first aux_rows workgroups of the launch behind their own tile. */
+    float* ddpm_out2; int64_t ldx2;
+    const float* aux_src; const int64_t* aux_idx; const float* aux_add; float* aux_dst; int64_t aux_dst_ld;
+    int32_t aux_rows, aux_cols, aux_idx_max;
 } afm_linear_args;
 
 #define AFM_ARITH_DEFAULT 0
@@ -469,6 +479,7 @@ typedef struct {
 #define AFM_CMDM_NO_L0_CACHE 0x1           /* measurement: recompute layer 0's q|k|v rows of the condition tokens every step */
 #define AFM_CMDM_NO_LN_FOLD  0x4           /* measurement: separate afm_layernorm launches although the folded tensors are present */
 #define AFM_CMDM_WIDE_TILE_SHIFT 8        /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the encoder GEMMs with N >= 512 and M >= 2048 (bit-neutral) */
+#define AFM_CMDM_NO_RIDERS   0x20          /* measurement: the per-step prologue launch of round 3 instead of the riders on the first / last GEMM of a step (bit-identical) */
 #define AFM_CMDM_CLIP_X0     0x10          /* clip_denoised=True (gaussian_diffusion.py:289-294): pred_xstart clamped to [-1, 1] inside the fused DDPM update */
 #define AFM_CMDM_ALL_QUERIES 0x8           /* measurement: the last layer's attention computes all T query rows (bit-identical on the rows that are read) */
 #define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */

@@ -462,6 +462,13 @@ def test_last_layer_attention_on_the_motion_queries_only_is_bit_neutral():
         model.all_queries = False
         assert torch.isfinite(outs[False][0]).all()
         assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1]), f"B={B}, L={L}"
+        # round 4: the per-step prologue launch is gone (time tokens and the K-padded x_t ride on the step's first / last GEMM): same bits as
+        # with the launch, also when the chain is cut into slices (progress bar) and continued
+        model.no_riders = True
+        with_launch = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=44).clone()
+        model.no_riders = False
+        sliced = diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=44, snapshots={3: None, 5: None})
+        assert torch.equal(with_launch, outs[False][0]) and torch.equal(sliced, outs[False][0]), f"riders, B={B}, L={L}"
 
 
 def test_clip_denoised_native_loop_matches_the_step_by_step_path(cmdm):
