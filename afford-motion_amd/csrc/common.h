@@ -193,19 +193,25 @@ __device__ __forceinline__ void layernorm_row(const float* __restrict__ xp, cons
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// The same function with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at f32 rounding level): 1 - erf(|z|) = poly(t) exp(-z^2),
-// t = 1 / (1 + 0.3275911 |z|).  For x < 0 the small factor 1 + erf(z) is that product itself (no cancellation).  12 VALU with two
-// transcendentals against ~45 for erff: the fused CDM decoder evaluates 256 of these per point (dec_point_kernel).
+// The same function for the fused CDM decoder, which evaluates 256 of these per point (dec_point_kernel is bound by their VALU issue slots):
+// GELU(x) = max(x, 0) - |x| q / 2 with q = erfc(|x| / sqrt 2) (both signs of x; for x < 0 the small factor 1 + erf is q itself: no cancellation),
+// and q / 2 = 2^P(a), a = min(|x|, 5.5), P the degree-9 least-squares fit of log2(erfc(a / sqrt 2) / 2) at 6000 Chebyshev nodes of [0, 5.5]
+// (beyond 5.5, |x| q / 2 < 1e-7).  ONE transcendental (v_exp_f32, quarter rate) and 12 full-rate instructions: 16 issue slots per element against
+// 19 for round 3's Abramowitz & Stegun 7.1.26 form (reciprocal + exponential), and more accurate: max |error| against float64 over all f32 inputs
+// in [-9, 9] 2.4e-7 (A&S form: 3.3e-7; erff-based gelu_erf: 1.2e-7), evaluated with the f32 operations below (round 4, fit and error
+// scan: numpy / scipy in the build container).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    // GELU(x) = max(x, 0) - |x| q / 2 with q = 1 - erf(|z|) = poly(t) exp(-z^2) (both signs of x; the 1/2 is inside the coefficients)
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float pl = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    pl = __builtin_fmaf(pl, t, 0.5f * 1.421413741f);
-    pl = __builtin_fmaf(pl, t, 0.5f * -0.284496736f);
-    pl = __builtin_fmaf(pl, t, 0.5f * 0.254829592f);
-    const float qh = pl * t * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);      // q / 2;  exp(-z^2) = 2^(-x^2 log2(e) / 2)
-    return __builtin_fmaf(-ax, qh, fmaxf(x, 0.f));
+    const float a = fminf(fabsf(x), 5.5f);
+    float p = __builtin_fmaf(7.329674645e-08f, a, -1.913058668e-06f);
+    p = __builtin_fmaf(p, a, 1.896382855e-05f);
+    p = __builtin_fmaf(p, a, -6.020677392e-05f);
+    p = __builtin_fmaf(p, a, -5.156729021e-04f);
+    p = __builtin_fmaf(p, a, 7.680844516e-03f);
+    p = __builtin_fmaf(p, a, -5.303888768e-02f);
+    p = __builtin_fmaf(p, a, -4.589743018e-01f);
+    p = __builtin_fmaf(p, a, -1.151143670e+00f);
+    p = __builtin_fmaf(p, a, -9.999989867e-01f);
+    return __builtin_fmaf(-fabsf(x), __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
