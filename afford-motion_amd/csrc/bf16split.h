@@ -16,13 +16,38 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
+// x - bf16 half of a packed pair.  Round 4 tried ONE instruction for it - v_dot2c_f32_bf16 (acc + a.lo * b.lo + a.hi * b.hi with b = {-1, 0} /
+// {0, -1}: 7 instead of 11 VALU instructions per pair of floats, and the split is what the K loops are bound by) - and measured it in one call:
+// NOT exact (tests/test_gpu_ops.py::test_linear_shapes fails: the dot unit does not deliver the residual bit for bit) and SLOWER (B = 32:
+// 460 against 468 steps/s, B = 1: 472 against 427 us per step - the instruction is not full rate).  Kept behind AFM_SPLIT_DOT2 for the record;
+// the shipped form is the shift / mask + v_sub pair, whose exactness tests/test_gpu_ops.py::test_split_reconstructs_f32_exactly pins.
+#ifndef AFM_SPLIT_DOT2
+#define AFM_SPLIT_DOT2 0
+#endif
+__device__ __forceinline__ float sub_bf16_lo(float x, uint32_t p) {
+#if AFM_SPLIT_DOT2
+    const bf16x2 m = {(__bf16)-1.0f, (__bf16)0.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), m, x, false);
+#else
+    return x - __uint_as_float(p << 16);
+#endif
+}
+__device__ __forceinline__ float sub_bf16_hi(float x, uint32_t p) {
+#if AFM_SPLIT_DOT2
+    const bf16x2 m = {(__bf16)0.0f, (__bf16)-1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), m, x, false);
+#else
+    return x - __uint_as_float(p & 0xffff0000u);
+#endif
+}
+
 // two f32 -> three packed bf16 pairs; every residual subtraction is exact (|x - bf16(x)| <= half a bf16 ulp of x)
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
     p1 = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    float r0 = sub_bf16_lo(x0, p1), r1 = sub_bf16_hi(x1, p1);
     p2 = cvt_pk_bf16(r0, r1);
-    r0 -= __uint_as_float(p2 << 16);
-    r1 -= __uint_as_float(p2 & 0xffff0000u);
+    r0 = sub_bf16_lo(r0, p2);
+    r1 = sub_bf16_hi(r1, p2);
     p3 = cvt_pk_bf16(r0, r1);
 }
 

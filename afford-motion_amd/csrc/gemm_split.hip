@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
             sp[u][lvl] = pk;
             if (lvl < 2) {
                 if (!(AFM_ABLATE & 2)) {
-                    r0[u] -= __uint_as_float(pk << 16);
-                    r1[u] -= __uint_as_float(pk & 0xffff0000u);
+                    r0[u] = sub_bf16_lo(r0[u], pk);              // (one v_dot2c_f32_bf16 each: bf16split.h)
+                    r1[u] = sub_bf16_hi(r1[u], pk);
                 }
             } else if (c == 1) {
                 unsigned char* d = wbase + dst[i];

@@ -367,6 +367,27 @@ def test_mha_workgroup_groupings_are_bit_identical(B, T):
         ops.mha(qkv, None, H, group_waves=3)
 
 
+def test_split_reconstructs_f32_exactly():
+    """The three-way bf16 split is EXACT: x = x1 + x2 + x3 bit for bit.  A GEMM against the identity returns sum_k A[m][k] I[n][k] = the three
+    terms of A[m][n] (times 1 = the only non-zero term of the identity's split) added in f32, so C == A bit for bit iff every split is exact -
+    for both operand roles (A x I and I x A^T), over values that stress the residual arithmetic (round 4: the residuals come from
+    v_dot2c_f32_bf16): powers of two and their neighbours, numbers one ulp around bf16 rounding ties, tiny and huge magnitudes, both signs."""
+    K = 512
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(768, K, generator=g)
+    edge = torch.tensor([1.0, 1.0 + 2**-7, 1.0 + 2**-8, 1.0 + 2**-8 + 2**-23, 1.0 + 2**-8 - 2**-23, 1.5 - 2**-23, 2.0 - 2**-23, 0.999999, 3.0e-30, 7.0e29, 65504.0,
+                         1.0 + 2**-16, 1.0 + 2**-15 + 2**-23, 255.99998, 0.0, 1.17549435e-38 * 1024])
+    x = base.clone()
+    x[:64] = edge.repeat(64 * K // edge.numel() + 1)[: 64 * K].view(64, K) * torch.where(torch.rand(64, K, generator=g) < 0.5, -1.0, 1.0)
+    x[64:128] *= torch.exp2(torch.randint(-60, 60, (64, K), generator=g).float())
+    x = x.to(dev())
+    eye = torch.eye(K, device=dev())
+    got = ops.linear(x, eye)                                  # A = x (activation role), W = I
+    assert torch.equal(got, x), f"A-side split inexact: {(got != x).sum().item()} elements, max diff {(got - x).abs().max().item():.3e}"
+    got_t = ops.linear(eye, x[:512])                          # A = I, W = x (weight role): C[m][n] = x[n][m]
+    assert torch.equal(got_t, x[:512].t()), f"W-side split inexact: {(got_t != x[:512].t()).sum().item()} elements"
+
+
 def test_linear_row_maps_with_a_hole():
     """ABI v6 (afm_linear_args.a_skip / c_skip): one launch over the time token and the L motion tokens of every sample, skipping the
     n_cond condition tokens between them - layer 0's in_proj of the sampling loop.  Rows are independent: bit-identical to the two
