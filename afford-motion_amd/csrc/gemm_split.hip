@@ -41,6 +41,8 @@ constexpr int KSEG = 256;
 // Energy attribution builds (tools/gpu_power_ablate.sh only, never the library): -DAFM_ABLATE=<bits> removes one ingredient of the K loop at a time -
 // wrong results, same control flow - so that time, clock and board power can be read per ingredient (profiles/r03_power_limit.md).
 //   1 no global loads after the first two K-tiles, 2 no split arithmetic, 4 no LDS stores, 8 operand ds_reads only for the first K-tile, 16 no MFMAs
+//   32 (round 4) the W operand's whole staging path removed after the first two K-tiles - no loads, no split, no LDS stores for the W items: the
+//      upper bound of what weights handed over as ready-made bf16 planes (LDS-DMA, no VGPR / VALU work) could save
 #ifndef AFM_ABLATE
 #define AFM_ABLATE 0
 #endif
@@ -116,7 +118,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
             return;
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) g[S][i] = *reinterpret_cast<const f32x4*>(src[i] + k);
+        for (int i = 0; i < NI; ++i) {
+            if ((AFM_ABLATE & 32) && i >= NA && kt >= 2) { asm volatile("" : "+v"(g[S][i])); continue; }
+            g[S][i] = *reinterpret_cast<const f32x4*>(src[i] + k);
+        }
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         int piece = 0, m = 0;
         auto do_piece = [&](int t) {
             const int u = t / 3, lvl = t % 3, i = u / 2, c = u % 2;
+            if ((AFM_ABLATE & 32) && i >= NA && kt >= 1) return;          // W items: nothing to split, nothing to store
             if (lvl == 0) {
                 r0[u] = g[cur ^ 1][i][2 * c];
                 r1[u] = g[cur ^ 1][i][2 * c + 1];

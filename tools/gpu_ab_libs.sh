@@ -9,7 +9,7 @@ for rep in 1 2; do
   for v in old new; do
     cp tools/ab_libs/libafm_$v.so $L
     for b in ${@:-1 4}; do
-      ( timeout 300 python bench.py --batch $b --steps 300 --warmup 30 --no-cpu-baseline --no-alt-gemm --latency-runs 0 --latency-runs-b1 0 ) > $O/${v}_b${b}_$rep.json 2>&1
+      ( timeout 300 python bench.py --batch $b --steps 300 --warmup 30 --no-secondary --no-cpu-baseline --no-alt-gemm --latency-runs 0 --latency-runs-b1 0 ) > $O/${v}_b${b}_$rep.json 2>&1
       python - <<PY
 import json
 try:
