@@ -43,6 +43,7 @@ constexpr int KSEG = 256;
 //   1 no global loads after the first two K-tiles, 2 no split arithmetic, 4 no LDS stores, 8 operand ds_reads only for the first K-tile, 16 no MFMAs
 //   32 (round 4) the W operand's whole staging path removed after the first two K-tiles - no loads, no split, no LDS stores for the W items: the
 //      upper bound of what weights handed over as ready-made bf16 planes (LDS-DMA, no VGPR / VALU work) could save
+//   64 (round 4) the same for the A operand: the floor of a GEMM whose A rows are already split in LDS (out_proj fused behind the attention)
 #ifndef AFM_ABLATE
 #define AFM_ABLATE 0
 #endif
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if ((AFM_ABLATE & 32) && i >= NA && kt >= 2) { asm volatile("" : "+v"(g[S][i])); continue; }
+            if ((AFM_ABLATE & 64) && i < NA && kt >= 2) { asm volatile("" : "+v"(g[S][i])); continue; }
             g[S][i] = *reinterpret_cast<const f32x4*>(src[i] + k);
         }
     };
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         auto do_piece = [&](int t) {
             const int u = t / 3, lvl = t % 3, i = u / 2, c = u % 2;
             if ((AFM_ABLATE & 32) && i >= NA && kt >= 1) return;          // W items: nothing to split, nothing to store
+            if ((AFM_ABLATE & 64) && i < NA && kt >= 1) return;           // A items likewise (the floor of "A already in LDS": out_proj fused behind attention)
             if (lvl == 0) {
                 r0[u] = g[cur ^ 1][i][2 * c];
                 r1[u] = g[cur ^ 1][i][2 * c + 1];
