@@ -395,6 +395,8 @@ int launch_regs(const afm_linear_args& a, bool vec, hipStream_t s) {       // re
 
 int afm_linear_split_mode(const afm_linear_args& a);                  // gemm_split.hip
 int afm_linear_split(const afm_linear_args& a, int mode, hipStream_t s);
+int afm_linear_thin_mode(const afm_linear_args& a);                   // gemm_thin.hip
+int afm_linear_thin(const afm_linear_args& a, int mode, hipStream_t s);
 
 extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (!args) return AFM_E_BADARG;
@@ -443,6 +445,7 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                      (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
     if (const int mode = afm_linear_split_mode(a)) return afm_linear_split(a, mode, s);
+    if (const int thin = afm_linear_thin_mode(a)) return afm_linear_thin(a, thin, s);       // one side <= 16 wide, flat rows: a stream, not a GEMM
     if (lnfold || a.aux_dst) return AFM_E_UNSUPPORTED;         // the native kernels carry neither the row statistics nor the riders
     // Native f32 MFMA.  Tile choice (measured on MI355X, profiles/r01_gemm_investigation.md): with the 64-cycle f32 MFMA neither LDS
     // nor L2 bandwidth limits; what limits is keeping every SIMD's matrix pipe busy across the barrier / load phases of its waves

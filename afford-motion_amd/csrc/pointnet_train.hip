@@ -81,6 +81,64 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     }
 }
 
+// The same sums with 16-byte lanes for C a power of two (every BatchNorm of the point transformer: 32 .. 512 channels): a thread owns four
+// consecutive columns and every 256 / (C / 4)-th row of the chunk, and the loads of UNR rows are issued before the first is consumed - the
+// scalar kernel above has one 4-byte load per thread in flight and ran at 0.5 - 1.6 TB/s (profiles/r04_train_full_calls_before.txt).
+// Rows are added in ascending order per (column, row lane), the row lanes in a fixed LDS order: deterministic, independent of the launch.
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats4_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int64_t rows, int C,
+                                                        int64_t rows_per_chunk, float* __restrict__ part) {
+    extern __shared__ float red[];                       // [RL][2][C]
+    constexpr int UNR = MODE == 0 ? 4 : 2;
+    const int QW = C >> 2, tx = threadIdx.x % QW, ty = threadIdx.x / QW, RL = 256 / QW;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    // MODE 0: sums are taken about the tensor's first row (shifted-data variance: no E[x^2] - m^2 cancellation)
+    const float4 mu = *reinterpret_cast<const float4*>((MODE == 1 ? mean : a) + tx * 4);
+    const float4 rs = MODE == 1 ? *reinterpret_cast<const float4*>(rstd + tx * 4) : s0;
+    auto add = [&](const float4& av, const float4& xv, const float4& yv) {
+        if (MODE == 0) {
+            const float vx = av.x - mu.x, vy = av.y - mu.y, vz = av.z - mu.z, vw = av.w - mu.w;
+            s0.x += vx; s0.y += vy; s0.z += vz; s0.w += vw;
+            s1.x += vx * vx; s1.y += vy * vy; s1.z += vz * vz; s1.w += vw * vw;
+        } else {
+            float4 g = av;
+            if (y) { g.x = yv.x > 0.0f ? g.x : 0.0f; g.y = yv.y > 0.0f ? g.y : 0.0f; g.z = yv.z > 0.0f ? g.z : 0.0f; g.w = yv.w > 0.0f ? g.w : 0.0f; }
+            s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+            s1.x += g.x * ((xv.x - mu.x) * rs.x); s1.y += g.y * ((xv.y - mu.y) * rs.y);
+            s1.z += g.z * ((xv.z - mu.z) * rs.z); s1.w += g.w * ((xv.w - mu.w) * rs.w);
+        }
+    };
+    int64_t r = r0 + ty;
+    for (; r + (int64_t)(UNR - 1) * RL < r1; r += (int64_t)UNR * RL) {
+        float4 av[UNR], xv[UNR], yv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = (r + (int64_t)u * RL) * C + tx * 4;
+            av[u] = *reinterpret_cast<const float4*>(a + i);
+            if (MODE == 1) { xv[u] = *reinterpret_cast<const float4*>(x + i); if (y) yv[u] = *reinterpret_cast<const float4*>(y + i); }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) add(av[u], xv[u], yv[u]);
+    }
+    for (; r < r1; r += RL) {
+        const int64_t i = r * C + tx * 4;
+        const float4 av = *reinterpret_cast<const float4*>(a + i);
+        float4 xv = av, yv = av;
+        if (MODE == 1) { xv = *reinterpret_cast<const float4*>(x + i); if (y) yv = *reinterpret_cast<const float4*>(y + i); }
+        add(av, xv, yv);
+    }
+    *reinterpret_cast<float4*>(&red[(ty * 2 + 0) * C + tx * 4]) = s0;
+    *reinterpret_cast<float4*>(&red[(ty * 2 + 1) * C + tx * 4]) = s1;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+        float v = 0.f;
+        for (int t = 0; t < RL; ++t) v += red[t * 2 * C + e];
+        part[(int64_t)blockIdx.x * 2 * C + e] = v;
+    }
+}
+
 struct StatPlan { int CW, NC, chunks; int64_t rows_per_chunk; };
 StatPlan stat_plan(int64_t rows, int C) {
     StatPlan p;
@@ -103,8 +161,22 @@ int launch_colstats(const float* a, const float* x, const float* y, const float*
     const StatPlan p = stat_plan(rows, C);
     if (!ws || ws_bytes < (int64_t)p.chunks * 2 * C * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
     float* part = (float*)ws;
-    const size_t lds = (size_t)(256 / p.CW) * 2 * C * sizeof(float);
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, s);
+    const uintptr_t al = (uintptr_t)a | (uintptr_t)x | (uintptr_t)y | (uintptr_t)mean | (uintptr_t)rstd;
+    if (C >= 16 && C <= 512 && (C & (C - 1)) == 0 && (al & 15) == 0) {          // 16-byte lanes (the choice depends on C and alignment only)
+        const int RL = 1024 / C;
+        int64_t ch = (rows + (int64_t)RL * 32 - 1) / ((int64_t)RL * 32);        // >= 32 rows per row lane
+        if (ch > 2048) ch = 2048;
+        if (ch > p.chunks) ch = p.chunks;                                       // (the workspace is sized by stat_plan)
+        if (ch < 1) ch = 1;
+        const int64_t rpc = (rows + ch - 1) / ch;
+        hipLaunchKernelGGL((colstats4_kernel<MODE>), dim3((unsigned)ch), dim3(256), (size_t)RL * 2 * C * sizeof(float), s, a, x, y, mean, rstd, rows, C, rpc, part);
+        AFM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(reduce_cols2_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, part, (int64_t)2 * C, (int)ch, stats, 2 * C);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
+    const size_t lds = (size_t)(256 / p.CW) * 2 * C * sizeof(float);
 #define AFM_CS(NC) hipLaunchKernelGGL((colstats_kernel<MODE, NC>), dim3(p.chunks), dim3(256), lds, s, a, x, y, mean, rstd, rows, C, p.CW, p.rows_per_chunk, part)
     if (p.NC == 1) AFM_CS(1); else if (p.NC == 2) AFM_CS(2); else if (p.NC <= 4) AFM_CS(4); else AFM_CS(8);
 #undef AFM_CS

@@ -154,29 +154,32 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 }
 
 // Few columns, many partial rows: dst[c] (+)= sum_s src[s * stride + c] for c < n_total; columns >= n0 go to dst1[c - n0].
-// Block = 64 columns x 16 partial-row lanes (loads of one thread are independent and unrolled), fixed-order LDS tree.
+// Block = CW columns x 1024 / CW partial-row lanes (loads of one thread are independent and unrolled), fixed-order LDS tree.  CW = 16: the
+// tiny gradients (N * K <= 16: 64 lanes share the partial rows of one column instead of 16).
+template <int CW = 64>
 __global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restrict__ src, int64_t stride, int S, float* __restrict__ dst0,
                                                            float* __restrict__ dst1, int n0, int n_total, int accumulate) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    constexpr int RL = 1024 / CW;
+    __shared__ float red[RL][CW];
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + tx;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < n_total) {
         int s = ty;
-        for (; s + 48 < S; s += 64) {
+        for (; s + 3 * RL < S; s += 4 * RL) {
             a0 += src[(int64_t)s * stride + c];
-            a1 += src[(int64_t)(s + 16) * stride + c];
-            a2 += src[(int64_t)(s + 32) * stride + c];
-            a3 += src[(int64_t)(s + 48) * stride + c];
+            a1 += src[(int64_t)(s + RL) * stride + c];
+            a2 += src[(int64_t)(s + 2 * RL) * stride + c];
+            a3 += src[(int64_t)(s + 3 * RL) * stride + c];
         }
-        for (; s < S; s += 16) a0 += src[(int64_t)s * stride + c];
+        for (; s < S; s += RL) a0 += src[(int64_t)s * stride + c];
     }
     red[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (ty == 0 && c < n_total) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v += red[i][tx];
+        for (int i = 0; i < RL; ++i) v += red[i][tx];
         float* d = c < n0 ? dst0 + c : dst1 + (c - n0);
         *d = accumulate ? *d + v : v;
     }
@@ -262,6 +265,135 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const float* __restri
         const float t = bsum[i] + xor32(bsum[i]);
         if (part_b && hh == 0 && i * 32 + r32 < N) part_b[(int64_t)gw * N + i * 32 + r32] = t;
     }
+}
+
+// The same gradient when dY and X are dense (lddy == N, ldx == K: every point-cloud linear): a block of RB rows of either operand is ONE
+// contiguous array, so it is fetched with full 16-byte lanes whatever N and K are (3, 35, 67 ...: wgrad_skinny_kernel above loads a row of
+// three floats as a 24-byte wave access and ran at 0.2 - 1 TB/s, profiles/r04_train_full_calls_before.txt), parked in LDS (double
+// buffered: the next block's loads fly under this block's MFMAs) and read from there in the MFMA operand layout.  Wave w of the workgroup
+// takes the row pairs w, w + 4, ... of every block; one partial per wave, summed afterwards in a fixed order that depends on (M, N, K) only.
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_flat_kernel(const float* __restrict__ dY, const float* __restrict__ X, int M, int N, int K, int RB,
+                                                         int blocks_per_wg, float* __restrict__ part, int want_bias) {
+    __shared__ __align__(16) float sm[2][4096];           // per buffer: RB * N floats of dY, then RB * K floats of X (each <= 2048)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, hh = lane >> 5;
+    const int ny = RB * N, nx = RB * K;                   // multiples of 4 (RB % 8 == 0)
+    const int64_t blk0 = (int64_t)blockIdx.x * blocks_per_wg;
+    const int64_t nblk_all = ((int64_t)M + RB - 1) / RB;
+    const int nblk = (int)(nblk_all - blk0 < blocks_per_wg ? (nblk_all - blk0 > 0 ? nblk_all - blk0 : 0) : blocks_per_wg);
+    f32x16 acc[TN][TK];
+    float bsum[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    float4 ry[2], rx[2];
+    auto gload = [&](int b) {
+        const int64_t m = (blk0 + b) * RB;
+        const int vr = (int)(M - m < RB ? M - m : RB);
+        const float* sy = dY + m * N;
+        const float* sx = X + m * K;
+        const int cy = vr * N, cx = vr * K;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = (tid + u * 256) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i + 3 < cy) v = *reinterpret_cast<const float4*>(sy + i);
+            else if (i < cy) { v.x = sy[i]; if (i + 1 < cy) v.y = sy[i + 1]; if (i + 2 < cy) v.z = sy[i + 2]; }
+            ry[u] = v;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i + 3 < cx) w = *reinterpret_cast<const float4*>(sx + i);
+            else if (i < cx) { w.x = sx[i]; if (i + 1 < cx) w.y = sx[i + 1]; if (i + 2 < cx) w.z = sx[i + 2]; }
+            rx[u] = w;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = (tid + u * 256) * 4;
+            if (i < ny) *reinterpret_cast<float4*>(&sm[buf][i]) = ry[u];           // rows past M are zeros: they add nothing
+            if (i < nx) *reinterpret_cast<float4*>(&sm[buf][ny + i]) = rx[u];
+        }
+    };
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) gload(b + 1);
+        const float* Ys = sm[b & 1];
+        const float* Xs = Ys + ny;
+        for (int sp = wave; sp < RB / 2; sp += 4) {
+            const int row = 2 * sp + hh;
+            float a[TN], bb[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = (i * 32 + r32 < N) ? Ys[row * N + i * 32 + r32] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TK; ++j) bb[j] = (j * 32 + r32 < K) ? Xs[row * K + j * 32 + r32] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                bsum[i] += a[i];
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = mfma32(a[i], bb[j], acc[i][j]);
+            }
+        }
+        if (b + 1 < nblk) lstore((b + 1) & 1);
+        __syncthreads();
+    }
+    // the four waves' accumulators are summed through LDS, (w0 + w1) + w2) + w3, so that the workgroup writes ONE record:
+    // [N * K] weight-gradient partial, then [N] bias-gradient partial (one reduce launch sums both over the workgroups)
+    float* red = &sm[0][0];                               // [4 waves][16 registers][64 lanes]; the loop's last barrier freed the buffers
+    float* pw = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + u * 256, r = idx >> 6, l = idx & 63;
+                const float v = ((red[idx] + red[1024 + idx]) + red[2048 + idx]) + red[3072 + idx];
+                const int n = i * 32 + mfma_row(r, l), k = j * 32 + (l & 31);
+                if (n < N && k < K) pw[(int64_t)n * K + k] = v;
+            }
+            __syncthreads();
+        }
+    }
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const float t = bsum[i] + xor32(bsum[i]);
+            if (hh == 0) red[wave * 256 + i * 32 + r32] = t;
+        }
+        __syncthreads();
+        if (tid < N) pw[(int64_t)N * K + tid] = ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid];
+    }
+}
+
+struct FlatPlan { bool ok; int tn, tk, rb, blocks_per_wg, nwg; };
+FlatPlan flat_plan(int M, int N, int K) {
+    FlatPlan p;
+    p.tn = (N + 31) / 32; p.tk = (K + 31) / 32;
+    const int big = N > K ? N : K;
+    p.ok = p.tn * p.tk <= 12 && big <= 256 && M >= 4096;
+    p.rb = p.blocks_per_wg = p.nwg = 0;
+    if (!p.ok) return p;
+    int rb = (2048 / big) & ~7;
+    if (rb > 512) rb = 512;
+    p.rb = rb;
+    const int64_t nblk = ((int64_t)M + rb - 1) / rb;
+    int64_t nwg = 1024;                                       // four workgroups per CU
+    const int64_t cap = (4ll << 20) / ((int64_t)N * K * 4);   // the partials (one per workgroup) stay under 4 MB: written and read once more
+    if (nwg > cap) nwg = cap;
+    if (nwg < 1) nwg = 1;
+    if (nwg > nblk) nwg = nblk;
+    p.blocks_per_wg = (int)((nblk + nwg - 1) / nwg);
+    p.nwg = (int)((nblk + p.blocks_per_wg - 1) / p.blocks_per_wg);
+    return p;
 }
 
 struct SkinnyPlan { bool ok; int tn, tk, nwaves, rows_per_wave; };
@@ -532,7 +664,11 @@ extern "C" int64_t afm_linear_wgrad_workspace_bytes(int32_t M, int32_t N, int32_
     const SkinnyPlan sp = skinny_plan(M, N, K);
     const int64_t tiled = (int64_t)w.S * N * K + (int64_t)w.chunks * N;
     const int64_t skinny = sp.ok ? (int64_t)sp.nwaves * ((int64_t)N * K + N) : 0;
-    return (tiled > skinny ? tiled : skinny) * (int64_t)sizeof(float);
+    const FlatPlan fp = flat_plan(M, N, K);
+    const int64_t flat = fp.ok ? (int64_t)fp.nwg * ((int64_t)N * K + N) : 0;
+    int64_t need = tiled > skinny ? tiled : skinny;
+    if (flat > need) need = flat;
+    return need * (int64_t)sizeof(float);
 }
 
 extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream) {
@@ -547,6 +683,45 @@ extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream)
             if (e != hipSuccess) return (int)e;
             if (a.db) { e = hipMemsetAsync(a.db, 0, (size_t)a.N * sizeof(float), s); if (e != hipSuccess) return (int)e; }
         }
+        return 0;
+    }
+    const FlatPlan fp = flat_plan(a.M, a.N, a.K);
+    if (fp.ok && !a.dy_grp && !a.x_grp && a.lddw == a.K && a.lddy == a.N && a.ldx == a.K && ((((uintptr_t)a.dY) | ((uintptr_t)a.X)) & 15) == 0) {
+        const int nparts = fp.nwg;
+        if (!a.ws || a.ws_bytes < (int64_t)nparts * ((int64_t)a.N * a.K + a.N) * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
+        float* pw = (float*)a.ws;
+        {
+            AfmProf prof(AFM_PROF_WGRAD_SKINNY, 4.0 * a.M * (a.N + a.K), s);          // work = bytes streamed
+#define AFM_FL(TN_, TK_) hipLaunchKernelGGL((wgrad_flat_kernel<TN_, TK_>), dim3(fp.nwg), dim3(256), 0, s, a.dY, a.X, a.M, a.N, a.K, fp.rb, fp.blocks_per_wg, pw, a.db ? 1 : 0)
+#define AFM_FLK(TN_, MAXTK_)                                                        \
+    case TN_:                                                                       \
+        switch (fp.tk) {                                                            \
+            case 1: AFM_FL(TN_, 1); break;                                          \
+            case 2: if (MAXTK_ >= 2) AFM_FL(TN_, (MAXTK_ >= 2 ? 2 : 1)); break;     \
+            case 3: if (MAXTK_ >= 3) AFM_FL(TN_, (MAXTK_ >= 3 ? 3 : 1)); break;     \
+            case 4: if (MAXTK_ >= 4) AFM_FL(TN_, (MAXTK_ >= 4 ? 4 : 1)); break;     \
+            case 5: if (MAXTK_ >= 5) AFM_FL(TN_, (MAXTK_ >= 5 ? 5 : 1)); break;     \
+            case 6: if (MAXTK_ >= 6) AFM_FL(TN_, (MAXTK_ >= 6 ? 6 : 1)); break;     \
+            case 7: if (MAXTK_ >= 7) AFM_FL(TN_, (MAXTK_ >= 7 ? 7 : 1)); break;     \
+            case 8: if (MAXTK_ >= 8) AFM_FL(TN_, (MAXTK_ >= 8 ? 8 : 1)); break;     \
+            default: return AFM_E_UNSUPPORTED;                                      \
+        }                                                                           \
+        break;
+            switch (fp.tn) {                                  // tn * tk <= 12 (flat_plan)
+                AFM_FLK(1, 8) AFM_FLK(2, 6) AFM_FLK(3, 4) AFM_FLK(4, 3) AFM_FLK(5, 2) AFM_FLK(6, 2) AFM_FLK(7, 1) AFM_FLK(8, 1)
+                default: return AFM_E_UNSUPPORTED;
+            }
+#undef AFM_FLK
+#undef AFM_FL
+            AFM_CHECK_LAUNCH();
+        }
+        AfmProf prof(AFM_PROF_TRAIN_MISC, 0.0, s);
+        const int nk = a.N * a.K, ntot = nk + (a.db ? a.N : 0);
+        if (ntot <= 16)
+            hipLaunchKernelGGL(reduce_cols_kernel<16>, dim3(1), dim3(1024), 0, s, pw, (int64_t)nk + a.N, nparts, a.dW, a.db, nk, ntot, a.accumulate);
+        else
+            hipLaunchKernelGGL(reduce_cols_kernel<64>, dim3((ntot + 63) / 64), dim3(1024), 0, s, pw, (int64_t)nk + a.N, nparts, a.dW, a.db, nk, ntot, a.accumulate);
+        AFM_CHECK_LAUNCH();
         return 0;
     }
     const SkinnyPlan sp = skinny_plan(a.M, a.N, a.K);
@@ -565,8 +740,8 @@ extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream)
         }
         AfmProf prof(AFM_PROF_TRAIN_MISC, 0.0, s);
         const int nk = a.N * a.K;
-        hipLaunchKernelGGL(reduce_cols_kernel, dim3((nk + 63) / 64), dim3(1024), 0, s, pw, (int64_t)nk, sp.nwaves, a.dW, a.dW, nk, nk, a.accumulate);
-        if (a.db) hipLaunchKernelGGL(reduce_cols_kernel, dim3((a.N + 63) / 64), dim3(1024), 0, s, pb, (int64_t)a.N, sp.nwaves, a.db, a.db, a.N, a.N, a.accumulate);
+        hipLaunchKernelGGL(reduce_cols_kernel<64>, dim3((nk + 63) / 64), dim3(1024), 0, s, pw, (int64_t)nk, sp.nwaves, a.dW, a.dW, nk, nk, a.accumulate);
+        if (a.db) hipLaunchKernelGGL(reduce_cols_kernel<64>, dim3((a.N + 63) / 64), dim3(1024), 0, s, pb, (int64_t)a.N, sp.nwaves, a.db, a.db, a.N, a.N, a.accumulate);
         AFM_CHECK_LAUNCH();
         return 0;
     }
@@ -597,7 +772,7 @@ extern "C" int afm_linear_wgrad(const afm_linear_wgrad_args* args, void* stream)
         hipLaunchKernelGGL(colsum_kernel, dim3((a.N + 63) / 64, w.chunks), dim3(256), 0, s, a.dY, a.lddy, RowMap3{a.dy_grp, a.dy_stride, a.dy_off},
                            a.M, a.N, w.rows_per_chunk, colpart);
         AFM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(reduce_cols_kernel, dim3((a.N + 63) / 64), dim3(1024), 0, s, colpart, (int64_t)a.N, w.chunks, a.db, a.db, a.N, a.N,
+        hipLaunchKernelGGL(reduce_cols_kernel<64>, dim3((a.N + 63) / 64), dim3(1024), 0, s, colpart, (int64_t)a.N, w.chunks, a.db, a.db, a.N, a.N,
                            a.accumulate);
         AFM_CHECK_LAUNCH();
     }
@@ -639,7 +814,7 @@ extern "C" int afm_layernorm_bwd(const float* x, const float* gamma, const float
     AFM_CHECK_LAUNCH();
     }
     AfmProf prof(AFM_PROF_TRAIN_MISC, 0.0, s);
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3((2 * dim + 63) / 64), dim3(1024), 0, s, part, (int64_t)2 * dim, nb, dgamma, dbeta, dim, 2 * dim, 0);
+    hipLaunchKernelGGL(reduce_cols_kernel<64>, dim3((2 * dim + 63) / 64), dim3(1024), 0, s, part, (int64_t)2 * dim, nb, dgamma, dbeta, dim, 2 * dim, 0);
     AFM_CHECK_LAUNCH();
     return 0;
 }

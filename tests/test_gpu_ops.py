@@ -29,6 +29,28 @@ def test_linear_shapes(M, N, K):
     report(f"linear {M}x{N}x{K}", got, want, 2e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(70001, 3, 3), (50000, 4, 4), (33333, 8, 8), (40000, 32, 3), (40001, 32, 4), (20000, 64, 8), (9999, 32, 9), (3000, 128, 3),
+                                   (2000, 256, 3), (1, 3, 3), (255, 7, 5), (40003, 3, 32), (30000, 4, 32), (20001, 3, 64), (20000, 8, 64), (257, 16, 36),
+                                   (100, 1, 64)])
+@pytest.mark.parametrize("act", [0, ffi.ACT_RELU])
+def test_linear_thin_layers(M, N, K, act):
+    """One side of the weight <= 16 wide with dense rows (the point transformer's per-neighbour linears and their input gradients):
+    csrc/gemm_thin.hip streams them through LDS with an f32 FMA chain per output instead of a 64 x 64 MFMA tile."""
+    x = synth.gaussian("thin_x", (M, K)); w = synth.gaussian("thin_w", (N, K)) / math.sqrt(K)
+    b, sc = synth.gaussian("thin_b", (N,)), 1 + 0.1 * synth.gaussian("thin_s", (N,))
+    want = F.linear(x.double(), w.double()) * sc.double() + b.double()
+    want = (F.relu(want) if act else want).float()
+    got = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()), act=act, scale=sc.to(dev()))
+    report(f"thin linear {M}x{N}x{K} act={act}", got, want, 2e-5)
+    plain = ops.linear(x.to(dev()), w.to(dev()))
+    report(f"thin linear {M}x{N}x{K} no epilogue", plain, F.linear(x.double(), w.double()).float(), 2e-5)
+    # the arithmetic does not depend on M: a shard of the rows computes the same bits
+    if M > 1000:
+        lo, hi = 256 * 3 + 4, min(M, 256 * 3 + 4 + 777)
+        part = ops.linear(x[lo:hi].contiguous().to(dev()), w.to(dev()), b.to(dev()), act=act, scale=sc.to(dev()))
+        assert torch.equal(part, got[lo:hi])
+
+
 @pytest.mark.parametrize("M,N,K,R", [(5000, 256, 256, 6), (40000, 256, 256, 8), (33, 128, 256, 1), (777, 320, 512, 8), (1304, 512, 512, 1), (200, 256, 96, 3)])
 def test_linear_rowdot_epilogue(M, N, K, R):
     """ABI v4 row-dot epilogue (the CDM's linear2 + contact_layer collapse): rowdot_out[m, g, r] = sum over the 64-column group g of

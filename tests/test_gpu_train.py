@@ -32,7 +32,10 @@ def g(name, shape):
 @pytest.mark.parametrize("M,N,K", [(652, 512, 512), (10432, 1536, 512), (300, 263, 512), (300, 512, 263), (32, 512, 512), (7, 5, 3), (0, 8, 8),
                                    # point-cloud linears: millions of grouped rows, a few channels (stream kernel, no LDS)
                                    (300001, 32, 3), (100000, 4, 32), (70000, 3, 3), (50000, 64, 64), (40000, 256, 3), (40000, 16, 128),
-                                   (20000, 32, 256), (30000, 64, 35), (8000, 128, 67)])
+                                   (20000, 32, 256), (30000, 64, 35), (8000, 128, 67),
+                                   # dense rows: the flat-staged kernel (csrc/train.hip wgrad_flat_kernel), ragged tails, every tile-count family
+                                   (4096, 3, 3), (4097, 4, 4), (99999, 8, 8), (65536, 64, 64), (33001, 35, 64), (12345, 67, 128), (10001, 131, 67),
+                                   (9000, 256, 3), (9001, 8, 256), (5000, 96, 100), (70000, 16, 16), (6000, 192, 40)])
 def test_linear_wgrad(M, N, K):
     dy, x = g("wg_dy", (max(M, 1), N))[:M].contiguous(), g("wg_x", (max(M, 1), K))[:M].contiguous()
     dW, db = AG._wgrad(dy.to(dev()), x.to(dev()), M, N, K)
