@@ -127,16 +127,21 @@ class TransitionDown(nn.Module):
         return n_p, y
 
 
-    def run_train(self, p, x, batch: int):
-        """Differentiable form of `run` (pointtransformer.py:53-69)."""
-        if self.stride == 1:
-            return p, AP.batch_norm(AG.linear(x, self.linear.weight), self.bn, relu=True)
+    def geometry(self, p, batch: int):
+        """The part of the layer that depends on the coordinates only: (sampled points, their neighbours among the input points)."""
         n = p.shape[0] // batch
         m = n // self.stride
         with torch.no_grad():
             idx = pointops.furthest_point_sampling(p, batch, n, m)
             n_p = pointops.gather_rows(p, idx)
             knn_idx, _ = pointops.knn(self.nsample, p, n_p, batch, n, m)
+        return n_p, knn_idx
+
+    def run_train(self, p, x, batch: int, geo=None):
+        """Differentiable form of `run` (pointtransformer.py:53-69); `geo` = a precomputed `geometry(p, batch)`."""
+        if self.stride == 1:
+            return p, AP.batch_norm(AG.linear(x, self.linear.weight), self.bn, relu=True)
+        n_p, knn_idx = geo if geo is not None else self.geometry(p, batch)
         g = AP.group_points(p, n_p, x, knn_idx.reshape(-1), self.nsample)                  # [m*k, 3+c]
         y = AP.batch_norm(AG.linear(g, self.linear.weight), self.bn, relu=True)            # BN over all m*k rows
         return n_p, AP.group_max(y, self.nsample)
@@ -195,21 +200,52 @@ class SceneMapEncoder(nn.Module):
             layers.append(PointTransformerBlock(planes, planes, share_planes, nsample=nsample))
         return nn.Sequential(*layers)
 
+    def _geometry_pyramid(self, p0: torch.Tensor, B: int):
+        """Farthest-point sampling and the neighbour lists of all four levels depend on the coordinates only (pointtransformer.py:53-69 computes
+        them inside each layer), so a training step computes them up front on a side stream: the 2048-step FPS chain of level 2 occupies 32
+        workgroups for 1.5 ms and now runs UNDER level 1's feature passes instead of in front of level 2's.  One event per level; the main
+        stream waits for a level's event right before that level's first consumer.  -> [(sampled points, down-sampling kNN, level kNN, event)]."""
+        main = torch.cuda.current_stream(p0.device)
+        side = getattr(self, "_geo_stream", None)
+        if side is None or side.device != p0.device:
+            side = self._geo_stream = torch.cuda.Stream(device=p0.device)
+        side.wait_stream(main)
+        out = []
+        with torch.cuda.stream(side), torch.no_grad():
+            p = p0
+            for lvl in range(4):
+                enc = getattr(self, f"enc{lvl + 1}")
+                n_p, knn_down = (p, None) if enc[0].stride == 1 else enc[0].geometry(p, B)
+                n = n_p.shape[0] // B
+                knn_self = pointops.knn(self.nsamples[lvl], n_p, n_p, B, n, n)[0] if len(enc) > 1 else None
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for t in (n_p, knn_down, knn_self):
+                    if t is not None:
+                        t.record_stream(main)
+                out.append((n_p, knn_down, knn_self, ev))
+                p = n_p
+        return out
+
     def forward_train(self, p: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         """Same function with the autograd tape attached (BatchNorm per `self.training`)."""
         ffi.require_gpu(p, x)
         B, N = p.shape[0], p.shape[1]
         p0 = ffi.f32c(p).reshape(B * N, 3)
         x0 = p0 if self.c == 3 else torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+        main = torch.cuda.current_stream(p0.device)
+        geo = self._geometry_pyramid(p0, B)
         for lvl in range(4):
             enc = getattr(self, f"enc{lvl + 1}")
-            p0, x0 = enc[0].run_train(p0, x0, B)
-            n = p0.shape[0] // B
-            if len(enc) > 1:
-                with torch.no_grad():
-                    knn_idx, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
-                for blk in list(enc)[1:]:
-                    x0 = blk.run_train(p0, x0, knn_idx)
+            n_p, knn_down, knn_self, ev = geo[lvl]
+            if knn_down is None:                          # stride 1: a per-point linear, no geometry - run it before waiting
+                p0, x0 = enc[0].run_train(p0, x0, B)
+                main.wait_event(ev)
+            else:
+                main.wait_event(ev)
+                p0, x0 = enc[0].run_train(p0, x0, B, geo=(n_p, knn_down))
+            for blk in list(enc)[1:]:
+                x0 = blk.run_train(p0, x0, knn_self)
         return x0.view(B, -1, x0.shape[-1])
 
     def forward(self, p: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
