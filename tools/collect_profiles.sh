@@ -15,7 +15,7 @@ PMC="python $ROOT/tools/pmc_target.py $WHICH"
 if [ "$WHICH" = "cdm" ]; then
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PMC > /dev/null 2>&1
 else
-  BENCH="python $ROOT/bench.py --streams 1 --steps 100 --warmup 10 --latency-runs 0 --latency-runs-b1 0 --no-cpu-baseline --no-alt-gemm"
+  BENCH="python $ROOT/bench.py --streams 1 --steps 100 --warmup 10 --latency-runs 0 --latency-runs-b1 0 --no-cpu-baseline --no-alt-gemm --no-secondary"
   if [ "${SKIP_STATS:-0}" != "1" ]; then timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_under_rocprof.json 2>/dev/null; fi
 fi
 # counter passes on a lean target (rocprofv3 --pmc segfaults around the full bench process): 12 steps, same shapes.  Every pass in its
