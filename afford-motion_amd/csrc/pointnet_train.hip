@@ -382,6 +382,113 @@ __global__ __launch_bounds__(256) void pt_aggregate_bwd_w_kernel(const float* __
     }
 }
 
+// The forward aggregation staged the same way (see pt_aggregate_bwd_fused_kernel): the softmax of a (point, share-group) column is computed
+// once (the thread-per-channel kernel above recomputes it for each of its C / Cs planes), arithmetic and order unchanged.
+__global__ __launch_bounds__(256) void pt_aggregate_fused_kernel(const float* __restrict__ vg, const float* __restrict__ pr, const float* __restrict__ w2,
+                                                                 float* __restrict__ out, float* __restrict__ sw, int64_t m, int k, int C, int Cs, int G) {
+    extern __shared__ __align__(16) float sm[];
+    const int kC = k * C, kCs = k * Cs, tid = threadIdx.x;
+    float* As = sm;                       // [G][k][C]   vg + pr
+    float* Ws = As + G * kC;              // [G][k][Cs]  w2, then the softmax
+    for (int64_t g0 = (int64_t)blockIdx.x * G; g0 < m; g0 += (int64_t)gridDim.x * G) {
+        const int ng = (int)(m - g0 < G ? m - g0 : G);
+        __syncthreads();
+        {
+            const float4* v4 = reinterpret_cast<const float4*>(vg + g0 * kC);
+            const float4* p4 = reinterpret_cast<const float4*>(pr + g0 * kC);
+            for (int i = tid; i < ng * kC / 4; i += 256) {
+                const float4 a = v4[i], b = p4[i];
+                reinterpret_cast<float4*>(As)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            }
+            const float4* w4 = reinterpret_cast<const float4*>(w2 + g0 * kCs);
+            for (int i = tid; i < ng * kCs / 4; i += 256) reinterpret_cast<float4*>(Ws)[i] = w4[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < ng * Cs; i += 256) {          // one (point, share-group column) per thread
+            const int g = i / Cs, j = i - g * Cs;
+            float* w = Ws + g * kCs + j;
+            float mx = -INFINITY;
+            for (int t = 0; t < k; ++t) mx = fmaxf(mx, w[t * Cs]);
+            float den = 0.f;
+            for (int t = 0; t < k; ++t) den += __expf(w[t * Cs] - mx);
+            const float inv = 1.0f / den;
+            for (int t = 0; t < k; ++t) w[t * Cs] = __expf(w[t * Cs] - mx) * inv;
+        }
+        __syncthreads();
+        {
+            float4* s4 = reinterpret_cast<float4*>(sw + g0 * kCs);
+            for (int i = tid; i < ng * kCs / 4; i += 256) s4[i] = reinterpret_cast<const float4*>(Ws)[i];
+        }
+        for (int i = tid; i < ng * C; i += 256) {
+            const int g = i / C, c = i - g * C, j = c % Cs;
+            const float* a = As + g * kC + c;
+            const float* w = Ws + g * kCs + j;
+            float acc = 0.f;
+            for (int t = 0; t < k; ++t) acc += a[t * C] * w[t * Cs];
+            out[g0 * C + i] = acc;
+        }
+    }
+}
+
+// Both gradients of the aggregation in ONE pass for the shapes of the point transformer (k * C a multiple of 4, C / Cs = share planes): a workgroup
+// takes G consecutive points, fetches their (vg + pr) rows - G * k * C contiguous floats of each tensor - with 16-byte lanes into LDS, and writes
+// da (contiguous again) and dw2 from there.  The two-kernel form above reads a point's rows with a 16-byte-per-kilobyte pattern from a thread
+// per (point, share-group) and ran at ~1.5 TB/s of useful traffic (profiles/r04_train_full_calls_after.txt: 600 us for 0.9 GB).
+__global__ __launch_bounds__(256) void pt_aggregate_bwd_fused_kernel(const float* __restrict__ vg, const float* __restrict__ pr, const float* __restrict__ sw,
+                                                                     const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ dw2,
+                                                                     int64_t m, int k, int C, int Cs, int G) {
+    extern __shared__ __align__(16) float sm[];
+    const int kC = k * C, kCs = k * Cs, S = C / Cs, tid = threadIdx.x;
+    float* As = sm;                       // [G][k][C]   vg + pr
+    float* Ds = As + G * kC;              // [G][C]      dout
+    float* Ws = Ds + G * C;               // [G][k][Cs]  sw
+    float* Es = Ws + G * kCs;             // [G][k][Cs]  dsw
+    for (int64_t g0 = (int64_t)blockIdx.x * G; g0 < m; g0 += (int64_t)gridDim.x * G) {
+        const int ng = (int)(m - g0 < G ? m - g0 : G);
+        __syncthreads();
+        {
+            const float4* v4 = reinterpret_cast<const float4*>(vg + g0 * kC);
+            const float4* p4 = reinterpret_cast<const float4*>(pr + g0 * kC);
+            for (int i = tid; i < ng * kC / 4; i += 256) {
+                const float4 a = v4[i], b = p4[i];
+                reinterpret_cast<float4*>(As)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            }
+            const float4* d4 = reinterpret_cast<const float4*>(dout + g0 * C);
+            for (int i = tid; i < ng * C / 4; i += 256) reinterpret_cast<float4*>(Ds)[i] = d4[i];
+            const float4* w4 = reinterpret_cast<const float4*>(sw + g0 * kCs);
+            for (int i = tid; i < ng * kCs / 4; i += 256) reinterpret_cast<float4*>(Ws)[i] = w4[i];
+        }
+        __syncthreads();
+        // da[g, t, c] = dout[g, c] * sw[g, t, c % Cs]: four consecutive channels per thread (Cs % 4 == 0 or Cs divides 4 is NOT assumed: per element)
+        {
+            float4* o4 = reinterpret_cast<float4*>(da + g0 * kC);
+            for (int i = tid; i < ng * kC / 4; i += 256) {
+                const int e = i * 4, g = e / kC, r = e - g * kC, t = r / C, c = r - t * C;
+                const float* d = Ds + g * C + c;
+                const float* w = Ws + (g * k + t) * Cs;
+                o4[i] = make_float4(d[0] * w[c % Cs], d[1] * w[(c + 1) % Cs], d[2] * w[(c + 2) % Cs], d[3] * w[(c + 3) % Cs]);
+            }
+        }
+        // dsw[g, t, j] = sum_s dout[g, s Cs + j] * a[g, t, s Cs + j]   (s ascending, as the two-kernel form)
+        for (int i = tid; i < ng * kCs; i += 256) {
+            const int g = i / kCs, r = i - g * kCs, t = r / Cs, j = r - t * Cs;
+            const float* d = Ds + g * C + j;
+            const float* a = As + (g * k + t) * C + j;
+            float acc = 0.f;
+            for (int s2 = 0; s2 < S; ++s2) acc += d[s2 * Cs] * a[s2 * Cs];
+            Es[i] = acc;
+        }
+        __syncthreads();
+        // dw2 = sw * (dsw - sum_t sw * dsw)   (t ascending)
+        for (int i = tid; i < ng * kCs; i += 256) {
+            const int g = i / kCs, r = i - g * kCs, j = r % Cs;
+            float dot = 0.f;
+            for (int t = 0; t < k; ++t) dot += Es[(g * k + t) * Cs + j] * Ws[(g * k + t) * Cs + j];
+            dw2[g0 * kCs + i] = Ws[i] * (Es[i] - dot);
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -499,6 +606,18 @@ extern "C" int afm_pt_aggregate(const float* vg, const float* pr, const float* w
     if (m == 0) return 0;
     if (!vg || !pr || !w2 || !out || !sw || m < 0 || k <= 0 || k > 16 || C <= 0 || share_planes <= 0 || C % share_planes) return AFM_E_BADARG;
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    const int Cs = C / share_planes;
+    const uintptr_t al = (uintptr_t)vg | (uintptr_t)pr | (uintptr_t)w2 | (uintptr_t)sw;
+    if ((C & 3) == 0 && ((k * Cs) & 3) == 0 && (al & 15) == 0 && k * C <= 8192) {
+        int G = 8192 / (k * C);
+        if (G > 64) G = 64;
+        const size_t lds = (size_t)G * (k * C + k * Cs) * sizeof(float);
+        int64_t nb = (m + G - 1) / G;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(pt_aggregate_fused_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, vg, pr, w2, out, sw, m, k, C, Cs, G);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(pt_aggregate_kernel, dim3(grid_for(m * C)), dim3(256), 0, (hipStream_t)stream, vg, pr, w2, out, sw, m, k, C, C / share_planes);
     AFM_CHECK_LAUNCH();
     return 0;
@@ -510,6 +629,17 @@ extern "C" int afm_pt_aggregate_bwd(const float* vg, const float* pr, const floa
     if (!vg || !pr || !sw || !dout || !da || !dw2 || m < 0 || k <= 0 || k > 16 || C <= 0 || share_planes <= 0 || C % share_planes) return AFM_E_BADARG;
     const int Cs = C / share_planes;
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    const uintptr_t al = (uintptr_t)vg | (uintptr_t)pr | (uintptr_t)sw | (uintptr_t)dout | (uintptr_t)da | (uintptr_t)dw2;
+    if ((C & 3) == 0 && ((k * Cs) & 3) == 0 && (al & 15) == 0 && k * C <= 8192) {          // the fused form (a function of the shape only)
+        int G = 8192 / (k * C);
+        if (G > 64) G = 64;
+        const size_t lds = (size_t)G * (k * C + C + 2 * k * Cs) * sizeof(float);
+        int64_t nb = (m + G - 1) / G;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(pt_aggregate_bwd_fused_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, vg, pr, sw, dout, da, dw2, m, k, C, Cs, G);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(pt_aggregate_bwd_a_kernel, dim3(grid_for(m * k * C)), dim3(256), 0, (hipStream_t)stream, dout, sw, da, m, k, C, Cs);
     hipLaunchKernelGGL(pt_aggregate_bwd_w_kernel, dim3(grid_for(m * Cs)), dim3(256), 0, (hipStream_t)stream, vg, pr, sw, dout, dw2, m, k, C, Cs);
     AFM_CHECK_LAUNCH();

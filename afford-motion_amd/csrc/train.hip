@@ -146,8 +146,16 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
                                                             int64_t dst_ld, int rows, int cols, int accumulate) {
     const int64_t n = (int64_t)rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int s = 0; s < S; ++s) v += src[s * split_stride + i];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four partial rows in flight (one dependent load at a time: 0.7 us per slice)
+        int s = 0;
+        for (; s + 3 < S; s += 4) {
+            a0 += src[s * split_stride + i];
+            a1 += src[(s + 1) * split_stride + i];
+            a2 += src[(s + 2) * split_stride + i];
+            a3 += src[(s + 3) * split_stride + i];
+        }
+        for (; s < S; ++s) a0 += src[s * split_stride + i];
+        const float v = (a0 + a1) + (a2 + a3);
         float* d = dst + (i / cols) * dst_ld + (i % cols);
         *d = accumulate ? *d + v : v;
     }
@@ -424,6 +432,12 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     w.ntn = (N + WT - 1) / WT; w.ntk = (K + WT - 1) / WT; w.tiles = w.ntn * w.ntk;
     int S = (768 + w.tiles - 1) / w.tiles;                    // ~3 workgroups per CU in flight
     const int maxS = (M + 4 * RB - 1) / (4 * RB);             // at least 4 stages per slice
+    if (S > maxS) S = maxS;
+    // the S partial outputs are written and read once more: keep them under half of what the launch reads (a 128 x 128 gradient over 16384
+    // rows ran with 768 slices = 50 MB of partials for 17 MB of operands, 93 us; profiles/r04_train_full_calls_after.txt)
+    // - for outputs of at most 8 tiles only: the encoder-sized gradients (48 tiles x 16 slices) need every slice to fill the chip (capped: 197 -> 224 us)
+    const int64_t capS = ((int64_t)M * (N + K)) / (2ll * N * K);
+    if (w.tiles <= 8 && S > capS) S = (int)(capS < 4 ? 4 : capS);
     if (S > maxS) S = maxS;
     if (S > 1024) S = 1024;
     if (S < 1) S = 1;
