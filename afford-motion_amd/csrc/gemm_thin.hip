@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void linear_thin_kreg_kernel(const float* __re
                                                                int64_t nblk, int act) {
     extern __shared__ __align__(16) float sm[];
     const int tid = threadIdx.x, nq = N >> 2, cq = tid % nq, r0 = tid / nq, rstep = 256 / nq;
+    const int KP = (K & 7) ? K : K + 4;
     float w[4][KT];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -92,13 +93,22 @@ __global__ __launch_bounds__(256) void linear_thin_kreg_kernel(const float* __re
         const int64_t m0 = blk * R;
         const int vr = (int)(M - m0 < R ? M - m0 : R);
         __syncthreads();
-        stage_flat(A + m0 * K, sm, vr * K, tid, 256);
+        if (KP == K) {
+            stage_flat(A + m0 * K, sm, vr * K, tid, 256);
+        } else {                                       // K % 8 == 0: rows padded by four floats (rows of 32 floats would all start in bank 0)
+            const float* src = A + m0 * K;
+            const int kq = K >> 2;
+            for (int i4 = tid; i4 < vr * kq; i4 += 256) {
+                const int row = i4 / kq, cq4 = i4 - row * kq;
+                *reinterpret_cast<float4*>(sm + row * KP + cq4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)i4 * 4);
+            }
+        }
         __syncthreads();
         float* dst = C + m0 * N + cq * 4;
         for (int row = r0; row < vr; row += rstep) {
             float x[KT];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) x[k] = k < K ? sm[row * K + k] : 0.0f;
+            for (int k = 0; k < KT; ++k) x[k] = k < K ? sm[row * KP + k] : 0.0f;
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -186,9 +196,11 @@ int afm_linear_thin_mode(const afm_linear_args& a) {
     if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_BF16X9) return 0;      // explicit arithmetic requests keep their kernels
     if (!plain_epilogue(a) || a.lda != a.K || a.ldw != a.K || a.ldc != a.N) return 0;
     if ((((uintptr_t)a.A | (uintptr_t)a.C) & 15) != 0) return 0;
-    if (a.K <= THIN_MAX && a.N >= 4 && a.N <= THIN_K_NMAX && (a.N & (a.N - 1)) == 0 && ((((uintptr_t)a.bias | (uintptr_t)a.scale) & 15) == 0)) return 3;
+    const bool n_pow2 = a.N >= 4 && a.N <= THIN_K_NMAX && (a.N & (a.N - 1)) == 0 && ((((uintptr_t)a.bias | (uintptr_t)a.scale) & 15) == 0);
+    if (a.K <= THIN_MAX && n_pow2) return 3;
     if (a.K <= THIN_MAX && a.N * a.K <= 144) return 1;
     if (a.N <= THIN_MAX && (a.K & 3) == 0 && a.K <= THIN_N_KMAX) return 2;
+    // (K = 32 with the weights of a column quad in 128 registers: measured 76 us against the MFMA tile kernel's 52 over 262144 x 32 x 32 - not taken)
     return 0;
 }
 
@@ -210,11 +222,12 @@ int afm_linear_thin(const afm_linear_args& a, int mode, hipStream_t s) {
         return 0;
     }
     if (mode == 3) {
+        const int KP = (a.K & 7) ? a.K : a.K + 4;
         int R = 16384 / a.N;
-        if (R > 8192 / a.K) R = 8192 / a.K;
+        if (R > 8192 / KP) R = 8192 / KP;
         R &= ~3;
         const int64_t nblk = ((int64_t)a.M + R - 1) / R;
-        const size_t lds = (size_t)R * a.K * sizeof(float);
+        const size_t lds = (size_t)R * KP * sizeof(float);
         const unsigned grid = (unsigned)(nblk < 4096 ? nblk : 4096);
 #define AFM_THIN_KR(KT_) hipLaunchKernelGGL(linear_thin_kreg_kernel<KT_>, dim3(grid), dim3(256), lds, s, a.A, a.W, a.bias, a.scale, a.C, (int64_t)a.M, a.N, a.K, R, nblk, a.act)
         if (a.K <= 4) AFM_THIN_KR(4); else if (a.K <= 8) AFM_THIN_KR(8); else AFM_THIN_KR(16);

@@ -395,7 +395,9 @@ FlatPlan flat_plan(int M, int N, int K) {
     p.rb = rb;
     const int64_t nblk = ((int64_t)M + rb - 1) / rb;
     int64_t nwg = 1024;                                       // four workgroups per CU
-    const int64_t cap = (4ll << 20) / ((int64_t)N * K * 4);   // the partials (one per workgroup) stay under 4 MB: written and read once more
+    int64_t pbytes = (int64_t)M * (N + K) / 2;                // the partials (one per workgroup; written and read once more) stay under an eighth of
+    if (pbytes < (4ll << 20)) pbytes = 4ll << 20;             // the operand bytes, at least 4 MB
+    const int64_t cap = pbytes / ((int64_t)N * K * 4);
     if (nwg > cap) nwg = cap;
     if (nwg < 1) nwg = 1;
     if (nwg > nblk) nwg = nblk;
