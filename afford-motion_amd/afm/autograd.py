@@ -195,7 +195,7 @@ class _EncoderLayerFn(torch.autograd.Function):
     the attention-probability, dropout1, FFN and dropout2 masks."""
 
     @staticmethod
-    def forward(ctx, x, key_mask, heads, drops, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b):
+    def forward(ctx, x, key_mask, heads, drops, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, act=ffi.ACT_GELU):
         lib = ffi.load()
         xc = _c(x)
         B, T, d = xc.shape
@@ -216,19 +216,19 @@ class _EncoderLayerFn(torch.autograd.Function):
         x1 = _layernorm(s1, n1_w, n1_b)
         z = torch.empty(M, ff, device=dev, dtype=torch.float32)
         h = torch.empty(M, ff, device=dev, dtype=torch.float32)
-        _gemm(x1, l1_w, h, M, ff, d, bias=l1_b, act=ffi.ACT_GELU, preact=z, drop=(p, seed, id0 + 2))
+        _gemm(x1, l1_w, h, M, ff, d, bias=l1_b, act=act, preact=z, drop=(p, seed, id0 + 2))
         s2 = torch.empty(M, d, device=dev, dtype=torch.float32)
         _gemm(h, l2_w, s2, M, d, ff, bias=l2_b, residual=x1, drop=(p, seed, id0 + 3))
         x2 = _layernorm(s2, n2_w, n2_b)
         ctx.save_for_backward(xc, km, qkv, att, lse, s1, x1, z, h, s2, *P)
-        ctx.cfg = (B, T, d, ff, heads, drops)
+        ctx.cfg = (B, T, d, ff, heads, drops, act)
         return x2.view(B, T, d)
 
     @staticmethod
     def backward(ctx, dx2):
         lib = ffi.load()
         xc, km, qkv, att, lse, s1, x1, z, h, s2, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b = ctx.saved_tensors
-        B, T, d, ff, heads, (p, seed, id0) = ctx.cfg
+        B, T, d, ff, heads, (p, seed, id0), act = ctx.cfg
         M = B * T
         dev = xc.device
         dx2 = _c(dx2).view(M, d)
@@ -236,7 +236,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         ds2, ds2d, dn2w, dn2b = _layernorm_bwd(s2, n2_w, dx2, drop=(p, seed, id0 + 3))
         dl2w, dl2b = _wgrad(ds2d, h, M, d, ff)
         dz = torch.empty(M, ff, device=dev, dtype=torch.float32)
-        _gemm(ds2d, _transpose(l2_w), dz, M, ff, d, drop=(p, seed, id0 + 2), dact=ffi.ACT_GELU, dact_z=z)     # dh o mask o gelu'(z)
+        _gemm(ds2d, _transpose(l2_w), dz, M, ff, d, drop=(p, seed, id0 + 2), dact=act, dact_z=z)               # dh o mask o act'(z)
         dl1w, dl1b = _wgrad(dz, x1, M, ff, d)
         dx1 = torch.empty(M, d, device=dev, dtype=torch.float32)
         _gemm(dz, _transpose(l1_w), dx1, M, d, ff, residual=ds2)                                           # + residual path of s2
@@ -252,15 +252,15 @@ class _EncoderLayerFn(torch.autograd.Function):
         diw, dib = _wgrad(dqkv, xc.view(M, d), M, 3 * d, d)
         dx = torch.empty(M, d, device=dev, dtype=torch.float32)
         _gemm(dqkv, _transpose(in_w), dx, M, d, 3 * d, residual=ds1)
-        return (dx.view(B, T, d), None, None, None, diw, dib, dow, dob, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b)
+        return (dx.view(B, T, d), None, None, None, diw, dib, dow, dob, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b, None)
 
 
-def encoder_layer(x, layer: torch.nn.TransformerEncoderLayer, key_mask, heads: int, drops):
-    """One nn.TransformerEncoderLayer (post-LN, GELU, batch_first) forward with the HIP backward attached."""
+def encoder_layer(x, layer: torch.nn.TransformerEncoderLayer, key_mask, heads: int, drops, act: int = ffi.ACT_GELU):
+    """One nn.TransformerEncoderLayer (post-LN, GELU or ReLU, batch_first) forward with the HIP backward attached."""
     return _EncoderLayerFn.apply(x, key_mask, heads, drops, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
                                  layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
                                  layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
-                                 layer.norm2.bias)
+                                 layer.norm2.bias, act)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm / self-attention / Perceiver attention

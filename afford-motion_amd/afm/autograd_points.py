@@ -153,6 +153,49 @@ def gather(x, idx):
     return _GatherFn.apply(x, idx)
 
 
+def broadcast_rows(ctx_rows: torch.Tensor, n: int) -> torch.Tensor:
+    """[B, C] -> [B * n, C]: row b repeated for the n points of sample b (the `repeat` of a per-sample context onto its points,
+    cdm.py:236-243, pointtransformer.py:90-92); backward = the scatter-add of the row gather."""
+    B = ctx_rows.shape[0]
+    idx = torch.arange(B, device=ctx_rows.device, dtype=torch.int32).repeat_interleave(n)
+    return gather(ctx_rows, idx)
+
+
+class _InterpolateFn(torch.autograd.Function):
+    """pointops.interpolation (pointops.py:164-178) + the fused `base +` of TransitionUp (pointtransformer.py:98); idx / d2 [n, k] from afm_knn."""
+
+    @staticmethod
+    def forward(ctx, feat, base, idx, d2):
+        fc = _c(feat)
+        n, k = idx.shape
+        out = torch.empty(n, fc.shape[1], device=fc.device, dtype=torch.float32)
+        b = None if base is None else _c(base)
+        ffi.check(ffi.load().afm_interpolate(fc.data_ptr(), idx.data_ptr(), d2.data_ptr(), ffi.ptr(b), out.data_ptr(), n, fc.shape[1], k, _st(fc)),
+                  "afm_interpolate")
+        ctx.save_for_backward(idx, d2)
+        ctx.dims = (fc.shape[0], fc.shape[1], base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, d2 = ctx.saved_tensors
+        m, c, has_base = ctx.dims
+        dout = _c(dout)
+        n, k = idx.shape
+        dfeat = torch.empty(m, c, device=dout.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_interpolate_bwd(dout.data_ptr(), idx.data_ptr(), d2.data_ptr(), dfeat.data_ptr(), n, m, c, k, _st(dout)),
+                  "afm_interpolate_bwd")
+        return dfeat, (dout if has_base else None), None, None
+
+
+def interpolate(xyz_src, xyz_dst, feat, batch: int, m: int, n: int, base=None, k: int = 3):
+    """Differentiable form of afm.pointops.interpolate (the neighbour search itself carries no gradient)."""
+    from . import pointops
+    with torch.no_grad():
+        idx, d2 = pointops.knn(k, xyz_src, xyz_dst, batch, m, n)
+    return _InterpolateFn.apply(feat, base, idx, d2)
+
+
 class _GroupPointsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, new_xyz, feat, idx, k):

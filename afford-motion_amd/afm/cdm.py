@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import autograd as AG
+from . import autograd_points as AP
 from . import ffi, ops
 from .base import Model
 from ._cache import HeldKey
@@ -108,8 +109,8 @@ class ContactMLP(nn.Module):
 class ContactPointTrans(nn.Module):
     """`arch: 'PointTrans'` / `'PointTransV2'` (cdm.py:190-410): a 4-level Point Transformer U-Net over the noisy contact map
     itself (planes 64..512), the text / time context injected through small MLPs at the bottleneck (V1) or at levels 4, 3, 2
-    plus one ReLU transformer-encoder layer over the N/64 bottleneck tokens (V2).  Inference only; built from the fused point
-    kernels of afm.scene (eval-mode BatchNorm)."""
+    plus one ReLU transformer-encoder layer over the N/64 bottleneck tokens (V2).  `run`: the fused point kernels of afm.scene
+    (eval-mode BatchNorm); `run_train`: the differentiable operator graph."""
 
     def __init__(self, arch_cfg, contact_dim: int, point_feat_dim: int, text_feat_dim: int, time_emb_dim: int, v2: bool = False) -> None:
         super().__init__()
@@ -193,6 +194,48 @@ class ContactPointTrans(nn.Module):
             if self.v2 and lvl in (2, 1):
                 xl = self._ctx(self.ctx3 if lvl == 2 else self.ctx2, xl, context, B)
             y = dec[1].run(ps[lvl], dec[0].run_fuse(ps[lvl], xl, ps[lvl + 1], y, B), knns[lvl])
+        return y.view(B, N, -1)
+
+    # ---- training (cdm.py:190-410 under autograd): the same graph from differentiable HIP operators, BatchNorm per `self.training`
+    @staticmethod
+    def _ctx_train(seq: nn.Sequential, x, context, batch: int):
+        n = x.shape[0] // batch
+        cat = torch.cat((x, AP.broadcast_rows(context, n)), 1)
+        h = AP.batch_norm(AG.linear(cat, seq[0].weight, seq[0].bias), seq[1], relu=True)
+        return AG.linear(h, seq[3].weight, seq[3].bias)
+
+    def run_train(self, x, point_feat, language_feat, time_embedding, xyz, drop_seed: int = 0):
+        from . import pointops
+        B, N, _ = x.shape
+        if point_feat is not None:
+            x = torch.cat([x, point_feat], dim=-1)
+        context = torch.cat([language_feat, time_embedding], dim=-1)
+        p0 = ffi.f32c(xyz).reshape(B * N, 3)
+        x0 = torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+        ps, xs, knns = [], [], []
+        for lvl in range(4):
+            enc = getattr(self, f"enc{lvl + 1}")
+            p0, x0 = enc[0].run_train(p0, x0, B)
+            n = p0.shape[0] // B
+            with torch.no_grad():
+                ki, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
+            for blk in list(enc)[1:]:
+                x0 = blk.run_train(p0, x0, ki)
+            ps.append(p0); xs.append(x0); knns.append(ki)
+        if self.v2:
+            l = self.self_attn_layers.layers[0]
+            p = float(l.dropout.p) if self.training else 0.0
+            x4 = AG.encoder_layer(xs[3].view(B, -1, xs[3].shape[-1]), l, None, l.self_attn.num_heads, (p, drop_seed, 0), act=ffi.ACT_RELU)
+            x4 = self._ctx_train(self.ctx4, x4.reshape(xs[3].shape), context, B)
+        else:
+            x4 = self._ctx_train(self.ctx, xs[3], context, B)
+        y = self.dec4[1].run_train(ps[3], self.dec4[0].run_head_train(x4, B), knns[3])
+        for lvl in (2, 1, 0):
+            dec = getattr(self, f"dec{lvl + 1}")
+            xl = xs[lvl]
+            if self.v2 and lvl in (2, 1):
+                xl = self._ctx_train(self.ctx3 if lvl == 2 else self.ctx2, xl, context, B)
+            y = dec[1].run_train(ps[lvl], dec[0].run_fuse_train(ps[lvl], xl, ps[lvl + 1], y, B), knns[lvl])
         return y.view(B, N, -1)
 
 
@@ -652,10 +695,22 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         return AG.linear(h, self.contact_layer.weight, self.contact_layer.bias)
 
     def forward_pointtrans(self, x, timesteps, **kwargs):
-        """CDM.forward with ContactPointTrans / V2 (cdm.py:190-410,474-513); inference only."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the PointTrans archs are built for sampling only; call under torch.no_grad()")
+        """CDM.forward with ContactPointTrans / V2 (cdm.py:190-410,474-513): fused eval-mode kernels under no_grad, the differentiable
+        operator graph with the tape otherwise."""
         ffi.require_gpu(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            x = ffi.f32c(x)
+            dev = x.device
+            te = self.timestep_embedder
+            t_idx = timesteps.to(device=dev, dtype=torch.int64)
+            time_emb = AG.linear(AG.linear(te.pe[t_idx, 0, :], te.time_embed[0].weight, te.time_embed[0].bias, act=ffi.ACT_SILU),
+                                 te.time_embed[2].weight, te.time_embed[2].bias)                                 # [B, te]
+            text = ffi.f32c(self.encode_text(kwargs).to(dev))
+            self._train_calls = getattr(self, "_train_calls", 0) + 1
+            h = self.contact_model.run_train(x, self._point_features(x, kwargs), text, time_emb, kwargs["c_pc_xyz"].to(x),
+                                             drop_seed=self._train_calls)
+            B, N, c = h.shape
+            return AG.linear(h.reshape(B * N, c), self.contact_layer.weight, self.contact_layer.bias).view(B, N, -1)
         with torch.no_grad():
             x = ffi.f32c(x)
             dev = x.device

@@ -204,6 +204,7 @@ EXPORTS = {
     "afm_gather_rows": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),
     "afm_interpolate": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, i64, i32, i32, C.c_void_p]),
     "afm_segment_mean": (C.c_int, [c_f32p, c_f32p, i32, i32, i32, C.c_void_p]),
+    "afm_interpolate_bwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, i64, i64, i32, i32, C.c_void_p]),
     "afm_transition_down": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, C.c_void_p, i32, c_f32p, i32, c_f32p, c_f32p, c_f32p,
                                       i32, C.c_void_p]),
     "afm_pt_attention": (C.c_int, [C.POINTER(PtAttentionArgs), C.c_void_p]),

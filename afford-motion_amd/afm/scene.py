@@ -298,6 +298,19 @@ class TransitionUp(nn.Module):
         b = self._lin_bn_relu(x2, self.linear2[0], self.linear2[1])
         return pointops.interpolate(p2, p1, b, batch, n2, n1, base=a)
 
+    # ---- differentiable forms (BatchNorm per `self.training`; pointtransformer.py:84-99)
+    def run_head_train(self, x, batch: int):
+        n = x.shape[0] // batch
+        g = AG.linear(AG.segment_mean(x.view(batch, n, -1)), self.linear2[0].weight, self.linear2[0].bias, act=ffi.ACT_RELU)      # [B, c]
+        cat = torch.cat((x, AP.broadcast_rows(g, n)), 1)
+        return AP.batch_norm(AG.linear(cat, self.linear1[0].weight, self.linear1[0].bias), self.linear1[1], relu=True)
+
+    def run_fuse_train(self, p1, x1, p2, x2, batch: int):
+        n1, n2 = p1.shape[0] // batch, p2.shape[0] // batch
+        a = AP.batch_norm(AG.linear(x1, self.linear1[0].weight, self.linear1[0].bias), self.linear1[1], relu=True)
+        b = AP.batch_norm(AG.linear(x2, self.linear2[0].weight, self.linear2[0].bias), self.linear2[1], relu=True)
+        return AP.interpolate(p2, p1, b, batch, n2, n1, base=a)
+
 
 class SceneMapEncoderDecoder(nn.Module):
     """Multi-scale contact encoder of the CMDM `trans_dec` variant (reference models/modules.py:55-122): the SceneMapEncoder

@@ -429,6 +429,20 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const float* __restric
     }
 }
 
+// backward of interpolate_kernel with respect to feat: dfeat[idx[i,j], :] += w_ij * dout[i, :] (f32 atomics: a coarse point is the neighbour
+// of many fine points - the reference's CUDA interpolation backward does the same); the gradient of `base` is dout itself.
+__global__ __launch_bounds__(256) void interpolate_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx, const float* __restrict__ d2,
+                                                              float* __restrict__ dfeat, int64_t n, int c, int k) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * c; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / c;
+        const int ch = (int)(e - i * c);
+        float w[8], norm = 0.f;
+        for (int j = 0; j < k; ++j) { w[j] = 1.0f / (sqrtf(d2[i * k + j]) + 1e-8f); norm += w[j]; }
+        const float g = dout[e];
+        for (int j = 0; j < k; ++j) atomicAdd(dfeat + (int64_t)idx[i * k + j] * c + ch, g * (w[j] / norm));
+    }
+}
+
 // out[b,:] = mean over the n rows of sample b  (grid B, block 256; c <= 4096)
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int c) {
     const int b = blockIdx.x;
@@ -450,6 +464,23 @@ extern "C" int afm_interpolate(const float* feat, const int32_t* idx, const floa
     unsigned g = (unsigned)((total + 255) / 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(interpolate_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, feat, idx, dist2, base, out, n, c, k);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_interpolate_bwd(const float* dout, const int32_t* idx, const float* dist2, float* dfeat, int64_t n, int64_t m, int32_t c,
+                                   int32_t k, void* stream) {
+    if (c <= 0 || k <= 0 || k > 8 || n < 0 || m < 0) return AFM_E_BADARG;
+    if (m == 0) return 0;
+    if (!dfeat) return AFM_E_BADARG;
+    hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)m * c * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return 0;
+    if (!dout || !idx || !dist2) return AFM_E_BADARG;
+    const int64_t total = n * c;
+    unsigned g = (unsigned)((total + 255) / 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(interpolate_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dout, idx, dist2, dfeat, n, c, k);
     AFM_CHECK_LAUNCH();
     return 0;
 }

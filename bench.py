@@ -415,12 +415,17 @@ def main():
         diff_k2 = create_gaussian_diffusion(cfg); diff_k2.tables(dev)
 
         def rate(kwargs, nb, diffusion=diff_k2, steps=K2):
+            """steps/s of a `steps`-step loop call at this batch size: the faster of two calls after a warm-up call (the first call at a new
+            batch size allocates its workspace; single calls of the same process differed by up to 18 % at B = 8)."""
             run(diff_w, 1, kwargs, nb, 0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(diffusion, 2, kwargs, nb, 0)
-            torch.cuda.synchronize()
-            return steps / (time.perf_counter() - t0)
+            best = 0.0
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(diffusion, 2, kwargs, nb, 0)
+                torch.cuda.synchronize()
+                best = max(best, steps / (time.perf_counter() - t0))
+            return best
         try:
             # what each GPU runs when the 32-sample job is sharded over G GPUs (strong scaling): B = 32 / G samples; per-sample efficiency
             # against B = 32 bounds the speed-up at G GPUs (no collective inside the loop; the final all_gather is 0.8 MB per rank)

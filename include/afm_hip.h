@@ -402,6 +402,11 @@ int afm_gather_rows(const float* src, const int32_t* idx, float* out, int64_t ro
 int afm_interpolate(const float* feat, const int32_t* idx, const float* dist2, const float* base, float* out,
                     int64_t n, int32_t c, int32_t k, void* stream);
 int afm_segment_mean(const float* x, float* out, int32_t B, int32_t n, int32_t c, void* stream);
+/* backward of afm_interpolate with respect to feat (autograd of pointops.interpolation reached from loss.backward() of the PointTrans
+ * denoisers, utils/training.py:152): dfeat [m, c] = 0, then dfeat[idx[i,j], :] += w_ij * dout[i, :] over the n fine points (f32 atomics,
+ * as the reference's CUDA backward).  The gradient of `base` is dout itself. */
+int afm_interpolate_bwd(const float* dout, const int32_t* idx, const float* dist2, float* dfeat, int64_t n, int64_t m, int32_t c,
+                        int32_t k, void* stream);
 
 /* afm_transition_down: fused "set abstraction" of TransitionDown.forward (pointtransformer.py:53-69,
  * stride != 1, eval-mode BN folded to scale/shift):

@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans | --trans_dec]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans | --pointtrans_train | --trans_dec]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -203,6 +203,57 @@ def pointtrans_main():
             f.write("\n".join(f"{k} {tuple(cdm.state_dict()[k].shape)}" for k in keys) + "\n")
 
 
+def pointtrans_train_main():
+    """tests/golden/cdm_pointtrans{,v2}_training_grads.npz: the reference CDM with `arch: 'PointTrans'` (train() mode: BatchNorm on batch
+    statistics; the arch has no dropout) and `'PointTransV2'` (eval() mode: its bottleneck encoder layer has dropout 0.1, which torch
+    draws from its own generator) - training_losses + backward (utils/training.py:140-152), N = 1024."""
+    from afm import synth
+    from oracle.make_goldens import cdm_cfg
+    base, _ = import_reference()
+    B, Nc = 2, 1024
+    cxyz = synth.scene_cloud(B, Nc, seed=16)
+    x0 = synth.gaussian("cdm_pt_train_x0", (B, Nc, 6))
+    tn = synth.gaussian("cdm_pt_train_noise", (B, Nc, 6))
+    tt = torch.tensor([41, 388])
+    for arch, tag, train in (("PointTrans", "cdm_pointtrans_training_grads", True), ("PointTransV2", "cdm_pointtransv2_training_grads", False)):
+        torch.manual_seed(0)
+        mc = cdm_cfg(num_points=Nc)
+        mc.update(arch=arch, arch_pointtrans=dict(last_dim=64, num_points=Nc, blocks=[2, 2, 2, 2]))
+        cdm, cdiff = base.create_model_and_diffusion(to_attr(dict(model=mc, diffusion=diffusion_cfg(500, ""))), device="cpu")
+        synth.fill_module_(cdm)
+        cdm.train() if train else cdm.eval()
+        cdm.zero_grad()
+        terms = cdiff.training_losses(cdm, x0, tt, model_kwargs=dict(c_text=TEXTS, c_pc_xyz=cxyz), noise=tn)
+        terms["loss"].mean().backward()
+        out = {"t": tt, "loss": terms["loss"].detach()}
+        n = 0
+        for name, p in cdm.named_parameters():
+            if name.startswith("text_model.") or p.grad is None:
+                continue
+            sample, sums = grad_digest(p.grad)
+            out["g/" + name], out["s/" + name] = sample, sums
+            n += 1
+        if train:
+            mods = dict(cdm.named_modules())
+            for bn in ("contact_model.enc1.0.bn", "contact_model.dec2.0.linear2.1", "contact_model.ctx.1"):
+                out["rm/" + bn], out["rv/" + bn] = mods[bn].running_mean.detach(), mods[bn].running_var.detach()
+            # the same step in float64: ~40 batch-statistics BatchNorms in series (down to 32 rows per batch at the bottleneck) make some of
+            # these gradients ill-conditioned in f32 - the reference's OWN f32 result differs from its f64 result by what is stored as d64/
+            cdm64, cdiff64 = base.create_model_and_diffusion(to_attr(dict(model=mc, diffusion=diffusion_cfg(500, ""))), device="cpu")
+            synth.fill_module_(cdm64)
+            cdm64 = cdm64.double().train()
+            cdm64.zero_grad()
+            t64 = cdiff64.training_losses(cdm64, x0.double(), tt, model_kwargs=dict(c_text=TEXTS, c_pc_xyz=cxyz.double()), noise=tn.double())
+            t64["loss"].mean().backward()
+            p64 = dict(cdm64.named_parameters())
+            for k in [k for k in out if k.startswith("g/")]:
+                s64, _ = grad_digest(p64[k[2:]].grad)
+                out["g64/" + k[2:]] = s64.float()
+            out["loss64"] = t64["loss"].detach().float()
+        save(tag, **out)
+        print(f"{arch}: {n} parameter gradients, loss {terms['loss'].tolist()}")
+
+
 def trans_dec_main():
     """tests/golden/cmdm_trans_dec_N1024_L16.npz: CMDM.forward of the reference with `arch: 'trans_dec'`."""
     from afm import synth
@@ -223,7 +274,9 @@ def trans_dec_main():
 
 
 if __name__ == "__main__":
-    if "--trans_dec" in sys.argv:
+    if "--pointtrans_train" in sys.argv:
+        pointtrans_train_main()
+    elif "--trans_dec" in sys.argv:
         trans_dec_main()
     elif "--pointtrans" in sys.argv:
         pointtrans_main()

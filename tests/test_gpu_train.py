@@ -632,6 +632,61 @@ def test_cdm_training_losses_backward_vs_reference_gradients():
     print(f"[parity] 82 CDM gradients vs the reference's backward: worst scaled err {worst:.3e}")
 
 
+@pytest.mark.parametrize("arch,tag,train,count", [("PointTrans", "cdm_pointtrans_training_grads", True, 278),
+                                                   ("PointTransV2", "cdm_pointtransv2_training_grads", False, 302)])
+def test_cdm_pointtrans_training_vs_reference_gradients(arch, tag, train, count):
+    """`model.arch=PointTrans` (train() mode: every BatchNorm of the U-Net on batch statistics) and `PointTransV2` (eval() mode: its
+    bottleneck encoder layer carries a dropout torch draws from its own generator): training_losses(...)['loss'].mean().backward() on
+    the HIP operator graph vs the gradients of the REAL reference (oracle/make_goldens_train.py --pointtrans_train)."""
+    from afm.config import load_config
+    cfg = load_config("text_to_motion_contact_gen", "cdm", ["model.input_feats=6", "model.scene_model.use_scene_model=False", f"model.arch={arch}",
+                                                           "task.dataset.num_points=1024", "model.text_model.max_length=20", "diffusion.steps=500"])
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev())
+    model.train() if train else model.eval()
+    gg, gf = golden(tag), golden("cdm_forward_N256")
+    x0, tn = synth.gaussian("cdm_pt_train_x0", (2, 1024, 6)).to(dev()), synth.gaussian("cdm_pt_train_noise", (2, 1024, 6)).to(dev())
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_pc_xyz=synth.scene_cloud(2, 1024, seed=16).to(dev()))
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, gg["t"].to(dev()), model_kwargs=kw, noise=tn)
+    report(f"CDM {arch} training loss", terms["loss"], gg["loss"], 2e-4)
+    terms["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    names = [k[2:] for k in gg if k.startswith("g/")]
+    assert len(names) == count
+    # train mode: ~40 batch-statistics BatchNorms in series (down to 32 rows per batch at the bottleneck) make some gradients ill-conditioned
+    # in float32 - the reference's own f32 and f64 runs differ by up to 2.8e-2 (scaled) on them - so the train-mode golden carries the
+    # reference's FLOAT64 gradients (g64/) next to its float32 ones and the HIP result is held to the float64 ones
+    errs, own, tol = [], [], 2e-3
+    for n in names:
+        assert params[n].grad is not None, n
+        sample, _ = _digest(params[n].grad)
+        if train and _zero_grad_name(n):            # a bias in front of a batch-statistics BatchNorm: its true gradient is zero
+            assert sample.abs().max().item() < 5e-3, n
+            continue
+        want = gg["g64/" + n] if train else gg["g/" + n]
+        scale = max(want.abs().max().item(), 1e-3)
+        errs.append((((sample - want).abs().max() / scale).item(), n))
+        if train:                                     # what the reference's own float32 run is away from its float64 run on this tensor
+            own.append(((gg["g/" + n] - want).abs().max() / scale).item())
+    errs.sort(reverse=True)
+    p90 = errs[len(errs) // 10][0]
+    print(f"[parity] {count} CDM {arch} gradients vs the reference's {'float64 ' if train else ''}backward: worst scaled err {errs[0][0]:.2e} "
+          f"({errs[0][1]}), 90th percentile {p90:.2e}" + (f"; the reference's own f32 run vs its f64 run: worst {max(own):.2e}, "
+                                                           f"90th percentile {sorted(own, reverse=True)[len(own) // 10]:.2e}" if train else ""))
+    if train:       # the same noise class as the reference's own float32 run: no tensor further from float64 than its worst one, the bulk tight
+        assert errs[0][0] <= max(own), f"{errs[0][1]}: scaled grad err {errs[0][0]:.3e} vs float64 exceeds the reference's own worst f32 distance {max(own):.3e}"
+        assert p90 <= 3e-3, f"90th percentile of the scaled gradient errors {p90:.3e}"
+    else:
+        assert errs[0][0] <= tol, f"{errs[0][1]}: scaled grad err {errs[0][0]:.3e}"
+    if train:
+        mods = dict(model.named_modules())
+        for bn in ("contact_model.enc1.0.bn", "contact_model.dec2.0.linear2.1", "contact_model.ctx.1"):
+            report(f"running_mean {bn}", mods[bn].running_mean, gg["rm/" + bn], 2e-5)
+            report(f"running_var {bn}", mods[bn].running_var, gg["rv/" + bn], 2e-4)
+
+
 def test_cdm_train_mode_full_size_and_learning():
     """N = 8192 points, train mode (attention dropout on): reproducible with a fixed seed, loss falls under fused AdamW."""
     model, diff = _cdm_model()
