@@ -263,6 +263,117 @@ def encoder_layer(x, layer: torch.nn.TransformerEncoderLayer, key_mask, heads: i
                                  layer.norm2.bias, act)
 
 
+class _DecoderLayerFn(torch.autograd.Function):
+    """x [B, T, d], mem [B, n, d] -> post-LN nn.TransformerDecoderLayer(x, mem) (GELU): self-attention (key padding mask), cross-attention
+    over the memory (its K | V projections are part of the layer: in_proj rows d .. 3d), feed-forward - the CMDM's `trans_dec` variant
+    (cmdm.py:78-113,171-191).  drops = (p, seed, id0): ids id0 .. id0 + 5 are the self-attention probabilities, dropout1, the
+    cross-attention probabilities, dropout2, the FFN dropout and dropout3."""
+
+    @staticmethod
+    def forward(ctx, x, mem, key_mask, mem_mask, heads, drops, sa_in_w, sa_in_b, sa_out_w, sa_out_b, ca_in_w, ca_in_b, ca_out_w, ca_out_b,
+                l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, n3_w, n3_b):
+        lib = ffi.load()
+        xc, mc = _c(x), _c(mem)
+        B, T, d = xc.shape
+        n = mc.shape[1]
+        M, Mm, ff = B * T, B * n, l1_w.shape[0]
+        P = [_c(t) for t in (sa_in_w, sa_in_b, sa_out_w, sa_out_b, ca_in_w, ca_in_b, ca_out_w, ca_out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b,
+                             n2_w, n2_b, n3_w, n3_b)]
+        sa_in_w, sa_in_b, sa_out_w, sa_out_b, ca_in_w, ca_in_b, ca_out_w, ca_out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, n3_w, n3_b = P
+        p, seed, id0 = drops
+        dev = xc.device
+        km = None if key_mask is None else key_mask.to(torch.uint8).contiguous()
+        mm = None if mem_mask is None else mem_mask.to(torch.uint8).contiguous()
+        E = lambda r, c: torch.empty(r, c, device=dev, dtype=torch.float32)
+        # self-attention half
+        qkv = E(M, 3 * d)
+        _gemm(xc, sa_in_w, qkv, M, 3 * d, d, bias=sa_in_b)
+        att, lse1 = E(M, d), torch.empty(B * heads * T, device=dev, dtype=torch.float32)
+        ffi.check(lib.afm_mha_fwd_train(qkv.data_ptr(), ffi.ptr(km), att.data_ptr(), lse1.data_ptr(), B, T, heads, d // heads, p, seed, id0, _st(xc)),
+                  "afm_mha_fwd_train")
+        s1 = E(M, d)
+        _gemm(att, sa_out_w, s1, M, d, d, bias=sa_out_b, residual=xc, drop=(p, seed, id0 + 1))
+        x1 = _layernorm(s1, n1_w, n1_b)
+        # cross-attention half: q from the tokens, k | v from the memory
+        wq, bq, wkv, bkv = ca_in_w[:d], ca_in_b[:d], ca_in_w[d:], ca_in_b[d:]
+        qc, kv = E(M, d), E(Mm, 2 * d)
+        _gemm(x1, wq, qc, M, d, d, bias=bq)
+        _gemm(mc, wkv, kv, Mm, 2 * d, d, bias=bkv)
+        catt, lse2 = E(M, d), torch.empty(B * heads * T, device=dev, dtype=torch.float32)
+        ffi.check(lib.afm_mha_cross_fwd_train(qc.data_ptr(), kv.data_ptr(), ffi.ptr(mm), catt.data_ptr(), lse2.data_ptr(), B, T, n, heads, d // heads,
+                                              p, seed, id0 + 2, _st(xc)), "afm_mha_cross_fwd_train")
+        s2 = E(M, d)
+        _gemm(catt, ca_out_w, s2, M, d, d, bias=ca_out_b, residual=x1, drop=(p, seed, id0 + 3))
+        x2 = _layernorm(s2, n2_w, n2_b)
+        # feed-forward
+        z, h = E(M, ff), E(M, ff)
+        _gemm(x2, l1_w, h, M, ff, d, bias=l1_b, act=ffi.ACT_GELU, preact=z, drop=(p, seed, id0 + 4))
+        s3 = E(M, d)
+        _gemm(h, l2_w, s3, M, d, ff, bias=l2_b, residual=x2, drop=(p, seed, id0 + 5))
+        x3 = _layernorm(s3, n3_w, n3_b)
+        ctx.save_for_backward(xc, mc, km, mm, qkv, att, lse1, s1, x1, qc, kv, catt, lse2, s2, x2, z, h, s3, *P)
+        ctx.cfg = (B, T, n, d, ff, heads, drops)
+        return x3.view(B, T, d)
+
+    @staticmethod
+    def backward(ctx, dx3):
+        lib = ffi.load()
+        (xc, mc, km, mm, qkv, att, lse1, s1, x1, qc, kv, catt, lse2, s2, x2, z, h, s3, sa_in_w, sa_in_b, sa_out_w, sa_out_b, ca_in_w, ca_in_b,
+         ca_out_w, ca_out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, n3_w, n3_b) = ctx.saved_tensors
+        B, T, n, d, ff, heads, (p, seed, id0) = ctx.cfg
+        M, Mm = B * T, B * n
+        dev = xc.device
+        E = lambda r, c: torch.empty(r, c, device=dev, dtype=torch.float32)
+        dx3 = _c(dx3).view(M, d)
+        # ---- feed-forward:  x3 = LN3(s3), s3 = x2 + drop5(h W2^T + b2), h = drop4(gelu(z)), z = x2 W1^T + b1
+        ds3, ds3d, dn3w, dn3b = _layernorm_bwd(s3, n3_w, dx3, drop=(p, seed, id0 + 5))
+        dl2w, dl2b = _wgrad(ds3d, h, M, d, ff)
+        dz = E(M, ff)
+        _gemm(ds3d, _transpose(l2_w), dz, M, ff, d, drop=(p, seed, id0 + 4), dact=ffi.ACT_GELU, dact_z=z)
+        dl1w, dl1b = _wgrad(dz, x2, M, ff, d)
+        dx2 = E(M, d)
+        _gemm(dz, _transpose(l1_w), dx2, M, d, ff, residual=ds3)
+        # ---- cross-attention:  x2 = LN2(s2), s2 = x1 + drop3(catt Wo^T + bo), catt = MHA(qc, kv), qc = x1 Wq^T + bq, kv = mem Wkv^T + bkv
+        ds2, ds2d, dn2w, dn2b = _layernorm_bwd(s2, n2_w, dx2, drop=(p, seed, id0 + 3))
+        dcow, dcob = _wgrad(ds2d, catt, M, d, d)
+        dcatt = E(M, d)
+        _gemm(ds2d, _transpose(ca_out_w), dcatt, M, d, d)
+        dqc, dkv = E(M, d), E(Mm, 2 * d)
+        ws = torch.empty(B * heads * T, device=dev, dtype=torch.float32)
+        ffi.check(lib.afm_mha_cross_bwd(qc.data_ptr(), kv.data_ptr(), ffi.ptr(mm), catt.data_ptr(), dcatt.data_ptr(), lse2.data_ptr(), dqc.data_ptr(),
+                                        dkv.data_ptr(), B, T, n, heads, d // heads, p, seed, id0 + 2, ws.data_ptr(), ws.numel() * 4, _st(xc)),
+                  "afm_mha_cross_bwd")
+        wq, wkv = ca_in_w[:d], ca_in_w[d:]
+        dwq, dbq = _wgrad(dqc, x1, M, d, d)
+        dwkv, dbkv = _wgrad(dkv, mc.view(Mm, d), Mm, 2 * d, d)
+        dmem = E(Mm, d)
+        _gemm(dkv, _transpose(wkv), dmem, Mm, d, 2 * d)
+        dx1 = E(M, d)
+        _gemm(dqc, _transpose(wq), dx1, M, d, d, residual=ds2)
+        # ---- self-attention:  x1 = LN1(s1), s1 = x + drop1(att Wo^T + bo), att = MHA(qkv), qkv = x Win^T + bin
+        ds1, ds1d, dn1w, dn1b = _layernorm_bwd(s1, n1_w, dx1, drop=(p, seed, id0 + 1))
+        dow, dob = _wgrad(ds1d, att, M, d, d)
+        datt = E(M, d)
+        _gemm(ds1d, _transpose(sa_out_w), datt, M, d, d)
+        dqkv = E(M, 3 * d)
+        ffi.check(lib.afm_mha_bwd(qkv.data_ptr(), ffi.ptr(km), att.data_ptr(), datt.data_ptr(), lse1.data_ptr(), dqkv.data_ptr(), B, T, heads,
+                                  d // heads, p, seed, id0, ws.data_ptr(), ws.numel() * 4, _st(xc)), "afm_mha_bwd")
+        diw, dib = _wgrad(dqkv, xc.view(M, d), M, 3 * d, d)
+        dx = E(M, d)
+        _gemm(dqkv, _transpose(sa_in_w), dx, M, d, 3 * d, residual=ds1)
+        return (dx.view(B, T, d), dmem.view(B, n, d), None, None, None, None, diw, dib, dow, dob, torch.cat((dwq, dwkv), 0), torch.cat((dbq, dbkv), 0),
+                dcow, dcob, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b, dn3w, dn3b)
+
+
+def decoder_layer(x, mem, layer: torch.nn.TransformerDecoderLayer, key_mask, mem_mask, heads: int, drops):
+    """One nn.TransformerDecoderLayer (post-LN, GELU, batch_first) forward with the HIP backward attached."""
+    sa, ca = layer.self_attn, layer.multihead_attn
+    return _DecoderLayerFn.apply(x, mem, key_mask, mem_mask, heads, drops, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                                 ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight, ca.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
+                                 layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias,
+                                 layer.norm3.weight, layer.norm3.bias)
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm / self-attention / Perceiver attention
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod

@@ -394,9 +394,9 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
     def forward_trans_dec(self, x, timesteps, **kwargs):
         """CMDM.forward, `trans_dec` branch (cmdm.py:171-191): tokens [time | text | motion]; five self-attention stacks
         interleaved with four decoder layers whose memories are the multi-scale scene features (N/64 ... N points)."""
-        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("trans_dec is built for sampling only; call under torch.no_grad() / model.eval()")
         ffi.require_gpu(x)
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            return self._forward_trans_dec_train(x, timesteps, **kwargs)
         with torch.no_grad():
             x = ffi.f32c(x)
             B, L, _ = x.shape
@@ -425,6 +425,57 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
                         mem_mask = kwargs["c_pc_mask"].to(dev).bool().reshape(B, 1).repeat(1, kvs[i].shape[1])
                     tok = self._dec_layer(tok, self.cross_attn_layers[i], key_mask, kvs[i], mem_mask)
             return ops.linear(tok.view(B * T, d), self.motion_layer.weight, self.motion_layer.bias, a_map=(L, T, 2), rows=B * L).view(B, L, self.motion_dim)
+
+    def _forward_trans_dec_train(self, x, timesteps, **kwargs):
+        """The `trans_dec` branch under autograd (cmdm.py:171-191 reached from utils/training.py:140-152): the same graph from differentiable
+        HIP operators - the multi-scale SceneMapEncoderDecoder, kv_mappling (Linear + LayerNorm), the self-attention stacks
+        (AG.encoder_layer) and the decoder layers (AG.decoder_layer: self-attention, cross-attention over a memory, feed-forward).  Train
+        mode applies the reference's dropouts with counter-hash masks."""
+        x = ffi.f32c(x)
+        B, L, _ = x.shape
+        d, dev, T = self.latent_dim, x.device, 2 + L
+        p_drop = self.dropout_p if self.training else 0.0
+        p_pe = float(self.positional_encoder.dropout.p) if self.training else 0.0
+        self._drop_calls += 1
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls + 0xD1B54A32D192ED03 * _dist_rank()) & (2**64 - 1)
+        # memories: [x4, x3, x2, x1] -> kv_mappling (the K | V projections live inside the decoder layer operator)
+        feats = self.contact_encoder(kwargs["c_pc_xyz"], kwargs["c_pc_contact"])
+        mems = []
+        for i in range(len(self.cross_attn_layers)):
+            mem = feats[i]
+            if "c_pc_erase" in kwargs:
+                mem = mem * (1.0 - kwargs["c_pc_erase"].to(dev).float().reshape(-1, 1, 1))
+            km = self.kv_mappling_layers[i]
+            Bm, n, c = mem.shape
+            mems.append(AG.layer_norm(AG.linear(mem.reshape(Bm * n, c), km[0].weight, km[0].bias), km[1]).view(Bm, n, d))
+        # tokens [time | text | motion] + positional encoding (+ dropout)
+        te = self.timestep_embedder
+        t_idx = timesteps.to(device=dev, dtype=torch.int64)
+        time_emb = AG.linear(AG.linear(te.pe[t_idx, 0, :], te.time_embed[0].weight, te.time_embed[0].bias, act=ffi.ACT_SILU),
+                             te.time_embed[2].weight, te.time_embed[2].bias).view(B, 1, d)
+        text = self.encode_text(kwargs)
+        if "c_text_erase" in kwargs:
+            text = text * (1.0 - kwargs["c_text_erase"].to(dev).float().reshape(B, 1))
+        text_emb = AG.linear(text, self.language_adapter.weight, self.language_adapter.bias).view(B, 1, d)
+        h = AG.linear(x, self.motion_adapter.weight, self.motion_adapter.bias)
+        tok = AG.posenc_dropout(torch.cat([time_emb, text_emb, h], dim=1), self.positional_encoder.pe[:T, 0, :], (p_pe, seed, 1))
+        key_mask = None
+        if self.mask_motion:
+            tm = kwargs["c_text_mask"].to(dev).bool().reshape(B, 1) if "c_text_mask" in kwargs else torch.zeros(B, 1, dtype=torch.bool, device=dev)
+            key_mask = torch.cat([torch.zeros(B, 1, dtype=torch.bool, device=dev), tm, kwargs["x_mask"].to(dev).bool().reshape(B, L)], dim=1)
+        did = 16
+        for i, stack in enumerate(self.self_attn_layers):
+            for layer in stack.layers:
+                tok = AG.encoder_layer(tok, layer, key_mask, self.num_heads, (p_drop, seed, did))
+                did += 4
+            if i != len(self.self_attn_layers) - 1:
+                mem_mask = None
+                if "c_pc_mask" in kwargs:
+                    mem_mask = kwargs["c_pc_mask"].to(dev).bool().reshape(B, 1).repeat(1, mems[i].shape[1])
+                tok = AG.decoder_layer(tok, mems[i], self.cross_attn_layers[i], key_mask, mem_mask, self.num_heads, (p_drop, seed, did))
+                did += 6
+        out = AG.linear(tok.view(B * T, d), self.motion_layer.weight, self.motion_layer.bias, a_map=(L, T, 2), rows=B * L)
+        return out.view(B, L, self.motion_dim)
 
     # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
     def forward_train(self, x, timesteps, **kwargs):

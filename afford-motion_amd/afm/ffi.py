@@ -171,6 +171,9 @@ EXPORTS = {
     "afm_mha_fwd_train": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
     "afm_mha_bwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, C.c_float, u64, C.c_uint32,
                               C.c_void_p, i64, C.c_void_p]),
+    "afm_mha_cross_fwd_train": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, i32, i32, i32, i32, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
+    "afm_mha_cross_bwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, C.c_float, u64,
+                                   C.c_uint32, C.c_void_p, i64, C.c_void_p]),
     "afm_masked_mse_bwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, i32, i32, i32, C.c_void_p]),
     "afm_rowop": (C.c_int, [c_f32p, c_f32p, i32, c_f32p, i32, c_f32p, i64, i32, C.c_float, u64, C.c_uint32, C.c_void_p]),
     "afm_colstats_workspace_bytes": (i64, [i64, i32]),

@@ -341,7 +341,7 @@ class SceneMapEncoderDecoder(nn.Module):
     def forward(self, p: torch.Tensor, x: torch.Tensor):
         ffi.require_gpu(p, x)
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            raise NotImplementedError("SceneMapEncoderDecoder is built for sampling only; call under torch.no_grad()")
+            return self.forward_train(p, x)
         with torch.no_grad():
             B, N = p.shape[0], p.shape[1]
             p0 = ffi.f32c(p).reshape(B * N, 3)
@@ -363,6 +363,30 @@ class SceneMapEncoderDecoder(nn.Module):
                 y = dec[1].run(ps[lvl], dec[0].run_fuse(ps[lvl], xs[lvl], ps[lvl + 1], y, B), knns[lvl])
                 outs[lvl] = y
             return [outs[l].view(B, -1, outs[l].shape[-1]) for l in (3, 2, 1, 0)]
+
+    def forward_train(self, p: torch.Tensor, x: torch.Tensor):
+        """Same function with the autograd tape attached (BatchNorm per `self.training`): differentiable HIP operators level by level."""
+        B, N = p.shape[0], p.shape[1]
+        p0 = ffi.f32c(p).reshape(B * N, 3)
+        x0 = p0 if self.c == 3 else torch.cat((p0, ffi.f32c(x).reshape(B * N, -1)), 1)
+        ps, xs, knns = [], [], []
+        for lvl in range(4):
+            enc = getattr(self, f"enc{lvl + 1}")
+            p0, x0 = enc[0].run_train(p0, x0, B)
+            n = p0.shape[0] // B
+            with torch.no_grad():
+                ki, _ = pointops.knn(self.nsamples[lvl], p0, p0, B, n, n)
+            for blk in list(enc)[1:]:
+                x0 = blk.run_train(p0, x0, ki)
+            ps.append(p0); xs.append(x0); knns.append(ki)
+        outs = [None] * 4
+        y = self.dec4[1].run_train(ps[3], self.dec4[0].run_head_train(xs[3], B), knns[3])
+        outs[3] = y
+        for lvl in (2, 1, 0):
+            dec = getattr(self, f"dec{lvl + 1}")
+            y = dec[1].run_train(ps[lvl], dec[0].run_fuse_train(ps[lvl], xs[lvl], ps[lvl + 1], y, B), knns[lvl])
+            outs[lvl] = y
+        return [outs[l].view(B, -1, outs[l].shape[-1]) for l in (3, 2, 1, 0)]
 
 
 class PointTransformerSeg(nn.Module):

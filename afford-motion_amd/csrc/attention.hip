@@ -700,3 +700,9 @@ extern "C" int afm_mha_cross_fwd(const float* q, const float* kv, const uint8_t*
     const int D = H * dh;
     return mha_fwd_launch(q, D, kv, kv ? kv + D : nullptr, 2 * D, key_mask, out, nullptr, B, Tq, Tk, H, dh, 0.0f, 0, 0, false, -1, stream);
 }
+
+extern "C" int afm_mha_cross_fwd_train(const float* q, const float* kv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t Tq,
+                                       int32_t Tk, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream) {
+    const int D = H * dh;
+    return mha_fwd_launch(q, D, kv, kv ? kv + D : nullptr, 2 * D, key_mask, out, lse, B, Tq, Tk, H, dh, drop_p, drop_seed, drop_id, true, -1, stream);
+}

@@ -29,6 +29,21 @@ constexpr int KB = 32;
 constexpr int LDP = 68;            // padded LDS row (floats): conflict-free ds_read_b128 rows and b32 columns
 constexpr int MAX_WAVES = 8;        // 2 waves per SIMD -> 256 VGPRs each (the dK/dV pass holds 4 accumulator tiles + V + S + dP)
 
+// Tq queries (rows of q, stride ldq) over Tk keys / values (rows of k / v, stride ldkv).  Self-attention passes the packed in_proj output and
+// its gradient three times (q | k | v, every stride 3D, Tq == Tk); cross-attention (nn.TransformerDecoderLayer.multihead_attn of the CMDM's
+// trans_dec variant, cmdm.py:78-113) a [B, Tq, D] query and a packed [B, Tk, 2D] memory projection.  out / dout are [B, Tq, D], lse / Dws [B H, Tq].
+struct MhaBwd {
+    const float* q; int ldq;
+    const float* k; const float* v; int ldkv;
+    const uint8_t* key_mask;                 // [B, Tk] or null
+    const float* out; const float* dout; const float* lse;
+    float* dq; int lddq;
+    float* dk; float* dv; int lddkv;
+    float* Dws;
+    int Tq, Tk, H;
+    float scale, drop_p; uint64_t drop_seed; uint32_t drop_id;
+};
+
 // 32x32 product over the 64 head dims with the k index permuted per lane half (as in attention.hip):
 // acc[reg r] (+)= sum_d rows[row (l&31)][32*hh + d] * breg[d]
 __device__ __forceinline__ void prod_rows(const float* __restrict__ rows_lds /* + r32*LDP + hh*32 */, const float (&breg)[32], f32x16& acc) {
@@ -44,10 +59,16 @@ __device__ __forceinline__ void prod_rows(const float* __restrict__ rows_lds /* 
 
 // ------------------------------------------------------------------------------------------------ pass 1: dQ, D
 template <int NST, bool DROP>
-__global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
-                                                                    const float* __restrict__ out, const float* __restrict__ dout,
-                                                                    const float* __restrict__ lse, float* __restrict__ dqkv, float* __restrict__ Dws,
-                                                                    int T, int H, float scale, float drop_p, uint64_t drop_seed, uint32_t drop_id) {
+__global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const MhaBwd a) {
+    const uint8_t* __restrict__ key_mask = a.key_mask;
+    const float* __restrict__ out = a.out;
+    const float* __restrict__ dout = a.dout;
+    const float* __restrict__ lse = a.lse;
+    float* __restrict__ Dws = a.Dws;
+    const int Tq = a.Tq, T = a.Tk, H = a.H;
+    const float scale = a.scale, drop_p = a.drop_p;
+    const uint64_t drop_seed = a.drop_seed;
+    const uint32_t drop_id = a.drop_id;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                               // [2][KB][LDP]
     float* Vs = smem + 2 * KB * LDP;                // [2][KB][LDP]
@@ -57,9 +78,11 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
-    const int D = H * DH, ld = 3 * D;
-    const int nkb = (T + KB - 1) / KB, nqb = nkb;
-    const float* base = qkv + (int64_t)b * T * ld + h * DH;
+    const int D = H * DH;
+    const int nkb = (T + KB - 1) / KB, nqb = (Tq + KB - 1) / KB;
+    const float* qbase = a.q + (int64_t)b * Tq * a.ldq + h * DH;
+    const float* kbase = a.k + (int64_t)b * T * a.ldkv + h * DH;
+    const float* vbase = a.v + (int64_t)b * T * a.ldkv + h * DH;
     const float NEG_INF = -INFINITY;
     const DropKey dk(DROP ? drop_p : 0.0f, drop_seed, drop_id);
 
@@ -80,7 +103,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
             if (e < 1024) {
                 const int isv = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
                 const int key = kb * KB + row;
-                if (key < T) v = *reinterpret_cast<const float4*>(base + (int64_t)key * ld + (1 + isv) * D + c4 * 4);
+                if (key < T) v = *reinterpret_cast<const float4*>((isv ? vbase : kbase) + (int64_t)key * a.ldkv + c4 * 4);
             }
             stage[i] = v;
         }
@@ -100,13 +123,13 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
     for (int q0 = 0; q0 < nqb; q0 += nw) {
         const int qb = q0 + wave;
         const bool active = qb < nqb;
-        const int qrow = min((active ? qb : 0) * 32 + r32, T - 1);
+        const int qrow = min((active ? qb : 0) * 32 + r32, Tq - 1);
         float q[32], dO[32];
         float lse_q, D_q;
         {
-            const float* qp = base + (int64_t)qrow * ld + hh * 32;
-            const float* dop = dout + ((int64_t)b * T + qrow) * D + h * DH + hh * 32;
-            const float* op = out + ((int64_t)b * T + qrow) * D + h * DH + hh * 32;
+            const float* qp = qbase + (int64_t)qrow * a.ldq + hh * 32;
+            const float* dop = dout + ((int64_t)b * Tq + qrow) * D + h * DH + hh * 32;
+            const float* op = out + ((int64_t)b * Tq + qrow) * D + h * DH + hh * 32;
             float dsum = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -118,8 +141,8 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
                 dsum += (g.x * o.x + g.y * o.y) + (g.z * o.z + g.w * o.w);
             }
             D_q = dsum + xor32(dsum);
-            lse_q = lse[(int64_t)blockIdx.x * T + qrow];
-            if (active && hh == 0 && qb * 32 + r32 < T) Dws[(int64_t)blockIdx.x * T + qrow] = D_q;
+            lse_q = lse[(int64_t)blockIdx.x * Tq + qrow];
+            if (active && hh == 0 && qb * 32 + r32 < Tq) Dws[(int64_t)blockIdx.x * Tq + qrow] = D_q;
         }
         f32x16 dq0, dq1;
 #pragma unroll
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
                 __builtin_amdgcn_sched_barrier(0);
                 prod_rows(Vs + (buf * KB + r32) * LDP + hh * 32, dO, dp);        // dP^T
                 __builtin_amdgcn_sched_barrier(0);
-                const uint32_t row_ix = blockIdx.x * T + qrow, col0 = kb * KB + 4 * hh;
+                const uint32_t row_ix = blockIdx.x * Tq + qrow, col0 = kb * KB + 4 * hh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 ma = *reinterpret_cast<const float4*>(madd + kb * KB + 8 * g + 4 * hh);
@@ -169,8 +192,8 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
             __syncthreads();
         }
 
-        if (active && qb * 32 + r32 < T) {
-            float* gp = dqkv + ((int64_t)b * T + qb * 32 + r32) * ld + h * DH + 4 * hh;
+        if (active && qb * 32 + r32 < Tq) {
+            float* gp = a.dq + ((int64_t)b * Tq + qb * 32 + r32) * a.lddq + h * DH + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 *reinterpret_cast<float4*>(gp + 8 * g) =
@@ -184,10 +207,15 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dq_kernel(const float*
 
 // ------------------------------------------------------------------------------------------------ pass 2: dK, dV
 template <int NST, bool DROP>
-__global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
-                                                                     const float* __restrict__ dout, const float* __restrict__ lse,
-                                                                     const float* __restrict__ Dws, float* __restrict__ dqkv, int T, int H, float scale,
-                                                                     float drop_p, uint64_t drop_seed, uint32_t drop_id) {
+__global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const MhaBwd a) {
+    const uint8_t* __restrict__ key_mask = a.key_mask;
+    const float* __restrict__ dout = a.dout;
+    const float* __restrict__ lse = a.lse;
+    const float* __restrict__ Dws = a.Dws;
+    const int Tq = a.Tq, T = a.Tk, H = a.H;
+    const float scale = a.scale, drop_p = a.drop_p;
+    const uint64_t drop_seed = a.drop_seed;
+    const uint32_t drop_id = a.drop_id;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* Qs = smem;                               // [2][KB][LDP]
@@ -199,10 +227,12 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
-    const int D = H * DH, ld = 3 * D;
-    const int nqb = (T + KB - 1) / KB, nkb = nqb;
-    const float* base = qkv + (int64_t)b * T * ld + h * DH;
-    const float* gbase = dout + (int64_t)b * T * D + h * DH;
+    const int D = H * DH;
+    const int nqb = (Tq + KB - 1) / KB, nkb = (T + KB - 1) / KB;
+    const float* qbase = a.q + (int64_t)b * Tq * a.ldq + h * DH;
+    const float* kbase = a.k + (int64_t)b * T * a.ldkv + h * DH;
+    const float* vbase = a.v + (int64_t)b * T * a.ldkv + h * DH;
+    const float* gbase = dout + (int64_t)b * Tq * D + h * DH;
     const float NEG_INF = -INFINITY;
     const DropKey dk(DROP ? drop_p : 0.0f, drop_seed, drop_id);
 
@@ -217,15 +247,15 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
             if (e < 1024) {
                 const int isg = e >> 9, row = (e & 511) >> 4, c4 = e & 15;
                 const int qr = qb * KB + row;
-                if (qr < T) v = isg ? *reinterpret_cast<const float4*>(gbase + (int64_t)qr * D + c4 * 4)
-                                    : *reinterpret_cast<const float4*>(base + (int64_t)qr * ld + c4 * 4);
+                if (qr < Tq) v = isg ? *reinterpret_cast<const float4*>(gbase + (int64_t)qr * D + c4 * 4)
+                                     : *reinterpret_cast<const float4*>(qbase + (int64_t)qr * a.ldq + c4 * 4);
             }
             stage[i] = v;
         }
         if (tid < 64) {
             const int qr = qb * KB + (tid & 31);
             // padded queries: lse = +inf makes their probability exactly 0
-            stage_x = (qr < T) ? ((tid < 32) ? lse[(int64_t)blockIdx.x * T + qr] : Dws[(int64_t)blockIdx.x * T + qr]) : ((tid < 32) ? INFINITY : 0.f);
+            stage_x = (qr < Tq) ? ((tid < 32) ? lse[(int64_t)blockIdx.x * Tq + qr] : Dws[(int64_t)blockIdx.x * Tq + qr]) : ((tid < 32) ? INFINITY : 0.f);
         }
     };
     auto store_block = [&](int buf) {
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
         const bool any_valid = __any(key_ok);
         float v[32];
         {
-            const float* vp = base + (int64_t)key * ld + 2 * D + hh * 32;
+            const float* vp = vbase + (int64_t)key * a.ldkv + hh * 32;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float4 t = *reinterpret_cast<const float4*>(vp + i * 4);
@@ -260,7 +290,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
         __syncthreads();                 // previous pass done with Kw / the Q blocks
         {
             // this wave's K block -> its private LDS region, pre-scaled: lane (row r32, half hh) copies 32 floats
-            const float* kp = base + (int64_t)key * ld + D + hh * 32;
+            const float* kp = kbase + (int64_t)key * a.ldkv + hh * 32;
             float* kd = Kw + (wave * KB + r32) * LDP + hh * 32;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -301,7 +331,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
                 prod_rows(grows, v, dp);                                          // dP = dO V^T
                 __builtin_amdgcn_sched_barrier(0);
                 // reg r <-> query qb*32 + (r&3) + 8*(r>>2) + 4*hh, key = this lane's
-                const uint32_t row0 = blockIdx.x * T + qb * KB + 4 * hh;
+                const uint32_t row0 = blockIdx.x * Tq + qb * KB + 4 * hh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 l4 = *reinterpret_cast<const float4*>(lseS + buf * KB + 8 * g + 4 * hh);
@@ -341,8 +371,8 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
         }
 
         if (active && kblk * KB + r32 < T) {
-            float* kp = dqkv + ((int64_t)b * T + kblk * KB + r32) * ld + D + h * DH + 4 * hh;
-            float* vp = kp + D;
+            float* kp = a.dk + ((int64_t)b * T + kblk * KB + r32) * a.lddkv + h * DH + 4 * hh;
+            float* vp = a.dv + ((int64_t)b * T + kblk * KB + r32) * a.lddkv + h * DH + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 *reinterpret_cast<float4*>(kp + 8 * g) =
@@ -358,49 +388,79 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void mha_bwd_dkv_kernel(const float
 
 }  // namespace
 
-extern "C" int afm_mha_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse, float* dqkv,
-                           int32_t B, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws,
-                           int64_t ws_bytes, void* stream) {
+namespace {
+
+int mha_bwd_launch(MhaBwd a, int B, int dh, void* ws, int64_t ws_bytes, hipStream_t s) {
     if (dh != DH) return AFM_E_UNSUPPORTED;
     if (B == 0) return 0;
-    if (!qkv || !out || !dout || !lse || !dqkv || B < 0 || T <= 0 || H <= 0) return AFM_E_BADARG;
-    if ((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) return AFM_E_BADARG;
-    if (drop_p < 0.0f || drop_p >= 1.0f) return AFM_E_BADARG;
-    if (!ws || ws_bytes < (int64_t)B * H * T * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
-    float* Dws = (float*)ws;
-    const int nqb = (T + 31) / 32;
-    const int nw = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);
-    const size_t lds1 = (size_t)(4 * KB * LDP + nqb * KB) * sizeof(float) + (size_t)nqb * sizeof(int);
-    const size_t lds2 = (size_t)(4 * KB * LDP + 4 * KB + nw * KB * LDP) * sizeof(float);
+    if (!a.q || !a.k || !a.v || !a.out || !a.dout || !a.lse || !a.dq || !a.dk || !a.dv || B < 0 || a.Tq <= 0 || a.Tk <= 0 || a.H <= 0) return AFM_E_BADARG;
+    if ((((uintptr_t)a.q) | ((uintptr_t)a.k) | ((uintptr_t)a.v) | ((uintptr_t)a.out) | ((uintptr_t)a.dout) | ((uintptr_t)a.dq) | ((uintptr_t)a.dk) |
+         ((uintptr_t)a.dv)) & 15) return AFM_E_BADARG;
+    if ((a.ldq | a.ldkv | a.lddq | a.lddkv) & 3) return AFM_E_BADARG;
+    if (a.drop_p < 0.0f || a.drop_p >= 1.0f) return AFM_E_BADARG;
+    if (!ws || ws_bytes < (int64_t)B * a.H * a.Tq * (int64_t)sizeof(float)) return AFM_E_WORKSPACE;
+    a.Dws = (float*)ws;
+    const int nqb = (a.Tq + 31) / 32, nkb = (a.Tk + 31) / 32;
+    const int nw1 = nqb < 4 ? 4 : (nqb > MAX_WAVES ? MAX_WAVES : nqb);             // pass 1: a wave per query block
+    const int nw2 = nkb < 4 ? 4 : (nkb > MAX_WAVES ? MAX_WAVES : nkb);             // pass 2: a wave per key block
+    const size_t lds1 = (size_t)(4 * KB * LDP + nkb * KB) * sizeof(float) + (size_t)nkb * sizeof(int);
+    const size_t lds2 = (size_t)(4 * KB * LDP + 4 * KB + nw2 * KB * LDP) * sizeof(float);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return AFM_E_UNSUPPORTED;
-    const float scale = 1.0f / sqrtf((float)dh);
-    hipStream_t s = (hipStream_t)stream;
-    const double flops_prod = 2.0 * B * H * (double)T * T * dh;
+    a.scale = 1.0f / sqrtf((float)dh);
+    const double flops_prod = 2.0 * B * a.H * (double)a.Tq * a.Tk * dh;
     static std::atomic<bool> attr_set{false};         // > 64 KB of dynamic LDS must be opted into once per kernel (idempotent)
     if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipSuccess;
-        const void* fns[4] = {(const void*)mha_bwd_dkv_kernel<2, false>, (const void*)mha_bwd_dkv_kernel<4, false>,
-                              (const void*)mha_bwd_dkv_kernel<2, true>, (const void*)mha_bwd_dkv_kernel<4, true>};
-        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fns[8] = {(const void*)mha_bwd_dkv_kernel<2, false>, (const void*)mha_bwd_dkv_kernel<4, false>,
+                              (const void*)mha_bwd_dkv_kernel<2, true>, (const void*)mha_bwd_dkv_kernel<4, true>,
+                              (const void*)mha_bwd_dq_kernel<2, false>, (const void*)mha_bwd_dq_kernel<4, false>,
+                              (const void*)mha_bwd_dq_kernel<2, true>, (const void*)mha_bwd_dq_kernel<4, true>};
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.store(true, std::memory_order_release);
     }
-    const bool drop = drop_p > 0.0f;
-#define AFM_DQ(NST, DR) hipLaunchKernelGGL((mha_bwd_dq_kernel<NST, DR>), dim3(B * H), dim3(nw * 64), lds1, s, qkv, key_mask, out, dout, lse, dqkv, Dws, T, H, scale, drop_p, drop_seed, drop_id)
-#define AFM_DKV(NST, DR) hipLaunchKernelGGL((mha_bwd_dkv_kernel<NST, DR>), dim3(B * H), dim3(nw * 64), lds2, s, qkv, key_mask, dout, lse, Dws, dqkv, T, H, scale, drop_p, drop_seed, drop_id)
+    const bool drop = a.drop_p > 0.0f;
+#define AFM_DQ(NST, DR) hipLaunchKernelGGL((mha_bwd_dq_kernel<NST, DR>), dim3(B * a.H), dim3(nw1 * 64), lds1, s, a)
+#define AFM_DKV(NST, DR) hipLaunchKernelGGL((mha_bwd_dkv_kernel<NST, DR>), dim3(B * a.H), dim3(nw2 * 64), lds2, s, a)
     {
         AfmProf prof(AFM_PROF_MHA_BWD_DQ, 3.0 * flops_prod, s);
-        if (nw >= 8) { if (drop) AFM_DQ(2, true); else AFM_DQ(2, false); }
+        if (nw1 >= 8) { if (drop) AFM_DQ(2, true); else AFM_DQ(2, false); }
         else { if (drop) AFM_DQ(4, true); else AFM_DQ(4, false); }
         AFM_CHECK_LAUNCH();
     }
     {
         AfmProf prof(AFM_PROF_MHA_BWD_DKV, 4.0 * flops_prod, s);
-        if (nw >= 8) { if (drop) AFM_DKV(2, true); else AFM_DKV(2, false); }
+        if (nw2 >= 8) { if (drop) AFM_DKV(2, true); else AFM_DKV(2, false); }
         else { if (drop) AFM_DKV(4, true); else AFM_DKV(4, false); }
         AFM_CHECK_LAUNCH();
     }
 #undef AFM_DQ
 #undef AFM_DKV
     return 0;
+}
+
+}  // namespace
+
+extern "C" int afm_mha_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse, float* dqkv,
+                           int32_t B, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws,
+                           int64_t ws_bytes, void* stream) {
+    if (!qkv || !dqkv || H <= 0) return B == 0 ? 0 : AFM_E_BADARG;
+    const int D = H * dh;
+    MhaBwd a = {};
+    a.q = qkv; a.ldq = 3 * D; a.k = qkv + D; a.v = qkv + 2 * D; a.ldkv = 3 * D; a.key_mask = key_mask; a.out = out; a.dout = dout; a.lse = lse;
+    a.dq = dqkv; a.lddq = 3 * D; a.dk = dqkv + D; a.dv = dqkv + 2 * D; a.lddkv = 3 * D; a.Tq = T; a.Tk = T; a.H = H;
+    a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_id = drop_id;
+    return mha_bwd_launch(a, B, dh, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int afm_mha_cross_bwd(const float* q, const float* kv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse,
+                                 float* dq, float* dkv, int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed,
+                                 uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream) {
+    if (!q || !kv || !dq || !dkv || H <= 0) return B == 0 ? 0 : AFM_E_BADARG;
+    const int D = H * dh;
+    MhaBwd a = {};
+    a.q = q; a.ldq = D; a.k = kv; a.v = kv + D; a.ldkv = 2 * D; a.key_mask = key_mask; a.out = out; a.dout = dout; a.lse = lse;
+    a.dq = dq; a.lddq = D; a.dk = dkv; a.dv = dkv + D; a.lddkv = 2 * D; a.Tq = Tq; a.Tk = Tk; a.H = H;
+    a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_id = drop_id;
+    return mha_bwd_launch(a, B, dh, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -290,6 +290,14 @@ int afm_mha_fwd_train(const float* qkv, const uint8_t* key_mask, float* out, flo
 int afm_mha_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse,
                 float* dqkv, int32_t B, int32_t T, int32_t H, int32_t dh,
                 float drop_p, uint64_t drop_seed, uint32_t drop_id, void* ws, int64_t ws_bytes, void* stream);
+/* The same pair for cross-attention (nn.TransformerDecoderLayer.multihead_attn of the CMDM's `trans_dec` variant under autograd, cmdm.py:78-113,
+ * 171-191): q [B,Tq,H*dh], kv [B,Tk,2*H*dh] = packed K | V projections of the memory, key_mask [B,Tk] or NULL; the forward also writes
+ * lse [B*H, Tq]; the backward fills dq [B,Tq,H*dh] and dkv [B,Tk,2*H*dh].  ws: B*H*Tq floats.  Dropout as afm_mha_fwd_train. */
+int afm_mha_cross_fwd_train(const float* q, const float* kv, const uint8_t* key_mask, float* out, float* lse, int32_t B, int32_t Tq, int32_t Tk,
+                            int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, void* stream);
+int afm_mha_cross_bwd(const float* q, const float* kv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse, float* dq,
+                      float* dkv, int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id,
+                      void* ws, int64_t ws_bytes, void* stream);
 
 /* d(afm_masked_mse)/d(pred): dpred[b,l,:] = dloss[b] * 2 * (pred - target) * keep[b,l] / (sum(keep[b]) * D). */
 int afm_masked_mse_bwd(const float* target, const float* pred, const uint8_t* frame_mask, const float* dloss,

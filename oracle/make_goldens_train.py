@@ -1,7 +1,7 @@
 """Generate tests/golden/cmdm_training_grads.npz by running the REAL reference's
 training_losses + backward (utils/training.py:140-152) on the reduced CMDM of make_goldens.py.
 
-Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans | --pointtrans_train | --trans_dec]
+Run in the build container only:   python -m oracle.make_goldens_train  [--scene | --cdm | --masks | --mlp | --pointtrans | --pointtrans_train | --trans_dec | --trans_dec_train]
 eval() mode (dropout off, BatchNorm on running statistics) so the result is a deterministic function of the inputs;
 gradients of the denoiser trunk, the adapters and the TimestepEmbedder are stored (small tensors in full, large ones as a
 strided sample + sum / abs-sum).
@@ -273,8 +273,43 @@ def trans_dec_main():
         f.write("\n".join(f"{k} {tuple(model.state_dict()[k].shape)}" for k in keys) + "\n")
 
 
+def trans_dec_train_main():
+    """tests/golden/cmdm_trans_dec_training_grads.npz: the reference CMDM with `arch: 'trans_dec'` (multi-scale SceneMapEncoderDecoder memories,
+    decoder layers with cross-attention) - training_losses + backward, eval() mode (dropout off, BatchNorm on running statistics), every
+    parameter gradient incl. the scene encoder-decoder's."""
+    from afm import synth
+    base, _ = import_reference()
+    torch.manual_seed(0)
+    g = np.load(os.path.join(GOLD, "cmdm_forward_N1024_L16.npz"))
+    xyz, con, x_mask = torch.from_numpy(g["xyz"]), torch.from_numpy(g["contact"]), torch.from_numpy(g["x_mask"])
+    B, L, N = 2, 16, xyz.shape[1]
+    mc = cmdm_cfg(num_points=N)
+    mc["arch"] = "trans_dec"
+    model, diff = base.create_model_and_diffusion(to_attr(dict(model=mc, diffusion=diffusion_cfg(1000, ""))), device="cpu")
+    synth.fill_module_(model)
+    model.eval()
+    x0 = synth.gaussian("train_x0", (B, L, 263))
+    tn = synth.gaussian("train_noise", (B, L, 263))
+    tt = torch.tensor([17, 803])
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, tt, model_kwargs=dict(c_text=TEXTS, c_pc_xyz=xyz, c_pc_contact=con, x_mask=x_mask), noise=tn)
+    terms["loss"].mean().backward()
+    out = {"t": tt, "loss": terms["loss"].detach()}
+    n = 0
+    for name, p in model.named_parameters():
+        if name.startswith("text_model.") or p.grad is None:
+            continue
+        sample, sums = grad_digest(p.grad)
+        out["g/" + name], out["s/" + name] = sample, sums
+        n += 1
+    save("cmdm_trans_dec_training_grads", **out)
+    print(f"trans_dec: {n} parameter gradients, loss {terms['loss'].tolist()}")
+
+
 if __name__ == "__main__":
-    if "--pointtrans_train" in sys.argv:
+    if "--trans_dec_train" in sys.argv:
+        trans_dec_train_main()
+    elif "--pointtrans_train" in sys.argv:
         pointtrans_train_main()
     elif "--trans_dec" in sys.argv:
         trans_dec_main()

@@ -687,6 +687,97 @@ def test_cdm_pointtrans_training_vs_reference_gradients(arch, tag, train, count)
             report(f"running_var {bn}", mods[bn].running_var, gg["rv/" + bn], 2e-4)
 
 
+@pytest.mark.parametrize("B,T,n,heads", [(2, 37, 300, 2), (3, 198, 1024, 8), (1, 5, 33, 1)])
+def test_decoder_layer_fwd_bwd_vs_torch_float64(B, T, n, heads):
+    """AG.decoder_layer (self-attention with a key padding mask, cross-attention over a masked memory with Tq != Tk - afm_mha_cross_fwd_train /
+    afm_mha_cross_bwd -, feed-forward; post-LN, GELU) against nn.TransformerDecoderLayer in float64 on the CPU: output and every gradient."""
+    d = 64 * heads
+    torch.manual_seed(5)
+    layer = torch.nn.TransformerDecoderLayer(d_model=d, nhead=heads, dim_feedforward=2 * d, dropout=0.0, activation="gelu", batch_first=True)
+    for name, p_ in layer.named_parameters():
+        p_.data = synth.gaussian("dl_" + name, tuple(p_.shape)) * (2.0 / d ** 0.5 if p_.dim() > 1 else 0.1) + (1.0 if "norm" in name and "weight" in name else 0.0)
+    x, mem, dy = g("dl_x", (B, T, d)), g("dl_mem", (B, n, d)), g("dl_dy", (B, T, d))
+    km = torch.zeros(B, T, dtype=torch.bool); km[0, T - T // 3:] = True
+    mm = torch.zeros(B, n, dtype=torch.bool); mm[B - 1, n // 2:] = True
+    ref = torch.nn.TransformerDecoderLayer(d_model=d, nhead=heads, dim_feedforward=2 * d, dropout=0.0, activation="gelu", batch_first=True).double()
+    ref.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    xr, mr = x.double().requires_grad_(True), mem.double().requires_grad_(True)
+    out_r = ref(xr, mr, tgt_key_padding_mask=km, memory_key_padding_mask=mm)
+    valid = ~km                                        # rows of padded queries are not compared (nothing reads them)
+    (out_r * dy.double() * valid[..., None]).sum().backward()
+    layer = layer.to(dev())
+    xg, mg = x.to(dev()).requires_grad_(True), mem.to(dev()).requires_grad_(True)
+    out = AG.decoder_layer(xg, mg, layer, km.to(dev()), mm.to(dev()), heads, (0.0, 0, 0))
+    report(f"decoder layer forward B={B} T={T} n={n}", out.detach().cpu()[valid], out_r.detach()[valid].float(), 1e-4)
+    (out * (dy * valid[..., None]).to(dev())).sum().backward()
+    rel("decoder layer dx", xg.grad.cpu()[valid], xr.grad[valid], 1e-4)
+    rel("decoder layer dmem", mg.grad, mr.grad, 1e-4)
+    pr = dict(ref.named_parameters())
+    for name, p_ in layer.named_parameters():
+        rel(f"decoder layer d{name}", p_.grad, pr[name].grad, 1e-4)
+
+
+def test_cross_attention_dropout_mask_is_the_same_in_forward_and_backward():
+    """afm_mha_cross_fwd_train / afm_mha_cross_bwd with attention dropout: V = identity over Tk = dh = 64 keys makes the output row the dropped
+    probability row itself, which recovers the keep mask; forward and all three gradients are then checked against float64 with THAT mask."""
+    lib = ffi.load()
+    B, Tq, Tk, H, p = 2, 40, 64, 1, 0.25
+    q, k, dO = g("xd_q", (B, Tq, 64)), g("xd_k", (B, Tk, 64)), g("xd_do", (B, Tq, 64))
+    v = torch.eye(64).expand(B, Tk, 64).contiguous()
+    kv = torch.cat((k, v), -1).contiguous()
+    qd, kvd = q.to(dev()), kv.to(dev())
+    out, lse = torch.empty(B, Tq, 64, device=dev()), torch.empty(B * H * Tq, device=dev())
+    ffi.check(lib.afm_mha_cross_fwd_train(qd.data_ptr(), kvd.data_ptr(), None, out.data_ptr(), lse.data_ptr(), B, Tq, Tk, H, 64, p, 1234, 7,
+                                          ffi.stream_of(qd)), "afm_mha_cross_fwd_train")
+    P = torch.softmax(q.double() @ k.double().transpose(1, 2) / 8.0, -1)
+    M = torch.where(out.cpu().double() > 0.5 * P, torch.full_like(P, 1.0 / (1.0 - p)), torch.zeros_like(P))
+    kept = (M > 0).double().mean().item()
+    assert abs(kept - (1 - p)) < 0.05, kept
+    report("cross-attention dropped probabilities", out, (P * M).float(), 2e-6)
+    dq, dkv = torch.empty_like(qd), torch.empty_like(kvd)
+    ws = torch.empty(B * H * Tq, device=dev())
+    dOd = dO.to(dev())
+    ffi.check(lib.afm_mha_cross_bwd(qd.data_ptr(), kvd.data_ptr(), None, out.data_ptr(), dOd.data_ptr(), lse.data_ptr(), dq.data_ptr(), dkv.data_ptr(),
+                                    B, Tq, Tk, H, 64, p, 1234, 7, ws.data_ptr(), ws.numel() * 4, ffi.stream_of(qd)), "afm_mha_cross_bwd")
+    dOr, Vr = dO.double(), v.double()
+    dV = (P * M).transpose(1, 2) @ dOr
+    dP = (dOr @ Vr.transpose(1, 2)) * M
+    dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+    rel("cross-attention dropout dQ", dq, dS @ k.double() / 8.0, 2e-5)
+    rel("cross-attention dropout dK", dkv[..., :64], dS.transpose(1, 2) @ q.double() / 8.0, 2e-5)
+    rel("cross-attention dropout dV", dkv[..., 64:], dV, 2e-5)
+
+
+def test_cmdm_trans_dec_training_vs_reference_gradients():
+    """`model.arch=trans_dec` under autograd: training_losses(...)['loss'].mean().backward() through the multi-scale SceneMapEncoderDecoder,
+    kv_mappling, the self-attention stacks and the decoder layers vs the 424 gradients of the REAL reference (eval mode: dropout off,
+    BatchNorm on running statistics; oracle/make_goldens_train.py --trans_dec_train)."""
+    cfg = cmdm_cfg()
+    cfg.model.arch = "trans_dec"
+    model, diff = create_model_and_diffusion(cfg, device=dev())
+    load_named_weights(model)
+    model = model.to(dev()).eval()
+    gf, gg = golden("cmdm_forward_N1024_L16"), golden("cmdm_trans_dec_training_grads")
+    x0, tn = synth.gaussian("train_x0", (2, 16, 263)).to(dev()), synth.gaussian("train_noise", (2, 16, 263)).to(dev())
+    kw = dict(c_text_feat=gf["text_feat"].to(dev()), c_pc_xyz=gf["xyz"].to(dev()), c_pc_contact=gf["contact"].to(dev()), x_mask=gf["x_mask"].to(dev()))
+    model.zero_grad()
+    terms = diff.training_losses(model, x0, gg["t"].to(dev()), model_kwargs=kw, noise=tn)
+    report("trans_dec training loss", terms["loss"], gg["loss"], 5e-5)
+    terms["loss"].mean().backward()
+    names = [k[2:] for k in gg if k.startswith("g/")]
+    assert len(names) == 424
+    params = dict(model.named_parameters())
+    errs = []
+    for n in names:
+        assert params[n].grad is not None, n
+        sample, _ = _digest(params[n].grad)
+        scale = max(gg["g/" + n].abs().max().item(), 1e-4)
+        errs.append((((sample - gg["g/" + n]).abs().max() / scale).item(), n))
+    errs.sort(reverse=True)
+    print(f"[parity] 424 CMDM trans_dec gradients vs the reference's backward: worst scaled errs " + ", ".join(f"{e:.2e} {n}" for e, n in errs[:3]))
+    assert errs[0][0] <= 2e-3, f"{errs[0][1]}: scaled grad err {errs[0][0]:.3e}"
+
+
 def test_cdm_train_mode_full_size_and_learning():
     """N = 8192 points, train mode (attention dropout on): reproducible with a fixed seed, loss falls under fused AdamW."""
     model, diff = _cdm_model()

@@ -2,5 +2,6 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r04z; mkdir -p $O
-( timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_cdm.py -m gpu -q -x --timeout=600 -k "pointtrans" -s 2>&1 ) > $O/pytest.log 2>&1
-tail -40 $O/pytest.log | cut -c1-250
+( timeout 1500 python -m pytest tests -m gpu -q -x --timeout=900 2>&1 | tail -6 ) > $O/pytest.log 2>&1
+tail -4 $O/pytest.log
+( timeout 300 python tools/bench_train.py --cpu-steps 0 --steps 20 --warmup 3 ) 2>/dev/null | tail -1 | cut -c1-300
