@@ -23,6 +23,10 @@ import statistics
 import sys
 import time
 
+# multi-process GPU work on this host driver needs dmabuf IPC (RCCL / device-tensor sharing fail with `hipIpcGetMemHandle: invalid argument`
+# otherwise); the launcher normally exports it - keep it if it does not.  Read by the HSA runtime at its initialisation: before `import torch`.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "afford-motion_amd")):
     if p not in sys.path:
