@@ -208,6 +208,7 @@ int afm_linear_thin(const afm_linear_args& a, int mode, hipStream_t s) {
     AfmProf prof(AFM_PROF_MISC, 4.0 * a.M * (a.N + a.K), s);          // work = bytes streamed
     if (mode == 1) {
         int R = 4096 / a.N;
+        if (R > 8192 / a.K) R = 8192 / a.K;                             // x rows of a block: at most 32 KB of LDS
         R &= ~3;
         if (R > 1024) R = 1024;
         if (R < 4) R = 4;                                               // N > 1024 never gets here

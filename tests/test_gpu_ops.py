@@ -31,7 +31,7 @@ def test_linear_shapes(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(70001, 3, 3), (50000, 4, 4), (33333, 8, 8), (40000, 32, 3), (40001, 32, 4), (20000, 64, 8), (9999, 32, 9), (3000, 128, 3),
                                    (2000, 256, 3), (1, 3, 3), (255, 7, 5), (40003, 3, 32), (30000, 4, 32), (20001, 3, 64), (20000, 8, 64), (257, 16, 36),
-                                   (100, 1, 64), (50001, 32, 16), (20000, 64, 8)])
+                                   (100, 1, 64), (50001, 32, 16), (20000, 64, 8), (30001, 3, 16), (5000, 9, 16), (777, 1, 3)])
 @pytest.mark.parametrize("act", [0, ffi.ACT_RELU])
 def test_linear_thin_layers(M, N, K, act):
     """One side of the weight <= 16 wide with dense rows (the point transformer's per-neighbour linears and their input gradients):
