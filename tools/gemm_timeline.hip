@@ -3,7 +3,7 @@
 // resident round take vs the tail round, how many workgroups are resident over time, when the last CU goes idle.
 // Compiles the library's own gemm sources with -DAFM_TIMELINE (instrumentation that is never part of libafm_hip.so):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAFM_TIMELINE -Iinclude -Iafford-motion_amd/csrc tools/gemm_timeline.hip \
-//         afford-motion_amd/csrc/profile.hip -o tools/gemm_timeline
+//         afford-motion_amd/csrc/profile.hip afford-motion_amd/csrc/gemm_slab.hip afford-motion_amd/csrc/gemm_thin.hip -o tools/gemm_timeline
 //   tools/gemm_timeline [M N K [tile [arith]]]        arith: 1 = f32 MFMA (default), 9 / 6 = bf16 split
 #include "../afford-motion_amd/csrc/gemm.hip"
 #include "../afford-motion_amd/csrc/gemm_split.hip"
