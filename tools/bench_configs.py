@@ -127,7 +127,7 @@ def config0(quick, cpu=True):
 def config2(quick):
     """CDM Perceiver over N = 8192 points + text token, B = 32 (H3D variant: 9 input channels, 500-step schedule), and the HUMANISE variant
     (41 input channels: 32 scene features per point of the frozen backbone, hoisted out of the loop - SURVEY 8d[2] secondary)."""
-    steps = 20 if quick else 100
+    steps = 100            # (also in the quick pass of bench.py's `secondary` block: a 20-step call is 3.5 ms of stepping behind ~0.4 ms of per-call setup, 5100 vs 5800 steps/s)
     adm, d_adm, _, _ = cdm_models(str(steps), "2")
     lines = []
     for tag, model, diff, extra in (("H3D variant (9 input channels)", adm, d_adm, {}), ("HUMANISE variant (41 input channels, scene features hoisted)", None, None, None)):
@@ -141,7 +141,7 @@ def config2(quick):
             extra = dict(c_pc_feat=synth.gaussian("cfg2_feat", (B, N, 32)).to(dev))
         kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev), **extra)
         run = lambda: diff.p_sample_loop(model, (B, N, 6), clip_denoised=False, model_kwargs=kw, seed=1)
-        dt = timed(run, 1) / steps
+        dt = timed(run, 2 if quick else 3) / steps
         ffi.profile_enable(True); ffi.profile_read(); run(); prof = ffi.profile_read(); ffi.profile_enable(False)
         dom = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
         roof = None
