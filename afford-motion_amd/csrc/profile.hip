@@ -14,7 +14,7 @@ bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_free;
 const char* kNames[AFM_PROF_NTAGS] = {"gemm_f32_mfma<128,128>", "gemm_f32_mfma<64,128>", "gemm_f32_mfma<64,64>", "mha_fwd_kernel",
-                                      "layernorm_kernel", "ddpm_randn_misc", "fps_kernel", "knn_kernel",
+                                      "layernorm_kernel", "misc (ddpm, randn, thin linears)", "fps_kernel", "knn_kernel",
                                       "transition_down_kernel", "pt_attention_kernel", "cdm_perceiver", "gemm_f32_mfma_dma<128,128>",
                                       "gemm_f32_mfma_dma<64,128>", "gemm_f32_mfma_dma<64,64>", "wgrad_kernel", "layernorm_bwd_kernel",
                                       "mha_bwd_dq_kernel", "mha_bwd_dkv_kernel", "train_misc", "point_train_passes", "wgrad_skinny_kernel", "cdm_train_attention", "gemm_f32_split_bf16<128, 128>", "gemm_f32_split_bf16<64, 64>", "gemm_f32_mfma_dma<32,32>", "gemm_f32_mfma_dma<32,64>", "gemm_f32_split_bf16<64, 64, split-K>", "gemm_f32_split_rowdot_slab", "mha_fwd_split_kernel",
