@@ -30,7 +30,8 @@ def sinusoid_table(max_len: int, d: int) -> torch.Tensor:
 
 
 def _lin(sd, pre, x):
-    return F.linear(x, sd[pre + ".weight"], sd.get(pre + ".bias"))
+    w = sd[pre + ".weight"]
+    return F.linear(x.to(w.dtype), w, sd.get(pre + ".bias"))          # (float32 tables / features into a float64 state dict: train_ref's double runs)
 
 
 def _ln(sd, pre, x):
