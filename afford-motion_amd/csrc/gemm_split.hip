@@ -63,6 +63,14 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // K segment of this 256-thread group
     unsigned char* lds = lds_raw + grp * (2 * STAGE);
+#if defined(AFM_TIMELINE) && defined(AFM_DESYNC_TICKS)
+    // experiment (tools/gemm_timeline builds only): half of the workgroups of a CU start AFM_DESYNC_TICKS x 10 ns late, so that the prologue /
+    // epilogue phases of one half meet the K loops of the other - what a desynchronised (persistent, stream-K like) schedule would buy
+    if ((blockIdx.x >> 8) & 1) {
+        const unsigned long long td = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - td < AFM_DESYNC_TICKS) __builtin_amdgcn_s_sleep(20);
+    }
+#endif
 #ifdef AFM_TIMELINE          // tools/gemm_timeline.hip only (single translation unit with gemm.hip, which defines the record type)
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = afm_cycles();
 #endif
