@@ -251,6 +251,49 @@ __device__ __forceinline__ void gemm_epilogue(const afm_linear_args& p, const fl
             if (p.ln_out) store_f4_sc1(p.C + orow * p.ldc + gcol, v);           // uniform: published to the row block's last arriver
             else *reinterpret_cast<float4*>(p.C + orow * p.ldc + gcol) = v;
         }
+    } else if (p.ddpm_out && !p.scale && !p.preact && !p.act && !p.dact && !drop && !p.residual && !p.rowtab && !p.act_post && !p.ln_out) {
+        // The sampling loop's output layer (N = 263: rows are not 16-byte multiples, so this is the scalar branch; at one sample per GPU its
+        // 8 dependent trips of ~1 us each were half of the launch).  Four elements per trip: every load of the four is issued before the
+        // first is used (addresses clamped instead of predicated), the arithmetic per element is the general branch's, expression for expression.
+        constexpr int U = 4;
+        for (int e0 = tid; e0 < BM * BN; e0 += U * NT) {
+            float v[U], xt[U], nz[U], c1[U], c2[U], sg[U], ga[U], bi[U], mu[U], rs[U];
+            int64_t orow[U], ix[U];
+            int gc[U];
+            bool ok[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int e = min(e0 + j * NT, BM * BN - 1);
+                const int row = e / BN, c = e % BN;
+                const int grow = bm * BM + row, gcol = col0 + c;
+                ok[j] = e0 + j * NT < BM * BN && grow < p.M && gcol < p.N;
+                const int gr = min(grow, p.M - 1);
+                gc[j] = min(gcol, p.N - 1);
+                orow[j] = cmap(gr);
+                ix[j] = orow[j] * p.ldx + gc[j];
+                const int b = gr / p.rows_per_sample;
+                v[j] = lds[row * LDC + c];
+                mu[j] = p.a_stat ? rowst[2 * row] : 0.f;
+                rs[j] = p.a_stat ? rowst[2 * row + 1] : 0.f;
+                ga[j] = p.a_stat ? p.a_fold_g[gc[j]] : 0.f;
+                bi[j] = p.bias ? p.bias[gc[j]] : 0.f;
+                xt[j] = p.ddpm_xt[ix[j]]; nz[j] = p.ddpm_noise[ix[j]];
+                c1[j] = p.ddpm_c1[b]; c2[j] = p.ddpm_c2[b]; sg[j] = p.ddpm_sigma[b];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                float w = v[j];
+                if (p.a_stat) w = rs[j] * (w - mu[j] * ga[j]);
+                if (p.bias) w += bi[j];
+                if (p.ddpm_clip) w = w < -1.0f ? -1.0f : (w > 1.0f ? 1.0f : w);
+                const float xn = (c1[j] * w + c2[j] * xt[j]) + sg[j] * nz[j];
+                if (ok[j]) {
+                    if (p.C) p.C[orow[j] * p.ldc + gc[j]] = w;
+                    p.ddpm_out[ix[j]] = xn;
+                    if (p.ddpm_out2) p.ddpm_out2[orow[j] * p.ldx2 + gc[j]] = xn;
+                }
+            }
+        }
     } else {
         for (int e = tid; e < BM * BN; e += NT) {
             const int row = e / BN, c = e % BN;
