@@ -25,7 +25,7 @@ from typing import Callable, Dict, Iterable, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import ops
+from . import ffi, ops
 
 
 def betas_for_alpha_bar(num_diffusion_timesteps: int, alpha_bar: Callable[[float], float], max_beta: float = 0.999):
@@ -171,7 +171,10 @@ class GaussianDiffusion:
             if denoised_fn is not None:
                 x0 = denoised_fn(x0)
             if clip_denoised:
-                x0 = ops.clamp_(x0.clone() if x0 is x else x0, -1.0, 1.0)       # afm_clamp (HIP), in place on the denoiser's own output
+                # afm_clamp (HIP) on a PRIVATE copy: the denoiser (or denoised_fn) may hand back x itself, a view of it, a non-contiguous /
+                # non-f32 tensor, or a buffer it caches - `x0.clamp(-1, 1)` of the reference never mutates its input, so neither do we
+                # (one copy of [B, L, D] per step on the step-by-step path; the native loop clamps inside its fused DDPM epilogue)
+                x0 = ops.clamp_(ffi.f32c(x0).clone(), -1.0, 1.0)
             sample = ops.ddpm_step(x0, x, noise, tab.coef1[t], tab.coef2[t], tab.sigma[t], seed=seed,
                                    sample_index0=sample_index0, step=step)
         return {"sample": sample, "pred_xstart": x0}

@@ -83,6 +83,53 @@ def all_gather_rows(local: torch.Tensor, world: int = None) -> list:
     return bufs
 
 
+def ranks_seen(device: torch.device = None, world: int = None) -> list:
+    """Who is in the job: every rank's (rank, local_rank, backend, device index, device name, PCI bus id) gathered on all ranks, in rank
+    order.  On an N-GPU box under "nccl" this is the proof that RCCL saw N ranks on N DISTINCT devices (bench.py puts it into the N > 1
+    line and refuses to report a line whose ranks share a device unless the shared-GPU test switch says so); under gloo (CPU tests,
+    shared-GPU functional tests) it exercises the same bookkeeping.  One all_gather_object of a small dict per rank."""
+    rank, env_world, local = env_rank_world()
+    world = (dist.get_world_size() if dist.is_initialized() else env_world) if world is None else world
+    me = {"rank": rank, "local_rank": local, "backend": dist.get_backend() if dist.is_initialized() else None, "device": None,
+          "device_name": None, "pci_bus_id": None, "pid": os.getpid()}
+    if device is not None and device.type == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        me.update(device=idx, device_name=torch.cuda.get_device_name(idx), pci_bus_id=getattr(props, "pci_bus_id", None))
+        me["visible_devices"] = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if world == 1 or not dist.is_initialized():
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return sorted(out, key=lambda r: r["rank"])
+
+
+def distinct_devices(seen: list) -> int:
+    """Number of distinct (visible-device mask, device index) pairs among the ranks of `ranks_seen` (None entries - CPU ranks - count once each)."""
+    return len({(r.get("visible_devices"), r["device"]) if r["device"] is not None else ("cpu", r["rank"]) for r in seen})
+
+
+def time_all_gather(local: torch.Tensor, world: int = None, reps: int = 20) -> dict:
+    """Wall time of the path's only collective, measured on its own: `reps` all_gathers of this rank's shard, each between a barrier and a
+    device synchronise; the median in microseconds (max over ranks is taken by the caller when it wants one number)."""
+    import statistics
+    import time
+    world = dist.get_world_size() if world is None else world
+    ts = []
+    for _ in range(reps + 2):
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        all_gather_rows(local, world)
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        ts.append(1e6 * (time.perf_counter() - t0))
+    ts = ts[2:]                                         # the first calls set the communicator up
+    return {"median_us": round(statistics.median(ts), 1), "min_us": round(min(ts), 1), "max_us": round(max(ts), 1), "reps": reps,
+            "bytes_per_rank": local.numel() * local.element_size(), "backend": dist.get_backend()}
+
+
 def sharded_sample(sample_fn: Callable[[Dict[str, Any], int, int], torch.Tensor], total: int, model_kwargs: Dict[str, Any],
                    rank: int = None, world: int = None, gather: bool = True) -> torch.Tensor:
     """Run ``sample_fn(shard_kwargs, count, sample_index0) -> [count, ...]`` on this rank's shard and

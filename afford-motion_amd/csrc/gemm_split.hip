@@ -47,10 +47,23 @@ constexpr int KSEG = 256;
 #ifndef AFM_ABLATE
 #define AFM_ABLATE 0
 #endif
+#ifndef AFM_SPLITK_PIPELINED          // 1: launches of <= 256 tiles take the three-stage split-K forms (round 5); 0: round 4's two-stage forms everywhere
+#define AFM_SPLITK_PIPELINED 1
+#endif
 
-template <int BM, int BN, int BKS, int NPROD, int KG = 1>
+// RING = 3 (round 5, small launches): THREE LDS stages and two sets of operand fragment registers.  With two stages a K-tile is a serial chain
+// barrier -> 6 ds_read_b128 -> wait -> 9 dependent MFMAs -> last ds_write -> wait -> barrier (profiles/r04_gemm_timeline_small.txt: 0.48 us per
+// K-tile against 0.14 us of MFMA issue when a CU holds one workgroup).  With three, tile kt + 2 is split into the third stage while the MFMAs of
+// tile kt run on fragments that were read during kt - 1, and the fragments of tile kt + 1 (published by the previous barrier) are requested right
+// behind the first MFMA: nothing but the barrier itself stands between two K-tiles' matrix work, and the split is finished two MFMAs before the
+// barrier so that its LDS stores land under them.  Same MFMAs on the same accumulators in the same order: bit-identical.
+// GSEG = 2 (split-K groups only): every group walks TWO consecutive K segments (K = 1024 on two groups instead of four: the three stages of four
+// groups do not fit the LDS); group g > 0 hands its two segment sums over separately, so the sum order ((s0 + s1) + s2) + s3 is unchanged.
+template <int BM, int BN, int BKS, int NPROD, int KG = 1, int RING = 2, int GSEG = 1>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
     static_assert(BKS == 16, "one K16 MFMA step per K-tile");
+    static_assert(RING == 2 || RING == 3, "two or three LDS stages");
+    static_assert(GSEG == 1 || (GSEG == 2 && KG > 1), "two segments per group: split-K forms only");
     constexpr int TM = BM / 64, TN = BN / 64;
     static_assert(KG == 1 || (BM == 64 && BN == 64), "the split-K form exists for 64x64 tiles");
     constexpr int ROWB = BKS * 2 + 16;                // LDS row bytes (bf16 + pad)
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // K segment of this 256-thread group
-    unsigned char* lds = lds_raw + grp * (2 * STAGE);
+    unsigned char* lds = lds_raw + grp * (RING * STAGE);
 #if defined(AFM_TIMELINE) && defined(AFM_DESYNC_TICKS)
     // experiment (tools/gemm_timeline builds only): half of the workgroups of a CU start AFM_DESYNC_TICKS x 10 ns late, so that the prologue /
     // epilogue phases of one half meet the K loops of the other - what a desynchronised (persistent, stream-K like) schedule would buy
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     for (int i = 0; i < NI; ++i) {
         const int it = tid + 256 * (i < NA ? i : i - NA), q = it & 3, v = it >> 2, row = (v & ~7) + ((v & 3) << 1) + ((v >> 2) & 1);
         src[i] = (i < NA ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
-                         : p.W + (int64_t)min(bn * BN + row, p.N - 1) * p.ldw) + q * 4 + grp * KSEG;
+                         : p.W + (int64_t)min(bn * BN + row, p.N - 1) * p.ldw) + q * 4 + grp * (GSEG * KSEG);
         dst[i] = ((i < NA ? 0 : BM) + row) * ROWB + q * 8;
     }
 
@@ -113,8 +126,13 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     // Two register sets, always indexed with compile-time constants: at the top of K-tile kt the set (kt & 1) is free (its
     // tile went to LDS during kt - 1) and receives tile kt + 2; the other set holds tile kt + 1 (loaded one full K-tile
     // ago) and is split into the other LDS stage between the MFMAs of tile kt.
-    f32x4 g[2][NI];
-    const int nk = KG > 1 ? KSEG / BKS : p.K / BKS;
+    // RING == 3 keeps NSET = 4 register sets: tile j lives in set j % 4 and is requested THREE K-tiles before its split (round 5: with one
+    // K-tile of lead - ~950 cycles on a small launch - the split waited for operands that the previous kernel had just written on other
+    // XCDs, an HBM / Infinity-Cache round trip of the same length; removing all split arithmetic moved a small launch by 0.3 us, removing one
+    // operand's loads by 1.2: profiles/r04_gemm_w_ablation.txt).  A small launch holds two waves per SIMD: the registers are there.
+    constexpr int NSET = RING == 3 ? 4 : 2;
+    f32x4 g[NSET][NI];
+    const int nk = KG > 1 ? GSEG * KSEG / BKS : p.K / BKS;
     constexpr int SEGT = KSEG / BKS;                  // K-tiles per segment
     f32x16 tot[TM][TN];                               // sum of the finished segments (KG == 1 with K > KSEG only)
     bool have_tot = false;
@@ -137,17 +155,31 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
     using Set1 = std::integral_constant<int, 1>;
     load(Set0{}, 0);
     load(Set1{}, 1);
-    float* rowst = reinterpret_cast<float*>(lds_raw + KG * 2 * STAGE);      // folded LayerNorm: row statistics, an LDS region of their own
+    float* rowst = reinterpret_cast<float*>(lds_raw + KG * RING * STAGE);   // folded LayerNorm: row statistics, an LDS region of their own
     gemm_rowstats<BM>(p, rowst, bm);                  // (loads in flight with the operands'; published by the barrier below)
+    auto split_set = [&](auto SETC, int stage) {      // prologue only: a whole register set -> one LDS stage, no interleaving
+        constexpr int S = decltype(SETC)::value;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        uint32_t a1, a2, a3, b1, b2, b3;
-        split2(g[0][i][0], g[0][i][1], a1, a2, a3);
-        split2(g[0][i][2], g[0][i][3], b1, b2, b3);
-        unsigned char* d = lds + dst[i];
-        *reinterpret_cast<u32x2*>(d) = u32x2{a1, b1};
-        *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{a2, b2};
-        *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{a3, b3};
+        for (int i = 0; i < NI; ++i) {
+            unsigned char* d = lds + stage * STAGE + dst[i];
+            uint32_t a1, a2, a3, b1, b2, b3;
+            split2(g[S][i][0], g[S][i][1], a1, a2, a3);
+            split2(g[S][i][2], g[S][i][3], b1, b2, b3);
+            *reinterpret_cast<u32x2*>(d) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{a2, b2};
+            *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{a3, b3};
+        }
+    };
+    using Set2 = std::integral_constant<int, 2>;
+    using Set3 = std::integral_constant<int, 3>;
+    if constexpr (RING == 3) {                        // tiles 0 .. 4 requested, tiles 0 and 1 in LDS (K-tile 0 splits set 2 and refills set 1 with tile 5)
+        load(Set2{}, 2);
+        load(Set3{}, 3);
+        split_set(Set0{}, 0);
+        load(Set0{}, 4);
+        split_set(Set1{}, 1);
+    } else {
+        split_set(Set0{}, 0);
     }
     __syncthreads();
 #ifdef AFM_TIMELINE
@@ -221,7 +253,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
                     piece = (m * NPIECE) / NMFMA;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-        if (KG == 1 && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {        // segment finished, more to come: bank it, restart from zero
+        if ((KG == 1 || GSEG > 1) && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {        // segment finished, more to come: bank it, restart from zero
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -235,15 +267,115 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
         }
         __syncthreads();
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        body(Set0{}, kt);
-        if (kt + 1 < nk) body(Set1{}, kt + 1);
+    // RING == 3: K-tile kt runs its MFMAs on fragment set kt & 1 (read during kt - 1), requests tile kt + 1's fragments from stage
+    // (kt + 1) % 3 (written during kt - 1, published by that K-tile's barrier) into the other set, and splits tile kt + 2 (register set
+    // kt & 1, loaded during kt - 1) into stage (kt + 2) % 3, whose previous tile (kt - 1) was last read during kt - 2.
+    u32x4 fa[2][TM][3], fb[2][TN][3];
+    auto read_frag = [&](auto FC, int stage) {
+        constexpr int F = decltype(FC)::value;
+        const unsigned char* base = lds + stage * STAGE;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[F][i][pl] = *reinterpret_cast<const u32x4*>(base + pl * PLANE + a_off + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[F][j][pl] = *reinterpret_cast<const u32x4*>(base + pl * PLANE + w_off + j * 32 * ROWB);
+        }
+    };
+#ifndef AFM_R3_TAIL
+#define AFM_R3_TAIL 2         // MFMAs at the end of a K-tile that carry no split work: the last LDS stores land under them
+#endif
+    auto body3 = [&](auto SC, int kt, int st_next, int st_wr) {          // K-tile kt, S = kt % 4
+        constexpr int S = decltype(SC)::value;
+        constexpr int cur = S & 1;                    // fragment set of this K-tile
+        constexpr int SS = (S + 2) & 3;               // register set that is split (tile kt + 2)
+        using LoadSet = std::integral_constant<int, (S + 1) & 3>;       // ... and the one that is refilled (tile kt + 5)
+        using FragNext = std::integral_constant<int, cur ^ 1>;
+        unsigned char* wbase = lds + st_wr * STAGE;
+        float r0[NI * 2], r1[NI * 2];
+        uint32_t sp[NI * 2][3];
+        int piece = 0, m = 0;
+        auto do_piece = [&](int t) {
+            const int u = t / 3, lvl = t % 3, i = u / 2, c = u % 2;
+            if (lvl == 0) {
+                r0[u] = g[SS][i][2 * c];
+                r1[u] = g[SS][i][2 * c + 1];
+            }
+            const uint32_t pk = cvt_pk_bf16(r0[u], r1[u]);
+            sp[u][lvl] = pk;
+            if (lvl < 2) {
+                r0[u] = sub_bf16_lo(r0[u], pk);
+                r1[u] = sub_bf16_hi(r1[u], pk);
+            } else if (c == 1) {
+                unsigned char* d = wbase + dst[i];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * PLANE) = u32x2{sp[2 * i][pl], sp[2 * i + 1][pl]};
+            }
+        };
+        constexpr int NFILL = NMFMA - 1 - AFM_R3_TAIL > 0 ? NMFMA - 1 - AFM_R3_TAIL : 1;      // MFMAs 2 .. NFILL + 1 carry the split
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 9 - NPROD; q < 9; ++q)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = mfma_bf16(fa[cur][tm][AFM_PA[q]], fb[cur][tn][AFM_PB[q]], acc[tm][tn]);
+                    ++m;
+                    if (m == 1) {               // behind the first MFMA: the requests of this K-tile (nothing in it waits for them)
+                        __builtin_amdgcn_sched_barrier(0);
+                        load(LoadSet{}, kt + 5);
+                        read_frag(FragNext{}, st_next);
+                    } else {
+                        const int want = ((m - 1) * NPIECE + NFILL - 1) / NFILL;
+#pragma unroll
+                        for (int t = 0; t < NPIECE; ++t)
+                            if (t >= piece && t < want) do_piece(t);
+                        piece = want < NPIECE ? want : NPIECE;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+        for (int t = 0; t < NPIECE; ++t)              // (NPROD == 1: a single MFMA per K-tile has no slot for the split)
+            if (t >= piece) do_piece(t);
+        if ((KG == 1 || GSEG > 1) && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tot[tm][tn][r] = have_tot ? tot[tm][tn][r] + acc[tm][tn][r] : acc[tm][tn][r];
+                        acc[tm][tn][r] = 0.f;
+                    }
+            have_tot = true;
+        }
+        __syncthreads();
+    };
+    if constexpr (RING == 2) {
+        for (int kt = 0; kt < nk; kt += 2) {
+            body(Set0{}, kt);
+            if (kt + 1 < nk) body(Set1{}, kt + 1);
+        }
+    } else {
+        read_frag(Set0{}, 0);
+        int s1 = 1, s2 = 2;                           // (kt + 1) % 3, (kt + 2) % 3
+        for (int kt = 0; kt < nk; kt += 4) {         // nk % 4 == 0 (the launcher checks K)
+            body3(Set0{}, kt, s1, s2);
+            s1 = s2; s2 = (s1 + 1) % 3;
+            body3(Set1{}, kt + 1, s1, s2);
+            s1 = s2; s2 = (s1 + 1) % 3;
+            body3(Set2{}, kt + 2, s1, s2);
+            s1 = s2; s2 = (s1 + 1) % 3;
+            body3(Set3{}, kt + 3, s1, s2);
+            s1 = s2; s2 = (s1 + 1) % 3;
+        }
     }
 
 #ifdef AFM_TIMELINE
     const unsigned long long tl_kloop = __builtin_amdgcn_s_memrealtime();        // K loop done
 #endif
-    if (KG == 1 && have_tot) {                        // ((s0 + s1) + ...) + s_last
+    if (have_tot && (KG == 1 || grp == 0)) {          // ((s0 + s1) + ...) + s_last (of a later split-K group: both segment sums travel, see below)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -252,21 +384,29 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] = tot[tm][tn][r] + acc[tm][tn][r];
     }
     if (KG > 1) {
-        // groups 1 .. KG-1 hand their segment sums to group 0 through their own (now idle) operand regions: [r / 4][thread] float4
+        // groups 1 .. KG-1 hand their segment sums (GSEG of them, in segment order) to group 0 through their own (now idle) operand
+        // regions: [segment][r / 4][thread] float4
+        static_assert(RING * STAGE >= GSEG * 4 * 256 * 16, "the segment sums of a group fit its operand stages");
         f32x4* part = reinterpret_cast<f32x4*>(lds);
         if (grp > 0) {
+            if (GSEG == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) part[q * 256 + tid] = f32x4{acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+                for (int q = 0; q < 4; ++q) part[q * 256 + tid] = f32x4{tot[0][0][4 * q], tot[0][0][4 * q + 1], tot[0][0][4 * q + 2], tot[0][0][4 * q + 3]};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[((GSEG - 1) * 4 + q) * 256 + tid] = f32x4{acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
         }
         __syncthreads();
         if (grp == 0) {
             for (int gI = 1; gI < KG; ++gI) {
-                const f32x4* pg = reinterpret_cast<const f32x4*>(lds_raw + gI * (2 * STAGE));
+                const f32x4* pg = reinterpret_cast<const f32x4*>(lds_raw + gI * (RING * STAGE));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = pg[q * 256 + tid];
-                    acc[0][0][4 * q] += v[0]; acc[0][0][4 * q + 1] += v[1]; acc[0][0][4 * q + 2] += v[2]; acc[0][0][4 * q + 3] += v[3];
-                }
+                for (int sI = 0; sI < GSEG; ++sI)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = pg[(sI * 4 + q) * 256 + tid];
+                        acc[0][0][4 * q] += v[0]; acc[0][0][4 * q + 1] += v[1]; acc[0][0][4 * q + 2] += v[2]; acc[0][0][4 * q + 3] += v[3];
+                    }
             }
         }
     }
@@ -311,18 +451,19 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16
 #endif
 }
 
-template <int BM, int BN, int BKS, int NPROD, int KG = 1>
+template <int BM, int BN, int BKS, int NPROD, int KG = 1, int RING = 2, int GSEG = 1>
 int launch_split(const afm_linear_args& a, hipStream_t s) {
     constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
-    static_assert(KG * 2 * STAGE >= BM * (BN + 4) * 4, "the staged accumulators fit the operand stages");
-    constexpr int LDS_BYTES = KG * 2 * STAGE + 2 * BM * 2 * 4;             // operand stages (reused for the staged accumulators) + row statistics of the folded LayerNorm
+    static_assert(RING * STAGE >= BM * (BN + 4) * 4, "the staged accumulators fit group 0's operand stages");
+    constexpr int LDS_BYTES = KG * RING * STAGE + 2 * BM * 2 * 4;          // operand stages (reused for the staged accumulators) + row statistics of the folded LayerNorm
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
     static const int attr = []() {
-        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG, RING, GSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }();
     if (attr != 0) return attr;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     AfmProf prof(BM == 128 ? AFM_PROF_GEMM_SPLIT128 : (KG > 1 ? AFM_PROF_GEMM_SPLIT64_KG : AFM_PROF_GEMM_SPLIT64), 2.0 * a.M * a.N * a.K, s);
-    hipLaunchKernelGGL((gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG>), dim3(nbm * nbn), dim3(256 * KG), LDS_BYTES, s, a, nbm, nbn);
+    hipLaunchKernelGGL((gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG, RING, GSEG>), dim3(nbm * nbn), dim3(256 * KG), LDS_BYTES, s, a, nbm, nbn);
     AFM_CHECK_LAUNCH();
     return 0;
 }
@@ -342,6 +483,17 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
         const int64_t tiles64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
         const int nseg = a.K / KSEG;
         const bool splittable = (a.K % KSEG) == 0 && nseg >= 2 && nseg <= 4;
+        // Round 5: the pipelined forms (RING = 3: three LDS stages, operand fragments requested one K-tile ahead).  Two wave groups with three
+        // stages are 111 KB - one workgroup per CU - so they take the launches of at most one tile per CU (<= 256 tiles); K = 1024 runs on
+        // two groups of two segments each there (four groups x three stages do not fit the LDS).  tile 10 forces them, 7 the two-stage forms.
+        const bool pipelined = AFM_SPLITK_PIPELINED && (nseg == 2 || nseg == 4) && tiles64 <= 256;
+        if (splittable && nseg != 3 && (tile == 10 || (tile == 0 && pipelined))) {
+            if (nseg == 2) return launch_split<64, 64, 16, NPROD, 2, 3>(a, s);
+            return launch_split<64, 64, 16, NPROD, 2, 3, 2>(a, s);
+        }
+        if (tile == 10) return AFM_E_UNSUPPORTED;
+        if (splittable && nseg == 4 && tile == 11) return launch_split<64, 64, 16, NPROD, 2, 2, 2>(a, s);      // measurement: two groups x two segments on two stages
+        if (tile == 11) return AFM_E_UNSUPPORTED;
         if (splittable && (tile == 7 || (tile == 0 && tiles64 <= (nseg == 2 ? 512 : 256)))) {
             if (nseg == 2) return launch_split<64, 64, 16, NPROD, 2>(a, s);
             if (nseg == 3) return launch_split<64, 64, 16, NPROD, 3>(a, s);
@@ -349,6 +501,8 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
         }
         if (tile == 7) return AFM_E_UNSUPPORTED;
     }
+    if (tile == 9 && (a.K % 64) != 0) return AFM_E_UNSUPPORTED;              // (its K loop is unrolled four K-tiles deep)
+    if (tile == 9) return launch_split<64, 64, 16, NPROD, 1, 3>(a, s);      // measurement: the sequential 64x64 form on three stages (55 KB: two workgroups per CU)
     // 128x128 amortises the split best (each thread splits 16 floats per 36 MFMAs of its wave) but holds 2 workgroups per CU = 512
     // resident tiles, so it only pays when its last resident round is nearly full; otherwise 64x64 tiles fill the chip better.
     // Measured (profiles/r02_kernel_sweep.txt, x9, us): N=1536 M=10432 (984 tiles, 96 % full) 161 vs 174 for 64x64; M=5216 (492, 96 %) 80 vs 86;

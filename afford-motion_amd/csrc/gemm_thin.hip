@@ -7,8 +7,8 @@
 //   K <= 16 (linear_thin_k): x rows and W in LDS; a thread produces four consecutive outputs of the flat C block.
 //   N <= 16, K % 4 == 0, K <= 64 (linear_thin_n): a thread owns a row, its accumulators live in registers, W comes through the scalar
 //   cache (uniform addresses), x as 16-byte LDS reads from rows padded by four floats (conflict-free).
-// The choice is a function of (N, K, strides, alignment, epilogue fields) and never of M, so a batch and its shards run the same
-// arithmetic.  Epilogue: scale, bias, act (the forms these layers use); anything else takes the MFMA kernels.
+// The choice is a function of (N, K, strides, epilogue fields) - never of M and never of pointer alignment (unaligned views run the same
+// chain through scalar accesses) -, so a batch and its shards run the same arithmetic.  Epilogue: scale, bias, act (the forms these layers use); anything else takes the MFMA kernels.
 #include "common.h"
 #include "profile.h"
 
@@ -183,6 +183,24 @@ __global__ __launch_bounds__(256) void linear_thin_n_kernel(const float* __restr
     }
 }
 
+// The same layers through pointers that are NOT 16-byte aligned (an offset view of a row pool): one output per thread, scalar loads, the same
+// FMA chain (k ascending from zero, then scale, bias, activation) - slow, and bit-identical to the staged kernels above, so that WHICH
+// arithmetic a layer runs is a function of its shape alone and never of where its rows happen to start.
+__global__ __launch_bounds__(256) void linear_thin_scalar_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                 const float* __restrict__ scale, float* __restrict__ C, int64_t M, int N, int K, int act) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M * N; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / N;
+        const int n = (int)(e - row * N);
+        const float* x = A + row * K;
+        const float* w = W + (int64_t)n * K;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = __builtin_fmaf(x[k], w[k], acc);
+        if (scale) acc *= scale[n];
+        if (bias) acc += bias[n];
+        C[e] = apply_act(acc, act);
+    }
+}
+
 bool plain_epilogue(const afm_linear_args& a) {
     return a.C && !a.residual && !a.rowtab && !a.act_post && !a.a_grp && !a.c_grp && !a.ddpm_out && !a.preact && !a.dact_z && !a.dact &&
            !(a.drop_p > 0.0f) && !a.rowdot_w && !a.rowdot_out && !a.ln_out && !a.stat_out && !a.a_stat && !a.res_stat && !a.aux_dst &&
@@ -195,8 +213,8 @@ bool plain_epilogue(const afm_linear_args& a) {
 int afm_linear_thin_mode(const afm_linear_args& a) {
     if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_BF16X9) return 0;      // explicit arithmetic requests keep their kernels
     if (!plain_epilogue(a) || a.lda != a.K || a.ldw != a.K || a.ldc != a.N) return 0;
-    if ((((uintptr_t)a.A | (uintptr_t)a.C) & 15) != 0) return 0;
-    const bool n_pow2 = a.N >= 4 && a.N <= THIN_K_NMAX && (a.N & (a.N - 1)) == 0 && ((((uintptr_t)a.bias | (uintptr_t)a.scale) & 15) == 0);
+    // (shape, strides and epilogue fields only - NOT pointer alignment: unaligned rows take linear_thin_scalar_kernel, the same FMA chain)
+    const bool n_pow2 = a.N >= 4 && a.N <= THIN_K_NMAX && (a.N & (a.N - 1)) == 0;
     if (a.K <= THIN_MAX && n_pow2) return 3;
     if (a.K <= THIN_MAX && a.N * a.K <= 144) return 1;
     if (a.N <= THIN_MAX && (a.K & 3) == 0 && a.K <= THIN_N_KMAX) return 2;
@@ -206,6 +224,13 @@ int afm_linear_thin_mode(const afm_linear_args& a) {
 
 int afm_linear_thin(const afm_linear_args& a, int mode, hipStream_t s) {
     AfmProf prof(AFM_PROF_MISC, 4.0 * a.M * (a.N + a.K), s);          // work = bytes streamed
+    if ((((uintptr_t)a.A | (uintptr_t)a.C | (uintptr_t)a.W | (uintptr_t)a.bias | (uintptr_t)a.scale) & 15) != 0) {      // an offset view: same arithmetic, scalar accesses
+        const int64_t n = (int64_t)a.M * a.N;
+        const unsigned grid = (unsigned)(((n + 255) / 256) < 8192 ? ((n + 255) / 256) : 8192);
+        hipLaunchKernelGGL(linear_thin_scalar_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, a.A, a.W, a.bias, a.scale, a.C, (int64_t)a.M, a.N, a.K, a.act);
+        AFM_CHECK_LAUNCH();
+        return 0;
+    }
     if (mode == 1) {
         int R = 4096 / a.N;
         if (R > 8192 / a.K) R = 8192 / a.K;                             // x rows of a block: at most 32 KB of LDS

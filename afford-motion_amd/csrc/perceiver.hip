@@ -426,7 +426,15 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
     for (int s = 0; chain_side && s < nsub; ++s) {
         side[s].chain = sidest[s];
         if (hipEventCreateWithFlags(&side[s].forked, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&side[s].joined, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+            hipEventCreateWithFlags(&side[s].joined, hipEventDisableTiming) != hipSuccess) {
+            const int rc_ev = (int)hipGetLastError();
+            for (int u = 0; u <= s; ++u) {                 // nothing created so far may leak (the first event of a failed pair did)
+                if (side[u].forked) (void)hipEventDestroy(side[u].forked);
+                if (side[u].joined) (void)hipEventDestroy(side[u].joined);
+            }
+            if (fork) (void)hipEventDestroy(fork);
+            return rc_ev;
+        }
         (void)hipStreamWaitEvent(sidest[s], fork, 0);
     }
     const int64_t per = (int64_t)N * cd;

@@ -608,10 +608,14 @@ extern "C" int afm_pt_aggregate(const float* vg, const float* pr, const float* w
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
     const int Cs = C / share_planes;
     const uintptr_t al = (uintptr_t)vg | (uintptr_t)pr | (uintptr_t)w2 | (uintptr_t)sw;
-    if ((C & 3) == 0 && ((k * Cs) & 3) == 0 && (al & 15) == 0 && k * C <= 8192) {
-        int G = 8192 / (k * C);
-        if (G > 64) G = 64;
-        const size_t lds = (size_t)G * (k * C + k * Cs) * sizeof(float);
+    // the fused form's dynamic LDS stays inside the 64 KB every kernel may use without opting in (small share_planes make the weight slab as
+    // large as the value slab): G shrinks until it fits, a shape whose single point does not fit takes the two-pass kernels below
+    auto lds_of = [&](int g) { return (size_t)g * (k * C + k * Cs) * sizeof(float); };
+    int G = k * C <= 8192 ? 8192 / (k * C) : 0;
+    if (G > 64) G = 64;
+    while (G > 1 && lds_of(G) > 65536) --G;
+    if ((C & 3) == 0 && ((k * Cs) & 3) == 0 && (al & 15) == 0 && G >= 1 && lds_of(G) <= 65536) {
+        const size_t lds = lds_of(G);
         int64_t nb = (m + G - 1) / G;
         if (nb > 4096) nb = 4096;
         hipLaunchKernelGGL(pt_aggregate_fused_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, vg, pr, w2, out, sw, m, k, C, Cs, G);
@@ -630,10 +634,12 @@ extern "C" int afm_pt_aggregate_bwd(const float* vg, const float* pr, const floa
     const int Cs = C / share_planes;
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
     const uintptr_t al = (uintptr_t)vg | (uintptr_t)pr | (uintptr_t)sw | (uintptr_t)dout | (uintptr_t)da | (uintptr_t)dw2;
-    if ((C & 3) == 0 && ((k * Cs) & 3) == 0 && (al & 15) == 0 && k * C <= 8192) {          // the fused form (a function of the shape only)
-        int G = 8192 / (k * C);
-        if (G > 64) G = 64;
-        const size_t lds = (size_t)G * (k * C + C + 2 * k * Cs) * sizeof(float);
+    auto lds_of = [&](int g) { return (size_t)g * (k * C + C + 2 * k * Cs) * sizeof(float); };      // (share_planes = 1, k = 16, C = 32: 100 KB at the old G)
+    int G = k * C <= 8192 ? 8192 / (k * C) : 0;
+    if (G > 64) G = 64;
+    while (G > 1 && lds_of(G) > 65536) --G;
+    if ((C & 3) == 0 && ((k * Cs) & 3) == 0 && (al & 15) == 0 && G >= 1 && lds_of(G) <= 65536) {          // the fused form (a function of the shape only)
+        const size_t lds = lds_of(G);
         int64_t nb = (m + G - 1) / G;
         if (nb > 4096) nb = 4096;
         hipLaunchKernelGGL(pt_aggregate_bwd_fused_kernel, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, vg, pr, sw, dout, da, dw2, m, k, C, Cs, G);

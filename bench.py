@@ -115,13 +115,17 @@ def cpu_baseline(n_steps: int = 20, reps: int = 3):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cands = sorted({c for c in (avail, avail // 2, avail // 4, 64, 32, 16, 8) if 1 <= c <= avail}, reverse=True)
     best = (None, float("inf"))
+    probe = {}                                         # thread count -> ms per step (best of two single steps after a warm-up step): the whole probe is reported
     with torch.no_grad():
         for c in cands:
             torch.set_num_threads(c)
             df.p_sample(s, model, x0, t, nz)                              # warm-up at this thread count
-            t0 = time.perf_counter()
-            df.p_sample(s, model, x0, t, nz)
-            d1 = time.perf_counter() - t0
+            d1 = float("inf")
+            for _ in range(2):
+                t0 = time.perf_counter()
+                df.p_sample(s, model, x0, t, nz)
+                d1 = min(d1, time.perf_counter() - t0)
+            probe[c] = round(1e3 * d1, 1)
             if d1 < best[1]:
                 best = (c, d1)
             if d1 > 4 * best[1]:
@@ -142,7 +146,8 @@ def cpu_baseline(n_steps: int = 20, reps: int = 3):
     return {"value": round(1.0 / dt, 4), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} x {n_steps} chained p_sample steps at B={B_PER_GPU}, L={L}, T=326 tokens, f32, conditions hoisted "
                       f"(torch-CPU restatement of the reference; median {1e3 * dt:.0f} ms/step, per repetition "
-                      f"{[round(1e3 * v) for v in per_rep]} ms/step; best of thread counts {cands}, {avail} logical CPUs available)",
+                      f"{[round(1e3 * v) for v in per_rep]} ms/step; thread-count probe, ms per single step: {probe}; {avail} logical CPUs available)",
+            "thread_probe_ms_per_step": {str(k): v for k, v in probe.items()},
             "host": {"cpu": cpu_model, "logical_cpus": avail, "torch": torch.__version__, "threads_used": torch.get_num_threads()}}
 
 
@@ -157,7 +162,8 @@ def main():
                          "steps/s of that job; weak: --batch samples on EVERY GPU; auto (default): strong when N > 1 (at N = 1 both are the same job)")
     ap.add_argument("--settle-s", type=float, default=0.0, help="idle time after the setup's priming loop call (process-start transient, see the comment at its use); 0 = none")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (other BASELINE configs, faithful headline, small-batch table; N = 1 only)")
-    ap.add_argument("--latency-runs", type=int, default=5, help="full 1000-step loops at B=32 for the p50 sample latency (N=1 only)")
+    ap.add_argument("--latency-runs", type=int, default=20, help="full 1000-step loops at B=32 for the p50 sample latency (N=1 only; SURVEY 8d: >= 20 runs after 3 warm-ups)")
+    ap.add_argument("--latency-warmups", type=int, default=3, help="untimed full 1000-step loops in front of the latency runs of each batch size")
     ap.add_argument("--latency-runs-b1", type=int, default=20, help="full 1000-step loops at B=1 for the p50 sample latency (N=1 only)")
     ap.add_argument("--cpu-steps", type=int, default=20, help="p_sample steps per repetition of the CPU baseline")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -180,6 +186,12 @@ def main():
     dev = torch.device("cuda:0" if os.environ.get("AFM_BENCH_SHARE_GPU") else f"cuda:{local}")
     torch.cuda.set_device(dev)
     ffi.load()
+    # who is in the job: (rank, device, name, bus id) of every rank, gathered over the job's own backend.  One rank per DISTINCT device is a
+    # precondition of the N > 1 line - fail loudly instead of reporting a "2-GPU" number from two ranks on one device (the shared-GPU
+    # switch of the functional tests is the only exemption, and the line says so)
+    seen = adist.ranks_seen(dev, world)
+    shared_gpu = bool(os.environ.get("AFM_BENCH_SHARE_GPU"))
+    assert shared_gpu or adist.distinct_devices(seen) == world, f"{world} ranks on {adist.distinct_devices(seen)} distinct devices: {seen}"
 
     K, W = args.steps, args.warmup
     model, diff_k, cfg = build(dev, str(K))
@@ -279,11 +291,25 @@ def main():
         time.sleep(args.settle_s)
     preflight = {"priming_loop_steps": 2, "priming_loop_ms": round(prime_ms, 2), "setup_repeats_after_priming": 16,
                  "ms_between_priming_and_warmup": round(1e3 * (time.perf_counter() - t0), 1), "settle_sleep_s": args.settle_s,
-                 "why": "one-time ~70 ms device stall 50-150 ms after a process's first native-loop call (profiles/r04_first_loop_transient.md)"}
+                 "why": "one-time ~70 ms device stall 50-150 ms after a process's first native-loop call (profiles/r04_first_loop_transient.md)",
+                 "unprimed_first_request": {"first_loop_call_ms": round(prime_ms, 2), "steps": 2, "one_time_stall_ms": 70,
+                                            "note": "a process's FIRST loop call pays workspace / stream allocation and first launches (first_loop_call_ms for 2 steps) and is followed "
+                                                    "by the one-time stall: a first 1000-step request of a fresh process takes about first_loop_call_ms + 70 ms longer than sample_latency's p50"}}
     if world > 1:
         dist.barrier()
 
     dt, t_enq = timed()
+
+    # the path's only collective on its own (N > 1): all_gather of this rank's [B / G, L, D] f32 shard - already inside `dt`, priced here
+    gather = None
+    if world > 1:
+        gather = adist.time_all_gather(torch.zeros(B, L, D, device=dev), world)
+        gt = torch.tensor([gather["median_us"]], device=dev, dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            gt = gt.cpu()
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather["max_over_ranks_median_us"] = round(float(gt.item()), 1)
+        gather["fraction_of_timed_region"] = round(gather["max_over_ranks_median_us"] * 1e-6 / dt, 6)
 
     # the other scaling mode in the same invocation (N > 1 only; informational): the driver calls bench.py without --scaling, so a
     # weak run also reports the strong-scaling rate of ONE 32-sample job sharded over the ranks (B/N samples per GPU), and vice versa
@@ -338,12 +364,14 @@ def main():
         cfg.diffusion.timestep_respacing = ""
         diff_full = create_gaussian_diffusion(cfg)
         diff_full.tables(dev)
-        lat = {"steps": 1000, "warmups": 1}
+        lat = {"steps": 1000, "warmups": args.latency_warmups, "protocol": "SURVEY 8d: p50 of >= 20 full 1000-step p_sample_loop calls after 3 warm-up calls, wall time incl. the final synchronise"}
         for nb, runs in ((args.batch, args.latency_runs), (1, args.latency_runs_b1)):
             if runs <= 0:
                 continue
             kwb = kw if nb == B else {k: v[:nb].contiguous() for k, v in kw.items()}
-            run(diff_w, 3, kwb, nb, 0)                 # warm-up at this batch size (condition tokens, workspaces)
+            run(diff_w, 3, kwb, nb, 0)                 # first call at this batch size (condition tokens, workspaces)
+            for i in range(args.latency_warmups):
+                run(diff_full, 3 + i, kwb, nb, 0)
             ts = []
             for i in range(runs):
                 torch.cuda.synchronize()
@@ -419,17 +447,17 @@ def main():
         diff_k2 = create_gaussian_diffusion(cfg); diff_k2.tables(dev)
 
         def rate(kwargs, nb, diffusion=diff_k2, steps=K2):
-            """steps/s of a `steps`-step loop call at this batch size: the faster of two calls after a warm-up call (the first call at a new
+            """steps/s of a `steps`-step loop call at this batch size: the MEDIAN of three calls after a warm-up call (the first call at a new
             batch size allocates its workspace; single calls of the same process differed by up to 18 % at B = 8)."""
             run(diff_w, 1, kwargs, nb, 0)
-            best = 0.0
-            for _ in range(2):
+            rs = []
+            for _ in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 run(diffusion, 2, kwargs, nb, 0)
                 torch.cuda.synchronize()
-                best = max(best, steps / (time.perf_counter() - t0))
-            return best
+                rs.append(steps / (time.perf_counter() - t0))
+            return statistics.median(rs)
         try:
             # what each GPU runs when the 32-sample job is sharded over G GPUs (strong scaling): B = 32 / G samples; per-sample efficiency
             # against B = 32 bounds the speed-up at G GPUs (no collective inside the loop; the final all_gather is 0.8 MB per rank)
@@ -440,7 +468,7 @@ def main():
                 r = rate(kwb, nb)
                 tab[f"B{nb}"] = {"steps_per_s": round(r, 1), "ms_per_step": round(1e3 / r, 4), "gpus_at_32_samples": 32 // nb,
                                  "per_sample_efficiency_vs_B32": round((r * nb) / (base * B), 4), "predicted_speedup_at_that_gpu_count": round(r / base, 2)}
-            secondary["strong_scaling_batch_per_gpu"] = {"steps": K2, "B32_steps_per_s": round(base, 1), **tab}
+            secondary["strong_scaling_batch_per_gpu"] = {"steps": K2, "statistic": "median of 3 loop calls", "B32_steps_per_s": round(base, 1), **tab}
             model.condition_tokens(**kw)
         except Exception as e:                          # noqa: BLE001
             secondary["strong_scaling_batch_per_gpu"] = {"error": f"{type(e).__name__}: {e}"}
@@ -502,6 +530,10 @@ def main():
                            "SURVEY 8d step (257 GFLOP at B=32), executed_tflops what the kernels really did",
             "host_enqueue_ms_per_step": round(1e3 * t_enq / K, 4),
             "setup_ms": round(setup_ms, 2), "setup_ms_steady": round(setup_ms_steady, 2), "preflight": preflight,
+            "ranks_seen": seen, "distinct_devices": adist.distinct_devices(seen), "shared_gpu_test_mode": shared_gpu,
+            "batch_per_gpu_by_rank": [adist.job_shard(args.scaling, args.batch, r, world)[1] for r in range(world)],
+            "final_all_gather": gather,
+            "scaling_modes": ({args.scaling: round(job_steps / dt, 2), other["scaling"]: other["value"]} if other else {args.scaling: round(job_steps / dt, 2)}),
             "roofline": roof, "cpu_baseline": cpu, "sample_latency": lat, "alt_gemm_modes": alt, "other_scaling_mode": other,
             "secondary": secondary,
         }

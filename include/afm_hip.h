@@ -156,7 +156,7 @@ typedef struct {
 #define AFM_ARITH_BF16X9  9
 
 #define AFM_TUNE_NO_DMA      0x1     /* register-staged operand loads instead of global_load_lds                         */
-#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128, 7 = 64x64 with the K segments split over wave groups, 8 = weight-stationary 64-column slabs (row-dot launches with K = 256) (bf16-split arithmetic) */
+#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128, 7 = 64x64 with the K segments split over wave groups, 8 = weight-stationary 64-column slabs (row-dot launches with K = 256), 9 = 64x64 on three LDS stages, 10 = split-K on three LDS stages (K = 1024: two groups x two segments), 11 = split-K two groups x two segments on two stages (bf16-split arithmetic) */
 #define AFM_TUNE_TILE_MASK   0xF0
 
 int afm_linear(const afm_linear_args* args, void* stream);
@@ -243,7 +243,10 @@ int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_
 /* ------------------------------------------------------------------------------------------
  * Training (backward) entry points - the kernels behind `loss.backward()` of training_losses
  * (gaussian_diffusion.py:757-823 called from utils/training.py:140-152).  Gradients are
- * deterministic (fixed-order split reductions, no atomics).
+ * deterministic (fixed-order split reductions, no atomics) with TWO stated exceptions, both scatter-adds of the point branch whose
+ * reference CUDA kernels use f32 atomics as well: afm_scatter_add_rows (backward of a row gather / of the neighbour grouping) and
+ * afm_interpolate_bwd (PointTrans / trans_dec decoders only).  Their sums depend on the arrival order of the atomics (last-bit
+ * differences run to run); the tests compare them with tolerances and exclude them from every bit-identity assertion.
  */
 
 /* out[c][r] = in[r][c] (rows x cols -> cols x rows).  The input-gradient GEMM dX = dY @ W is run as

@@ -72,6 +72,43 @@ def test_strong_scaling_two_ranks_equal_one_process():
     assert torch.equal(got[0], want) and torch.equal(got[1], want)
 
 
+def _seen_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_process_group("gloo")
+    seen = adist.ranks_seen(torch.device("cpu"), world)
+    g = adist.time_all_gather(torch.full((3, 4), float(rank)), world, reps=3)
+    q.put((rank, seen, g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_seen_and_gather_timing_bookkeeping_two_ranks():
+    """What bench.py puts into the N > 1 line (`ranks_seen`, `distinct_devices`, `final_all_gather`): every rank sees every rank, in rank
+    order, with the backend that carried the gather; CPU ranks count as distinct; the gather timing reports the shard size."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (seen, g) for r, seen, g in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        seen, g = got[r]
+        assert [e["rank"] for e in seen] == [0, 1] and [e["local_rank"] for e in seen] == [0, 1]
+        assert all(e["backend"] == "gloo" and e["device"] is None for e in seen) and seen[0]["pid"] != seen[1]["pid"]
+        assert adist.distinct_devices(seen) == 2
+        assert g["bytes_per_rank"] == 48 and g["reps"] == 3 and g["backend"] == "gloo" and 0 < g["min_us"] <= g["median_us"] <= g["max_us"]
+    # two ranks on ONE device are seen as one device (what bench.py refuses outside the shared-GPU test mode)
+    shared = [dict(rank=0, device=0, visible_devices=None), dict(rank=1, device=0, visible_devices=None)]
+    assert adist.distinct_devices(shared) == 1
+    assert adist.distinct_devices([dict(rank=0, device=0, visible_devices="0"), dict(rank=1, device=0, visible_devices="1")]) == 2
+    # single process: no process group needed
+    assert adist.ranks_seen(torch.device("cpu"), 1)[0]["rank"] == 0
+
+
 def test_shard_kwargs_slices_only_per_sample_entries():
     kw = dict(x_mask=torch.zeros(6, 4), c_text=["a"] * 6, sigma=0.8, table=torch.zeros(3, 2))
     out = adist.shard_kwargs(kw, 2, 3, 6)

@@ -74,3 +74,28 @@ def test_bench_two_ranks_end_to_end():
     other = line["other_scaling_mode"]
     assert other["scaling"] == "weak" and other["batch_per_gpu"] == 32 and other["job_samples"] == 64 and other["value"] > 0
     assert line["roofline"] and line["roofline"]["frac"] < 1 and line["secondary"] is None and line["cpu_baseline"] is None
+    # who was in the job, and what the final all_gather costs on its own
+    seen = line["ranks_seen"]
+    assert [e["rank"] for e in seen] == [0, 1] and all(e["device_name"] for e in seen) and line["batch_per_gpu_by_rank"] == [16, 16]
+    assert line["shared_gpu_test_mode"] == share and line["distinct_devices"] == (1 if share else 2)
+    assert all(e["backend"] == ("gloo" if share else "nccl") for e in seen)
+    g = line["final_all_gather"]
+    assert g["bytes_per_rank"] == 16 * 196 * 263 * 4 and g["max_over_ranks_median_us"] > 0 and g["backend"] == seen[0]["backend"]
+    assert set(line["scaling_modes"]) == {"weak", "strong"}
+
+
+def test_bench_two_ranks_over_rccl_one_rank_per_gpu():
+    """The first multi-GPU lease, made boring: `bench.py --gpus 2` with NO backend override and NO device sharing, i.e.
+    exactly the driver's command - the line must prove that RCCL saw two ranks on two DISTINCT devices (`ranks_seen` comes from an
+    all_gather over the job's own backend).  A 1-GPU box cannot run it and says why."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"needs >= 2 GPUs for one rank per GPU over RCCL; this box has {n} (the shared-GPU gloo variant above covers the control flow)")
+    env = {k: "" for k in ("AFM_BENCH_SHARE_GPU", "AFM_DIST_BACKEND")}
+    r = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"], env)
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    seen = line["ranks_seen"]
+    assert line["n_gpus"] == 2 and line["distinct_devices"] == 2 and not line["shared_gpu_test_mode"]
+    assert [e["rank"] for e in seen] == [0, 1] and all(e["backend"] == "nccl" for e in seen)
+    assert len({(e["visible_devices"], e["device"]) for e in seen}) == 2 and line["batch_per_gpu_by_rank"] == [16, 16]
+    assert line["final_all_gather"]["backend"] == "nccl" and line["final_all_gather"]["max_over_ranks_median_us"] > 0

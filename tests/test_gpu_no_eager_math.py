@@ -36,7 +36,7 @@ def _device_kernel_names(fn):
 
 def _check(names, what):
     if not names:
-        pytest.skip("torch.profiler recorded no device kernels on this box (tools/gpu_validate_round.sh checks the rocprofv3 CSV instead)")
+        pytest.skip("torch.profiler recorded no device kernels on this box (`tools/gpu_call.sh validate` keeps the rocprofv3 kernel CSVs instead)")
     ours = [n for n in names if ("afm" in n or "_kernel" in n or "gemm_f32" in n) and not _FORBIDDEN.search(n)]
     assert ours, f"{what}: no product kernel among {sorted(names)[:20]}"
     bad = {n: c for n, c in names.items() if _FORBIDDEN.search(n) and not _MOVERS.search(n)}

@@ -49,6 +49,17 @@ def test_linear_thin_layers(M, N, K, act):
         lo, hi = 256 * 3 + 4, min(M, 256 * 3 + 4 + 777)
         part = ops.linear(x[lo:hi].contiguous().to(dev()), w.to(dev()), b.to(dev()), act=act, scale=sc.to(dev()))
         assert torch.equal(part, got[lo:hi])
+    # ... nor on where the rows start: an OFFSET VIEW of a row pool (not 16-byte aligned when K % 4 != 0) and offset bias / scale vectors run the
+    # same FMA chain through scalar accesses (the choice used to depend on pointer alignment)
+    xd = x.to(dev())
+    for first in (1, 2, 3):
+        view = xd[first:first + min(M - 3, 300)]
+        assert view.is_contiguous()
+        part = ops.linear(view, w.to(dev()), b.to(dev()), act=act, scale=sc.to(dev()))
+        assert torch.equal(part, got[first:first + view.shape[0]]), (first, view.data_ptr() % 16)
+    pad = torch.cat([torch.zeros(1), b]).to(dev())[1:]              # bias at a 4-byte offset
+    assert pad.data_ptr() % 16 != 0
+    assert torch.equal(ops.linear(xd, w.to(dev()), pad, act=act, scale=sc.to(dev())), got)
 
 
 @pytest.mark.parametrize("M,N,K,R", [(5000, 256, 256, 6), (40000, 256, 256, 8), (33, 128, 256, 1), (777, 320, 512, 8), (1304, 512, 512, 1), (200, 256, 96, 3)])
@@ -281,6 +292,12 @@ def test_linear_tile_shapes_are_bit_identical(M, N, K):
     saved, saved_tune = ops.get_gemm_split(), ops.set_gemm_tune(0)
     try:
         kg = (7,) if K % 256 == 0 and 2 <= K // 256 <= 4 else ()       # split-K form: the K segments of a tile on separate wave groups
+        if K // 256 in (2, 4) and K % 256 == 0:
+            kg += (10,)                                                  # round 5: the same on three LDS stages (K = 1024: two groups x two segments)
+        if K == 1024:
+            kg += (11,)
+        if K >= 128 and K % 16 == 0:
+            kg += (9,)                                                   # sequential 64x64 on three LDS stages
         for products, tiles in ((0, (0, 1, 2, 3, 4, 5)), (9, (0, 3, 5) + kg), (6, (0, 3, 5) + kg)):
             ops.set_gemm_split(products, 0)
             outs = []

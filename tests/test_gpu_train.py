@@ -421,8 +421,10 @@ def test_gather_group_and_max_ops():
     rel("gather backward", f2.grad, f2r.grad, 1e-5)
 
 
-def test_vector_attention_glue_ops():
-    m, k, C, share = 300, 16, 64, 8
+@pytest.mark.parametrize("m,k,C,share", [(300, 16, 64, 8), (200, 16, 32, 1), (130, 8, 64, 2), (77, 16, 512, 4)])
+def test_vector_attention_glue_ops(m, k, C, share):
+    """share_planes = 8 is the reference's; small share_planes make the fused kernels' weight slab as large as their value slab - their
+    workgroup shrinks until its LDS fits 64 KB (share_planes = 1, k = 16, C = 32 asked for 100 KB and failed to launch)."""
     kg, pr, vg = g("va_kg", (m * k, C)), g("va_pr", (m * k, C)), g("va_vg", (m * k, C))
     q, w2 = g("va_q", (m, C)), g("va_w2", (m * k, C // share))
     d0, d1 = g("va_d0", (m * k, C)), g("va_d1", (m, C))

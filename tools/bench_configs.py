@@ -29,6 +29,22 @@ dev = torch.device("cuda:0")
 B, N, L = 32, 8192, 196
 
 
+def pmc_traffic(which, prefix):
+    """HBM bytes per launch of the kernel whose rocprof name starts with `prefix`, from the committed PMC passes of this round's
+    `tools/collect_profiles.sh <round> cdm | points` (profiles/traffic_<which>.json: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, corrected
+    as MI355X_MICROARCH.md prescribes); None when the file or the kernel is absent (counters cannot be read from inside the process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"traffic_{which}.json")) as f:
+            tr = json.load(f)
+    except (OSError, ValueError):
+        return None
+    cands = [(v.get("launches", 0), k, v) for k, v in tr.get("kernels", {}).items() if k.replace(" ", "").startswith(prefix)]
+    if not cands:
+        return None
+    _, name, v = max(cands, key=lambda c: c[0])
+    return dict(v, kernel=name, source=tr.get("source"))
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -155,7 +171,9 @@ def config2(quick):
             ach = tiles * cyc / (us * 1e-6) / 1e9
             peak = 256 * 4 * 2.4
             roof = {"bound": "valu", "kernel": dom, "avg_launch_us": round(us, 2), "achieved": round(ach, 1), "peak": round(peak, 1),
-                    "unit": "G issue-cycles/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "unit": "G issue-cycles/s", "frac": round(ach / peak, 4),
+                    "traffic": pmc_traffic("cdm" if "H3D" in tag else "cdm_h", dom.split("<")[0]),
+                    "algorithmic_bytes_per_launch": B * N * (9 + 6) * 4,          # a point's 9 inputs read, its 6 outputs written (+ the per-sample tables)
                     "model": f"{cyc:.0f} VALU/MFMA issue cycles per 16-point tile per wave (instruction count of the kernel's tile loop), one wave per tile"}
         lines.append({"config": f"configs[2] CDM Perceiver, B=32, N=8192, text token, 1 MI355X: {tag}", "metric": "denoising steps/sec", "value": round(1 / dt, 2), "roofline": roof,
                       "ms_per_step": round(1e3 * dt, 4), "dtype": "f32", "as_written_tflops": round(313.4e9 / dt / 1e12, 1),
@@ -187,7 +205,10 @@ def config3(quick):
                     "fps_ms": round(prof["fps_kernel"]["total_ms"], 3), "fps_us_per_round": round(1e3 * prof["fps_kernel"]["total_ms"] / (m - 1), 3),
                     "knn_ms": round(prof["knn_kernel"]["total_ms"], 3), "fused_gather_mlp_max_ms": round(fused, 4),
                     "fused_algorithmic_GBps": round(alg_bytes / (fused * 1e-3) / 1e9, 1), "fused_tflops": round(2 * 35 * 64 * B * m * 16 / (fused * 1e-3) / 1e12, 2),
-                    "bounds": "FPS latency-bound (dependent rounds); kNN VALU; fused stage L2-gather / f32 MFMA"})
+                    "bounds": "FPS latency-bound (dependent rounds); kNN VALU; fused stage L2-gather / f32 MFMA",
+                    "fused_algorithmic_bytes": alg_bytes,
+                    "traffic": {k: pmc_traffic("points", k) for k in ("fps_pruned_kernel", "knn_kernel", "transition_down_kernel")}
+                               if stride == 4 else "see the 8192 -> 2048 entry (one PMC target runs both strides; the json's means are over both)"})
     return out
 
 
@@ -207,12 +228,12 @@ def config4(quick):
 def secondary_block(quick=True):
     """The `secondary` object of bench.py's JSON line (N = 1 only, after the headline, outside its timed region): every BASELINE config the
     headline does not cover, measured by the same driver-run process.  `quick`: bounded repetitions (the whole block stays within ~1-2 min;
-    the CPU oracle's faithful variant of configs[0] - seconds per step - is left to `tools/bench_configs.py`).  A failing part records its
+    configs[0]'s CPU oracle: 20 chained hoisted steps and ONE faithful step - the contact encoder over 4 x 8192 points is seconds per call).  A failing part records its
     error instead of taking the headline line down with it."""
     ffi.load()
     out = {"note": "N = 1 only; measured after the headline by the same process, outside its timed region; tools/bench_configs.py functions"}
     for key, fn in (("configs[4]", lambda: config4(False)), ("configs[2]", lambda: config2(quick)), ("configs[3]", lambda: config3(quick)),
-                    ("configs[0]", lambda: config0(quick, cpu=False))):
+                    ("configs[0]", lambda: config0(quick, cpu=True))):      # BASELINE configs[0] IS the reference's CPU path: the oracle on the host cores, bounded (20 hoisted steps, one faithful step, ~10 s)
         try:
             out[key] = fn()
         except Exception as e:                       # noqa: BLE001 - reported, never silenced

@@ -3,16 +3,18 @@
 # separate PMC passes (HBM read / write bytes, MFMA busy) as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
 #   tools/collect_profiles.sh r2          CMDM headline path (bench.py) -> gpurun_out/prof_r2
 #   tools/collect_profiles.sh r2 cdm      CDM Perceiver loop (BASELINE configs[2]) -> gpurun_out/prof_r2_cdm
+#   tools/collect_profiles.sh r2 points   set abstraction (BASELINE configs[3]: FPS, kNN, fused gather-MLP-max) -> gpurun_out/prof_r2_points
 set -u
 R=${1:-r1}
 WHICH=${2:-cmdm}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$R
 [ "$WHICH" = "cdm" ] && OUT=${OUT}_cdm
+[ "$WHICH" = "points" ] && OUT=${OUT}_points
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PMC="python $ROOT/tools/pmc_target.py $WHICH"
-if [ "$WHICH" = "cdm" ]; then
+if [ "$WHICH" = "cdm" ] || [ "$WHICH" = "points" ]; then
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PMC > /dev/null 2>&1
 else
   BENCH="python $ROOT/bench.py --streams 1 --steps 100 --warmup 10 --latency-runs 0 --latency-runs-b1 0 --no-cpu-baseline --no-alt-gemm --no-secondary"
@@ -23,7 +25,7 @@ fi
 timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMC > /dev/null 2>&1
 timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMC > /dev/null 2>&1
 timeout 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- $PMC > /dev/null 2>&1
-python $ROOT/tools/summarize_profiles.py $OUT > $OUT/summary.md 2>&1
+python $ROOT/tools/summarize_profiles.py $OUT $WHICH > $OUT/summary.md 2>&1
 cat $OUT/summary.md
 # the raw kernel traces are large; keep only stats + the summary
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete

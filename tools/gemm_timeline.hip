@@ -105,6 +105,8 @@ static void one(int M, int N, int K, int tile, int arith = AFM_ARITH_F32, int pa
     if (arith != AFM_ARITH_F32) {          // bf16-split kernels: the four trailing fields are phase spans in 10 ns ticks (gemm_split.hip)
         double a = 0, b = 0, c = 0, d = 0;
         for (auto& x : r) { a += x.wait_c; b += x.barrier_c; c += x.issue_c; d += x.mfma_c; }
+        { double cyc = 0, us = 0; for (auto& x : r) { cyc += (double)(x.c1 - x.c0); us += (x.t1 - x.t0) * tick_us; }
+          printf("   shader clock over the workgroups' lifetimes: %.2f GHz (cycle counter / s_memrealtime)\n", cyc / us / 1e3); }
         printf("   phases of thread 0, mean over workgroups (us): prologue (operand + statistic loads, first split) %.2f | K loop %.2f | K-group merge + staging %.2f | epilogue %.2f;  launch overhead = event time - (first entry -> last exit) = %.1f us\n",
                a / n * tick_us, b / n * tick_us, c / n * tick_us, d / n * tick_us, ms * 1e3 - (tmax - tmin) * tick_us);
     } else
@@ -144,6 +146,20 @@ int main(int argc, char** argv) {
                 if (lf != 1) one(M, 1536, 512, 0, AFM_ARITH_BF16X9, 0, 0, lf);
                 if (lf != 2) one(M, 512, 1024, 0, AFM_ARITH_BF16X9, 0, 0, lf);
             }
+        return 0;
+    }
+    if (argc == 2 && !strcmp(argv[1], "r5")) {          // round 5: two-stage (7 / 3) against three-stage (10 / 9) forms, loop epilogues, warm and cold
+        for (int cold : {0, 1}) {
+            g_cold = cold;
+            for (int M : {1304, 326}) {
+                for (int tile : {7, 10}) { one(M, 512, 512, tile, AFM_ARITH_BF16X9, 0, 0, 1); one(M, 512, 1024, tile, AFM_ARITH_BF16X9, 0, 0, 1); }
+                one(M, 512, 1024, 11, AFM_ARITH_BF16X9, 0, 0, 1);
+                for (int tile : {7, 10, 9}) { one(M, 1024, 512, tile, AFM_ARITH_BF16X9, 0, 0, 2); one(M, 1536, 512, tile, AFM_ARITH_BF16X9, 0, 0, 2); }
+            }
+        }
+        g_cold = 0;
+        for (int M : {10432, 5216})
+            for (int tile : {3, 9}) { one(M, 512, 512, tile, AFM_ARITH_BF16X9, 0, 0, 1); one(M, 512, 1024, tile, AFM_ARITH_BF16X9, 0, 0, 1); one(M, 1024, 512, tile, AFM_ARITH_BF16X9, 0, 0, 2); }
         return 0;
     }
     for (int tile : {3, 5}) one(10432, 512, 512, tile);

@@ -1,7 +1,9 @@
 """Lean target for rocprofv3 --pmc / --kernel-trace passes: 12 native steps at the bench shape, single stream, no profiler events.
     python tools/pmc_target.py          -> CMDM trans_enc loop (BASELINE configs[1]: B = 32, L = 196, T = 326)
     python tools/pmc_target.py cdm      -> CDM Perceiver loop  (BASELINE configs[2]: B = 32, N = 8192 points + text token)
-    python tools/pmc_target.py cdm_h    -> the same loop, HUMANISE variant (41 input channels: 32 hoisted scene features per point)"""
+    python tools/pmc_target.py cdm_h    -> the same loop, HUMANISE variant (41 input channels: 32 hoisted scene features per point)
+    python tools/pmc_target.py points   -> BASELINE configs[3]: set abstraction TransitionDown(32 -> 64, k = 16) at N = 8192 -> 2048 and -> 1024, B = 32
+                                           (fps_pruned_kernel, knn_kernel<16>, transition_down_kernel), three repetitions each"""
 import os
 import sys
 
@@ -17,7 +19,18 @@ from afm.config import load_config  # noqa: E402
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "cmdm"
 B = 32
-if which in ("cdm", "cdm_h"):
+if which == "points":
+    from afm import scene as S
+    N = 8192
+    p = synth.scene_cloud(B, N).reshape(B * N, 3).to(dev)
+    x = synth.gaussian("sa_feat", (B * N, 32)).to(dev)
+    for stride in (4, 8):
+        td = S.TransitionDown(32, 64, stride=stride, nsample=16)
+        synth.fill_module_(td)
+        td = td.to(dev).eval()
+        for _ in range(3):
+            td.run(p, x, B)
+elif which in ("cdm", "cdm_h"):
     N = 8192
     scene = (["model.scene_model.use_scene_model=True", "model.scene_model.use_openscene=True", "model.scene_model.point_feat_dim=32",
               "model.scene_model.pretrained_weight=''", "task.dataset.use_openscene=True"] if which == "cdm_h" else ["model.scene_model.use_scene_model=False"])

@@ -1,6 +1,11 @@
 """Condense rocprofv3 outputs (kernel stats + PMC passes) into a markdown summary (profiles/<round>_summary.md)."""
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
+which = sys.argv[2] if len(sys.argv) > 2 else "cmdm"
+TARGET = {"cmdm": "tools/pmc_target.py (12 native steps, B = 32, one stream: launches of M = 10432 rows)",
+          "cdm": "tools/pmc_target.py cdm (2 x 12 native CDM steps, B = 32, N = 8192, one stream)",
+          "cdm_h": "tools/pmc_target.py cdm_h (HUMANISE variant)",
+          "points": "tools/pmc_target.py points (TransitionDown 32 -> 64, k = 16, B = 32, N = 8192 -> 2048 and -> 1024, three repetitions each: means over both strides)"}.get(which, which)
 
 
 def short(n):
@@ -45,8 +50,7 @@ try:
     kernels = {k: {"read_bytes_per_launch": 2 * v["FETCH_SIZE"], "write_bytes_per_launch": v["WRITE_SIZE"],
                    "bytes_per_launch": 2 * v["FETCH_SIZE"] + v["WRITE_SIZE"], "launches": v["launches"]}
                for k, v in per.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
-    json.dump({"kernels": kernels, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), tools/pmc_target.py "
-                                             "(12 native steps, B = 32, one stream: launches of M = 10432 rows)"},
+    json.dump({"kernels": kernels, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), " + TARGET},
               open(os.path.join(out, "traffic.json"), "w"), indent=1)
 except Exception as e:   # noqa
     print(f"(traffic.json not written: {e})")
