@@ -140,7 +140,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     packed = os.environ.get("AFM_PACKED_FP32") == "1"          # build-time switch of THIS script (the library reads no environment)
     flags = FLAGS + ([] if packed else NO_PACKED_F32)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     os.makedirs(OBJ, exist_ok=True)
     jobs = []
     for s in srcs:

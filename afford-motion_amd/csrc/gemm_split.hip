@@ -61,394 +61,45 @@ constexpr int KSEG = 256;
 // groups do not fit the LDS); group g > 0 hands its two segment sums over separately, so the sum order ((s0 + s1) + s2) + s3 is unchanged.
 template <int BM, int BN, int BKS, int NPROD, int KG = 1, int RING = 2, int GSEG = 1>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_f32_split_bf16(const afm_linear_args p, int nbm, int nbn) {
-    static_assert(BKS == 16, "one K16 MFMA step per K-tile");
-    static_assert(RING == 2 || RING == 3, "two or three LDS stages");
-    static_assert(GSEG == 1 || (GSEG == 2 && KG > 1), "two segments per group: split-K forms only");
-    constexpr int TM = BM / 64, TN = BN / 64;
-    static_assert(KG == 1 || (BM == 64 && BN == 64), "the split-K form exists for 64x64 tiles");
-    constexpr int ROWB = BKS * 2 + 16;                // LDS row bytes (bf16 + pad)
-    constexpr int ROWS = BM + BN;                     // A rows then W rows
-    constexpr int PLANE = ROWS * ROWB;
-    constexpr int STAGE = 3 * PLANE;
-    constexpr int NA = BM / 64, NW = BN / 64;         // (row, 4 consecutive k) items of A / of W per thread and K-tile
-    constexpr int NI = NA + NW;
-    constexpr int LDC = BN + 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // K segment of this 256-thread group
-    unsigned char* lds = lds_raw + grp * (RING * STAGE);
-#if defined(AFM_TIMELINE) && defined(AFM_DESYNC_TICKS)
-    // experiment (tools/gemm_timeline builds only): half of the workgroups of a CU start AFM_DESYNC_TICKS x 10 ns late, so that the prologue /
-    // epilogue phases of one half meet the K loops of the other - what a desynchronised (persistent, stream-K like) schedule would buy
-    if ((blockIdx.x >> 8) & 1) {
-        const unsigned long long td = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - td < AFM_DESYNC_TICKS) __builtin_amdgcn_s_sleep(20);
-    }
-#endif
-#ifdef AFM_TIMELINE          // tools/gemm_timeline.hip only (single translation unit with gemm.hip, which defines the record type)
-    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = afm_cycles();
-#endif
+#define AFM_WG ((int)blockIdx.x)
+#define AFM_TIDX threadIdx.x
+#define AFM_TIMELINE_SLOT blockIdx.x
+#include "gemm_split_body.inc"
+#undef AFM_WG
+#undef AFM_TIDX
+#undef AFM_TIMELINE_SLOT
+}
 
-    const int nblk = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = bid / nbn, bn = bid % nbn;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // position inside the 256-thread group
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r32 = lane & 31, hh = lane >> 5;
-
-    // Staging items are (row, quarter) = 4 floats: the four lanes of a row fetch its 64 contiguous bytes of the K-tile with ONE
-    // load instruction (16 cache lines per wave-instruction; an 8-float item needs two instructions of 32 lines each:
-    // TCP_TOTAL_CACHE_ACCESSES 11.7 M -> 6.0 M per out_proj launch, 2-3 % faster), and every thread carries the same mix of A and W
-    // work.  16 consecutive lanes (the unit ds_write_b64 is serviced in) take the four quarters of four rows of equal parity inside a
-    // block of 8 rows: with rows 48 B apart those are four disjoint 32-byte windows of the 128-byte bank row.
-    const RowMap amap{p.a_grp, p.a_stride, p.a_off, p.a_skip_after, p.a_skip};
-    const float* src[NI];
-    int dst[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int it = tid + 256 * (i < NA ? i : i - NA), q = it & 3, v = it >> 2, row = (v & ~7) + ((v & 3) << 1) + ((v >> 2) & 1);
-        src[i] = (i < NA ? p.A + amap(min(bm * BM + row, p.M - 1)) * p.lda
-                         : p.W + (int64_t)min(bn * BN + row, p.N - 1) * p.ldw) + q * 4 + grp * (GSEG * KSEG);
-        dst[i] = ((i < NA ? 0 : BM) + row) * ROWB + q * 8;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // Two register sets, always indexed with compile-time constants: at the top of K-tile kt the set (kt & 1) is free (its
-    // tile went to LDS during kt - 1) and receives tile kt + 2; the other set holds tile kt + 1 (loaded one full K-tile
-    // ago) and is split into the other LDS stage between the MFMAs of tile kt.
-    // RING == 3 keeps NSET = 4 register sets: tile j lives in set j % 4 and is requested THREE K-tiles before its split (round 5: with one
-    // K-tile of lead - ~950 cycles on a small launch - the split waited for operands that the previous kernel had just written on other
-    // XCDs, an HBM / Infinity-Cache round trip of the same length; removing all split arithmetic moved a small launch by 0.3 us, removing one
-    // operand's loads by 1.2: profiles/r04_gemm_w_ablation.txt).  A small launch holds two waves per SIMD: the registers are there.
-    constexpr int NSET = RING == 3 ? 4 : 2;
-    f32x4 g[NSET][NI];
-    const int nk = KG > 1 ? GSEG * KSEG / BKS : p.K / BKS;
-    constexpr int SEGT = KSEG / BKS;                  // K-tiles per segment
-    f32x16 tot[TM][TN];                               // sum of the finished segments (KG == 1 with K > KSEG only)
-    bool have_tot = false;
-    auto load = [&](auto SETC, int kt) {
-        constexpr int S = decltype(SETC)::value;
-        const int k = min(kt, nk - 1) * BKS;          // past the end: re-load the last tile (never consumed)
-        if ((AFM_ABLATE & 1) && kt >= 2) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(g[S][i]));
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if ((AFM_ABLATE & 32) && i >= NA && kt >= 2) { asm volatile("" : "+v"(g[S][i])); continue; }
-            if ((AFM_ABLATE & 64) && i < NA && kt >= 2) { asm volatile("" : "+v"(g[S][i])); continue; }
-            g[S][i] = *reinterpret_cast<const f32x4*>(src[i] + k);
-        }
-    };
-    using Set0 = std::integral_constant<int, 0>;
-    using Set1 = std::integral_constant<int, 1>;
-    load(Set0{}, 0);
-    load(Set1{}, 1);
-    float* rowst = reinterpret_cast<float*>(lds_raw + KG * RING * STAGE);   // folded LayerNorm: row statistics, an LDS region of their own
-    gemm_rowstats<BM>(p, rowst, bm);                  // (loads in flight with the operands'; published by the barrier below)
-    auto split_set = [&](auto SETC, int stage) {      // prologue only: a whole register set -> one LDS stage, no interleaving
-        constexpr int S = decltype(SETC)::value;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            unsigned char* d = lds + stage * STAGE + dst[i];
-            uint32_t a1, a2, a3, b1, b2, b3;
-            split2(g[S][i][0], g[S][i][1], a1, a2, a3);
-            split2(g[S][i][2], g[S][i][3], b1, b2, b3);
-            *reinterpret_cast<u32x2*>(d) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{a2, b2};
-            *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{a3, b3};
-        }
-    };
-    using Set2 = std::integral_constant<int, 2>;
-    using Set3 = std::integral_constant<int, 3>;
-    if constexpr (RING == 3) {                        // tiles 0 .. 4 requested, tiles 0 and 1 in LDS (K-tile 0 splits set 2 and refills set 1 with tile 5)
-        load(Set2{}, 2);
-        load(Set3{}, 3);
-        split_set(Set0{}, 0);
-        load(Set0{}, 4);
-        split_set(Set1{}, 1);
-    } else {
-        split_set(Set0{}, 0);
-    }
-    __syncthreads();
-#ifdef AFM_TIMELINE
-    const unsigned long long tl_pro = __builtin_amdgcn_s_memrealtime();          // prologue done: first K-tile split and published
+// ---- WALK (round 5; MEASUREMENT ONLY, AFM_TUNE tile code 12): `gridDim.x` RESIDENT workgroups walk the tiles of a launch (tile wg = blockIdx.x,
+// + gridDim.x, ...) instead of one workgroup per tile - the first half of the "layer-resident" schedule VERDICT r4 asked for: no lockstep
+// rounds, no tail round.  Built, bit-identical (same tile program, same tile order), and SLOWER where it counts (profiles/r05_layer_resident.md):
+// single launches 63.6 -> 69.1 us (linear1 at M = 5216), the two-stream B = 32 loop 478-479 -> 452-457 steps/s for every grid size and register
+// budget tried (hipcc needs 168-202 VGPRs for the looped tile program against 93 for the plain one: 2-3 workgroups per CU instead of 4-5).
+// The library never selects it.
+template <int BM, int BN, int BKS, int NPROD>
+#ifndef AFM_WALK_LB
+#define AFM_WALK_LB 3
 #endif
-
-    const int a_off = (wm * (BM / 2) + r32) * ROWB + hh * 16;
-    const int w_off = (BM + wn * (BN / 2) + r32) * ROWB + hh * 16;
-    constexpr int NMFMA = NPROD * TM * TN;                    // MFMAs per wave per K-tile
-    constexpr int NPIECE = NI * 2 * 3;                        // split pieces per thread per K-tile (pair of floats x residual level)
-
-    // One K-tile.  The instruction order is written out and pinned with sched_barrier fences (hipcc otherwise hoists all
-    // MFMAs in front of the split and chains the nine MFMAs of one accumulator back to back): after every MFMA a piece of
-    // the next tile's split (~5 VALU) issues in the shadow of the 32-cycle matrix op.
-    uint4 af[TM][3], bf[TN][3];
-    auto body = [&](auto CURC, int kt) {          // K-tile kt with kt & 1 == cur: register set cur is free, set cur ^ 1 holds tile kt + 1
-        constexpr int cur = decltype(CURC)::value;
-        load(CURC, kt + 2);
-        const unsigned char* base = lds + cur * STAGE;
-        unsigned char* wbase = lds + (cur ^ 1) * STAGE;
-        float r0[NI * 2], r1[NI * 2];
-        uint32_t sp[NI * 2][3];
-        int piece = 0, m = 0;
-        auto do_piece = [&](int t) {
-            const int u = t / 3, lvl = t % 3, i = u / 2, c = u % 2;
-            if ((AFM_ABLATE & 32) && i >= NA && kt >= 1) return;          // W items: nothing to split, nothing to store
-            if ((AFM_ABLATE & 64) && i < NA && kt >= 1) return;           // A items likewise (the floor of "A already in LDS": out_proj fused behind attention)
-            if (lvl == 0) {
-                r0[u] = g[cur ^ 1][i][2 * c];
-                r1[u] = g[cur ^ 1][i][2 * c + 1];
-            }
-            const uint32_t pk = (AFM_ABLATE & 2) ? __float_as_uint(lvl == 1 ? r1[u] : r0[u]) : cvt_pk_bf16(r0[u], r1[u]);
-            sp[u][lvl] = pk;
-            if (lvl < 2) {
-                if (!(AFM_ABLATE & 2)) {
-                    r0[u] = sub_bf16_lo(r0[u], pk);              // (one v_dot2c_f32_bf16 each: bf16split.h)
-                    r1[u] = sub_bf16_hi(r1[u], pk);
-                }
-            } else if (c == 1) {
-                unsigned char* d = wbase + dst[i];
-                if (AFM_ABLATE & 4) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) asm volatile("" :: "v"(sp[2 * i][pl]), "v"(sp[2 * i + 1][pl]), "v"(d));
-                } else {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * PLANE) = u32x2{sp[2 * i][pl], sp[2 * i + 1][pl]};
-                }
-            }
-        };
-        if (!(AFM_ABLATE & 8) || kt == 0)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + a_off + i * 32 * ROWB);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j][pl] = *reinterpret_cast<const uint4*>(base + pl * PLANE + w_off + j * 32 * ROWB);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 9 - NPROD; q < 9; ++q)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    if (AFM_ABLATE & 16) asm volatile("" : "+v"(acc[tm][tn][q]) : "v"(af[tm][AFM_PA[q]].x), "v"(af[tm][AFM_PA[q]].w), "v"(bf[tn][AFM_PB[q]].x), "v"(bf[tn][AFM_PB[q]].w));
-                    else acc[tm][tn] = mfma_bf16(af[tm][AFM_PA[q]], bf[tn][AFM_PB[q]], acc[tm][tn]);
-                    ++m;
-#pragma unroll
-                    for (int t = 0; t < NPIECE; ++t)
-                        if (t >= piece && t < (m * NPIECE) / NMFMA) do_piece(t);
-                    piece = (m * NPIECE) / NMFMA;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        if ((KG == 1 || GSEG > 1) && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {        // segment finished, more to come: bank it, restart from zero
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        tot[tm][tn][r] = have_tot ? tot[tm][tn][r] + acc[tm][tn][r] : acc[tm][tn][r];
-                        acc[tm][tn][r] = 0.f;
-                    }
-            have_tot = true;
-        }
-        __syncthreads();
-    };
-    // RING == 3: K-tile kt runs its MFMAs on fragment set kt & 1 (read during kt - 1), requests tile kt + 1's fragments from stage
-    // (kt + 1) % 3 (written during kt - 1, published by that K-tile's barrier) into the other set, and splits tile kt + 2 (register set
-    // kt & 1, loaded during kt - 1) into stage (kt + 2) % 3, whose previous tile (kt - 1) was last read during kt - 2.
-    u32x4 fa[2][TM][3], fb[2][TN][3];
-    auto read_frag = [&](auto FC, int stage) {
-        constexpr int F = decltype(FC)::value;
-        const unsigned char* base = lds + stage * STAGE;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[F][i][pl] = *reinterpret_cast<const u32x4*>(base + pl * PLANE + a_off + i * 32 * ROWB);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[F][j][pl] = *reinterpret_cast<const u32x4*>(base + pl * PLANE + w_off + j * 32 * ROWB);
-        }
-    };
-#ifndef AFM_R3_TAIL
-#define AFM_R3_TAIL 2         // MFMAs at the end of a K-tile that carry no split work: the last LDS stores land under them
+#ifndef AFM_WALK_OPAQUE
+#define AFM_WALK_OPAQUE 1
 #endif
-    auto body3 = [&](auto SC, int kt, int st_next, int st_wr) {          // K-tile kt, S = kt % 4
-        constexpr int S = decltype(SC)::value;
-        constexpr int cur = S & 1;                    // fragment set of this K-tile
-        constexpr int SS = (S + 2) & 3;               // register set that is split (tile kt + 2)
-        using LoadSet = std::integral_constant<int, (S + 1) & 3>;       // ... and the one that is refilled (tile kt + 5)
-        using FragNext = std::integral_constant<int, cur ^ 1>;
-        unsigned char* wbase = lds + st_wr * STAGE;
-        float r0[NI * 2], r1[NI * 2];
-        uint32_t sp[NI * 2][3];
-        int piece = 0, m = 0;
-        auto do_piece = [&](int t) {
-            const int u = t / 3, lvl = t % 3, i = u / 2, c = u % 2;
-            if (lvl == 0) {
-                r0[u] = g[SS][i][2 * c];
-                r1[u] = g[SS][i][2 * c + 1];
-            }
-            const uint32_t pk = cvt_pk_bf16(r0[u], r1[u]);
-            sp[u][lvl] = pk;
-            if (lvl < 2) {
-                r0[u] = sub_bf16_lo(r0[u], pk);
-                r1[u] = sub_bf16_hi(r1[u], pk);
-            } else if (c == 1) {
-                unsigned char* d = wbase + dst[i];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(d + pl * PLANE) = u32x2{sp[2 * i][pl], sp[2 * i + 1][pl]};
-            }
-        };
-        constexpr int NFILL = NMFMA - 1 - AFM_R3_TAIL > 0 ? NMFMA - 1 - AFM_R3_TAIL : 1;      // MFMAs 2 .. NFILL + 1 carry the split
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 9 - NPROD; q < 9; ++q)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = mfma_bf16(fa[cur][tm][AFM_PA[q]], fb[cur][tn][AFM_PB[q]], acc[tm][tn]);
-                    ++m;
-                    if (m == 1) {               // behind the first MFMA: the requests of this K-tile (nothing in it waits for them)
-                        __builtin_amdgcn_sched_barrier(0);
-                        load(LoadSet{}, kt + 5);
-                        read_frag(FragNext{}, st_next);
-                    } else {
-                        const int want = ((m - 1) * NPIECE + NFILL - 1) / NFILL;
-#pragma unroll
-                        for (int t = 0; t < NPIECE; ++t)
-                            if (t >= piece && t < want) do_piece(t);
-                        piece = want < NPIECE ? want : NPIECE;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-        for (int t = 0; t < NPIECE; ++t)              // (NPROD == 1: a single MFMA per K-tile has no slot for the split)
-            if (t >= piece) do_piece(t);
-        if ((KG == 1 || GSEG > 1) && ((kt + 1) % SEGT) == 0 && kt + 1 < nk) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        tot[tm][tn][r] = have_tot ? tot[tm][tn][r] + acc[tm][tn][r] : acc[tm][tn][r];
-                        acc[tm][tn][r] = 0.f;
-                    }
-            have_tot = true;
-        }
-        __syncthreads();
-    };
-    if constexpr (RING == 2) {
-        for (int kt = 0; kt < nk; kt += 2) {
-            body(Set0{}, kt);
-            if (kt + 1 < nk) body(Set1{}, kt + 1);
-        }
-    } else {
-        read_frag(Set0{}, 0);
-        int s1 = 1, s2 = 2;                           // (kt + 1) % 3, (kt + 2) % 3
-        for (int kt = 0; kt < nk; kt += 4) {         // nk % 4 == 0 (the launcher checks K)
-            body3(Set0{}, kt, s1, s2);
-            s1 = s2; s2 = (s1 + 1) % 3;
-            body3(Set1{}, kt + 1, s1, s2);
-            s1 = s2; s2 = (s1 + 1) % 3;
-            body3(Set2{}, kt + 2, s1, s2);
-            s1 = s2; s2 = (s1 + 1) % 3;
-            body3(Set3{}, kt + 3, s1, s2);
-            s1 = s2; s2 = (s1 + 1) % 3;
-        }
+__global__ __launch_bounds__(256, AFM_WALK_LB) void gemm_f32_split_bf16_walk(const afm_linear_args p, int nbm, int nbn) {
+    constexpr int KG = 1, RING = 2, GSEG = 1;
+    const int ntiles_ = nbm * nbn;
+    for (int wg_ = blockIdx.x; wg_ < ntiles_; wg_ += gridDim.x) {
+        if (wg_ != (int)blockIdx.x) __syncthreads();         // the previous tile's epilogue has left the LDS
+        // an opaque copy of the thread index per tile: hipcc otherwise hoists every thread-dependent address of prologue AND epilogue out of
+        // the tile loop (202 VGPRs, two waves per SIMD; capped at 128 it spilled 260 bytes per lane) - recomputed per tile they cost nothing
+        int tidx_ = (int)threadIdx.x;
+        if (AFM_WALK_OPAQUE) asm volatile("" : "+v"(tidx_));
+#define AFM_WG wg_
+#define AFM_TIDX tidx_
+#define AFM_TIMELINE_SLOT wg_
+#include "gemm_split_body.inc"
+#undef AFM_WG
+#undef AFM_TIDX
+#undef AFM_TIMELINE_SLOT
     }
-
-#ifdef AFM_TIMELINE
-    const unsigned long long tl_kloop = __builtin_amdgcn_s_memrealtime();        // K loop done
-#endif
-    if (have_tot && (KG == 1 || grp == 0)) {          // ((s0 + s1) + ...) + s_last (of a later split-K group: both segment sums travel, see below)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = tot[tm][tn][r] + acc[tm][tn][r];
-    }
-    if (KG > 1) {
-        // groups 1 .. KG-1 hand their segment sums (GSEG of them, in segment order) to group 0 through their own (now idle) operand
-        // regions: [segment][r / 4][thread] float4
-        static_assert(RING * STAGE >= GSEG * 4 * 256 * 16, "the segment sums of a group fit its operand stages");
-        f32x4* part = reinterpret_cast<f32x4*>(lds);
-        if (grp > 0) {
-            if (GSEG == 2) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) part[q * 256 + tid] = f32x4{tot[0][0][4 * q], tot[0][0][4 * q + 1], tot[0][0][4 * q + 2], tot[0][0][4 * q + 3]};
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) part[((GSEG - 1) * 4 + q) * 256 + tid] = f32x4{acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
-        }
-        __syncthreads();
-        if (grp == 0) {
-            for (int gI = 1; gI < KG; ++gI) {
-                const f32x4* pg = reinterpret_cast<const f32x4*>(lds_raw + gI * (RING * STAGE));
-#pragma unroll
-                for (int sI = 0; sI < GSEG; ++sI)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = pg[(sI * 4 + q) * 256 + tid];
-                        acc[0][0][4 * q] += v[0]; acc[0][0][4 * q + 1] += v[1]; acc[0][0][4 * q + 2] += v[2]; acc[0][0][4 * q + 3] += v[3];
-                    }
-            }
-        }
-    }
-    float* ldsf = reinterpret_cast<float*>(lds_raw);
-    if (grp == 0) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ldsf[(wm * (BM / 2) + tm * 32 + mfma_row(r, lane)) * LDC + wn * (BN / 2) + tn * 32 + r32] = acc[tm][tn][r];
-    }
-    __syncthreads();
-#ifdef AFM_TIMELINE
-    const unsigned long long tl_staged = __builtin_amdgcn_s_memrealtime();       // K groups merged, accumulators staged in LDS
-#endif
-    // The split-K form's epilogue runs on ALL its wave groups (512 / 1024 threads: two trips / one over the 64 x 64 tile instead of four -
-    // a small launch has nothing else to hide the trips' memory round trips behind; profiles/r04_gemm_timeline_small.txt: epilogue 3.5 of
-    // 14.8 us).  An output element's arithmetic does not depend on which thread handles it: bit-identical.
-    constexpr int ENT = (KG == 2 || KG == 4) ? 256 * KG : 256;
-    if (ENT > 256) gemm_epilogue<BM, BN, ENT>(p, ldsf, bm, bn, (int)threadIdx.x, rowst);
-    else if (grp == 0) gemm_epilogue<BM, BN>(p, ldsf, bm, bn, tid, rowst);
-    gemm_ln_tail<BM>(p, bm, nbn, reinterpret_cast<int*>(ldsf));
-    if (p.aux_dst && (int)blockIdx.x < p.aux_rows) {          // rider: one row copy (+ add) per workgroup, behind its own tile
-        const int r = blockIdx.x;
-        int64_t ix = p.aux_idx ? p.aux_idx[r] : r;
-        ix = ix < 0 ? 0 : (ix >= p.aux_idx_max ? p.aux_idx_max - 1 : ix);
-        for (int c = threadIdx.x; c < p.aux_cols; c += blockDim.x)
-            p.aux_dst[(int64_t)r * p.aux_dst_ld + c] = p.aux_src[ix * p.aux_cols + c] + (p.aux_add ? p.aux_add[c] : 0.0f);
-    }
-#ifdef AFM_TIMELINE
-    if (afm_timeline && threadIdx.x == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores have left the wave
-        const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime();
-        // phase spans in s_memrealtime ticks (10 ns): prologue | K loop | merge + staging | epilogue
-        afm_timeline[blockIdx.x] = AfmTimelineRec{tl_t0, tl_end, hw, xcc, tl_c0, afm_cycles(), tl_pro - tl_t0, tl_kloop - tl_pro, tl_staged - tl_kloop, tl_end - tl_staged};
-    }
-#endif
 }
 
 template <int BM, int BN, int BKS, int NPROD, int KG = 1, int RING = 2, int GSEG = 1>
@@ -464,6 +115,26 @@ int launch_split(const afm_linear_args& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     AfmProf prof(BM == 128 ? AFM_PROF_GEMM_SPLIT128 : (KG > 1 ? AFM_PROF_GEMM_SPLIT64_KG : AFM_PROF_GEMM_SPLIT64), 2.0 * a.M * a.N * a.K, s);
     hipLaunchKernelGGL((gemm_f32_split_bf16<BM, BN, BKS, NPROD, KG, RING, GSEG>), dim3(nbm * nbn), dim3(256 * KG), LDS_BYTES, s, a, nbm, nbn);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+#ifndef AFM_WALK_GRID
+#define AFM_WALK_GRID 0            // > 0 (A/B builds only): every 64x64 launch with more tiles than this walks them on this many resident workgroups
+#endif
+#ifndef AFM_WALK_GRID_FORCED
+#define AFM_WALK_GRID_FORCED 768   // resident workgroups of the forced form (tile code 12): three per CU
+#endif
+template <int NPROD>
+int launch_split_walk(const afm_linear_args& a, hipStream_t s) {
+    constexpr int BM = 64, BN = 64, BKS = 16;
+    constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
+    constexpr int LDS_BYTES = 2 * STAGE + 2 * BM * 2 * 4;
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    const int64_t tiles = (int64_t)nbm * nbn;
+    AfmProf prof(AFM_PROF_GEMM_SPLIT64, 2.0 * a.M * a.N * a.K, s);
+    const int64_t grid = AFM_WALK_GRID > 0 ? AFM_WALK_GRID : AFM_WALK_GRID_FORCED;
+    hipLaunchKernelGGL((gemm_f32_split_bf16_walk<BM, BN, BKS, NPROD>), dim3((unsigned)(tiles < grid ? tiles : grid)), dim3(256), LDS_BYTES, s, a, nbm, nbn);
     AFM_CHECK_LAUNCH();
     return 0;
 }
@@ -514,7 +185,12 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     // per SIMD weigh twice as much as at K = 512 and the 64x64 kernel (four waves per SIMD) wins, 0.367 vs 0.384 ms (configs[2]: 1323 vs 1284
     // steps/s in one call).  Round 3 also measured 128x64 / 64x128 tiles in the CMDM loop: 431 / 437 steps/s against 449 for this rule.
     const bool full_rounds = tiles128 * 10 >= rounds * resident * 9 && a.K > KSEG;      // >= 90 % of the resident slots used over all rounds
-    if (tile == 3 || (tile != 5 && !full_rounds)) return launch_split<64, 64, 16, NPROD>(a, s);
+    if (tile == 12) return launch_split_walk<NPROD>(a, s);          // measurement: force the walking form
+    if (tile == 3 || (tile != 5 && !full_rounds)) {
+        const int64_t tiles64w = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        if (tile != 3 && AFM_WALK_GRID > 0 && tiles64w > AFM_WALK_GRID) return launch_split_walk<NPROD>(a, s);      // (A/B builds only: AFM_WALK_GRID is 0 in the library)
+        return launch_split<64, 64, 16, NPROD>(a, s);
+    }
     return launch_split<128, 128, 16, NPROD>(a, s);
 }
 

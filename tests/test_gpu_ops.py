@@ -297,7 +297,7 @@ def test_linear_tile_shapes_are_bit_identical(M, N, K):
         if K == 1024:
             kg += (11,)
         if K >= 128 and K % 16 == 0:
-            kg += (9,)                                                   # sequential 64x64 on three LDS stages
+            kg += (9, 12)                                                # sequential 64x64 on three LDS stages; 64x64 tiles walked by resident workgroups
         for products, tiles in ((0, (0, 1, 2, 3, 4, 5)), (9, (0, 3, 5) + kg), (6, (0, 3, 5) + kg)):
             ops.set_gemm_split(products, 0)
             outs = []

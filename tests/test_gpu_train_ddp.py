@@ -52,7 +52,7 @@ def _rank(rank, world, port, out_path, blocks):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("blocks,tight_tol,loose_tol", [((2, 2, 2, 1), 1e-4, 5e-4), ((2, 2, 2, 2), 5e-3, 2e-2)])
+@pytest.mark.parametrize("blocks,tight_tol,loose_tol", [((2, 2, 2, 1), 2e-5, 1e-4), ((2, 2, 2, 2), 5e-3, 2e-2)])
 def test_syncbn_ddp_two_ranks_equal_one_process(tmp_path, blocks, tight_tol, loose_tol):
     from test_gpu_train import _zero_grad_name
     path = str(tmp_path / "rank0.pt")
@@ -70,16 +70,37 @@ def test_syncbn_ddp_two_ranks_equal_one_process(tmp_path, blocks, tight_tol, loo
     # order (here: per-rank partial statistics) can flip a ReLU whose pre-activation is within rounding of 0.  With the
     # reference's block layout (2,2,2,2) and this input exactly one element of the last level (64 rows) flips: the few
     # gradients it feeds move by ~1e-2 and everything upstream by ~1e-3, so that case gets a loose bound; the (2,2,2,1) layout
-    # has no flip: median 1e-4, the worst tensors (3-channel BatchNorm weights of the position MLPs) 5e-4 (3.2e-4 measured since the library
-    # is built without packed-f32 instructions, round 3) - the synchronised statistics and gradient averaging themselves are exact.
+    # has no flip: measured in round 5 median 6.0e-6, worst tensor 2.0e-5 - the bound is back at 1e-4 for the worst tensor (round 3 had loosened it to
+    # 5e-4) and 2e-5 for the median; the synchronised statistics and gradient averaging themselves are exact.  The (2,2,2,2)
+    # bounds stay where they were and are now justified by the measurement below: the SAME batch in reverse sample order on ONE process moves the
+    # same tensors by 3.5e-3 (worst) - the flip belongs to the network and this input, not to the two ranks (2 ranks vs 1 process: 1.4e-3 worst).
     errs = []
     for n, p in enc.named_parameters():
         if _zero_grad_name(n):
             continue
         ref = p.grad.cpu().double()
         errs.append(((got["grads"][n].double() - ref).norm().item() / max(ref.norm().item(), 1e-9), n))
+    # What "the same mathematics in another summation order" costs ON ONE PROCESS (justify the bound per tensor): the same
+    # batch with its samples in reverse order - BatchNorm statistics, weight gradients and every reduction over the concatenated rows then add
+    # the same numbers in another order, exactly what two ranks' partial sums do.  A tensor may differ between 2 ranks and 1 process by a small
+    # multiple of what it differs between these two single-process runs (or 1e-4, whichever is larger).
+    enc2 = _make(dev, blocks)
+    out2 = enc2(xyz.flip(0).contiguous().to(dev), con.flip(0).contiguous().to(dev))
+    ((out2 * dy.flip(0).contiguous().to(dev)).sum() / 4).backward()
+    enc3 = _make(dev, blocks)
+    out3 = enc3(xyz.to(dev), con.to(dev))
+    ((out3 * dy.to(dev)).sum() / 4).backward()
+    noise = {}
+    for (n, p2), (_, p3) in zip(enc2.named_parameters(), enc3.named_parameters()):
+        ref = p3.grad.cpu().double()
+        noise[n] = (p2.grad.cpu().double() - ref).norm().item() / max(ref.norm().item(), 1e-9)
     errs.sort(reverse=True)
     median = errs[len(errs) // 2][0]
+    worst_noise = sorted(((v, n) for n, v in noise.items() if not _zero_grad_name(n)), reverse=True)[:2]
+    print(f"[parity] blocks={blocks}: summation-order noise of ONE process (samples reversed): largest {[(round(v, 6), n) for v, n in worst_noise]}")
+    if tight_tol <= 1e-4:            # the layout without a ReLU flip: every tensor within 1e-4 or 4 x its own single-process order noise
+        over = [(e, noise[n], n) for e, n in errs if e > max(1e-4, 4.0 * noise[n])]
+        assert not over, over[:5]
     print(f"[parity] blocks={blocks}: DDP-averaged gradients vs single-process full batch over {len(errs)} tensors: rel-L2 median {median:.2e}, "
           f"largest {[(round(e, 6), n) for e, n in errs[:2]]}")
     assert median <= tight_tol and errs[0][0] <= loose_tol, errs[:5]

@@ -11,18 +11,7 @@
 #   cdm_check                CDM parity tests + tools/cdm_ab.py + rocprofv3 --stats of the CDM loop (H3D and HUMANISE variants)
 #   points                   configs[3] kernels: timings + PMC passes (FETCH / WRITE / SQ) -> points_summary.md
 #   pk_repro                 the packed-f32 reproducer with its controls
-#   validate <rNN>           end-of-round validation: full -m gpu suite, smoke, both bench commands, rocprofv3 stats + PMC passes (CMDM, CDM, cdm_check)
-  # CDM parity tests + A/B of the sampling forms + per-kernel durations of the default form (both variants)
-  ( timeout 900 python -m pytest tests/test_gpu_cdm.py -q -x --timeout=600 -s 2>&1 | grep -v "^$" | tail -40 ) > $O/pytest.log 2>&1
-  ( timeout 600 python tools/cdm_ab.py 100 ) > $O/cdm_ab.jsonl 2> $O/cdm_ab.err
-  grep "passed\|failed\|default\|Error" $O/pytest.log | tail -12 | cut -c1-200; cut -c1-220 $O/cdm_ab.jsonl; tail -2 $O/cdm_ab.err
-  for v in cdm cdm_h; do
-    ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$v -- python $GRAFT_REPO_ROOT/tools/pmc_target.py $v > /dev/null 2>&1 )
-    find $O/stats_$v -name "*kernel_trace.csv" -delete
-    f=$(find $O/stats_$v -name "*kernel_stats.csv" | head -1); echo "---- $v"; head -12 "$f" | cut -d, -f1-4 | cut -c1-160
-  done
-  ;;
-points), training benches
+#   validate <rNN>           end-of-round validation: full -m gpu suite, smoke, both bench commands, rocprofv3 stats + PMC passes (CMDM, CDM, points), training benches
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 RECIPE=${1:-validate}; shift
@@ -103,6 +92,17 @@ small_batch)
   for b in 4 1 32; do
     ( timeout 300 python bench.py --batch $b --steps 200 --warmup 20 $BENCH_LEAN ) > $O/bench_b$b.json 2>&1
     bench_line "B=$b:" $O/bench_b$b.json
+  done
+  ;;
+cdm_check)
+  # CDM parity tests + A/B of the sampling forms + per-kernel durations of the default form (both variants)
+  ( timeout 900 python -m pytest tests/test_gpu_cdm.py -q -x --timeout=600 -s 2>&1 | grep -v "^$" | tail -40 ) > $O/pytest.log 2>&1
+  ( timeout 600 python tools/cdm_ab.py 100 ) > $O/cdm_ab.jsonl 2> $O/cdm_ab.err
+  grep "passed\|failed\|default\|Error" $O/pytest.log | tail -12 | cut -c1-200; cut -c1-220 $O/cdm_ab.jsonl; tail -2 $O/cdm_ab.err
+  for v in cdm cdm_h; do
+    ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$v -- python $GRAFT_REPO_ROOT/tools/pmc_target.py $v > /dev/null 2>&1 )
+    find $O/stats_$v -name "*kernel_trace.csv" -delete
+    f=$(find $O/stats_$v -name "*kernel_stats.csv" | head -1); echo "---- $v"; head -12 "$f" | cut -d, -f1-4 | cut -c1-160
   done
   ;;
 points)

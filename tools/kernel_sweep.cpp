@@ -44,7 +44,7 @@ static void gemm_sweep(const std::vector<int>& batches) {
     const int T = 326, L = 196;
     const GemmCfg cfgs[] = {{AFM_ARITH_F32, 0, 0, "f32 auto"},   {AFM_ARITH_F32, 0, 1, "f32 32x32"},   {AFM_ARITH_F32, 0, 2, "f32 32x64"},
                             {AFM_ARITH_F32, 0, 3, "f32 64x64"},  {AFM_ARITH_F32, 0, 4, "f32 64x128"},  {AFM_ARITH_F32, 0, 5, "f32 128x128"},
-                            {AFM_ARITH_BF16X9, 0, 0, "x9 auto"}, {AFM_ARITH_BF16X9, 0, 3, "x9 64x64"}, {AFM_ARITH_BF16X9, 0, 7, "x9 64x64 split-K"}, {AFM_ARITH_BF16X9, 0, 10, "x9 split-K 3-stage"}, {AFM_ARITH_BF16X9, 0, 11, "x9 split-K 2x2seg"}, {AFM_ARITH_BF16X9, 0, 9, "x9 64x64 3-stage"}, {AFM_ARITH_BF16X9, 0, 5, "x9 128x128"},
+                            {AFM_ARITH_BF16X9, 0, 0, "x9 auto"}, {AFM_ARITH_BF16X9, 0, 3, "x9 64x64"}, {AFM_ARITH_BF16X9, 0, 7, "x9 64x64 split-K"}, {AFM_ARITH_BF16X9, 0, 10, "x9 split-K 3-stage"}, {AFM_ARITH_BF16X9, 0, 11, "x9 split-K 2x2seg"}, {AFM_ARITH_BF16X9, 0, 9, "x9 64x64 3-stage"}, {AFM_ARITH_BF16X9, 0, 12, "x9 64x64 walked"}, {AFM_ARITH_BF16X9, 0, 5, "x9 128x128"},
                             {AFM_ARITH_BF16X6, 0, 0, "x6 auto"}};
     std::mt19937 rng(7);
     std::normal_distribution<float> nd(0.f, 1.f);

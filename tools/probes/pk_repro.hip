@@ -475,6 +475,114 @@ static int mode_opsel3(int reps) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ mode opsel4 (round 5: the two missing controls)
+// (a) PADDING: the triggering co-runner (bf16 MFMA on a VGPR accumulator + v_accvgpr_write / read) with idle wait states around its moves - if the
+//     failure were a missing hazard wait of the co-runner's own instruction stream, padding would remove it.
+//       0 as in opsel3   1 s_nop 7 x 2 in front of the write and behind the read   2 three s_nop 15 between the MFMA and the moves (the MFMA has retired)
+// (b) PLACEMENT: victim and co-runner on CU-masked streams (hipExtStreamCreateWithCUMask); every workgroup records (XCC id, HW_ID CU bits) so the
+//     placement that was actually obtained is printed next to the counts.  same CUs / same XCD but disjoint CUs / different XCDs.
+template <int PAD>
+__global__ __launch_bounds__(256) void pad_corunner(float* sink, int iters, unsigned char* seen) {
+    if (seen && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        seen[(xcc & 7) * 256 + ((hw >> 8) & 0xFF)] = 1;
+    }
+    float y = 0.5f + 0.001f * threadIdx.x;
+    f16v acc = {};
+    bf8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (i + 1)); }
+    for (int it = 0; it < iters; ++it) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        if (PAD == 0) asm volatile("v_accvgpr_write_b32 a0, %0\n\ts_nop 1\n\tv_accvgpr_read_b32 %0, a0" : "+v"(y) :: "a0");
+        else if (PAD == 1) asm volatile("s_nop 7\n\ts_nop 7\n\tv_accvgpr_write_b32 a0, %0\n\ts_nop 1\n\tv_accvgpr_read_b32 %0, a0\n\ts_nop 7\n\ts_nop 7" : "+v"(y) :: "a0");
+        else asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_accvgpr_write_b32 a0, %0\n\ts_nop 1\n\tv_accvgpr_read_b32 %0, a0\n\ts_nop 15" : "+v"(y) :: "a0");
+        y = y * 0.999f + 0.001f;
+    }
+    if (y == 12345.678f) sink[threadIdx.x] = y + acc[0];
+}
+__global__ __launch_bounds__(256) void placed_victim(unsigned* __restrict__ bad_by_lane, unsigned* __restrict__ bad_lo_hi, int iters, unsigned char* seen) {
+    if (seen && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        seen[(xcc & 7) * 256 + ((hw >> 8) & 0xFF)] = 1;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned bad = 0, bad_lo = 0, bad_hi = 0;
+    f2 a = {1.0f + 0.001f * threadIdx.x, 2.0f + 0.003f * threadIdx.x};
+    const f2 p = {3.0f + 0.01f * lane, 0.5f + 0.001f * lane};
+    for (int it = 0; it < iters; ++it) {
+        f2 d;
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(p));
+        const float e0 = __fmul_rn(a.x, p.y), e1 = __fmul_rn(a.y, p.y);
+        if (__float_as_uint(d.x) != __float_as_uint(e0)) { ++bad; ++bad_lo; }
+        if (__float_as_uint(d.y) != __float_as_uint(e1)) { ++bad; ++bad_hi; }
+        a.x = a.x * 1.000001f + 1e-3f; a.y = a.y * 0.999999f + 2e-3f;
+        if (a.x > 1e6f) a.x = 1.0f;
+    }
+    if (bad) { atomicAdd(&bad_by_lane[lane], bad); atomicAdd(&bad_lo_hi[0], bad_lo); atomicAdd(&bad_lo_hi[1], bad_hi); }
+}
+
+static int mode_opsel4(int reps) {
+    unsigned *bad_lane, *bad_lh; CK(hipMalloc(&bad_lane, 64 * 4)); CK(hipMalloc(&bad_lh, 16));
+    unsigned char *seen_v, *seen_c; CK(hipMalloc(&seen_v, 2048)); CK(hipMalloc(&seen_c, 2048));
+    float* sink = dev_empty(4096);
+    auto counts = [&](unsigned long q[4], unsigned lh[4]) {
+        unsigned h[64]; CK(hipMemcpy(h, bad_lane, 256, hipMemcpyDeviceToHost)); CK(hipMemcpy(lh, bad_lh, 16, hipMemcpyDeviceToHost));
+        q[0] = q[1] = q[2] = q[3] = 0;
+        for (int l = 0; l < 64; ++l) q[l >> 4] += h[l];
+        CK(hipMemset(bad_lane, 0, 64 * 4)); CK(hipMemset(bad_lh, 0, 16));
+    };
+    CK(hipMemset(bad_lane, 0, 64 * 4)); CK(hipMemset(bad_lh, 0, 16));
+    {   // (a) padding around the co-runner's moves, both kernels unmasked
+        hipStream_t st[2]; CK(hipStreamCreate(&st[0])); CK(hipStreamCreate(&st[1]));
+        const char* pn[3] = {"MFMA + accvgpr moves (as opsel3)", "... with s_nop 7 x 2 around the moves", "... with 3 x s_nop 15 between the MFMA and the moves"};
+        for (int k = 0; k < 3; ++k) {
+            for (int rep = 0; rep < reps; ++rep) {
+                for (int q = 0; q < 4; ++q) {
+                    if (k == 0) hipLaunchKernelGGL(pad_corunner<0>, dim3(512), dim3(256), 0, st[1], sink, 60000, (unsigned char*)nullptr);
+                    else if (k == 1) hipLaunchKernelGGL(pad_corunner<1>, dim3(512), dim3(256), 0, st[1], sink, 45000, (unsigned char*)nullptr);
+                    else hipLaunchKernelGGL(pad_corunner<2>, dim3(512), dim3(256), 0, st[1], sink, 30000, (unsigned char*)nullptr);
+                }
+                hipLaunchKernelGGL(placed_victim, dim3(512), dim3(256), 0, st[0], bad_lane, bad_lh, 400000, (unsigned char*)nullptr);
+                CK(hipDeviceSynchronize());
+            }
+            unsigned long q[4]; unsigned lh[4]; counts(q, lh);
+            printf("opsel4 padding   | co-runner %-58s: wrong results in lanes 0-15 / 16-31 / 32-47 / 48-63 = %lu / %lu / %lu / %lu (low result %u, high result %u)\n", pn[k], q[0], q[1], q[2], q[3], lh[0], lh[1]);
+        }
+    }
+    // (b) placement by CONTIGUOUS ranges of CU-mask bits (sparse masks were not honoured by the runtime in the first attempt of this round: a mask of
+    // every eighth bit ran on 192 CUs).  On this part the mask bits are shader-engine interleaved - bits 0..31 are 4 CUs in EACH of the 8 XCCs
+    // (recorded XCC mask 0xff) - so disjoint bit ranges are disjoint CU sets on the SAME XCDs: the control isolates "same CU", not "same XCD".
+    struct Case { const char* name; int v0, v1, c0, c1; } cases[6] = {
+        {"victim bits [0,256), co-runner bits [0,256): everything shared", 0, 256, 0, 256}, {"victim bits [0,128), co-runner bits [0,128): shared half", 0, 128, 0, 128},
+        {"victim bits [0,32), co-runner bits [0,32): shared eighth", 0, 32, 0, 32},          {"victim bits [0,128), co-runner bits [128,256): DISJOINT CUs", 0, 128, 128, 256},
+        {"victim bits [128,256), co-runner bits [0,128): DISJOINT CUs", 128, 256, 0, 128},   {"victim bits [0,32), co-runner bits [32,256): DISJOINT CUs", 0, 32, 32, 256}};
+    for (const Case& c : cases) {
+        uint32_t mv[8] = {0}, mc[8] = {0};
+        for (int b = c.v0; b < c.v1; ++b) mv[b >> 5] |= 1u << (b & 31);
+        for (int b = c.c0; b < c.c1; ++b) mc[b >> 5] |= 1u << (b & 31);
+        hipStream_t sv, sc;
+        if (hipExtStreamCreateWithCUMask(&sv, 8, mv) != hipSuccess || hipExtStreamCreateWithCUMask(&sc, 8, mc) != hipSuccess) { printf("opsel4 placement: hipExtStreamCreateWithCUMask failed\n"); return 1; }
+        CK(hipMemset(seen_v, 0, 2048)); CK(hipMemset(seen_c, 0, 2048));
+        for (int rep = 0; rep < reps; ++rep) {
+            for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(pad_corunner<0>, dim3(2 * (c.c1 - c.c0)), dim3(256), 0, sc, sink, 60000, seen_c);
+            hipLaunchKernelGGL(placed_victim, dim3(2 * (c.v1 - c.v0)), dim3(256), 0, sv, bad_lane, bad_lh, 400000, seen_v);
+            CK(hipDeviceSynchronize());
+        }
+        unsigned char hv[2048], hc[2048]; CK(hipMemcpy(hv, seen_v, 2048, hipMemcpyDeviceToHost)); CK(hipMemcpy(hc, seen_c, 2048, hipMemcpyDeviceToHost));
+        int nv = 0, nc = 0, both = 0; unsigned xv = 0, xc = 0;
+        for (int i = 0; i < 2048; ++i) { nv += hv[i]; nc += hc[i]; both += hv[i] && hc[i]; if (hv[i]) xv |= 1u << (i >> 8); if (hc[i]) xc |= 1u << (i >> 8); }
+        unsigned long q[4]; unsigned lh[4]; counts(q, lh);
+        printf("opsel4 placement | %-66s: victim ran on %3d CUs (XCC mask 0x%02x), co-runner on %3d CUs (XCC mask 0x%02x), %3d CUs shared, %.1e results checked: wrong in lanes 0-15 / 16-31 / 32-47 / 48-63 = %lu / %lu / %lu / %lu (low %u, high %u)\n",
+               c.name, nv, xv, nc, xc, both, 2.0 * reps * 2 * (c.v1 - c.v0) * 256 * 400000.0, q[0], q[1], q[2], q[3], lh[0], lh[1]);
+        CK(hipStreamDestroy(sv)); CK(hipStreamDestroy(sc));
+    }
+    return 0;
+}
+
 static int mode_opsel2(int reps) {
     hipStream_t st[2]; CK(hipStreamCreate(&st[0])); CK(hipStreamCreate(&st[1]));
     unsigned *bad_lane, *bad_lh; CK(hipMalloc(&bad_lane, 64 * 4)); CK(hipMalloc(&bad_lh, 8));
@@ -549,6 +657,7 @@ static int mode_opsel(int iters, const char* libpath) {
 int main(int argc, char** argv) {
     if (argc > 2 && !strcmp(argv[1], "lib")) return mode_lib(argv[2], argc > 3 ? atoi(argv[3]) : 20, argc > 4 ? argv[4] : "chain");
     if (argc > 1 && !strcmp(argv[1], "mini")) return mode_mini(argc > 2 ? atoi(argv[2]) : 20);
+    if (argc > 1 && !strcmp(argv[1], "opsel4")) return mode_opsel4(argc > 2 ? atoi(argv[2]) : 3);
     if (argc > 1 && !strcmp(argv[1], "opsel3")) return mode_opsel3(argc > 2 ? atoi(argv[2]) : 3);
     if (argc > 1 && !strcmp(argv[1], "opsel2")) return mode_opsel2(argc > 2 ? atoi(argv[2]) : 3);
     if (argc > 1 && !strcmp(argv[1], "opsel")) return mode_opsel(argc > 2 ? atoi(argv[2]) : 3, argc > 3 ? argv[3] : nullptr);
