@@ -67,15 +67,19 @@ def pmc_traffic(kernel: str):
         return None
     want = kernel.replace(" ", "").replace(",split-K", "").rstrip(">")
     split_k = "split-K" in kernel
-    # rocprof names carry every template argument: match on the prefix; the bf16-split kernel's last argument is the number of K groups per
-    # workgroup (1 = the large-launch form, > 1 = the split-K small-launch form) - keep the two apart, then take the most launched
+    # rocprof names carry every template argument: match on the prefix; the bf16-split kernel's template arguments are <BM, BN, BK, products,
+    # K groups, LDS stages, segments per group> (round 5) - K groups == 1 is the large-launch form, > 1 the split-K small-launch forms: keep the
+    # two apart, then take the most launched
     cands = []
     for name, v in tr.get("kernels", {}).items():
         n = name.replace(" ", "")
         if not n.startswith(want):
             continue
-        if "split_bf16" in n and (n.endswith(",1>") == split_k):
-            continue
+        if "split_bf16<" in n:
+            targs = n[n.index("<") + 1:].rstrip(">").split(",")
+            kg = int(targs[4]) if len(targs) > 4 and targs[4].isdigit() else 1
+            if (kg > 1) != split_k:
+                continue
         cands.append((v.get("launches", 0), name, v))
     if not cands:
         return None
