@@ -2,7 +2,7 @@
 # Round profile artifacts (run on the GPU box through gpurun): kernel-trace stats of the bench command and
 # separate PMC passes (HBM read / write bytes, MFMA busy) as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
 #   tools/collect_profiles.sh r2          CMDM headline path (bench.py) -> gpurun_out/prof_r2
-#   tools/collect_profiles.sh r2 cdm      CDM Perceiver loop (BASELINE configs[2]) -> gpurun_out/prof_r2_cdm
+#   tools/collect_profiles.sh r2 cdm      CDM Perceiver loop (BASELINE configs[2]) -> gpurun_out/prof_r2_cdm     (cdm_h: its HUMANISE variant)
 #   tools/collect_profiles.sh r2 points   set abstraction (BASELINE configs[3]: FPS, kNN, fused gather-MLP-max) -> gpurun_out/prof_r2_points
 set -u
 R=${1:-r1}
@@ -10,11 +10,12 @@ WHICH=${2:-cmdm}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$R
 [ "$WHICH" = "cdm" ] && OUT=${OUT}_cdm
+[ "$WHICH" = "cdm_h" ] && OUT=${OUT}_cdm_h
 [ "$WHICH" = "points" ] && OUT=${OUT}_points
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PMC="python $ROOT/tools/pmc_target.py $WHICH"
-if [ "$WHICH" = "cdm" ] || [ "$WHICH" = "points" ]; then
+if [ "$WHICH" = "cdm" ] || [ "$WHICH" = "cdm_h" ] || [ "$WHICH" = "points" ]; then
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PMC > /dev/null 2>&1
 else
   BENCH="python $ROOT/bench.py --streams 1 --steps 100 --warmup 10 --latency-runs 0 --latency-runs-b1 0 --no-cpu-baseline --no-alt-gemm --no-secondary"
