@@ -19,7 +19,8 @@
 //   the MFMA stream -> three bf16 planes in LDS ([row][BK] bf16, rows padded to 48 B: the 16 rows of each ds_read_b128 lane group
 //   {0-3,12-15,20-27} / {4-11,16-19,28-31} hit 16 distinct 16-byte slots; the 8-byte stores of a 16-lane group cover four rows of
 //   equal parity, also conflict-free) -> MFMA operands are one ds_read_b128 per (tile, plane, K16 step).
-//   One barrier per K-tile (double-buffered LDS), shared epilogue of gemm.hip.
+//   One barrier per K-tile (double-buffered LDS; the small-launch forms of round 5 run on three stages, RING = 3 below), shared epilogue of gemm.hip.
+//   The tile program itself is csrc/gemm_split_body.inc, included as text by the kernels that run it.
 #include <type_traits>
 #include "common.h"
 #include "profile.h"
