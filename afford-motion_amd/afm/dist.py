@@ -35,6 +35,37 @@ def init_process_group(backend: str = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def needs_self_launch(n_gpus: int, env=None) -> bool:
+    """True when a script asked for `n_gpus` > 1 ranks but was started as a plain process (no torch.distributed.run environment):
+    `python bench.py --gpus N` then launches its own ranks (self_launch) instead of failing on WORLD_SIZE."""
+    env = os.environ if env is None else env
+    return n_gpus > 1 and not (env.get("WORLD_SIZE") and env.get("RANK") is not None)
+
+
+def self_launch_command(script: str, argv: list, n_gpus: int, port: int = None, python: str = None) -> list:
+    """The command line a plain `python <script> --gpus N ...` re-executes itself as: the reference's own launch convention
+    (scripts/t2m_contact_motion/train_ddp.sh:9: one process per GPU of ONE node under torch.distributed.run, rendezvous on the loopback
+    address with a free port), with the script's arguments passed through unchanged."""
+    import socket
+    import sys
+    if port is None:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), script] + list(argv)
+
+
+def self_launch(script: str, argv: list, n_gpus: int) -> int:
+    """Run `script` as `n_gpus` ranks (see self_launch_command) and return the launcher's exit code; the ranks inherit stdout / stderr, so
+    rank 0's single JSON line is this process's output.  AFM_SELF_LAUNCHED marks the children (a child never launches again)."""
+    import subprocess
+    env = dict(os.environ, AFM_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")             # torch.distributed.run would set 1 (and warn): the CPU side of a rank is enqueue only
+    return subprocess.call(self_launch_command(script, argv, n_gpus), env=env)
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous shard [start, start+count) of `total` samples; the first total % world ranks get one extra."""
     base, extra = divmod(total, world)
@@ -90,12 +121,16 @@ def ranks_seen(device: torch.device = None, world: int = None) -> list:
     shared-GPU functional tests) it exercises the same bookkeeping.  One all_gather_object of a small dict per rank."""
     rank, env_world, local = env_rank_world()
     world = (dist.get_world_size() if dist.is_initialized() else env_world) if world is None else world
+    import socket
     me = {"rank": rank, "local_rank": local, "backend": dist.get_backend() if dist.is_initialized() else None, "device": None,
-          "device_name": None, "pci_bus_id": None, "pid": os.getpid()}
+          "device_name": None, "pci_bus_id": None, "pid": os.getpid(), "host": socket.gethostname()}
     if device is not None and device.type == "cuda":
         idx = device.index if device.index is not None else torch.cuda.current_device()
         props = torch.cuda.get_device_properties(idx)
-        me.update(device=idx, device_name=torch.cuda.get_device_name(idx), pci_bus_id=getattr(props, "pci_bus_id", None))
+        bus = getattr(props, "pci_bus_id", None)
+        if bus is not None:                           # domain:bus:device - the bus number alone is not unique across PCI domains
+            bus = f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(props, 'pci_device_id', 0):02x}"
+        me.update(device=idx, device_name=torch.cuda.get_device_name(idx), pci_bus_id=bus)
         me["visible_devices"] = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
     if world == 1 or not dist.is_initialized():
         return [me]
@@ -104,9 +139,20 @@ def ranks_seen(device: torch.device = None, world: int = None) -> list:
     return sorted(out, key=lambda r: r["rank"])
 
 
+def device_identity(r: dict):
+    """Physical identity of a rank's device: (host, PCI bus id) when the bus id is known - two ranks with different but overlapping
+    visibility masks that land on the same GPU collapse to one, ranks on different hosts with equal masks stay apart -, else the
+    (host, visible-device mask, device index) triple; CPU ranks (device None) count once each."""
+    if r.get("device") is None:
+        return ("cpu", r.get("host"), r["rank"])
+    if r.get("pci_bus_id") is not None:
+        return ("pci", r.get("host"), r["pci_bus_id"])
+    return ("idx", r.get("host"), r.get("visible_devices"), r["device"])
+
+
 def distinct_devices(seen: list) -> int:
-    """Number of distinct (visible-device mask, device index) pairs among the ranks of `ranks_seen` (None entries - CPU ranks - count once each)."""
-    return len({(r.get("visible_devices"), r["device"]) if r["device"] is not None else ("cpu", r["rank"]) for r in seen})
+    """Number of physically distinct devices among the ranks of `ranks_seen` (see device_identity)."""
+    return len({device_identity(r) for r in seen})
 
 
 def time_all_gather(local: torch.Tensor, world: int = None, reps: int = 20) -> dict:

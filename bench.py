@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the north-star hot path: denoising steps/sec of the CMDM (AMDM) `p_sample_loop`.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher environment: re-executes itself under the line below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -180,7 +180,13 @@ def main():
     ap.add_argument("--attn-group", type=int, default=None, help="waves per attention workgroup (bit-neutral tuning; default: library choice)")
     args = ap.parse_args()
 
-    from afm import dist as adist, ffi, synth
+    from afm import dist as adist
+    if adist.needs_self_launch(args.gpus) and not os.environ.get("AFM_SELF_LAUNCHED"):
+        # plain `python bench.py --gpus N` (no torch.distributed.run environment): launch the N ranks ourselves, exactly as the documented
+        # torchrun form does (one process per GPU, loopback rendezvous on a free port - the reference's convention,
+        # scripts/t2m_contact_motion/train_ddp.sh:9); rank 0's JSON line is this process's output, its exit code ours
+        sys.exit(adist.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    from afm import ffi, synth
     rank, world, local = adist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.scaling == "auto":

@@ -105,8 +105,52 @@ def test_ranks_seen_and_gather_timing_bookkeeping_two_ranks():
     shared = [dict(rank=0, device=0, visible_devices=None), dict(rank=1, device=0, visible_devices=None)]
     assert adist.distinct_devices(shared) == 1
     assert adist.distinct_devices([dict(rank=0, device=0, visible_devices="0"), dict(rank=1, device=0, visible_devices="1")]) == 2
+    # the physical identity wins over the visibility mask: overlapping masks that land on the same bus id are ONE device,
+    # the same mask and index on two hosts are two
+    same_gpu = [dict(rank=0, device=0, visible_devices="0,1", pci_bus_id="0000:05:00", host="a"), dict(rank=1, device=0, visible_devices="0", pci_bus_id="0000:05:00", host="a")]
+    assert adist.distinct_devices(same_gpu) == 1
+    two_hosts = [dict(rank=0, device=0, visible_devices="0", pci_bus_id="0000:05:00", host="a"), dict(rank=1, device=0, visible_devices="0", pci_bus_id="0000:05:00", host="b")]
+    assert adist.distinct_devices(two_hosts) == 2
     # single process: no process group needed
     assert adist.ranks_seen(torch.device("cpu"), 1)[0]["rank"] == 0
+
+
+def test_plain_bench_command_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher environment: the decision and the command line are host logic -
+    N > 1 and no RANK / WORLD_SIZE -> re-execute under torch.distributed.run with a loopback rendezvous on a free port, arguments passed
+    through; under a launcher (or N = 1) nothing is launched.  The launch itself is run end to end with a stand-in script whose ranks
+    rendezvous over gloo and print one line from rank 0."""
+    import subprocess
+    import sys
+    assert adist.needs_self_launch(2, env={}) and adist.needs_self_launch(8, env={"MASTER_ADDR": "127.0.0.1"})
+    assert not adist.needs_self_launch(1, env={}) and not adist.needs_self_launch(2, env={"WORLD_SIZE": "2", "RANK": "0"})
+    cmd = adist.self_launch_command("/x/bench.py", ["--gpus", "2", "--steps", "5"], 2, port=12345, python="py")
+    assert cmd == ["py", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "12345",
+                   "/x/bench.py", "--gpus", "2", "--steps", "5"]
+    assert adist.self_launch_command("/x/bench.py", [], 4)[7] != "0"          # a free port was picked
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "standin.py"
+    script.write_text(
+        "import json, os, sys\n"
+        f"sys.path.insert(0, {os.path.join(root, 'afford-motion_amd')!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from afm import dist as adist\n"
+        "n = int(sys.argv[sys.argv.index('--gpus') + 1])\n"
+        "if adist.needs_self_launch(n) and not os.environ.get('AFM_SELF_LAUNCHED'):\n"
+        "    sys.exit(adist.self_launch(os.path.abspath(__file__), sys.argv[1:], n))\n"
+        "rank, world, local = adist.init_process_group('gloo')\n"
+        "seen = adist.ranks_seen(None, world)\n"
+        "t = torch.tensor([float(rank + 1)]); dist.all_reduce(t)\n"
+        "if rank == 0: print(json.dumps({'n_gpus': world, 'ranks': [e['rank'] for e in seen], 'sum': t.item(), 'argv': sys.argv[1:]}))\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AFM_SELF_LAUNCHED")}
+    r = subprocess.run([sys.executable, str(script), "--gpus", "2", "--tag", "x"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    import json
+    line = json.loads(lines[0])
+    assert line == {"n_gpus": 2, "ranks": [0, 1], "sum": 3.0, "argv": ["--gpus", "2", "--tag", "x"]}
 
 
 def test_shard_kwargs_slices_only_per_sample_entries():

@@ -2,7 +2,7 @@
 over the native CMDM and CDM loops, Philox noise keyed by the global sample index, one all_gather at the end - and the gathered result
 must be bit-identical to the single-process run of the same job.  On a 1-GPU box both ranks share cuda:0 (gloo; the device shards are
 gathered through host memory); with >= 2 GPUs the same test also runs one rank per GPU over RCCL ("nccl"), so the first multi-GPU box
-exercises RCCL in the test suite and not first in the bench.  `bench.py --gpus 2` is run end to end as the driver launches it."""
+exercises RCCL in the test suite and not first in the bench.  `bench.py --gpus 2` is run end to end both ways: under torch.distributed.run and as the plain command (which launches its own ranks)."""
 import json
 import os
 import socket
@@ -84,6 +84,26 @@ def test_bench_two_ranks_end_to_end():
     assert set(line["scaling_modes"]) == {"weak", "strong"}
 
 
+def test_plain_bench_command_with_two_gpus_launches_its_own_ranks():
+    """the PLAIN command `python bench.py --gpus 2 --steps 5 --warmup 2` - no torch.distributed.run in front, no RANK /
+    WORLD_SIZE in the environment - returns rc 0 with one JSON line, n_gpus 2 and two ranks seen (bench.py re-executes itself under
+    torch.distributed.run; on a 1-GPU box the two ranks share cuda:0 over gloo, with >= 2 GPUs they run one per GPU over RCCL)."""
+    share = torch.cuda.device_count() < 2
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AFM_SELF_LAUNCHED")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if share:
+        env.update(AFM_BENCH_SHARE_GPU="1", AFM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"], capture_output=True, text=True,
+                       env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["value"] > 0
+    assert [e["rank"] for e in line["ranks_seen"]] == [0, 1] and len(line["ranks_seen"]) == 2
+    assert line["distinct_devices"] == (1 if share else 2) and line["batch_per_gpu_by_rank"] == [16, 16]
+
+
 def test_bench_two_ranks_over_rccl_one_rank_per_gpu():
     """The first multi-GPU lease, made boring: `bench.py --gpus 2` with NO backend override and NO device sharing, i.e.
     exactly the driver's command - the line must prove that RCCL saw two ranks on two DISTINCT devices (`ranks_seen` comes from an
@@ -97,5 +117,5 @@ def test_bench_two_ranks_over_rccl_one_rank_per_gpu():
     seen = line["ranks_seen"]
     assert line["n_gpus"] == 2 and line["distinct_devices"] == 2 and not line["shared_gpu_test_mode"]
     assert [e["rank"] for e in seen] == [0, 1] and all(e["backend"] == "nccl" for e in seen)
-    assert len({(e["visible_devices"], e["device"]) for e in seen}) == 2 and line["batch_per_gpu_by_rank"] == [16, 16]
+    assert len({(e["host"], e["pci_bus_id"]) for e in seen}) == 2 and line["batch_per_gpu_by_rank"] == [16, 16]
     assert line["final_all_gather"]["backend"] == "nccl" and line["final_all_gather"]["max_over_ranks_median_us"] > 0
