@@ -103,6 +103,9 @@ def test_syncbn_ddp_two_ranks_equal_one_process(tmp_path, blocks, tight_tol, loo
         assert not over, over[:5]
     print(f"[parity] blocks={blocks}: DDP-averaged gradients vs single-process full batch over {len(errs)} tensors: rel-L2 median {median:.2e}, "
           f"largest {[(round(e, 6), n) for e, n in errs[:2]]}")
-    assert median <= tight_tol and errs[0][0] <= loose_tol, errs[:5]
+    # the median bound is not one box's number either - at least `tight_tol`, or 4 x the median single-process order noise of the same
+    # tensors (gloo vs RCCL, one GPU vs two change the per-rank summation order, not its size)
+    noise_median = sorted(v for n, v in noise.items() if not _zero_grad_name(n))[len(errs) // 2]
+    assert median <= max(tight_tol, 4.0 * noise_median) and errs[0][0] <= loose_tol, (median, noise_median, errs[:5])
     assert (enc.enc1[0].bn.running_mean.cpu() - got["rm"]).abs().max().item() <= 1e-5
     assert (enc.enc1[0].bn.running_var.cpu() - got["rv"]).abs().max().item() <= 1e-4

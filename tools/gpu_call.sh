@@ -43,6 +43,7 @@ gemm_small)
 ab)
   TAG=${1:-ab}; shift
   cp $LIB $O/orig.so
+  trap 'cp $O/orig.so $LIB 2>/dev/null; rm -f $O/orig.so' EXIT          # a kill mid-recipe must not leave a variant build installed
   for rep in 1 2; do
     for so in tools/ab_libs/libafm_*.so; do
       v=$(basename $so .so); v=${v#libafm_}
@@ -53,7 +54,6 @@ ab)
       done
     done
   done | tee $O/$TAG.txt
-  cp $O/orig.so $LIB; rm $O/orig.so
   ;;
 flags)
   # A/B of bench.py FLAG sets with one library: tools/gpu_call.sh flags "<B list>" "<flags A>" "<flags B>" ... (alternating, two repetitions)
@@ -71,6 +71,7 @@ flags)
   ;;
 ab_cdm)
   cp $LIB $O/orig.so
+  trap 'cp $O/orig.so $LIB 2>/dev/null; rm -f $O/orig.so' EXIT
   for rep in 1 2; do
     for so in tools/ab_libs/libafm_*.so; do
       v=$(basename $so .so); v=${v#libafm_}
@@ -79,7 +80,20 @@ ab_cdm)
       echo "$v rep $rep: $(grep -o '"steps_per_s": [0-9.]*' $O/cdm_${v}_$rep.jsonl | tr '\n' ' ')"
     done
   done | tee $O/ab_cdm.txt
-  cp $O/orig.so $LIB; rm $O/orig.so
+  ;;
+arith)
+  # worst-case table of the GEMM arithmetics, then the WHOLE -m gpu suite with six products as the process default
+  # (AFM_GEMM_SPLIT=6 is read by afm/ops.py at import), then the headline under both settings in this one call
+  ( timeout 600 python -m pytest tests/test_gpu_arith.py -q -s --timeout=600 2>&1 | grep "\[arith\]\|passed\|failed\|Error\|assert" ) > $O/arith.log 2>&1
+  cat $O/arith.log | cut -c1-220
+  ( time AFM_GEMM_SPLIT=6 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 2>&1 | tail -40 ) > $O/pytest_x6.log 2>&1
+  tail -45 $O/pytest_x6.log | cut -c1-250
+  for rep in 1 2; do
+    for sp in 9 6; do
+      ( AFM_GEMM_SPLIT=$sp timeout 300 python bench.py --steps 200 --warmup 20 $BENCH_LEAN ) > $O/bench_x${sp}_$rep.json 2>&1
+      bench_line "x$sp rep $rep:" $O/bench_x${sp}_$rep.json
+    done
+  done
   ;;
 tests)
   ( time timeout 1500 python -m pytest ${@:-tests -m gpu} -q -x --timeout=900 2>&1 | tail -8 ) 2>&1 | tee $O/pytest.log
