@@ -52,7 +52,7 @@ def _gemm(A, W, out, M, N, K, *, lda=None, bias=None, residual=None, act=0, prea
         a.a_grp, a.a_stride, a.a_off = a_map
     if c_map:
         a.c_grp, a.c_stride, a.c_off = c_map
-    ops.fill_arith(a)
+    ops.fill_arith_train(a)             # the tape's arithmetic: all nine products unless the host says otherwise (afm.ops.set_train_gemm_split)
     ffi.check(ffi.load().afm_linear(C.byref(a), _st(out)), "afm_linear")
     return out
 

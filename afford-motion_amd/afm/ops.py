@@ -124,20 +124,37 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 # ---- arithmetic of the GEMMs: HOST state (this module), written into every afm_linear_args / weight pack that is built.
-# The library itself has no switch and reads no environment (ABI v3).  Initial value: AFM_GEMM_SPLIT / AFM_GEMM_SPLIT_MIN_N in the
-# environment of the Python process, else the library default (exact nine-product bf16 split on every eligible GEMM).
+# The library itself has no switch and reads no environment (ABI v3).  Two settings:
+#   sampling / inference operators (`linear`, `mha`, the CMDM / CDM weight packs): AFM_GEMM_SPLIT / AFM_GEMM_SPLIT_MIN_N in the environment of the
+#     Python process, else SIX products of the three-way bf16 operand split on every eligible GEMM and in the attention (round 6: the
+#     worst-case comparison of tests/test_gpu_arith.py - six products are never above nine and both sit in the error class of an f32 chain);
+#   training operators (afm.autograd: every forward and backward GEMM of the tape): AFM_GEMM_SPLIT_TRAIN, else all NINE products (exact f32
+#     products) - gradients through ~40 serial batch-statistics BatchNorms are ill-conditioned in float32 (the reference's own f32 backward sits
+#     2.8e-2 from its f64 backward on the CDM's PointTrans U-Net), so the tape keeps every bit the operands carry.
+DEFAULT_PRODUCTS, DEFAULT_TRAIN_PRODUCTS = 6, 9
+
+
 def _initial_split():
     import os
     p = os.environ.get("AFM_GEMM_SPLIT")
-    products = int(p) if p is not None else 9
+    products = int(p) if p is not None else DEFAULT_PRODUCTS
     if products not in (0, 1, 6, 9):
         products = 0
     n = os.environ.get("AFM_GEMM_SPLIT_MIN_N")
     return products, max(0, int(n)) if n is not None else 0
 
 
+def _initial_train_split():
+    import os
+    p = os.environ.get("AFM_GEMM_SPLIT_TRAIN")
+    products = int(p) if p is not None else DEFAULT_TRAIN_PRODUCTS
+    return products if products in (0, 6, 9) else 0
+
+
 _gemm_split = list(_initial_split())
+_train_split = [_initial_train_split()]
 _gemm_tune = 0
+_ARITH = {9: ffi.ARITH_BF16X9, 6: ffi.ARITH_BF16X6, 1: ffi.ARITH_BF16X1}
 
 
 def gemm_arith() -> Tuple[int, int]:
@@ -145,12 +162,30 @@ def gemm_arith() -> Tuple[int, int]:
     products, min_n = _gemm_split
     if products == 0:
         return ffi.ARITH_F32, 0
-    return {9: ffi.ARITH_BF16X9, 6: ffi.ARITH_BF16X6, 1: ffi.ARITH_BF16X1}[products], min_n
+    return _ARITH[products], min_n
+
+
+def set_train_gemm_split(products: int) -> int:
+    """Arithmetic of the TRAINING operators' GEMMs (afm.autograd): 9 (default, exact f32 products), 6 or 0 (native f32 MFMA).  Returns the previous value."""
+    if int(products) not in (0, 6, 9):
+        raise ffi.AfmError(f"set_train_gemm_split: products must be 0, 6 or 9 (got {products})")
+    prev, _train_split[0] = _train_split[0], int(products)
+    return prev
+
+
+def get_train_gemm_split() -> int:
+    return _train_split[0]
+
+
+def fill_arith_train(a) -> None:
+    """afm_linear_args of a training operator: the tape's arithmetic (see the note above), never the sampling setting."""
+    a.arith, a.arith_min_n = (ffi.ARITH_F32, 0) if _train_split[0] == 0 else (_ARITH[_train_split[0]], 0)
+    a.tune = _gemm_tune
 
 
 def set_gemm_split(products: int, min_n: Optional[int] = None):
-    """Arithmetic of `linear`'s GEMMs: 9 = exact three-way bf16 operand split on the bf16 matrix pipe with all nine cross products
-    (default, every eligible GEMM: K >= 128, K % 16 == 0, aligned), 6 = the six largest products, 0 = native f32 MFMA everywhere.  ``min_n`` moves the N threshold.
+    """Arithmetic of `linear`'s GEMMs and of `mha`: the three-way bf16 operand split on the bf16 matrix pipe with the 6 largest cross products
+    (default, every eligible GEMM: K >= 128, K % 16 == 0, aligned) or all 9 (exact f32 products), 0 = native f32 MFMA everywhere.  ``min_n`` moves the N threshold.
     Returns the previous setting in the same form (products, or (products, min_n) when ``min_n`` was given)."""
     if int(products) not in (0, 1, 6, 9):
         raise ffi.AfmError(f"set_gemm_split: products must be 0, 6 or 9 (or 1: plain bf16, informational only) (got {products})")
@@ -194,14 +229,15 @@ def mha(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], heads: int, group_w
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
         assert km.shape == (B, T)
+    arith = gemm_arith()[0]                             # the attention follows the host's GEMM arithmetic (six products by default)
     if q_first:
         out = torch.zeros(B, T, d, device=qkv.device, dtype=torch.float32)
-        ffi.check(lib.afm_mha_fwd_rows(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, int(q_first), int(group_waves),
-                                       ffi.stream_of(qkv)), "afm_mha_fwd_rows")
+        ffi.check(lib.afm_mha_fwd_arith(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, int(q_first), int(group_waves), arith,
+                                        ffi.stream_of(qkv)), "afm_mha_fwd_arith")
         return out
     out = torch.empty(B, T, d, device=qkv.device, dtype=torch.float32)
-    ffi.check(lib.afm_mha_fwd_grouped(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, int(group_waves),
-                                      ffi.stream_of(qkv)), "afm_mha_fwd_grouped")
+    ffi.check(lib.afm_mha_fwd_arith(qkv.data_ptr(), ffi.ptr(km), out.data_ptr(), B, T, heads, d // heads, 0, int(group_waves), arith,
+                                    ffi.stream_of(qkv)), "afm_mha_fwd_arith")
     return out
 
 

@@ -265,7 +265,9 @@ constexpr int PARK_FLOATS = 32 * 64 + 64;
 
 // second launch bound = waves per SIMD the grid needs: the sequential forms as in round 3 (12 waves: one workgroup of three waves per SIMD =
 // 168 VGPRs; 4 / 8 waves: two; 6: three), SEG2: one workgroup per CU (its LDS) of 2 NW waves
-template <int NW, bool SEG2>
+// NPROD (round 6): 9 = all cross products of the three-term operands (exact f32 products), 6 = without the three smallest (a2 b3, a3 b2, a3 b3:
+// each <= 2^-24 |a||b|) - the arithmetic of afm_linear's AFM_ARITH_BF16X6, chosen by the same argument (afm_mha_fwd_arith).
+template <int NW, bool SEG2, int NPROD>
 __global__ __launch_bounds__(64 * NW * (SEG2 ? 2 : 1), SEG2 ? (NW >= 2 ? NW / 2 : 1) : (NW == 4 || NW == 8 ? 2 : (NW == 6 || NW == 12 ? 3 : 1)))
 void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_, const float* __restrict__ vp_, int ldkv,
                           const uint8_t* __restrict__ key_mask, float* __restrict__ out, int Tq, int T, int H, float scale, int nchunk, int q_first) {
@@ -446,7 +448,7 @@ void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* _
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) ak[pl] = *reinterpret_cast<const u32x4*>(kpl + pl * KPLANE + st_ * 32);
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) s = mfma_bf16(ak[AFM_PA[q]], qpl[st_][AFM_PB[q]], s);
+                    for (int q = 9 - NPROD; q < 9; ++q) s = mfma_bf16(ak[AFM_PA[q]], qpl[st_][AFM_PB[q]], s);
                 }
                 // ---- mask + online softmax; reg r <-> key kb*32 + (r&3) + 8*(r>>2) + 4*hh
                 TL(asm volatile("" : "+v"(s)); const unsigned long long tl_b = afm_cyc(); tl_s += tl_b - tl_a;)
@@ -491,7 +493,7 @@ void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* _
                         av1[pl] = *reinterpret_cast<const u32x4*>(vpl + pl * VPLANE + 32 * VROWB + t * 32);
                     }
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
+                    for (int q = 9 - NPROD; q < 9; ++q) {
                         o0 = mfma_bf16(av0[AFM_PA[q]], pp[AFM_PB[q]], o0);
                         o1 = mfma_bf16(av1[AFM_PA[q]], pp[AFM_PB[q]], o1);
                     }
@@ -562,12 +564,12 @@ void mha_fwd_split_kernel(const float* __restrict__ qp_, int ldq, const float* _
 // or 100 + {2, 4}: the two key segments of a query block on two waves (workgroups of 2 x that many waves); 0 = the library's choice;
 // < 0 = one workgroup per (sample, head) that walks all query blocks (long-query cross-attention, training).  Inference runs the
 // bf16-split kernel, training (lse output, attention dropout) the f32-MFMA kernel.
-template <int NW, bool SEG2>
+template <int NW, bool SEG2, int NPROD>
 int launch_split_mha(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, int B, int Tq, int T, int H,
                      float scale, int nchunk, size_t lds, hipStream_t s, int q_first) {
-    static const int attr = (int)hipFuncSetAttribute((const void*)mha_fwd_split_kernel<NW, SEG2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const int attr = (int)hipFuncSetAttribute((const void*)mha_fwd_split_kernel<NW, SEG2, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != 0) return attr;
-    hipLaunchKernelGGL((mha_fwd_split_kernel<NW, SEG2>), dim3(B * H * nchunk), dim3(NW * 64 * (SEG2 ? 2 : 1)), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale,
+    hipLaunchKernelGGL((mha_fwd_split_kernel<NW, SEG2, NPROD>), dim3(B * H * nchunk), dim3(NW * 64 * (SEG2 ? 2 : 1)), lds, s, q, ldq, k, v, ldkv, key_mask, out, Tq, T, H, scale,
                        nchunk, q_first);
     AFM_CHECK_LAUNCH();
     return 0;
@@ -581,8 +583,11 @@ inline size_t split_mha_lds(int nkb, int nw, bool seg2) {
 
 int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int ldkv, const uint8_t* key_mask, float* out, float* lse, int32_t B,
                    int32_t Tq, int32_t T, int32_t H, int32_t dh, float drop_p, uint64_t drop_seed, uint32_t drop_id, bool train, int group_waves,
-                   void* stream, int q_first = 0) {
+                   void* stream, int q_first = 0, int arith = AFM_ARITH_DEFAULT) {
     if (dh != DH) return AFM_E_UNSUPPORTED;
+    if (arith != AFM_ARITH_DEFAULT && arith != AFM_ARITH_F32 && arith != AFM_ARITH_BF16X6 && arith != AFM_ARITH_BF16X9 && arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
+    // six products for AFM_ARITH_DEFAULT / AFM_ARITH_BF16X6, all nine (exact f32 products) for every other setting - a function of `arith` only
+    const bool six = arith == AFM_ARITH_DEFAULT || arith == AFM_ARITH_BF16X6;
     if (B == 0) return 0;                                     // empty batch (pointers may be null)
     if (!q || !k || !v || !out || B < 0 || T <= 0 || Tq <= 0 || H <= 0) return AFM_E_BADARG;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return AFM_E_BADARG;
@@ -649,7 +654,8 @@ int mha_fwd_launch(const float* q, int ldq, const float* k, const float* v, int 
     const size_t lds = split_mha_lds(nkb, nw, seg2);
     if (lds > lds_cap) return AFM_E_UNSUPPORTED;
     AfmProf prof(AFM_PROF_MHA_SPLIT, 4.0 * B * H * (double)Tq * T * dh, s);
-#define AFM_MHA_GO(NWV, S2) return launch_split_mha<NWV, S2>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first)
+#define AFM_MHA_GO(NWV, S2) do { if (six) return launch_split_mha<NWV, S2, 6>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first); \
+                                 return launch_split_mha<NWV, S2, 9>(q, ldq, k, v, ldkv, key_mask, out, B, Tq, T, H, scale2, nchunk, lds, s, q_first); } while (0)
     if (seg2) {
         if (nw == 2) AFM_MHA_GO(2, true);
         AFM_MHA_GO(4, true);
@@ -681,6 +687,14 @@ extern "C" int afm_mha_fwd_rows(const float* qkv, const uint8_t* key_mask, float
     const int D = H * dh;
     return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, nullptr, B, T, T, H, dh, 0.0f, 0, 0, false,
                           group_waves, stream, q_first);
+}
+
+extern "C" int afm_mha_fwd_arith(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H, int32_t dh, int32_t q_first,
+                                 int32_t group_waves, int32_t arith, void* stream) {
+    if (group_waves < 0) return AFM_E_BADARG;
+    const int D = H * dh;
+    return mha_fwd_launch(qkv, 3 * D, qkv ? qkv + D : nullptr, qkv ? qkv + 2 * D : nullptr, 3 * D, key_mask, out, nullptr, B, T, T, H, dh, 0.0f, 0, 0, false,
+                          group_waves, stream, q_first, arith);
 }
 
 extern "C" int afm_mha_fwd(const float* qkv, const uint8_t* key_mask, float* out, int32_t B, int32_t T, int32_t H,

@@ -15,6 +15,7 @@
 extern "C" int afm_linear(const afm_linear_args*, void*);
 extern "C" int afm_mha_fwd_grouped(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_mha_fwd_rows(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
+extern "C" int afm_mha_fwd_arith(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_layernorm(const float*, const float*, const float*, float*, int64_t, int32_t, float, void*);
 extern "C" int afm_layernorm_rows(const float*, const float*, const float*, float*, int64_t, int32_t, float, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_randn(float*, int32_t, int64_t, uint64_t, int64_t, int32_t, void*);
@@ -194,9 +195,9 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         // scattered by the row maps; the other rows of att/tmp/x1/y keep stale values nobody reads).
         const bool last = (li == w.n_layers - 1);
         if (last && w.n_cond > 0 && !(w.flags & AFM_CMDM_ALL_QUERIES))
-            AFM_TRY(afm_mha_fwd_rows(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, 1 + w.n_cond, w.attn_group_waves, s));
+            AFM_TRY(afm_mha_fwd_arith(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, 1 + w.n_cond, w.attn_group_waves, w.gemm_arith, s));
         else
-            AFM_TRY(afm_mha_fwd_grouped(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, w.attn_group_waves, s));
+            AFM_TRY(afm_mha_fwd_arith(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, 0, w.attn_group_waves, w.gemm_arith, s));
         const int rows = last ? B * L : M;
         const int g = last ? L : 0, gs = last ? T : 0, go = last ? 1 + w.n_cond : 0;
         a = {};

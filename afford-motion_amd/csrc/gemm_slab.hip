@@ -39,6 +39,7 @@ __device__ __forceinline__ float group_reduce16(float (&v)[16], int lane) {
 }
 __device__ __forceinline__ int group_owned_row(int lane) { return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1); }
 
+template <int NPROD>
 __global__ __launch_bounds__(64 * SLAB_WAVES) void gemm_f32_split_rowdot_slab(const afm_linear_args p, int nslab, int nchunk, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sl_raw[];
     int* counter = reinterpret_cast<int*>(sl_raw + SLAB_BYTES);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * SLAB_WAVES) void gemm_f32_split_rowdot_slab(co
             split2(hi[0], hi[1], p1, p2, p3); a[0][2] = p1; a[1][2] = p2; a[2][2] = p3;
             split2(hi[2], hi[3], p1, p2, p3); a[0][3] = p1; a[1][3] = p2; a[2][3] = p3;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 9 - NPROD; q < 9; ++q) {
                 acc0 = mfma_bf16(a[AFM_PA[q]], b[0][AFM_PB[q]], acc0);
                 acc1 = mfma_bf16(a[AFM_PA[q]], b[1][AFM_PB[q]], acc1);
             }
@@ -193,10 +194,11 @@ bool afm_linear_rowdot_slab_ok(const afm_linear_args& a) {
     return true;
 }
 
-int afm_linear_rowdot_slab(const afm_linear_args& a, hipStream_t s) {
+template <int NPROD>
+static int rowdot_slab_launch(const afm_linear_args& a, hipStream_t s) {
     constexpr int LDS_BYTES = SLAB_BYTES + 16 + SLAB_WAVES * SLAB_SCR;
     static const int attr = []() {
-        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_rowdot_slab, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_rowdot_slab<NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }();
     if (attr != 0) return attr;
     const int nslab = a.N / SLAB_N, ntile = (a.M + 31) / 32;
@@ -207,7 +209,12 @@ int afm_linear_rowdot_slab(const afm_linear_args& a, hipStream_t s) {
     while (nchunk > 8 && ntile < nchunk * 16) nchunk -= 8;
     const int tpc = (ntile + nchunk - 1) / nchunk;
     AfmProf prof(AFM_PROF_GEMM_SLAB, 2.0 * a.M * a.N * a.K, s);
-    hipLaunchKernelGGL(gemm_f32_split_rowdot_slab, dim3(nslab * nchunk), dim3(64 * SLAB_WAVES), LDS_BYTES, s, a, nslab, nchunk, tpc);
+    hipLaunchKernelGGL(gemm_f32_split_rowdot_slab<NPROD>, dim3(nslab * nchunk), dim3(64 * SLAB_WAVES), LDS_BYTES, s, a, nslab, nchunk, tpc);
     AFM_CHECK_LAUNCH();
     return 0;
+}
+
+// products = 9 (all cross products) or 6 (gemm_split.hip's NPROD): the same products in the same order as the tile kernels of that arithmetic
+int afm_linear_rowdot_slab(const afm_linear_args& a, int products, hipStream_t s) {
+    return products == 6 ? rowdot_slab_launch<6>(a, s) : rowdot_slab_launch<9>(a, s);
 }

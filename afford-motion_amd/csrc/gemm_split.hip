@@ -28,7 +28,7 @@
 #include "bf16split.h"
 
 bool afm_linear_rowdot_slab_ok(const afm_linear_args& a);       // gemm_slab.hip
-int afm_linear_rowdot_slab(const afm_linear_args& a, hipStream_t s);
+int afm_linear_rowdot_slab(const afm_linear_args& a, int products, hipStream_t s);
 
 namespace {
 
@@ -144,7 +144,7 @@ template <int NPROD>
 int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     const int tile = (a.tune & AFM_TUNE_TILE_MASK) >> AFM_TUNE_TILE_SHIFT;      // 3 = 64x64, 5 = 128x128, 7 = 64x64 split-K, 8 = weight-stationary slabs, 0 = heuristic
     // Row-dot launches with K = 256 (the CDM's linear1): the weight-stationary form (gemm_slab.hip) whatever M is
-    if (NPROD == 9 && (tile == 0 || tile == 8) && afm_linear_rowdot_slab_ok(a)) return afm_linear_rowdot_slab(a, s);
+    if ((NPROD == 9 || NPROD == 6) && (tile == 0 || tile == 8) && afm_linear_rowdot_slab_ok(a)) return afm_linear_rowdot_slab(a, NPROD, s);
     if (tile == 8) return AFM_E_UNSUPPORTED;
     // Small launches (every 64x64 tile resident at once, at most two per CU): the launch is bound by the serial K chain of one MFMA
     // tile, so the K segments of a tile go to separate 256-thread groups of one workgroup (bit-identical, see the kernel's header).
@@ -204,7 +204,7 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
 int afm_linear_split_mode(const afm_linear_args& a) {
     int mode, min_n;
     switch (a.arith) {
-        case AFM_ARITH_DEFAULT: mode = 9; min_n = 32; break;       // narrow outputs: native small-tile kernels (a function of N only, never of M)
+        case AFM_ARITH_DEFAULT: mode = 6; min_n = 32; break;       // round 6: six products (tests/test_gpu_arith.py); narrow outputs: native small-tile kernels (a function of N only, never of M)
         case AFM_ARITH_BF16X9: mode = 9; min_n = a.arith_min_n; break;
         case AFM_ARITH_BF16X6: mode = 6; min_n = a.arith_min_n; break;
         case AFM_ARITH_BF16X1: mode = 1; min_n = a.arith_min_n; break;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 6
+#define AFM_ABI_VERSION 7
 
 #define AFM_E_BADARG   (-1)   /* shape / pointer validation failed              */
 #define AFM_E_WORKSPACE (-2)  /* workspace too small                            */
@@ -87,13 +87,20 @@ typedef struct {
     /* ---- arithmetic of the product (ABI v3; replaces the process-wide afm_linear_set_split of v2).  A GEMM is ELIGIBLE for the
      * bf16-split path when K >= 128, K % 16 == 0 and A / W are 16-byte aligned with lda / ldw % 4 == 0; everything else always runs
      * the native f32 MFMA kernels (v_mfma_f32_32x32x2_f32, 157 TF peak on gfx950).
-     *   AFM_ARITH_DEFAULT  every eligible GEMM takes AFM_ARITH_BF16X9, all others AFM_ARITH_F32 (arith_min_n ignored);
+     *   AFM_ARITH_DEFAULT  every eligible GEMM with N >= 32 takes AFM_ARITH_BF16X6 (ABI v7; v3-v6: X9), all others AFM_ARITH_F32 (arith_min_n
+     *                      ignored).  Decided by a worst-case measurement, not an rms: over adversarial operand families (catastrophic
+     *                      cancellation, 2^+-60 dynamic range inside a row, mantissas that maximise the dropped terms with every product of one
+     *                      sign, K = 128 ... 4096) the worst output element of X6 is never above X9's and both sit in the error class of the
+     *                      native f32 MFMA kernel and of an unfused f32 multiply-add chain (tests/test_gpu_arith.py, profiles/r06_arith_worstcase.json).
+     *                      Domain of both split forms: operands of magnitude >= 2^-110 (or zero) - a split term below 2^-126 is a bf16
+     *                      subnormal and is flushed; AFM_ARITH_F32 has no such limit;
      *   AFM_ARITH_F32      native f32 MFMA;
      *   AFM_ARITH_BF16X9   eligible GEMMs with N >= arith_min_n: every f32 operand is split exactly into three bf16 terms inside the
      *                      kernel and all nine cross products run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2500 TF peak)
      *                      with f32 accumulation: the same exact products as the f32 MFMA in a different summation order
      *                      (measured error vs float64 <= the native kernel's, tools/kernel_sweep.cpp);
-     *   AFM_ARITH_BF16X6   as X9 without the three smallest products (each <= 2^-24 |a||w|; what oneMKL calls float_to_bf16x3).
+     *   AFM_ARITH_BF16X6   as X9 without the three smallest products a2 w3, a3 w2, a3 w3 (together <= 2^-23 |a||w|, i.e. two f32 roundings of
+     *                      that product; what oneMKL calls float_to_bf16x3 and XLA's "highest" precision on bf16 matrix units).
      *   AFM_ARITH_BF16X1   INFORMATIONAL, not f32 arithmetic: only the product of the two leading bf16 terms (what a plain bf16 x bf16 GEMM with f32
      *                      accumulation computes; relative error ~2^-9 per product).  Exists to MEASURE what bf16 would cost in accuracy
      *                      (tests/test_gpu_cmdm.py::test_bf16_one_product_drift...); never selected by the library.
@@ -185,6 +192,12 @@ int afm_mha_fwd_grouped(const float* qkv, const uint8_t* key_mask, float* out,
  * to afm_mha_fwd_grouped on the rows it computes).  ABI v6. */
 int afm_mha_fwd_rows(const float* qkv, const uint8_t* key_mask, float* out,
                      int32_t B, int32_t T, int32_t H, int32_t dh, int32_t q_first, int32_t group_waves, void* stream);
+/* Same with the arithmetic of the two products S = Q K^T and O = P V as an argument (ABI v7), `arith` as in afm_linear_args: the inference
+ * kernel splits Q, K, V and the probabilities P exactly into three bf16 terms; AFM_ARITH_DEFAULT / AFM_ARITH_BF16X6 run the six largest cross
+ * products of every operand pair, every other setting all nine (exact f32 products).  q_first = 0: all query rows.  The entry points above
+ * (and afm_mha_cross_fwd) run AFM_ARITH_DEFAULT.  A query row's arithmetic depends on `arith` only - never on the grouping, q_first or B. */
+int afm_mha_fwd_arith(const float* qkv, const uint8_t* key_mask, float* out,
+                      int32_t B, int32_t T, int32_t H, int32_t dh, int32_t q_first, int32_t group_waves, int32_t arith, void* stream);
 
 /* Cross-attention core of nn.TransformerDecoderLayer (CMDM `trans_dec`, cmdm.py:78-113,171-191): Tq queries q [B*Tq, H*dh] over a
  * packed memory kv [B*Tk, 2*H*dh] (k | v), key_mask [B,Tk] or NULL.  Same kernel as afm_mha_fwd (dh = 64). */

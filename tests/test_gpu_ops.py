@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loaded_and_versioned():
     lib = ffi.load()
-    assert lib.afm_version() == ffi.ABI_VERSION == 6
+    assert lib.afm_version() == ffi.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (326, 512, 512), (1000, 1536, 512), (777, 263, 512),

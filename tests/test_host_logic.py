@@ -177,7 +177,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(ffi.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"missing export {name}"
-    assert ffi.load().afm_version() == ffi.ABI_VERSION == 6     # pure host call, no GPU needed
+    assert ffi.load().afm_version() == ffi.ABI_VERSION == 7     # pure host call, no GPU needed
 
 
 def test_ctypes_mirrors_match_the_c_structs(tmp_path):
@@ -211,7 +211,15 @@ def test_gemm_arithmetic_switches_are_host_state():
     """ABI v3: the GEMM arithmetic is a field of afm_linear_args / the weight packs; the switch lives in the Python host (afm.ops),
     initialised from AFM_GEMM_SPLIT* in the host's environment.  The library exports no setter and reads no environment."""
     from afm import ops
-    want = (int(os.environ.get("AFM_GEMM_SPLIT", "9")), int(os.environ.get("AFM_GEMM_SPLIT_MIN_N", "0")))
+    want = (int(os.environ.get("AFM_GEMM_SPLIT", "6")), int(os.environ.get("AFM_GEMM_SPLIT_MIN_N", "0")))      # round 6: six products for sampling
+    assert ops.get_train_gemm_split() == int(os.environ.get("AFM_GEMM_SPLIT_TRAIN", "9"))                        # ... nine on the training tape
+    la = ffi.LinearArgs(); ops.fill_arith_train(la)
+    assert la.arith == ffi.ARITH_BF16X9 or "AFM_GEMM_SPLIT_TRAIN" in os.environ
+    assert ops.set_train_gemm_split(6) == ops.DEFAULT_TRAIN_PRODUCTS or "AFM_GEMM_SPLIT_TRAIN" in os.environ
+    ops.fill_arith_train(la)
+    assert la.arith == ffi.ARITH_BF16X6 and ops.set_train_gemm_split(int(os.environ.get("AFM_GEMM_SPLIT_TRAIN", "9"))) == 6
+    with pytest.raises(ffi.AfmError):
+        ops.set_train_gemm_split(1)
     saved = ops.get_gemm_split()
     assert saved == want
     try:
@@ -234,7 +242,7 @@ def test_gemm_arithmetic_switches_are_host_state():
         assert "afm_linear_set_split" not in syms                      # no process-wide switch left in the library
         imports = subprocess.run(["nm", "-D", "--undefined-only", ffi.lib_path()], capture_output=True, text=True).stdout
         assert " getenv" not in imports and "secure_getenv" not in imports, "libafm_hip.so must not read the environment"
-        assert ffi.load().afm_version() == ffi.ABI_VERSION == 6
+        assert ffi.load().afm_version() == ffi.ABI_VERSION == 7
 
 
 def _build_hip_module():
