@@ -204,6 +204,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.no_riders = False             # measurement: the per-step prologue launch instead of the riders on the step's first / last GEMM (bit-identical)
         self.all_queries = False           # measurement: the last layer's attention computes all T query rows (only the L motion rows are read)
         self.no_ln_fold = False            # measurement: separate LayerNorm launches instead of the statistics-carrying epilogues (afm_linear_args.a_stat ...)
+        self.pair_launch = False           # native loop, two sub-batch streams: sub-batch A's out_proj + sub-batch B's linear1 as ONE 128 x 128-tile launch per layer (afm_linear_pair; bit-identical)
         self.fused_layernorm = False       # norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; measured slower on MI355X, profiles/r03_ln_fusion.md)
         self._pack = None          # (version, CmdmWeights, keep-alive tensors)
         self._cond_cache = None    # (key, cond_tokens)
@@ -272,7 +273,8 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         w.gemm_arith, w.gemm_arith_min_n = ops.gemm_arith()
         w.attn_group_waves = int(self.attn_group_waves)
         w.flags = (ffi.CMDM_NO_L0_CACHE if self.no_l0_cache else 0) | (ffi.CMDM_FUSED_LN if self.fused_layernorm else 0) | \
-            (ffi.CMDM_NO_LN_FOLD if self.no_ln_fold else 0) | (ffi.CMDM_ALL_QUERIES if self.all_queries else 0) | (ffi.CMDM_NO_RIDERS if self.no_riders else 0) | ((int(self.gemm_tile) & 0xF) << 8)
+            (ffi.CMDM_NO_LN_FOLD if self.no_ln_fold else 0) | (ffi.CMDM_ALL_QUERIES if self.all_queries else 0) | (ffi.CMDM_NO_RIDERS if self.no_riders else 0) | ((int(self.gemm_tile) & 0xF) << 8) | \
+            (ffi.CMDM_PAIR_LAUNCH if self.pair_launch else 0)
         return w
 
     def _workspace(self, w: ffi.CmdmWeights, B: int, L: int, device) -> torch.Tensor:

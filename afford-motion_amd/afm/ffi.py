@@ -19,7 +19,7 @@ _lib = None
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ARITH_DEFAULT, ARITH_F32, ARITH_BF16X1, ARITH_BF16X6, ARITH_BF16X9 = 0, 1, 3, 6, 9       # afm_linear_args.arith (include/afm_hip.h)
 TUNE_NO_DMA, TUNE_TILE_SHIFT = 0x1, 4
-CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES, CMDM_CLIP_X0, CMDM_NO_RIDERS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+CMDM_NO_L0_CACHE, CMDM_FUSED_LN, CMDM_NO_LN_FOLD, CMDM_ALL_QUERIES, CMDM_CLIP_X0, CMDM_NO_RIDERS, CMDM_PAIR_LAUNCH = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 CDM_NO_GEN, CDM_CHAIN_SIDE, CDM_DEC_CHUNKS_SHIFT, CDM_CLIP_X0 = 0x2, 0x4, 12, 0x8
 ABI_VERSION = 7
 MAX_LAYERS = 16
@@ -150,6 +150,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     "afm_version": (C.c_int, []),
     "afm_linear": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "afm_linear_pair": (C.c_int, [C.POINTER(LinearArgs), C.POINTER(LinearArgs), C.c_void_p]),
     "afm_mha_fwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, C.c_void_p]),
     "afm_mha_fwd_grouped": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i32, i32, i32, i32, i32, C.c_void_p]),
     "afm_clamp": (C.c_int, [c_f32p, i64, C.c_float, C.c_float, C.c_void_p]),

@@ -25,7 +25,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, ln_out: Optional[torch.Tensor] = None,
            ln_counters: Optional[torch.Tensor] = None, stat_out: Optional[torch.Tensor] = None,
            a_stat: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-           res_stat: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None, ln_eps: float = 1e-5) -> torch.Tensor:
+           res_stat: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None, ln_eps: float = 1e-5, defer: bool = False) -> torch.Tensor:
     """``act_post(act(scale * (x @ weight.T) + bias) + residual + rowtab[row % len(rowtab)])`` on f32 MFMA.
 
     x [..., K] (or a 2-D row pool when ``a_map`` gathers rows), weight [N, K] as in nn.Linear.
@@ -119,8 +119,20 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             if ptr and ptr % 16:
                 raise ffi.AfmError(f"afm_linear with folded LayerNorm statistics: `{nm}` is not 16-byte aligned")
     fill_arith(a)
+    if defer:                                           # linear_pair: the argument block instead of the launch
+        return a, out, keep
     ffi.check(lib.afm_linear(C.byref(a), ffi.stream_of(x)), "afm_linear")
     return out
+
+
+def linear_pair(first: dict, second: dict) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Two independent `linear` calls (keyword dicts of `linear`) as ONE launch of 128 x 128 tiles (afm_linear_pair): bit-identical to the
+    two calls; raises AfmError (AFM_E_UNSUPPORTED) when the pair is not eligible (both on the bf16-split path, one arithmetic, K > 256)."""
+    a0, out0, keep0 = linear(**first, defer=True)
+    a1, out1, keep1 = linear(**second, defer=True)
+    ffi.check(ffi.load().afm_linear_pair(C.byref(a0), C.byref(a1), ffi.stream_of(out0)), "afm_linear_pair")
+    del keep0, keep1
+    return out0, out1
 
 
 # ---- arithmetic of the GEMMs: HOST state (this module), written into every afm_linear_args / weight pack that is built.

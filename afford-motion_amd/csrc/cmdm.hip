@@ -13,6 +13,7 @@
 #include "common.h"
 
 extern "C" int afm_linear(const afm_linear_args*, void*);
+extern "C" int afm_linear_pair(const afm_linear_args*, const afm_linear_args*, void*);
 extern "C" int afm_mha_fwd_grouped(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_mha_fwd_rows(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
 extern "C" int afm_mha_fwd_arith(const float*, const uint8_t*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*);
@@ -108,17 +109,53 @@ __global__ void expand_schedule_kernel(const int64_t* __restrict__ tmap, const f
 
 #define AFM_TRY(expr) do { int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
 
+// ---- the launches of one step as DATA (round 6, AFM_CMDM_PAIR_LAUNCH): with a Recorder, forward_impl does not launch - it lists the step's
+// launches in order, tagged, and the paired schedule (issue_paired below) interleaves the lists of the two sub-batches on their streams and
+// fuses sub-batch A's out_proj with sub-batch B's linear1 into ONE afm_linear_pair launch per layer.
+enum { OP_LINEAR = 0, OP_MHA = 1 };
+enum { TAG_NONE = 0, TAG_OUT_PROJ = 1, TAG_LINEAR1 = 2 };
+struct Op {
+    int kind, tag;
+    afm_linear_args a;
+    const float* qkv; const uint8_t* keymask; float* out; int B, T, H, dh, q_first, group_waves, arith;
+};
+struct Recorder { Op ops[8 * AFM_MAX_LAYERS + 8]; int n = 0; };
+
+inline int launch_op(const Op& o, hipStream_t s) {
+    if (o.kind == OP_LINEAR) return afm_linear(&o.a, s);
+    return afm_mha_fwd_arith(o.qkv, o.keymask, o.out, o.B, o.T, o.H, o.dh, o.q_first, o.group_waves, o.arith, s);
+}
+
 // every nn.Linear of the denoiser runs with the arithmetic the caller put into the weight pack (ABI v3: no process-wide switch)
-inline int run_linear(const afm_cmdm_weights& w, afm_linear_args& a, hipStream_t s) {
+inline int run_linear(const afm_cmdm_weights& w, afm_linear_args& a, hipStream_t s, Recorder* rec = nullptr, int tag = TAG_NONE) {
     a.arith = w.gemm_arith; a.arith_min_n = w.gemm_arith_min_n;
     const int tile = (w.flags >> AFM_CMDM_WIDE_TILE_SHIFT) & 0xF;          // measurement knob (tile shapes of one arithmetic are bit-identical)
     if (tile && a.N >= 512 && a.M >= 2048) a.tune = tile << AFM_TUNE_TILE_SHIFT;
+    if (rec) {
+        if (rec->n >= (int)(sizeof(rec->ops) / sizeof(rec->ops[0]))) return AFM_E_UNSUPPORTED;
+        Op& o = rec->ops[rec->n++];
+        o = Op{};
+        o.kind = OP_LINEAR; o.tag = tag; o.a = a;
+        return 0;
+    }
     return afm_linear(&a, s);
+}
+
+inline int run_mha(const afm_cmdm_weights& w, const float* qkv, const uint8_t* keymask, float* out, int B, int T, int q_first, hipStream_t s, Recorder* rec) {
+    if (rec) {
+        if (rec->n >= (int)(sizeof(rec->ops) / sizeof(rec->ops[0]))) return AFM_E_UNSUPPORTED;
+        Op& o = rec->ops[rec->n++];
+        o = Op{};
+        o.kind = OP_MHA; o.qkv = qkv; o.keymask = keymask; o.out = out; o.B = B; o.T = T; o.H = w.heads; o.dh = w.d / w.heads; o.q_first = q_first;
+        o.group_waves = w.attn_group_waves; o.arith = w.gemm_arith;
+        return 0;
+    }
+    return afm_mha_fwd_arith(qkv, keymask, out, B, T, w.heads, w.d / w.heads, q_first, w.attn_group_waves, w.gemm_arith, s);
 }
 
 int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, const float* cond,
                  const uint8_t* frame_mask, float* x0_out, const afm_ddpm_args* ddpm, int B, int L, const Workspace& ws,
-                 bool copy_cond, hipStream_t s) {
+                 bool copy_cond, hipStream_t s, Recorder* rec = nullptr) {
     const int d = w.d, T = 1 + w.n_cond + L;
     const int M = B * T;
     uint8_t* keymask = frame_mask ? ws.keymask : nullptr;
@@ -128,6 +165,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
     // launch (aux_*) - one launch less per step (~8 us of a 430 us step at one sample per GPU).
     const bool riders = !copy_cond && ddpm && ws.xpad && !(w.flags & AFM_CMDM_NO_RIDERS) && w.gemm_arith != AFM_ARITH_F32 &&
                         (w.gemm_arith == AFM_ARITH_DEFAULT || w.gemm_arith_min_n <= d) && B <= ((B * L + 127) / 128) * ((d + 127) / 128);
+    if (rec && !riders) return AFM_E_UNSUPPORTED;       // (a recorded step has no prologue launch: the caller records riders-steps only)
     if (!riders) {
         hipLaunchKernelGGL(prologue_kernel, dim3(B, 1 + w.n_cond), dim3(128), 0, s, ws.seq0, w.time_table, w.pos_table, t, cond,
                            frame_mask, keymask, T, L, w.n_cond, d, w.n_timesteps, copy_cond ? 1 : 0, x_t, ws.xpad, w.motion_dim, w.motion_adapter_kpad);
@@ -146,7 +184,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
             a.aux_src = w.time_table; a.aux_idx = t; a.aux_idx_max = w.n_timesteps; a.aux_add = w.pos_table; a.aux_dst = ws.seq0;
             a.aux_dst_ld = (int64_t)T * d; a.aux_rows = B; a.aux_cols = d;
         }
-        AFM_TRY(run_linear(w, a, s));
+        AFM_TRY(run_linear(w, a, s, rec));
     }
 
     // LayerNorm folded across the kernel boundaries (round 3): with the folded tensors in the pack (eval mode) and every GEMM of the layer on
@@ -184,10 +222,10 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
             a.M = B * (1 + L);
             a.a_grp = 1 + L; a.a_stride = T; a.a_off = 0; a.a_skip_after = 1; a.a_skip = w.n_cond;
             a.c_grp = 1 + L; a.c_stride = T; a.c_off = 0; a.c_skip_after = 1; a.c_skip = w.n_cond;
-            AFM_TRY(run_linear(w, a, s));
+            AFM_TRY(run_linear(w, a, s, rec));
         } else {
             a.M = M;
-            AFM_TRY(run_linear(w, a, s));
+            AFM_TRY(run_linear(w, a, s, rec));
         }
         // After the LAST layer only the L motion tokens of each sample are read (motion_layer, cmdm.py:169,195), and
         // everything after the attention's key / value side is row-local: the attention computes the motion tokens' QUERY rows only
@@ -195,9 +233,9 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         // scattered by the row maps; the other rows of att/tmp/x1/y keep stale values nobody reads).
         const bool last = (li == w.n_layers - 1);
         if (last && w.n_cond > 0 && !(w.flags & AFM_CMDM_ALL_QUERIES))
-            AFM_TRY(afm_mha_fwd_arith(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, 1 + w.n_cond, w.attn_group_waves, w.gemm_arith, s));
+            AFM_TRY(run_mha(w, qkv, keymask, ws.att, B, T, 1 + w.n_cond, s, rec));
         else
-            AFM_TRY(afm_mha_fwd_arith(qkv, keymask, ws.att, B, T, w.heads, d / w.heads, 0, w.attn_group_waves, w.gemm_arith, s));
+            AFM_TRY(run_mha(w, qkv, keymask, ws.att, B, T, 0, s, rec));
         const int rows = last ? B * L : M;
         const int g = last ? L : 0, gs = last ? T : 0, go = last ? 1 + w.n_cond : 0;
         a = {};
@@ -212,22 +250,23 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         if (fold) {
             a.stat_out = ws.stat1; a.ln_eps2 = 1e-5f;
             if (li > 0) { a.res_stat = ws.stat2; a.res_gamma = w.layer[li - 1].norm2_w; a.res_beta = w.layer[li - 1].norm2_b; }     // residual = LayerNorm(raw X)
-            AFM_TRY(run_linear(w, a, s));
+            AFM_TRY(run_linear(w, a, s, rec, TAG_OUT_PROJ));
             a = {};                                   // linear1 on the raw rows, norm1 folded
             a.A = ws.tmp; a.lda = d; a.W = lw.lin1_wg; a.ldw = d; a.C = ws.hid; a.ldc = w.ff;
             a.M = rows; a.N = w.ff; a.K = d; a.bias = lw.lin1_c; a.act = AFM_ACT_GELU;
             a.a_stat = ws.stat1; a.a_stat_groups = sg; a.a_fold_g = lw.lin1_g; a.ln_eps2 = 1e-5f;
             a.a_grp = g; a.a_stride = gs; a.a_off = go;
-            AFM_TRY(run_linear(w, a, s));
+            AFM_TRY(run_linear(w, a, s, rec, TAG_LINEAR1));
             a = {};                                   // linear2 + LayerNorm1(raw) as the residual -> raw output + its statistics
             a.A = ws.hid; a.lda = w.ff; a.W = lw.lin2_w; a.ldw = w.ff; a.C = ws.y; a.ldc = d;
             a.M = rows; a.N = d; a.K = w.ff; a.bias = lw.lin2_b; a.residual = ws.tmp; a.ldr = d;
             a.res_stat = ws.stat1; a.res_gamma = lw.norm1_w; a.res_beta = lw.norm1_b; a.stat_out = ws.stat2; a.ln_eps2 = 1e-5f;
             a.c_grp = g; a.c_stride = gs; a.c_off = go;
-            AFM_TRY(run_linear(w, a, s));
+            AFM_TRY(run_linear(w, a, s, rec));
             X = ws.y;
             continue;
         }
+        if (rec) return AFM_E_UNSUPPORTED;             // (the paired schedule exists for the folded-LayerNorm step only)
         if (fuse_ln) { a.ln_gamma = lw.norm1_w; a.ln_beta = lw.norm1_b; a.ln_out = ws.x1; a.ldo = d; a.ln_eps = 1e-5f; a.ln_counters = ws.lncnt; }
         AFM_TRY(run_linear(w, a, s));
         if (!fuse_ln) AFM_TRY(afm_layernorm_rows(ws.tmp, lw.norm1_w, lw.norm1_b, ws.x1, rows, d, 1e-5f, g, gs, go, s));
@@ -257,6 +296,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
         a.a_grp = L; a.a_stride = T; a.a_off = 1 + w.n_cond;
         if (ddpm) {
             const float* nz = ddpm->noise;
+            if (rec && !nz) return AFM_E_UNSUPPORTED;      // (recorded steps get their noise from the loop)
             if (!nz) {
                 AFM_TRY(afm_randn(ws.noise, B, (int64_t)L * w.motion_dim, ddpm->seed, ddpm->sample_index0, ddpm->step, s));
                 nz = ws.noise;
@@ -266,7 +306,7 @@ int forward_impl(const afm_cmdm_weights& w, const float* x_t, const int64_t* t, 
             a.ddpm_clip = (w.flags & AFM_CMDM_CLIP_X0) ? 1 : 0;
             if (ws.xpad) { a.ddpm_out2 = ws.xpad; a.ldx2 = w.motion_adapter_kpad; }      // x_next also as the NEXT step's K-padded A rows (the padding columns stay zero)
         }
-        AFM_TRY(run_linear(w, a, s));
+        AFM_TRY(run_linear(w, a, s, rec));
     }
     return 0;
 }
@@ -333,6 +373,35 @@ extern "C" int64_t afm_cmdm_loop_workspace_bytes(const afm_cmdm_weights* w, int3
     return total;
 }
 
+// ---- the paired schedule of one step (AFM_CMDM_PAIR_LAUNCH; two sub-batches A, B on streams sa, sb).  Both lists hold the same launch
+// sequence.  Per layer: sub-batch B runs up to and including its out_proj on sb; then ONE launch on sa computes A's out_proj AND B's linear1
+// (afm_linear_pair: 164 + 328 = 492 tiles of 128 x 128 at 16 samples per sub-batch - one full resident round); B continues with linear2 on
+// sb, A with linear1 on sa.  Two cross-stream edges per layer: sb -> sa before the pair (B's out_proj output and statistics), sa -> sb after
+// it (B's hidden rows).  Every element is computed by the same tile program on the same operands: bit-identical to the unpaired schedule.
+static int issue_paired(const Recorder& A, const Recorder& B, hipStream_t sa, hipStream_t sb, hipEvent_t* ev, int nev) {
+    if (A.n != B.n) return AFM_E_UNSUPPORTED;
+    int ia = 0, ib = 0, e = 0;
+    while (ia < A.n) {
+        const bool pair = A.ops[ia].tag == TAG_OUT_PROJ && ia + 1 < B.n && B.ops[ia + 1].tag == TAG_LINEAR1 && ib <= ia + 1 && e + 2 <= nev;
+        if (pair) {
+            while (ib <= ia) AFM_TRY(launch_op(B.ops[ib++], sb));                     // B up to and including its out_proj
+            if (hipEventRecord(ev[e], sb) != hipSuccess || hipStreamWaitEvent(sa, ev[e], 0) != hipSuccess) return (int)hipGetLastError();
+            const int rc = afm_linear_pair(&A.ops[ia].a, &B.ops[ia + 1].a, sa);
+            if (rc == AFM_E_UNSUPPORTED) {                                             // shapes the paired form does not take: two plain launches
+                AFM_TRY(launch_op(A.ops[ia], sa));
+                AFM_TRY(launch_op(B.ops[ia + 1], sa));
+            } else if (rc != 0) return rc;
+            if (hipEventRecord(ev[e + 1], sa) != hipSuccess || hipStreamWaitEvent(sb, ev[e + 1], 0) != hipSuccess) return (int)hipGetLastError();
+            e += 2;
+            ia += 1; ib = ia + 1;                                                      // B's linear1 is done
+        } else {
+            AFM_TRY(launch_op(A.ops[ia++], sa));
+        }
+    }
+    while (ib < B.n) AFM_TRY(launch_op(B.ops[ib++], sb));
+    return 0;
+}
+
 static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* cond_tokens, const uint8_t* frame_mask,
                             const float* step_noise, const int64_t* d_timestep_map, const float* d_c1,
                             const float* d_c2, const float* d_sigma, int32_t n_steps, int32_t first_step, uint64_t seed,
@@ -380,11 +449,36 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
     }
 
     const int T = 1 + w->n_cond + L;
+    // Tile shape of the wide encoder GEMMs inside the multi-stream loop (round 6).  afm_linear's own rule prices ONE launch: 128 x 128 tiles only
+    // when their last resident round is >= 90 % full (in_proj), 64 x 64 otherwise.  Inside this loop a second sub-batch's kernels fill the
+    // slots a partial round leaves, and what counts is the work per matrix instruction (the loop runs at the board's power limit): with the
+    // six-product arithmetic, 128 x 128 on EVERY GEMM with N >= 512 measured 588-590 against 568-574 steps/s at 16 + 16 samples in the same
+    // calls, but 853 against 995 at 8 + 8 and 1168 against 1470 at 4 + 4 (profiles/r06_tile_rule.md) - so: sub-batches of >= 4096 rows only.
+    // Tile shapes of one arithmetic are bit-identical; a caller's explicit AFM_CMDM_WIDE_TILE code wins.
+    afm_cmdm_weights wl = *w;
+    if (nsub >= 2 && ((wl.flags >> AFM_CMDM_WIDE_TILE_SHIFT) & 0xF) == 0) {
+        bool big = true;
+        for (int s = 0; s < nsub; ++s) big = big && (int64_t)count[s] * T >= 4096;
+        if (big) wl.flags |= 5 << AFM_CMDM_WIDE_TILE_SHIFT;
+    }
+    w = &wl;
     for (int s = 0; s < nsub; ++s)        // ticket words of the fused LayerNorm: zero once, every launch leaves them zero
         if (count[s] > 0 && (w->flags & AFM_CMDM_FUSED_LN) && hipMemsetAsync(ws[s].lncnt, 0, (size_t)(((int64_t)count[s] * T + 31) / 32) * 4, st[s]) != hipSuccess) return (int)hipGetLastError();
     const int64_t row = (int64_t)L * w->motion_dim;
     int rc = 0;
+    // paired schedule (AFM_CMDM_PAIR_LAUNCH, two sub-batches): every step after the first is recorded per sub-batch and issued interleaved
+    const bool paired = (w->flags & AFM_CMDM_PAIR_LAUNCH) && nsub == 2 && count[0] > 0 && count[1] > 0;
+    constexpr int NEV = 2 * AFM_MAX_LAYERS;
+    hipEvent_t pev[NEV] = {};
+    Recorder* recs = nullptr;
+    if (paired) {
+        for (int i = 0; i < NEV; ++i)
+            if (hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        recs = new Recorder[2];
+    }
     for (int j = 0; j < n_steps && rc == 0; ++j) {
+        const bool rec_step = paired && j > 0;
+        if (rec_step) recs[0].n = recs[1].n = 0;
         for (int s = 0; s < nsub && rc == 0; ++s) {
             if (count[s] == 0) continue;
             afm_ddpm_args dd = {};
@@ -403,8 +497,13 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
             rc = forward_impl(*w, x + (int64_t)start[s] * row, t_all + (int64_t)j * B + start[s],
                               cond_tokens ? cond_tokens + (int64_t)start[s] * w->n_cond * w->d : nullptr,
                               frame_mask ? frame_mask + (int64_t)start[s] * L : nullptr, nullptr, &dd, count[s], L, ws[s], j == 0,
-                              st[s]);
+                              st[s], rec_step ? &recs[s] : nullptr);
         }
+        if (rec_step && rc == 0) rc = issue_paired(recs[0], recs[1], st[0], st[1], pev, NEV);
+    }
+    if (paired) {
+        delete[] recs;
+        for (int i = 0; i < NEV; ++i) (void)hipEventDestroy(pev[i]);
     }
     if (nsub > 1) {      // join: `stream` continues only after every sub-batch loop has finished
         for (int s = 0; s < nsub; ++s) {

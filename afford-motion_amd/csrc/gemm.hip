@@ -398,10 +398,8 @@ int afm_linear_split(const afm_linear_args& a, int mode, hipStream_t s);
 int afm_linear_thin_mode(const afm_linear_args& a);                   // gemm_thin.hip
 int afm_linear_thin(const afm_linear_args& a, int mode, hipStream_t s);
 
-extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
-    if (!args) return AFM_E_BADARG;
-    const afm_linear_args& a = *args;
-    if (a.M == 0) return 0;                                   // empty batch: nothing to do (pointers may be null)
+// argument validation shared by afm_linear and afm_linear_pair (a.M > 0); 0 = fine
+static int validate_linear(const afm_linear_args& a) {
     if (!a.A || !a.W || a.M < 0 || a.N <= 0 || a.K <= 0) return AFM_E_BADARG;
     if (!a.C && !a.ddpm_out && !a.rowdot_out) return AFM_E_BADARG;
     if (a.rowdot_w || a.rowdot_out) {            // row-dot epilogue: the 16-byte-row form of the shared epilogue, plain forward inputs only
@@ -441,6 +439,15 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
     if (a.arith != AFM_ARITH_DEFAULT && a.arith != AFM_ARITH_F32 && a.arith != AFM_ARITH_BF16X6 && a.arith != AFM_ARITH_BF16X9 &&
         a.arith != AFM_ARITH_BF16X1) return AFM_E_BADARG;
     if (a.arith_min_n < 0) return AFM_E_BADARG;
+    return 0;
+}
+
+extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
+    if (!args) return AFM_E_BADARG;
+    const afm_linear_args& a = *args;
+    if (a.M == 0) return 0;                                   // empty batch: nothing to do (pointers may be null)
+    if (const int rc = validate_linear(a)) return rc;
+    const bool lnfold = a.stat_out || a.a_stat || a.res_stat;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                      (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.W & 15) == 0);
@@ -469,4 +476,20 @@ extern "C" int afm_linear(const afm_linear_args* args, void* stream) {
         case 5: return launch_dma<2, 2, 2, 2>(a, AFM_PROF_GEMM128_DMA, s);
         default: return AFM_E_BADARG;
     }
+}
+
+// ---- afm_linear_pair (ABI v7): TWO independent linear launches as ONE grid of 128 x 128 tiles of the bf16-split kernel (gemm_split.hip).
+// The sampling loop's two sub-batch streams each run out_proj (164 tiles at 16 samples) and linear1 (328): neither fills the 512 resident
+// slots of the 128 x 128 tile program, one sub-batch's out_proj together with the other's linear1 does (492).  Every output element is
+// computed by the tile program of afm_linear with the same operands in the same order: bit-identical to two afm_linear calls.
+int afm_linear_pair_split(const afm_linear_args& a0, const afm_linear_args& a1, int mode, hipStream_t s);       // gemm_split.hip
+extern "C" int afm_linear_pair(const afm_linear_args* args0, const afm_linear_args* args1, void* stream) {
+    if (!args0 || !args1) return AFM_E_BADARG;
+    if (args0->M == 0) return afm_linear(args1, stream);
+    if (args1->M == 0) return afm_linear(args0, stream);
+    if (const int rc = validate_linear(*args0)) return rc;
+    if (const int rc = validate_linear(*args1)) return rc;
+    const int m0 = afm_linear_split_mode(*args0), m1 = afm_linear_split_mode(*args1);
+    if (m0 == 0 || m0 != m1 || args0->K <= 256 || args1->K <= 256) return AFM_E_UNSUPPORTED;          // the paired form exists for the bf16-split tile program, one arithmetic per launch
+    return afm_linear_pair_split(*args0, *args1, m0, (hipStream_t)stream);
 }

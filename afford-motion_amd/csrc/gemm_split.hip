@@ -103,6 +103,55 @@ __global__ __launch_bounds__(256, AFM_WALK_LB) void gemm_f32_split_bf16_walk(con
     }
 }
 
+// ---- PAIR (round 6): two independent problems in ONE grid of 128 x 128 tiles.  Workgroups [0, tiles0) run problem 0's tiles, workgroups
+// [start1, start1 + tiles1) problem 1's (start1 = tiles0 rounded up to a multiple of 8, so that a tile's XCD - blockIdx.x & 7 - is what the
+// tile program's XCD-aware tile order assumes; the < 8 workgroups in between exit at once).  The tile program is the text every other kernel
+// of this file runs; which problem a workgroup belongs to is wave-uniform, its arguments are read from the kernel-argument segment with scalar
+// loads as before.  Why: the sampling loop's sub-batch launches of out_proj (164 tiles) and linear1 (328) do not fill the 512 resident slots
+// of this tile program, one sub-batch's out_proj + the other's linear1 do (492) - afm_linear_pair, csrc/cmdm.hip's paired schedule.
+struct afm_linear_pair_args {
+    afm_linear_args a[2];
+    int nbm[2], nbn[2];
+    int tiles0, start1;
+};
+template <int BM, int BN, int BKS, int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_pair(const afm_linear_pair_args pa) {
+    constexpr int KG = 1, RING = 2, GSEG = 1;
+    const int which = (int)blockIdx.x >= pa.start1 ? 1 : 0;
+    const int wg_ = (int)blockIdx.x - (which ? pa.start1 : 0);
+    if (!which && wg_ >= pa.tiles0) return;
+    const afm_linear_args& p = pa.a[which];
+    const int nbm = pa.nbm[which], nbn = pa.nbn[which];
+#define AFM_WG wg_
+#define AFM_TIDX threadIdx.x
+#define AFM_TIMELINE_SLOT blockIdx.x
+#include "gemm_split_body.inc"
+#undef AFM_WG
+#undef AFM_TIDX
+#undef AFM_TIMELINE_SLOT
+}
+
+template <int NPROD>
+int launch_split_pair(const afm_linear_args& a0, const afm_linear_args& a1, hipStream_t s) {
+    constexpr int BM = 128, BN = 128, BKS = 16;
+    constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
+    constexpr int LDS_BYTES = 2 * STAGE + 2 * BM * 2 * 4;
+    static const int attr = []() {
+        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16_pair<BM, BN, BKS, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }();
+    if (attr != 0) return attr;
+    afm_linear_pair_args g;
+    g.a[0] = a0; g.a[1] = a1;
+    for (int i = 0; i < 2; ++i) { g.nbm[i] = (g.a[i].M + BM - 1) / BM; g.nbn[i] = (g.a[i].N + BN - 1) / BN; }
+    g.tiles0 = g.nbm[0] * g.nbn[0];
+    g.start1 = (g.tiles0 + 7) & ~7;
+    const int grid = g.start1 + g.nbm[1] * g.nbn[1];
+    AfmProf prof(AFM_PROF_GEMM_SPLIT128, 2.0 * a0.M * a0.N * a0.K + 2.0 * a1.M * a1.N * a1.K, s);
+    hipLaunchKernelGGL((gemm_f32_split_bf16_pair<BM, BN, BKS, NPROD>), dim3(grid), dim3(256), LDS_BYTES, s, g);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int BM, int BN, int BKS, int NPROD, int KG = 1, int RING = 2, int GSEG = 1>
 int launch_split(const afm_linear_args& a, hipStream_t s) {
     constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
@@ -218,4 +267,9 @@ int afm_linear_split_mode(const afm_linear_args& a) {
 int afm_linear_split(const afm_linear_args& a, int mode, hipStream_t s) {
     if (mode == 1) return dispatch_split<1>(a, s);        // informational: plain bf16 x bf16 (top terms only), NOT f32 arithmetic
     return mode == 9 ? dispatch_split<9>(a, s) : dispatch_split<6>(a, s);
+}
+
+int afm_linear_pair_split(const afm_linear_args& a0, const afm_linear_args& a1, int mode, hipStream_t s) {
+    if (mode == 1) return launch_split_pair<1>(a0, a1, s);
+    return mode == 9 ? launch_split_pair<9>(a0, a1, s) : launch_split_pair<6>(a0, a1, s);
 }

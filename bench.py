@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--no-ln-fold", action="store_true", help="measurement: separate LayerNorm launches instead of the statistics-carrying GEMM epilogues")
     ap.add_argument("--fused-ln", action="store_true", help="measurement: norm1 / norm2 inside the out_proj / linear2 GEMMs (bit-identical; slower, profiles/r03_ln_fusion.md)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="measurement: AFM_TUNE_TILE code forced on the wide encoder GEMMs (5 = 128x128; bit-neutral)")
+    ap.add_argument("--pair-launch", type=int, default=None, help="1 / 0: sub-batch A's out_proj + sub-batch B's linear1 as one 128x128-tile launch per layer (bit-identical; default: the model's setting)")
     ap.add_argument("--attn-group", type=int, default=None, help="waves per attention workgroup (bit-neutral tuning; default: library choice)")
     args = ap.parse_args()
 
@@ -208,6 +209,8 @@ def main():
     if args.streams is not None:
         model.loop_streams, model.loop_streams_auto = args.streams, False
     model.gemm_tile = args.gemm_tile
+    if args.pair_launch is not None:
+        model.pair_launch = bool(args.pair_launch)
     if args.attn_group is not None:
         model.attn_group_waves = args.attn_group
     model.fused_layernorm = bool(args.fused_ln)
@@ -342,13 +345,19 @@ def main():
     if rank == 0:
         streams_timed = model.loop_streams
         model.loop_streams = 1
+        # the multi-stream loop runs its wide GEMMs on 128 x 128 tiles when every sub-batch has >= 4096 rows (csrc/cmdm.hip, round 6): the
+        # single-stream pass must time the SAME tile program, so the rule's outcome is forced here (tile shapes are bit-identical)
+        n_sub = max(1, min(streams_timed, B // 8 if model.loop_streams_auto else B))
+        tile_timed = model.gemm_tile
+        if n_sub >= 2 and not tile_timed and (B // n_sub) * (2 + NPTS // 64 + L) >= 4096:
+            model.gemm_tile = 5
         run(diff_w, 1, gather=False)                  # rank 0 only: no collective in this pass
         ffi.profile_enable(True)
         ffi.profile_read()
         run(diff_k, 2, gather=False)
         prof = ffi.profile_read()
         ffi.profile_enable(False)
-        model.loop_streams = streams_timed
+        model.loop_streams, model.gemm_tile = streams_timed, tile_timed
         name = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None      # dominant kernel of the step
         g = prof.get(name)
         if g:

@@ -167,6 +167,11 @@ typedef struct {
 #define AFM_TUNE_TILE_MASK   0xF0
 
 int afm_linear(const afm_linear_args* args, void* stream);
+/* Two independent afm_linear launches as ONE grid of 128 x 128 tiles of the bf16-split tile program (ABI v7): workgroups [0, tiles0) compute
+ * args0's output, the rest args1's.  Both must take the bf16-split path with the same arithmetic and K > 256 (AFM_E_UNSUPPORTED otherwise -
+ * the caller then issues two afm_linear calls).  Bit-identical to the two calls; the sampling loop pairs one sub-batch's out_proj with the
+ * other's linear1 (cmdm.py:66-77: 164 + 328 tiles = one resident round of 512). */
+int afm_linear_pair(const afm_linear_args* args0, const afm_linear_args* args1, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------
@@ -511,6 +516,7 @@ typedef struct {
 #define AFM_CMDM_NO_RIDERS   0x20          /* measurement: the per-step prologue launch of round 3 instead of the riders on the first / last GEMM of a step (bit-identical) */
 #define AFM_CMDM_CLIP_X0     0x10          /* clip_denoised=True (gaussian_diffusion.py:289-294): pred_xstart clamped to [-1, 1] inside the fused DDPM update */
 #define AFM_CMDM_ALL_QUERIES 0x8           /* measurement: the last layer's attention computes all T query rows (bit-identical on the rows that are read) */
+#define AFM_CMDM_PAIR_LAUNCH 0x40          /* ABI v7, native loop with two sub-batch streams: sub-batch A's out_proj and sub-batch B's linear1 of every layer as ONE 128 x 128-tile launch (afm_linear_pair; bit-identical) */
 #define AFM_CMDM_FUSED_LN    0x2           /* norm1 / norm2 inside out_proj / linear2 (afm_linear_args.ln_*; bit-identical, measured slower: off by default) */
 
 /* bytes of workspace afm_cmdm_forward needs for (B, L). */

@@ -494,6 +494,33 @@ def test_clip_denoised_native_loop_matches_the_step_by_step_path(cmdm):
     assert (unclipped - native).abs().max().item() > 1e-2           # the clamp is live on this input
 
 
+def test_paired_launch_loop_is_bit_identical():
+    """Round 6: with `model.pair_launch` the two-stream loop computes sub-batch A's out_proj and sub-batch B's linear1 of every
+    layer in ONE 128 x 128-tile launch (afm_linear_pair; two cross-stream edges per layer).  Same tile program on the same operands: the
+    sampling result must not change by a bit - against the unpaired two-stream loop and the single-stream loop, at the headline shape
+    (B = 32: 16 + 16 samples), an uneven split (B = 17: 9 + 8) and repeated runs (the cross-stream edges are the new hazard)."""
+    L, N = 196, 8192
+    model = create_model(cmdm_cfg(num_points=N), device=dev()); load_named_weights(model); model = model.to(dev()).eval()
+    diff = create_gaussian_diffusion(cmdm_cfg(steps=1000, respacing="30"))
+    for B in (32, 17):
+        kw = dict(c_text_feat=synth.text_feature(B).to(dev()), c_cont_emb=synth.gaussian("pl_cont", (B, 128, 256)).to(dev()),
+                  x_mask=synth.frame_mask(B, L, seed=6).to(dev()))
+
+        def run(streams, pair):
+            model.loop_streams, model.loop_streams_auto, model.pair_launch = streams, False, pair
+            return diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=14).clone()
+        try:
+            ref1, ref2 = run(1, False), run(2, False)
+            assert torch.isfinite(ref1).all() and torch.equal(ref1, ref2)
+            for r in range(4):
+                out = run(2, True)
+                bad = (out != ref1).flatten(1).any(1).nonzero().flatten().tolist()
+                assert not bad, f"B={B} run {r}: samples {bad} differ with the paired launch (max {(out - ref1).abs().max().item():.2e})"
+            assert torch.equal(run(1, True), ref1)                      # one stream: the flag changes nothing
+        finally:
+            model.loop_streams, model.loop_streams_auto, model.pair_launch = 2, True, False
+
+
 def test_two_stream_loop_soak():
     """Round 3: 50 two-stream 100-step loops of the headline CMDM shape (B = 32, L = 196, N = 8192) against the
     single-stream result, bit for bit - the harness that caught round 2's lat_decfold defect (profiles/r02_decfold_nondeterminism.md)."""

@@ -318,6 +318,37 @@ def test_linear_tile_shapes_are_bit_identical(M, N, K):
         ops.set_gemm_tune(saved_tune)
 
 
+@pytest.mark.parametrize("products", [6, 9])
+@pytest.mark.parametrize("M0,M1", [(5216, 5216), (3136, 3136), (700, 129), (64, 5000)])
+def test_linear_pair_is_bit_identical_to_two_launches(products, M0, M1):
+    """afm_linear_pair (ABI v7): two independent launches - one sub-batch's out_proj (N = 512, K = 512, bias + residual + row statistics) and the
+    other's linear1 (N = 1024, K = 512, folded-LayerNorm input statistics, GELU) - as ONE grid of 128 x 128 tiles.  Same tile program, same
+    operands, same order: every output bit equals the two afm_linear calls', for ragged row counts on either side and both arithmetics;
+    a pair the form does not take (native-path operand) is refused with AFM_E_UNSUPPORTED, not computed differently."""
+    d, ff = 512, 1024
+    g = lambda n, *s: synth.gaussian(f"pair_{n}", s).to(dev())
+    x0, w0, b0, r0 = g("x0", M0, d), g("w0", d, d) / math.sqrt(d), g("b0", d), g("r0", M0, d)
+    x1, w1, b1 = g("x1", M1, d), g("w1", ff, d) / math.sqrt(d), g("b1", ff)
+    # statistics of x1's rows as a producer would have written them (mean, M2 per 64-column group), folded-LayerNorm vector for linear1
+    grp = x1.view(M1, d // 64, 64)
+    st1 = torch.stack([grp.mean(-1), ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)], -1).contiguous()
+    fold = g("fold", ff)
+    saved = ops.get_gemm_split()
+    try:
+        ops.set_gemm_split(products, 0)
+        st_sep, st_pair = torch.zeros(M0, d // 64, 2, device=dev()), torch.zeros(M0, d // 64, 2, device=dev())
+        first = lambda st: dict(x=x0, weight=w0, bias=b0, residual=r0, stat_out=st)
+        second = dict(x=x1, weight=w1, bias=b1, act=ffi.ACT_GELU, a_stat=(st1, fold))
+        want0, want1 = ops.linear(**first(st_sep)), ops.linear(**second)
+        got0, got1 = ops.linear_pair(first(st_pair), second)
+        assert torch.equal(got0, want0) and torch.equal(got1, want1) and torch.equal(st_pair, st_sep)
+        assert torch.isfinite(got0).all() and torch.isfinite(got1).all()
+        with pytest.raises(ffi.AfmError):                       # K = 100 is not on the bf16-split path: no paired form
+            ops.linear_pair(dict(x=x0[:, :100].contiguous(), weight=w0[:, :100].contiguous()), second)
+    finally:
+        ops.set_gemm_split(*saved)
+
+
 def test_linear_detects_transposed_layouts():
     # asymmetric operands + identity A (guide: always A=I-check with asymmetric B)
     K = N = 64

@@ -95,6 +95,16 @@ arith)
     done
   done
   ;;
+pair_timeline)
+  # kernel-trace timeline of the paired launch against the unpaired two-stream loop (same tile program: 128 x 128 everywhere)
+  for pr in 0 1; do
+    ( cd /tmp && AFM_PROFILE_STREAMS=2 AFM_PROFILE_TILE=5 AFM_PROFILE_PAIR=$pr timeout 240 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_pair$pr -- python $GRAFT_REPO_ROOT/tools/pmc_target.py cmdm > /dev/null 2>&1 )
+  done
+  f0=$(find $O/trace_pair0 -name "*kernel_trace.csv" | head -1); f1=$(find $O/trace_pair1 -name "*kernel_trace.csv" | head -1)
+  python tools/pair_timeline.py "$f0" "$f1" > $O/pair_timeline.md 2> $O/pair_timeline.err
+  find $O -name "*kernel_trace.csv" -size +20M -delete
+  cat $O/pair_timeline.md | cut -c1-200; tail -3 $O/pair_timeline.err
+  ;;
 tests)
   ( time timeout 1500 python -m pytest ${@:-tests -m gpu} -q -x --timeout=900 2>&1 | tail -8 ) 2>&1 | tee $O/pytest.log
   ;;

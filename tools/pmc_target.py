@@ -53,7 +53,10 @@ else:
     model, diff = create_model_and_diffusion(cfg, device=dev)
     synth.fill_module_(model)
     model = model.to(dev).eval()
-    model.loop_streams = 1
+    # AFM_PROFILE_STREAMS / AFM_PROFILE_PAIR / AFM_PROFILE_TILE (round 6, tools/pair_timeline.py): the two-stream loop, with or without the paired launch
+    model.loop_streams = int(os.environ.get("AFM_PROFILE_STREAMS", "1"))
+    model.pair_launch = os.environ.get("AFM_PROFILE_PAIR", "0") == "1"
+    model.gemm_tile = int(os.environ.get("AFM_PROFILE_TILE", "0"))
     kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_cont_emb=synth.gaussian("c", (B, 128, 256)).to(dev), x_mask=synth.frame_mask(B, L, all_valid=True).to(dev))
     diff.p_sample_loop(model, (B, L, 263), clip_denoised=False, model_kwargs=kw, seed=1)
 torch.cuda.synchronize()
