@@ -340,6 +340,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self.no_gen = False             # measurement: round 2's folded form (per-point rows) instead of the row-less sampling form
         self.chain_side = False         # sub-batch streams: the latent chain of a sub-batch on its side stream (afm_cdm_weights.flags: AFM_CDM_CHAIN_SIDE)
         self.dec_chunks = 0             # dec_point workgroups per sample (0 = 16); bit-neutral tuning
+        self.pipeline = False           # sub-batches as a fixed-phase pipeline (AFM_CDM_PIPELINE): all point kernels on one stream in round-robin order, each sub-batch's latent chain on its side stream
         self.chain_cu_mask = None       # CU masks (lists of uint32 words) of the side / main streams of the native loop; None = ordinary streams
         self.point_cu_mask = None
 
@@ -491,13 +492,19 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
 
     def _flags(self) -> int:
         return (ffi.CDM_NO_GEN if self.no_gen else 0) | ((int(self.gemm_tile) & 0xF) << 8) | (ffi.CDM_CHAIN_SIDE if self.chain_side else 0) | \
-            ((int(self.dec_chunks) & 0x3F) << ffi.CDM_DEC_CHUNKS_SHIFT)
+            ((int(self.dec_chunks) & 0x3F) << ffi.CDM_DEC_CHUNKS_SHIFT) | (ffi.CDM_PIPELINE if self.pipeline else 0)
 
     def _loop_streams(self, need: int, dev):
         """Streams of the native loop: [main_0, side_0, main_1, side_1, ...].  With `chain_cu_mask` / `point_cu_mask` (lists of 32-bit words,
         one bit per CU) the side / main streams are created with hipExtStreamCreateWithCUMask, so that the latent chain of one sub-batch owns
         a few CUs while the point kernels of the other sub-batch fill the rest (round 4 experiment; results do not depend on it)."""
         key = (tuple(self.chain_cu_mask or ()), tuple(self.point_cu_mask or ()), str(dev))
+        if not self.chain_cu_mask and not self.point_cu_mask:
+            if self.pipeline and need > 1:
+                # AFM_CDM_PIPELINE: the point kernels run on the caller's stream, sub-batch s's chain on entry 2 s + 1: 1 + nsub streams in all
+                pool = ffi.stream_pool(dev, need // 2)
+                return [pool[i // 2] for i in range(need)]
+            return ffi.stream_pool(dev, need)              # process-wide pool (hardware queues are few: ffi.stream_pool)
         if getattr(self, "_streams_key", None) != key:
             self._streams, self._streams_key = [], key
         while len(self._streams) < need:
@@ -576,8 +583,8 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             nsub = max(1, min(self.sub_batches, B))
             bounds = [(B * i // nsub, B * (i + 1) // nsub) for i in range(nsub)]
             cur = torch.cuda.current_stream(x.device)
-            while len(self._streams) < 2 * nsub:
-                self._streams.append(torch.cuda.Stream(device=x.device))
+            if len(self._streams) < 2 * nsub:
+                self._streams = ffi.stream_pool(x.device, 2 * nsub)       # process-wide pool (hardware queues are few: ffi.stream_pool)
             fork = None
             if nsub > 1:
                 fork = torch.cuda.Event()

@@ -563,8 +563,7 @@ class CMDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             # sub-batch streams fill the wave-quantisation tails of B >= 16 launches; below that every launch is latency-bound and a
             # second stream only adds launches (B = 4: 1311 steps/s on one stream vs 1159 on two, profiles/r02_small_batch.md)
             nsub = max(1, min(int(self.loop_streams), B // 8 if self.loop_streams_auto else B))
-            while len(self._side_streams) < nsub:
-                self._side_streams.append(torch.cuda.Stream(device=x.device))
+            self._side_streams = ffi.stream_pool(x.device, nsub)          # process-wide pool (hardware queues are few: ffi.stream_pool)
             handles = (C.c_void_p * nsub)(*[s.cuda_stream for s in self._side_streams[:nsub]])
             nbytes = lib.afm_cmdm_loop_workspace_bytes(C.byref(w), B, L, nsub)
             if nbytes < 0:

@@ -208,7 +208,7 @@ class SceneMapEncoder(nn.Module):
         main = torch.cuda.current_stream(p0.device)
         side = getattr(self, "_geo_stream", None)
         if side is None or side.device != p0.device:
-            side = self._geo_stream = torch.cuda.Stream(device=p0.device)
+            side = self._geo_stream = ffi.stream_pool(p0.device, 1)[0]        # process-wide pool (hardware queues are few: ffi.stream_pool)
         side.wait_stream(main)
         out = []
         with torch.cuda.stream(side), torch.no_grad():

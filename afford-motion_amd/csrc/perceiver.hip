@@ -448,7 +448,60 @@ static int cdm_sample_loop_impl(const afm_cdm_weights* w, float* x, float* feat,
             rc = cdm_prepare_invariants(*w, feat + (int64_t)start[s] * N * fd, count[s], N, carve(*w, count[s], N, wsp[s]), mainst[s]);
         }
     }
-    for (int j = 0; j < n_steps && rc == 0; ++j) {
+    // ---- AFM_CDM_PIPELINE (round 6; row-less form, sub-batches): the step of a sub-batch is heavy - chain - heavy: enc_point (fills the chip,
+    // ~15 us per 32 samples), the 13-launch latent chain (~70 us of launch latency on a handful of CUs), dec_point (fills the chip, ~88 us).
+    // Independent sub-batch streams fall into lockstep (a stream that is behind gets the chip to itself and catches up: both chains end up
+    // under each other, profiles/r04_cdm_streams.jsonl).  Here the phase is FIXED by construction: the heavy kernels of ALL sub-batches run on
+    // ONE stream - the caller's - in round-robin order - dec(s, j), enc(s, j + 1) for s = 0 .. nsub - 1 - and the chain of sub-batch s on its
+    // own side stream (streams[2 s + 1]) between two events, so that the chain of one sub-batch always sits under the point kernels of the
+    // others.  1 + nsub streams: the runtime has four hardware queues, and two streams on one queue do not overlap whatever the events say.
+    // Per-sample arithmetic does not depend on the sub-batching: bit-identical.
+    const bool pipe = rowless && nsub > 1 && (w->flags & AFM_CDM_PIPELINE) && !chain_side;
+    if (pipe) {
+        hipStream_t H = s0;
+        hipEvent_t e1[8] = {}, e2[8] = {};
+        CdmWs wss[8];
+        for (int s = 0; s < nsub && rc == 0; ++s) {
+            wss[s] = carve(*w, count[s], N, wsp[s], false);
+            if (hipEventCreateWithFlags(&e1[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e2[s], hipEventDisableTiming) != hipSuccess)
+                rc = (int)hipGetLastError();
+        }
+        auto part1 = [&](int s, int j) -> int {           // noise (every NOISE_STEPS steps), enc_point on H; the chain + decoder tables on the sub-batch's side stream
+            if (count[s] == 0) return 0;
+            if (!step_noise && j % NOISE_STEPS == 0)
+                AFM_TRY(afm_randn_steps(noise[s], count[s], per, seed, sample_index0 + start[s], first_step + j, n_steps - j < NOISE_STEPS ? n_steps - j : NOISE_STEPS, H));
+            const int64_t* tj = t_all + (int64_t)j * B + start[s];
+            AFM_TRY(launch_enc_point(*w, text_u + (int64_t)start[s] * He * dkv, text_cu + (int64_t)start[s] * He, tj, count[s], N, wss[s],
+                                     x + (int64_t)start[s] * per, feat + (int64_t)start[s] * N * fd, H));
+            if (hipEventRecord(e1[s], H) != hipSuccess || hipStreamWaitEvent(sidest[s], e1[s], 0) != hipSuccess) return (int)hipGetLastError();
+            AFM_TRY(cdm_latent_chain(*w, text_q0 + (int64_t)start[s] * dq, tj, wss[s], count[s], sidest[s], true));
+            AFM_TRY(launch_dec_tables(*w, count[s], wss[s], sidest[s]));
+            if (hipEventRecord(e2[s], sidest[s]) != hipSuccess) return (int)hipGetLastError();
+            return 0;
+        };
+        auto part2 = [&](int s, int j) -> int {           // dec_point (+ DDPM update, in place) on H once the sub-batch's tables are there
+            if (count[s] == 0) return 0;
+            if (hipStreamWaitEvent(H, e2[s], 0) != hipSuccess) return (int)hipGetLastError();
+            afm_ddpm_args dd = {};
+            dd.noise = step_noise ? step_noise + ((int64_t)j * B + start[s]) * per : noise[s] + (int64_t)(j % NOISE_STEPS) * count[s] * per;
+            float* xs = x + (int64_t)start[s] * per;
+            dd.x_next = xs;
+            dd.c1 = c1_all + (int64_t)j * B + start[s]; dd.c2 = c2_all + (int64_t)j * B + start[s]; dd.sigma = sg_all + (int64_t)j * B + start[s];
+            dd.seed = seed; dd.sample_index0 = sample_index0 + start[s]; dd.step = first_step + j;
+            return launch_dec_point(*w, count[s], N, wss[s], xs, feat + (int64_t)start[s] * N * fd, nullptr, &dd, H, false);
+        };
+        for (int s = 0; s < nsub && rc == 0; ++s) rc = part1(s, 0);
+        for (int j = 0; j < n_steps && rc == 0; ++j)
+            for (int s = 0; s < nsub && rc == 0; ++s) {
+                rc = part2(s, j);
+                if (rc == 0 && j + 1 < n_steps) rc = part1(s, j + 1);
+            }
+        for (int s = 0; s < nsub; ++s) {
+            if (e1[s]) (void)hipEventDestroy(e1[s]);
+            if (e2[s]) (void)hipEventDestroy(e2[s]);
+        }
+    }
+    for (int j = 0; j < n_steps && rc == 0 && !pipe; ++j) {
         for (int s = 0; s < nsub && rc == 0; ++s) {
             if (count[s] == 0) continue;
             float* xs = x + (int64_t)start[s] * per;

@@ -342,7 +342,9 @@ template <int NKS> constexpr int dp_lds_floats() {
     return 16 * RL::NSTEP * 3 * 64 * 4 + RL::TAB + 8 * DP_LDW + 256 + RL::K * 16 * RL::NT + 8 * 16 * RL::NT + 16 + RL::NW * 16 * 17 + RL::NW * 16;
 }
 
-template <int NKS>
+// NPROD (round 6): cross products of linear1's three-term bf16 operands - 9 (all, exact f32 products) or 6 (the six largest: the arithmetic of
+// afm_linear's AFM_ARITH_BF16X6 / AFM_ARITH_DEFAULT, tests/test_gpu_arith.py), chosen by afm_cdm_weights.gemm_arith like every GEMM of the denoiser.
+template <int NKS, int NPROD>
 __global__ __launch_bounds__(64 * RowLess<NKS>::NW, NKS <= 4 ? 2 : 1)
 void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ qtab, const float* __restrict__ qdd, const float* __restrict__ twx,
                       const float* __restrict__ cvec, const float* __restrict__ w2f, const float* __restrict__ gen_qe, const float* __restrict__ c0, int N, int cd,
@@ -498,7 +500,7 @@ void dec_point_kernel(const float* __restrict__ twp, const float* __restrict__ q
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
-                for (int pq = 0; pq < 9; ++pq)
+                for (int pq = 9 - NPROD; pq < 9; ++pq)
 #pragma unroll
                     for (int q = 0; q < TG; ++q)
                         acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[q][st][AFM_PA[pq]]), __builtin_bit_cast(bf16x8, ub[st][AFM_PB[pq]]), acc[q], 0, 0, 0);
@@ -597,12 +599,12 @@ int launch_dec_tables(const afm_cdm_weights& w, int B, const CdmWs& ws, hipStrea
 
 namespace {
 
-template <int NKS>
-int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
+template <int NKS, int NPROD>
+int launch_dec_point_p(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
                        const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables) {
     constexpr int LDS = dp_lds_floats<NKS>() * (int)sizeof(float);
     static_assert(LDS <= 160 * 1024, "dec_point_kernel's tables fit the LDS");
-    static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
+    static const int attr = []() { return (int)hipFuncSetAttribute((const void*)dec_point_kernel<NKS, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }();
     if (attr != 0) return attr;
     if (with_tables) AFM_TRY(launch_dec_tables_t<NKS>(w, B, ws, s));
     int chunks = (N + 511) / 512;                     // 512 points per workgroup: the per-sample tables are staged once per 8 tiles and wave
@@ -610,12 +612,20 @@ int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, 
     if (cap) chunks = cap;
     else if (chunks > 16) chunks = 16;                // (three workgroups per CU measured slower: the kernel is bound by VALU + f32 MFMA issue, not by latency)
     if (chunks > (N + 15) / 16) chunks = (N + 15) / 16;
-    hipLaunchKernelGGL(dec_point_kernel<NKS>, dim3(chunks, B), dim3(64 * RowLess<NKS>::NW), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
+    hipLaunchKernelGGL((dec_point_kernel<NKS, NPROD>), dim3(chunks, B), dim3(64 * RowLess<NKS>::NW), LDS, s, ws.twp, ws.qtab, w.dec_qdd, w.dec_twx, w.dec_c,
                        w.fold_w2, w.gen_qe, w.fold_c0, N, w.contact_dim, x_t, feat, w.feat_dim, x0_out, ddpm ? ddpm->noise : nullptr,
                        ddpm ? ddpm->x_next : nullptr, ddpm ? ddpm->c1 : nullptr, ddpm ? ddpm->c2 : nullptr, ddpm ? ddpm->sigma : nullptr,
                        (ddpm && (w.flags & AFM_CDM_CLIP_X0)) ? 1 : 0);
     AFM_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NKS>
+int launch_dec_point_t(const afm_cdm_weights& w, int B, int N, const CdmWs& ws, const float* x_t, const float* feat, float* x0_out,
+                       const afm_ddpm_args* ddpm, hipStream_t s, bool with_tables) {
+    // six products for AFM_ARITH_DEFAULT / AFM_ARITH_BF16X6, all nine otherwise: a function of the pack's arithmetic only
+    if (w.gemm_arith == AFM_ARITH_DEFAULT || w.gemm_arith == AFM_ARITH_BF16X6) return launch_dec_point_p<NKS, 6>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, with_tables);
+    return launch_dec_point_p<NKS, 9>(w, B, N, ws, x_t, feat, x0_out, ddpm, s, with_tables);
 }
 
 }  // namespace

@@ -663,6 +663,7 @@ typedef struct {
 
 #define AFM_CDM_TILE_SHIFT     8       /* bits 8..11, measurement: AFM_TUNE_TILE code forced on the linear1 GEMM of the sampling forms (bit-neutral) */
 #define AFM_CDM_CHAIN_SIDE     0x4     /* row-less form with sub-batch streams: the 2-latent chain (lat_head .. lat_dectables) of a sub-batch runs on its SIDE stream (fork / join by events), so that it can sit on CUs of its own (a CU-masked stream) under the other sub-batch's point kernels; bit-identical */
+#define AFM_CDM_PIPELINE       0x10    /* ABI v7, row-less form with n_sub > 1: the point kernels (enc_point, dec_point) of ALL sub-batches in round-robin order on streams[0], the 2-latent chain of sub-batch s on streams[2 s + 1] between two events - one sub-batch's launch-latency-bound chain always runs under the other sub-batches' point kernels; bit-identical */
 #define AFM_CDM_DEC_CHUNKS_SHIFT 12    /* bits 12..17: workgroups per sample of enc_point's successor dec_point_kernel (0 = 16); a tuning knob, bit-identical (a point's arithmetic does not depend on its chunk) */
 #define AFM_CDM_CLIP_X0        0x8     /* clip_denoised=True: pred_xstart clamped to [-1, 1] inside the fused DDPM update of every sampling form */
 #define AFM_CDM_NO_GEN         0x2     /* measurement: round 2's folded form (step-invariant adapter parts materialised, per-point rows) although the row-less tables are present */

@@ -216,6 +216,32 @@ def test_config4_full_size_properties():
             assert torch.equal(got, whole[name]), f"{name}: {shards} shards of {per} samples differ from the single batch of {K}"
 
 
+def test_pipelined_sub_batches_are_bit_identical():
+    """Round 6: AFM_CDM_PIPELINE - the point kernels of all sub-batches in round-robin order on ONE stream, every sub-batch's latent chain on its
+    own side stream between two events (a fixed-phase software pipeline instead of free-running sub-batch streams).  Samples are
+    independent and a point's arithmetic does not depend on the sub-batching or on dec_chunks: the result must equal the single-stream
+    loop's bit for bit, for 2 / 3 / 4 sub-batches, uneven splits, more steps than one noise block (16), and repeated runs."""
+    N = 2048
+    adm = create_model(cdm_cfg(num_points=N), device=dev()); load_named_weights(adm); adm = adm.to(dev()).eval()
+    d = create_gaussian_diffusion(cdm_cfg(steps=500, respacing="40"))
+    for K in (32, 7):
+        kw = dict(c_text_feat=synth.text_feature(K).to(dev()), c_pc_xyz=synth.scene_cloud(K, N, seed=72).to(dev()))
+
+        def run(nsub, pipeline, chunks=0):
+            adm.loop_sub_batches, adm.pipeline, adm.dec_chunks = nsub, pipeline, chunks
+            return d.p_sample_loop(adm, (K, N, 6), clip_denoised=False, model_kwargs=kw, seed=6, sample_index0=3).clone()
+        try:
+            ref = run(1, False)
+            assert torch.isfinite(ref).all()
+            for nsub, chunks in ((2, 0), (3, 0), (3, 23), (4, 32)):
+                for r in range(3):
+                    out = run(nsub, True, chunks)
+                    bad = (out != ref).flatten(1).any(1).nonzero().flatten().tolist()
+                    assert not bad, f"K={K} nsub={nsub} chunks={chunks} run {r}: samples {bad} differ (max {(out - ref).abs().max().item():.2e})"
+        finally:
+            adm.loop_sub_batches, adm.pipeline, adm.dec_chunks = 1, False, 0
+
+
 def test_two_sub_batch_loop_repeats():
     """Round 2 regression (profiles/r02_decfold_nondeterminism.md): at configs[4]'s ADM size the native loop runs as two sub-batches on
     their own streams.  A build of lat_decfold_kernel that was correct on one stream lost single products in single waves in ~1/4 of

@@ -21,7 +21,7 @@ from afm.config import load_config  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, N = 32, 8192
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
 
 
 def build(feats: bool):
@@ -50,14 +50,22 @@ def measure(m, d, kw, tag, **attrs):
 
 m, d = build(False)
 kw = dict(c_text_feat=synth.text_feature(B).to(dev), c_pc_xyz=synth.scene_cloud(B, N).to(dev))
-base = dict(no_gen=False, loop_sub_batches=1, no_fold=False, gemm_tile=0)
+base = dict(no_gen=False, loop_sub_batches=1, no_fold=False, gemm_tile=0, pipeline=False, dec_chunks=0)
 measure(m, d, kw, "H3D default: no per-point rows (enc_point / lat_head / lat_dectables / dec_point), one stream", **base)
-measure(m, d, kw, "H3D default form, two sub-batch streams", **dict(base, loop_sub_batches=2))
-measure(m, d, kw, "H3D folded rows (round 2 form; linear1 weight-stationary), one stream", **dict(base, no_gen=True))
-measure(m, d, kw, "H3D folded rows, linear1 on staged 64x64 tiles", **dict(base, no_gen=True, gemm_tile=3))
+measure(m, d, kw, "H3D default form, two sub-batch streams", **dict(base, loop_sub_batches=2)) if "--all" in sys.argv else None
+for nsub, chunks in ((2, 0), (2, 24), (2, 32), (3, 0), (3, 23)):
+    measure(m, d, kw, f"H3D default form, PIPELINE of {nsub} sub-batches (point kernels round-robin on one stream, chains on side streams), dec chunks {chunks or 16}",
+            **dict(base, loop_sub_batches=nsub, pipeline=True, dec_chunks=chunks))
+if "--all" in sys.argv:
+    measure(m, d, kw, "H3D folded rows (round 2 form; linear1 weight-stationary), one stream", **dict(base, no_gen=True))
+    measure(m, d, kw, "H3D folded rows, linear1 on staged 64x64 tiles", **dict(base, no_gen=True, gemm_tile=3))
 del m
 mh, dh = build(True)
 kwh = dict(kw, c_pc_feat=synth.gaussian("cdm_ab_feat", (B, N, 32)).to(dev))
 measure(mh, dh, kwh, "HUMANISE variant (41 input channels, backbone features hoisted): no per-point rows (K = 44 inputs), one stream", **base)
-measure(mh, dh, kwh, "HUMANISE variant, two sub-batch streams", **dict(base, loop_sub_batches=2))
-measure(mh, dh, kwh, "HUMANISE variant, folded rows (round 2 form), one stream", **dict(base, no_gen=True))
+if "--all" in sys.argv:
+    measure(mh, dh, kwh, "HUMANISE variant, two sub-batch streams", **dict(base, loop_sub_batches=2))
+for nsub, chunks in ((2, 0), (3, 0), (3, 23)):
+    measure(mh, dh, kwh, f"HUMANISE variant, PIPELINE of {nsub} sub-batches, dec chunks {chunks or 16}", **dict(base, loop_sub_batches=nsub, pipeline=True, dec_chunks=chunks))
+if "--all" in sys.argv:
+    measure(mh, dh, kwh, "HUMANISE variant, folded rows (round 2 form), one stream", **dict(base, no_gen=True))
