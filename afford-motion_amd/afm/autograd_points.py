@@ -128,6 +128,42 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, *, relu: bool = False, residual: Opt
 
 
 # ------------------------------------------------------------------------------------------------ gather / group
+# Deterministic scatter-adds (round 6): the backward of every row gather is a segmented sum over the INVERSE of its index list
+# (afm_scatter_plan: for every destination row its entries, ascending), built once per index tensor and shared by every operator that
+# scatters through it (the k / v / position gathers and the grouping of a layer use ONE kNN list) - no f32 atomics, so two training steps on
+# the same data produce the same bits.  The cache is keyed by the index TENSOR OBJECT (a weak reference: an address alone could be a recycled
+# allocation with other contents) and a miss only costs a rebuild.
+_PLANS: dict = {}
+
+
+def scatter_plan(idx: torch.Tensor, n_dst: int) -> torch.Tensor:
+    """int32 plan of afm_scatter_plan for `idx` (any shape, flattened) over `n_dst` destination rows."""
+    import weakref
+    key = (id(idx), int(n_dst))
+    hit = _PLANS.get(key)
+    if hit is not None and hit[0]() is idx and hit[1] == idx._version:
+        return hit[2]
+    lib = ffi.load()
+    words = lib.afm_scatter_plan_words(idx.numel(), int(n_dst))
+    if words < 0:
+        ffi.check(int(words), "afm_scatter_plan_words")
+    plan = torch.empty(int(words), dtype=torch.int32, device=idx.device)
+    ffi.check(lib.afm_scatter_plan(idx.data_ptr(), idx.numel(), int(n_dst), plan.data_ptr(), _st(idx)), "afm_scatter_plan")
+    if len(_PLANS) > 64:                               # entries of dead tensors
+        for k_ in [k_ for k_, v_ in _PLANS.items() if v_[0]() is None]:
+            del _PLANS[k_]
+    _PLANS[key] = (weakref.ref(idx), idx._version, plan)
+    return plan
+
+
+def _segment_sum(src: torch.Tensor, col_offset: int, idx: torch.Tensor, n_dst: int, C_: int, row_div: int = 1, d2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    plan = scatter_plan(idx, n_dst)
+    dst = torch.empty(n_dst, C_, device=src.device, dtype=torch.float32)
+    ffi.check(ffi.load().afm_segment_sum_rows(src.data_ptr(), src.shape[1], col_offset, row_div, ffi.ptr(d2), plan.data_ptr(), dst.data_ptr(), n_dst, C_,
+                                              _st(src)), "afm_segment_sum_rows")
+    return dst
+
+
 class _GatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx):
@@ -142,10 +178,7 @@ class _GatherFn(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         dy = _c(dy)
-        dx = torch.zeros(ctx.shape, device=dy.device, dtype=torch.float32)
-        ffi.check(ffi.load().afm_scatter_add_rows(dy.data_ptr(), dy.shape[1], 0, idx.data_ptr(), dx.data_ptr(), idx.numel(), dy.shape[1], _st(dy)),
-                  "afm_scatter_add_rows")
-        return dx, None
+        return _segment_sum(dy, 0, idx, ctx.shape[0], dy.shape[1]), None
 
 
 def gather(x, idx):
@@ -156,9 +189,30 @@ def gather(x, idx):
 def broadcast_rows(ctx_rows: torch.Tensor, n: int) -> torch.Tensor:
     """[B, C] -> [B * n, C]: row b repeated for the n points of sample b (the `repeat` of a per-sample context onto its points,
     cdm.py:236-243, pointtransformer.py:90-92); backward = the scatter-add of the row gather."""
-    B = ctx_rows.shape[0]
-    idx = torch.arange(B, device=ctx_rows.device, dtype=torch.int32).repeat_interleave(n)
-    return gather(ctx_rows, idx)
+    return _BroadcastRowsFn.apply(ctx_rows, n)
+
+
+class _BroadcastRowsFn(torch.autograd.Function):
+    """Row b of [B, C] repeated n times; backward = the sum of every sample's n consecutive rows (afm_group_sum: one fixed-order reduction per
+    sample and channel - a segment of n rows is not a job for the inverse-index plan of the general gather)."""
+
+    @staticmethod
+    def forward(ctx, rows, n):
+        rc = _c(rows)
+        B = rc.shape[0]
+        idx = torch.arange(B, device=rc.device, dtype=torch.int32).repeat_interleave(n)
+        out = torch.empty(B * n, rc.shape[1], device=rc.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_gather_rows(rc.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), rc.shape[1], _st(rc)), "afm_gather_rows")
+        ctx.dims = (B, n, rc.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, n, Cn = ctx.dims
+        dy = _c(dy)
+        d = torch.empty(B, Cn, device=dy.device, dtype=torch.float32)
+        ffi.check(ffi.load().afm_group_sum(dy.data_ptr(), d.data_ptr(), B, n, Cn, 1.0, _st(dy)), "afm_group_sum")
+        return d, None
 
 
 class _InterpolateFn(torch.autograd.Function):
@@ -182,9 +236,7 @@ class _InterpolateFn(torch.autograd.Function):
         m, c, has_base = ctx.dims
         dout = _c(dout)
         n, k = idx.shape
-        dfeat = torch.empty(m, c, device=dout.device, dtype=torch.float32)
-        ffi.check(ffi.load().afm_interpolate_bwd(dout.data_ptr(), idx.data_ptr(), d2.data_ptr(), dfeat.data_ptr(), n, m, c, k, _st(dout)),
-                  "afm_interpolate_bwd")
+        dfeat = _segment_sum(dout, 0, idx, m, c, row_div=k, d2=d2)      # deterministic form of afm_interpolate_bwd (same weights, fixed order)
         return dfeat, (dout if has_base else None), None, None
 
 
@@ -216,9 +268,7 @@ class _GroupPointsFn(torch.autograd.Function):
         dfeat = None
         if ctx.fshape is not None and ctx.needs_input_grad[2]:
             dy = _c(dy)
-            dfeat = torch.zeros(ctx.fshape, device=dy.device, dtype=torch.float32)
-            ffi.check(ffi.load().afm_scatter_add_rows(dy.data_ptr(), dy.shape[1], 3, idx.data_ptr(), dfeat.data_ptr(), idx.numel(), ctx.fshape[1],
-                                                      _st(dy)), "afm_scatter_add_rows")
+            dfeat = _segment_sum(dy, 3, idx, ctx.fshape[0], ctx.fshape[1])
         return None, None, dfeat, None, None
 
 

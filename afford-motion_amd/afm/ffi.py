@@ -189,6 +189,9 @@ EXPORTS = {
     "afm_scatter_add_rows": (C.c_int, [c_f32p, i64, i32, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),
     "afm_group_max": (C.c_int, [c_f32p, c_f32p, C.c_void_p, i64, i32, i32, C.c_void_p]),
     "afm_group_max_bwd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i64, i32, i32, C.c_void_p]),
+    "afm_scatter_plan_words": (C.c_int64, [i64, i64]),
+    "afm_scatter_plan": (C.c_int, [C.c_void_p, i64, i64, C.c_void_p, C.c_void_p]),
+    "afm_segment_sum_rows": (C.c_int, [c_f32p, i64, i32, i32, C.c_void_p, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),
     "afm_group_sum": (C.c_int, [c_f32p, c_f32p, i64, i32, i32, C.c_float, C.c_void_p]),
     "afm_pt_w0": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, C.c_void_p]),
     "afm_pt_aggregate": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, i32, C.c_void_p]),

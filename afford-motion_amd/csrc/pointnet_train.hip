@@ -271,6 +271,84 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
     }
 }
 
+// ---- deterministic scatter-add (round 6): the f32 atomics above add in arrival order (last-bit differences run to run).  The index lists of
+// this path (kNN neighbour lists, the 3-NN of the interpolation) are fixed for a whole training step and used by several backward operators,
+// so their INVERSE is built once - for every destination row the list of entries that point at it, ASCENDING - and every scatter-add becomes a
+// segmented sum in that fixed order, one thread per (destination row, channel), no atomics on floats, no zero-fill of the destination.
+// Plan = seg_off [n_dst + 1] (exclusive prefix of the per-destination counts) | seg_ent [entries] (the entries of each destination, ascending).
+// Built with integer atomics only (their results do not depend on the order): count -> scan -> fill in arrival order -> rank inside the segment.
+__global__ __launch_bounds__(256) void plan_count_kernel(const int32_t* __restrict__ idx, int64_t entries, int64_t n_dst, int32_t* __restrict__ cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < entries; e += (int64_t)gridDim.x * 256) {
+        const int32_t d = idx[e];
+        if (d >= 0 && d < n_dst) atomicAdd(cnt + d, 1);
+    }
+}
+// exclusive prefix sum of cnt [n] -> off [n + 1], one workgroup of 1024 threads (a plan is built once per index list: n <= a few 100 k);
+// cnt is left ZERO (the fill pass uses it as its cursors)
+__global__ __launch_bounds__(1024) void plan_scan_kernel(int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ off) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    int32_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int32_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = tid ? part[tid - 1] : 0;
+    for (int64_t i = lo; i < hi; ++i) { const int32_t c = cnt[i]; off[i] = run; run += c; cnt[i] = 0; }
+    if (tid == 1023) off[n] = part[1023];
+}
+__global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restrict__ idx, int64_t entries, int64_t n_dst, const int32_t* __restrict__ off,
+                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < entries; e += (int64_t)gridDim.x * 256) {
+        const int32_t d = idx[e];
+        if (d >= 0 && d < n_dst) tmp[off[d] + atomicAdd(cursor + d, 1)] = (int32_t)e;
+    }
+}
+// entry at position p of its segment -> position (number of smaller entries of the segment): the segment in ascending order, whatever order
+// the fill pass wrote it in.  One thread per entry; the threads of a segment read the same short list (kNN lists: ~k entries per destination)
+__global__ __launch_bounds__(256) void plan_rank_kernel(const int32_t* __restrict__ idx, int64_t n_dst, const int32_t* __restrict__ off,
+                                                        const int32_t* __restrict__ tmp, int32_t* __restrict__ ent) {
+    const int64_t total = off[n_dst];
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+        const int32_t e = tmp[p], d = idx[e];
+        const int32_t lo = off[d], hi = off[d + 1];
+        int32_t rank = 0;
+        for (int32_t q = lo; q < hi; ++q) rank += tmp[q] < e ? 1 : 0;
+        ent[lo + rank] = e;
+    }
+}
+// dst[d, c] = sum over the entries e of destination d, ascending, of weight(e) * src[(e / row_div) * ld + col_offset + c]
+//   weight(e) = 1, or (d2 != NULL: the interpolation's backward) w_e / sum_j w_{row, j}, w = 1 / (sqrt(d2) + 1e-8), row = e / k - the expression of
+//   interpolate_bwd_kernel, so that both forms add the same numbers
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ src, int64_t ld, int off_col, int row_div, const float* __restrict__ d2,
+                                                          const int32_t* __restrict__ seg_off, const int32_t* __restrict__ seg_ent, float* __restrict__ dst,
+                                                          int64_t n_dst, int C) {
+    const int64_t n = n_dst * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t d = i / C;
+        const int c = (int)(i - d * C);
+        float acc = 0.f;
+        const int32_t lo = seg_off[d], hi = seg_off[d + 1];
+        for (int32_t q = lo; q < hi; ++q) {
+            const int64_t e = seg_ent[q], r = e / row_div;
+            float v = src[r * ld + off_col + c];
+            if (d2) {
+                float norm = 0.f, we = 0.f;
+                for (int j = 0; j < row_div; ++j) { const float wj = 1.0f / (sqrtf(d2[r * row_div + j]) + 1e-8f); norm += wj; if (r * row_div + j == e) we = wj; }
+                v = v * (we / norm);
+            }
+            acc += v;
+        }
+        dst[i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg, int64_t m, int k, int C) {
     const int64_t n = m * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -561,6 +639,38 @@ extern "C" int afm_scatter_add_rows(const float* src, int64_t ld, int32_t col_of
     if (!src || !idx || !dst || rows < 0 || C <= 0 || ld < col_offset + C) return AFM_E_BADARG;
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
     hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, src, ld, col_offset, idx, dst, rows, C);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t afm_scatter_plan_words(int64_t entries, int64_t n_dst) {
+    if (entries < 0 || n_dst < 0 || entries >= (int64_t)1 << 31 || n_dst >= (int64_t)1 << 31) return AFM_E_BADARG;
+    return (n_dst + 1) + entries + /* scratch: counters / cursors + arrival-order list */ n_dst + entries;
+}
+
+extern "C" int afm_scatter_plan(const int32_t* idx, int64_t entries, int64_t n_dst, int32_t* plan, void* stream) {
+    if (entries < 0 || n_dst <= 0 || entries >= (int64_t)1 << 31 || n_dst >= (int64_t)1 << 31 || !plan || (entries > 0 && !idx)) return AFM_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *off = plan, *ent = plan + (n_dst + 1), *cnt = ent + entries, *tmp = cnt + n_dst;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, s);
+    if (hipMemsetAsync(cnt, 0, (size_t)n_dst * 4, s) != hipSuccess) return (int)hipGetLastError();
+    if (entries > 0) hipLaunchKernelGGL(plan_count_kernel, dim3(grid_for(entries)), dim3(256), 0, s, idx, entries, n_dst, cnt);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, n_dst, off);
+    if (entries > 0) {
+        hipLaunchKernelGGL(plan_fill_kernel, dim3(grid_for(entries)), dim3(256), 0, s, idx, entries, n_dst, off, cnt, tmp);
+        hipLaunchKernelGGL(plan_rank_kernel, dim3(grid_for(entries)), dim3(256), 0, s, idx, n_dst, off, tmp, ent);
+    }
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int afm_segment_sum_rows(const float* src, int64_t ld, int32_t col_offset, int32_t row_div, const float* dist2, const int32_t* plan, float* dst,
+                                    int64_t n_dst, int32_t C, void* stream) {
+    if (n_dst == 0) return 0;
+    if (!src || !plan || !dst || n_dst < 0 || C <= 0 || row_div <= 0 || ld < col_offset + C || (dist2 && row_div > 8)) return AFM_E_BADARG;
+    AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(n_dst * C)), dim3(256), 0, (hipStream_t)stream, src, ld, col_offset, row_div, dist2, plan,
+                       plan + (n_dst + 1), dst, n_dst, C);
     AFM_CHECK_LAUNCH();
     return 0;
 }

@@ -261,10 +261,10 @@ int afm_masked_mse(const float* target, const float* pred, const uint8_t* frame_
 /* ------------------------------------------------------------------------------------------
  * Training (backward) entry points - the kernels behind `loss.backward()` of training_losses
  * (gaussian_diffusion.py:757-823 called from utils/training.py:140-152).  Gradients are
- * deterministic (fixed-order split reductions, no atomics) with TWO stated exceptions, both scatter-adds of the point branch whose
- * reference CUDA kernels use f32 atomics as well: afm_scatter_add_rows (backward of a row gather / of the neighbour grouping) and
- * afm_interpolate_bwd (PointTrans / trans_dec decoders only).  Their sums depend on the arrival order of the atomics (last-bit
- * differences run to run); the tests compare them with tolerances and exclude them from every bit-identity assertion.
+ * deterministic (fixed-order split reductions, no atomics on floats).  The two scatter-adds of the point branch whose reference CUDA
+ * kernels use f32 atomics - the backward of a row gather / of the neighbour grouping and of the 3-NN interpolation - run as segmented sums
+ * over an inverse index built once per index list (afm_scatter_plan + afm_segment_sum_rows, ABI v7); the atomic forms
+ * (afm_scatter_add_rows, afm_interpolate_bwd) remain for callers without a plan and are the only order-dependent entry points.
  */
 
 /* out[c][r] = in[r][c] (rows x cols -> cols x rows).  The input-gradient GEMM dX = dY @ W is run as
@@ -364,6 +364,16 @@ int afm_group_points(const float* xyz, const float* new_xyz, const float* feat, 
 /* dst[idx[r], c] += src[r*ld + col_offset + c], c < C  (backward of a row gather; f32 atomics like the CUDA original) */
 int afm_scatter_add_rows(const float* src, int64_t ld, int32_t col_offset, const int32_t* idx, float* dst, int64_t rows,
                          int32_t C, void* stream);
+/* Deterministic form (ABI v7).  afm_scatter_plan: the inverse of an index list idx [entries] with values in [0, n_dst) - plan = int32 words
+ * [n_dst + 1 segment offsets | entries: the entries of every destination, ASCENDING | scratch], afm_scatter_plan_words(entries, n_dst) words in
+ * all; integer atomics only, the result does not depend on any arrival order.  afm_segment_sum_rows: dst[d, c] = sum over the entries e of
+ * destination d, in ascending order, of weight(e) * src[(e / row_div) * ld + col_offset + c]  (every destination row is WRITTEN: no zero-fill;
+ * row_div = 1: the backward of a row gather, entry = source row; row_div = k with dist2 [rows, k]: the backward of afm_interpolate, weight(e) =
+ * w_e / sum_j w_(row, j), w = 1 / (sqrt(dist2) + 1e-8)).  One plan serves every operator that scatters through the same index list. */
+int64_t afm_scatter_plan_words(int64_t entries, int64_t n_dst);
+int afm_scatter_plan(const int32_t* idx, int64_t entries, int64_t n_dst, int32_t* plan, void* stream);
+int afm_segment_sum_rows(const float* src, int64_t ld, int32_t col_offset, int32_t row_div, const float* dist2, const int32_t* plan, float* dst,
+                         int64_t n_dst, int32_t C, void* stream);
 /* nn.MaxPool1d(k) over [m, k, C] with argmax, and its backward (pointtransformer.py:66-68) */
 int afm_group_max(const float* x, float* y, int32_t* arg, int64_t m, int32_t k, int32_t C, void* stream);
 int afm_group_max_bwd(const float* dy, const int32_t* arg, float* dx, int64_t m, int32_t k, int32_t C, void* stream);

@@ -397,6 +397,82 @@ def test_batch_norm_train_forward_backward(rows, C, relu, res):
     rel("BN eval dgamma", bn.weight.grad, ref.weight.grad, 5e-5)
 
 
+def test_scatter_adds_are_deterministic_segmented_sums():
+    """Round 6: the backward of every row gather / neighbour grouping and of the 3-NN interpolation is a segmented sum over
+    the inverse of the index list (afm_scatter_plan + afm_segment_sum_rows): no f32 atomics, so repeated runs produce the SAME bits - with
+    heavily shared destinations (a coarse point that is the neighbour of hundreds of fine points), empty destinations, and an index list in
+    arbitrary order.  Checked against float64 index_add_, against the atomic entry points they replace (same numbers, other order), and
+    bit for bit across repeats; the plan itself against a stable sort of the index list."""
+    import ctypes as C
+    lib = ffi.load()
+    gen = torch.Generator().manual_seed(7)
+    n_dst, m, k, Cn = 700, 3000, 16, 40
+    idx = torch.randint(0, n_dst - 50, (m * k,), generator=gen, dtype=torch.int32)      # the last 50 destinations stay empty
+    idx[: m * k // 4] = idx[: m * k // 4] % 5                                            # five destinations with thousands of entries each
+    src = g("ss_src", (m * k, 3 + Cn))
+    want = torch.zeros(n_dst, Cn, dtype=torch.float64).index_add_(0, idx.long(), src[:, 3:].double())
+    idx_d, src_d = idx.to(dev()), src.to(dev())
+    plan = AP.scatter_plan(idx_d, n_dst)
+    assert AP.scatter_plan(idx_d, n_dst) is plan                                         # cached per index tensor
+    off, ent = plan[: n_dst + 1].cpu().long(), plan[n_dst + 1: n_dst + 1 + m * k].cpu().long()
+    order = torch.sort(idx.long(), stable=True).indices
+    assert torch.equal(ent, order) and torch.equal(off[1:] - off[:-1], torch.bincount(idx.long(), minlength=n_dst))
+    outs = [AP._segment_sum(src_d, 3, idx_d, n_dst, Cn) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    rel("segmented scatter-add vs float64 index_add_", outs[0], want, 2e-6)
+    atomic = torch.zeros(n_dst, Cn, device=dev())
+    ffi.check(lib.afm_scatter_add_rows(src_d.data_ptr(), 3 + Cn, 3, idx_d.data_ptr(), atomic.data_ptr(), m * k, Cn, None), "afm_scatter_add_rows")
+    rel("segmented vs atomic scatter-add", outs[0], atomic.double(), 2e-6)
+    # interpolation backward: k = 3 weighted entries per fine point
+    nf, mc, c3 = 5000, 300, 32
+    idx3 = torch.randint(0, mc, (nf, 3), generator=gen, dtype=torch.int32).to(dev())
+    d2 = (torch.rand(nf, 3, generator=gen) + 1e-3).to(dev())
+    dout = g("ss_dout", (nf, c3)).to(dev())
+    a = [AP._segment_sum(dout, 0, idx3, mc, c3, row_div=3, d2=d2) for _ in range(2)]
+    assert torch.equal(a[0], a[1])
+    atom = torch.empty(mc, c3, device=dev())
+    ffi.check(lib.afm_interpolate_bwd(dout.data_ptr(), idx3.data_ptr(), d2.data_ptr(), atom.data_ptr(), nf, mc, c3, 3, None), "afm_interpolate_bwd")
+    rel("segmented vs atomic interpolation backward", a[0], atom.double(), 2e-6)
+    w = 1.0 / (d2.double().sqrt() + 1e-8)
+    w = w / w.sum(1, keepdim=True)
+    want3 = torch.zeros(mc, c3, dtype=torch.float64, device=dev())
+    for j in range(3):
+        want3.index_add_(0, idx3[:, j].long(), dout.double() * w[:, j:j + 1])
+    rel("interpolation backward vs float64", a[0], want3, 2e-6)
+    # broadcast_rows: the sum over a sample's n rows (afm_group_sum), repeatable
+    rows = g("ss_rows", (4, 24)).to(dev()).requires_grad_(True)
+    dyb = g("ss_dyb", (4 * 513, 24)).to(dev())
+    grads = []
+    for _ in range(2):
+        rows.grad = None
+        (AP.broadcast_rows(rows, 513) * dyb).sum().backward()
+        grads.append(rows.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    rel("broadcast_rows backward", grads[0], dyb.double().view(4, 513, 24).sum(1), 2e-6)
+
+
+def test_two_identical_training_steps_of_the_scene_branch_are_bit_identical():
+    """DESIGN section 2 lists bit-identity as an invariant; with the segmented scatter-adds it holds for the TRAINING step of the scene branch
+    too: SceneMapEncoder in train mode (batch-statistics BatchNorm, kNN grouping backward, vector attention), forward
+    + backward twice from the same weights on the same data - every gradient tensor and the output equal bit for bit."""
+    from afm import scene as S
+    from gpu_util import load_named_weights
+    xyz, con = synth.scene_cloud(4, 1024, seed=23).to(dev()), synth.contact_map(4, 1024, seed=23).to(dev())
+    dy = g("det_dy", (4, 16, 256)).to(dev())
+    runs = []
+    for _ in range(2):
+        enc = S.SceneMapEncoder(point_feat_dim=6, planes=[32, 64, 128, 256], blocks=[2, 2, 2, 2], num_points=1024)
+        load_named_weights(enc)
+        enc = enc.to(dev()).train()
+        out = enc(xyz, con)
+        (out * dy).sum().backward()
+        runs.append((out.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1].keys() == runs[1][1].keys() and len(runs[0][1]) > 100
+    diff = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[1][1][n])]
+    assert not diff, f"{len(diff)} gradient tensors differ between two identical steps: {diff[:4]}"
+
+
 def test_gather_group_and_max_ops():
     n, m, k, C = 500, 120, 16, 24
     feat, xyz = g("gg_f", (n, C)), g("gg_p", (n, 3))
@@ -413,7 +489,7 @@ def test_gather_group_and_max_ops():
     mx = AP.group_max(gg, k)
     report("group_max", mx, mx_r, 1e-6)
     ((gg * dy.to(dev())).sum() + (mx ** 2).sum()).backward()
-    rel("group_points/max dfeat (atomic scatter-add)", fg.grad, fr.grad, 1e-5)
+    rel("group_points/max dfeat (segmented scatter-add)", fg.grad, fr.grad, 1e-5)
     f2 = feat.to(dev()).requires_grad_(True)
     (AP.gather(f2, idx.to(dev()).view(-1)) * dy[:, 3:].to(dev())).sum().backward()
     f2r = feat.double().requires_grad_(True)

@@ -166,21 +166,30 @@ def config2(quick):
             # 64 erf-GELUs per lane with two quarter-rate transcendentals each + 91 f32 MFMAs that share the VALU's issue port; ~15 k at
             # K = 44), so the roofline is issue cycles: achieved = tiles x cycles per tile / launch time against 256 CUs x 4 SIMDs x 2.4 GHz.
             us = 1e3 * prof[dom]["total_ms"] / max(prof[dom]["launches"], 1)
-            cyc = 9500.0 if "H3D" in tag else 15000.0
+            # FLOP/s like every other line: the matrix products dec_point_kernel executes per 16-point tile, counted from its
+            # tile loop (csrc/perceiver_points.hip) - v_mfma_f32_16x16x4_f32 (2048 FLOP each): scores NKS, query-variance form NT NKS, variance
+            # form (1 + NT)(4 + NKS), row-dots 64, tail 4 + NKS = 91 at NKS = 3 (H3D) / 347 at NKS = 11 (HUMANISE); linear1 as 16 NSTEP f32-equivalent
+            # 16x16x32 products (16384 FLOP each; issued as 6 bf16 MFMAs per product) - against the f32 MFMA peak, the dtype's peak
+            nks, nt, nstep = (3, 1, 1) if "H3D" in tag else (11, 3, 2)
+            f32_mfma = nks + nt * nks + (1 + nt) * (4 + nks) + 64 + 4 + nks
+            flop_tile = f32_mfma * 2048.0 + 16 * nstep * 16384.0
             tiles = B * N / 16
-            ach = tiles * cyc / (us * 1e-6) / 1e9
-            peak = 256 * 4 * 2.4
-            roof = {"bound": "valu", "kernel": dom, "avg_launch_us": round(us, 2), "achieved": round(ach, 1), "peak": round(peak, 1),
-                    "unit": "G issue-cycles/s", "frac": round(ach / peak, 4),
+            ach = tiles * flop_tile / (us * 1e-6) / 1e12
+            cyc = 9500.0 if "H3D" in tag else 15000.0
+            roof = {"bound": "mfma", "kernel": dom, "avg_launch_us": round(us, 2), "achieved": round(ach, 2), "peak": 157.3,
+                    "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "flops_per_launch": tiles * flop_tile,
                     "traffic": pmc_traffic("cdm" if "H3D" in tag else "cdm_h", dom.split("<")[0]),
                     "algorithmic_bytes_per_launch": B * N * (9 + 6) * 4,          # a point's 9 inputs read, its 6 outputs written (+ the per-sample tables)
-                    "model": f"{cyc:.0f} VALU/MFMA issue cycles per 16-point tile per wave (instruction count of the kernel's tile loop), one wave per tile"}
+                    "counting": f"{f32_mfma} v_mfma_f32_16x16x4_f32 + {16 * nstep} f32-equivalent 16x16x32 products (x 6 bf16 MFMAs) per 16-point tile; the erf-GELU of 256 hidden "
+                                "channels per point (VALU) is not counted as FLOPs",
+                    "issue_model": {"note": "what actually bounds the kernel: VALU + MFMA issue slots", "cycles_per_tile": cyc,
+                                    "frac_of_issue_peak": round(tiles * cyc / (us * 1e-6) / 1e9 / (256 * 4 * 2.4), 4)}}
         lines.append({"config": f"configs[2] CDM Perceiver, B=32, N=8192, text token, 1 MI355X: {tag}", "metric": "denoising steps/sec", "value": round(1 / dt, 2), "roofline": roof,
                       "ms_per_step": round(1e3 * dt, 4), "dtype": "f32", "as_written_tflops": round(313.4e9 / dt / 1e12, 1),
                       "formulation": ("row-less sampling form (csrc/perceiver_points.hip): a point is its K = 12 / 44 inputs [x_t | features | 1] and 16 decoder attention "
                                       "weights; the 256-wide rows of the reference (adapters, LayerNorms, attention output, the MLP's input and hidden row) are never "
                                       "generated - enc_point / lat_head / 11 toklin launches / lat_dectables / dec_point per step; executed per step ~3 GF on the f32 "
-                                      "matrix pipe + 2.4 GF x 9 bf16 products (linear1 as a K = 28 / 60 product); CDM.no_gen = round 2's folded rows, CDM.no_fold = "
+                                      "matrix pipe + 2.4 GF x 6 bf16 products (linear1 as a K = 28 / 60 product, six-product arithmetic); CDM.no_gen = round 2's folded rows, CDM.no_fold = "
                                       "layer by layer (115 GF per step)"),
                       "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items()}})
         del model
@@ -225,6 +234,23 @@ def config4(quick):
             "as_written_pflop": round((d_adm.num_timesteps * 313.4e9 + d_amdm.num_timesteps * 257e9) / 1e15, 3)}
 
 
+def training_block(quick=True):
+    """SURVEY 8 row f-3 made driver-visible: one optimisation step of the FULL AMDM (trunk + SceneMapEncoder over 8192 points,
+    B = 32, L = 196, train mode: dropout on, batch-statistics BatchNorm) = training_losses forward + backward + AdamW (utils/training.py:140-155),
+    measured by tools/bench_train.py's function: steps/s, the step's dominant kernel with its `roofline`, the step against the f32 MFMA peak."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("afm_bench_train", os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_train.py"))
+    bt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bt)
+    r = bt.measure_cmdm(32, 196, True, 6 if quick else 20, 2 if quick else 3, 0, dev)
+    keep = ("config", "metric", "value", "ms_per_step", "samples_per_sec", "executed_tflops", "step_frac_of_f32_mfma_peak", "roofline", "trainable_params")
+    out = {k: r[k] for k in keep if k in r}
+    top = sorted(r["kernels_ms_per_step"].items(), key=lambda kv: -kv[1])[:8]
+    out["top_kernels_ms_per_step"] = dict(top)
+    out["gradients"] = "deterministic: every reduction in a fixed order, the scatter-adds of the point branch as segmented sums (tests/test_gpu_train.py::test_two_identical_training_steps_of_the_scene_branch_are_bit_identical)"
+    return out
+
+
 def secondary_block(quick=True):
     """The `secondary` object of bench.py's JSON line (N = 1 only, after the headline, outside its timed region): every BASELINE config the
     headline does not cover, measured by the same driver-run process.  `quick`: bounded repetitions (the whole block stays within ~1-2 min;
@@ -233,6 +259,7 @@ def secondary_block(quick=True):
     ffi.load()
     out = {"note": "N = 1 only; measured after the headline by the same process, outside its timed region; tools/bench_configs.py functions"}
     for key, fn in (("configs[4]", lambda: config4(False)), ("configs[2]", lambda: config2(quick)), ("configs[3]", lambda: config3(quick)),
+                    ("training", lambda: training_block(quick)),
                     ("configs[0]", lambda: config0(quick, cpu=True))):      # BASELINE configs[0] IS the reference's CPU path: the oracle on the host cores, bounded (20 hoisted steps, one faithful step, ~10 s)
         try:
             out[key] = fn()

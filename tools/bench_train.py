@@ -89,30 +89,19 @@ def main_cdm(a, dev):
     print(json.dumps(out))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=196)
-    ap.add_argument("--cpu-steps", type=int, default=1)
-    ap.add_argument("--cdm", action="store_true", help="train the ADM (CDM Perceiver over N=8192 points) instead of the AMDM")
-    ap.add_argument("--scene", action="store_true", help="train the SceneMapEncoder too (N=8192 points per sample, batch-statistics BatchNorm)")
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
-    B, L = a.batch, a.frames
-    if a.cdm:
-        return main_cdm(a, dev)
+def measure_cmdm(B, L, scene, steps, warmup, cpu_steps, dev):
+    """One training-step measurement of the AMDM (trunk, or trunk + SceneMapEncoder with `scene`) -> the JSON object of this tool; also the
+    `training` entry of bench.py's `secondary` block (tools/bench_configs.py::training_block)."""
     cfg = load_config("text_to_motion_contact_motion_gen", "cmdm", ["model.data_repr=h3d", "model.input_feats=263", "diffusion.steps=1000"])
     model, diff = create_model_and_diffusion(cfg, device=dev)
     synth.fill_module_(model)
     model = model.to(dev).train()
-    if not a.scene:
+    if not scene:
         model.contact_encoder.requires_grad_(False)
     params = [p for p in model.parameters() if p.requires_grad]
     x0 = synth.gaussian("bt_x0", (B, L, 263)).to(dev)
     kw = dict(c_text_feat=synth.text_feature(B).to(dev), x_mask=synth.frame_mask(B, L).to(dev))
-    if a.scene:
+    if scene:
         kw.update(c_pc_xyz=synth.scene_cloud(B, 8192).to(dev), c_pc_contact=synth.contact_map(B, 8192).to(dev))
     else:
         kw.update(c_cont_emb=(synth.gaussian("bt_cont", (B, 128, 256)) * 0.5).to(dev))
@@ -129,14 +118,14 @@ def main():
         AG.adamw_step(params, state, lr=1e-4)
         return loss
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
+    dt = (time.perf_counter() - t0) / steps
     ffi.profile_enable(True); ffi.profile_read()
     for _ in range(3):
         step()
@@ -147,18 +136,42 @@ def main():
     gemm = 2.0 * M * d * (3 * d + d + 2 * ff) * 5 + 2.0 * B * L * 263 * d * 2
     attn = 4.0 * B * 8 * T * T * 64 * 5
     flops = 3 * gemm + attn * (1 + 7 / 2)          # fwd + dX + dW GEMMs; attention fwd (2 products) + bwd (7 products)
-    what = "CMDM full-model (trunk + SceneMapEncoder over N=8192 points)" if a.scene else "CMDM trunk"
+    what = "CMDM full-model (trunk + SceneMapEncoder over N=8192 points)" if scene else "CMDM trunk"
     out = {"config": f"{what} training step, B={B}, L={L}, T={T} tokens, f32, train mode (dropout on), 1 MI355X",
            "metric": "optimisation steps/sec", "value": round(1 / dt, 3), "ms_per_step": round(1e3 * dt, 3), "samples_per_sec": round(B / dt, 1),
            "final_loss": round(loss.item(), 4), "executed_tflops": round(flops / dt / 1e12, 1),
            "trainable_params": sum(p.numel() for p in params),
            "kernels_ms_per_step": {k: round(v["total_ms"] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
            "kernels_tflops": {k: round(v["total_work"] / (v["total_ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["total_work"] > 0 and v["total_ms"] > 0}}
-    if a.cpu_steps > 0 and not a.scene:
-        cdt, nt = cpu_baseline(B, L, a.cpu_steps)
+    if cpu_steps > 0 and not scene:
+        cdt, nt = cpu_baseline(B, L, cpu_steps)
         out["cpu_baseline"] = {"value": round(1 / cdt, 4), "unit": "steps/s", "cores": nt, "kind": "port",
-                               "sample": f"{a.cpu_steps} forward+backward step(s) of the oracle restatement (torch autograd, f32), same B/L"}
-    print(json.dumps(out))
+                               "sample": f"{cpu_steps} forward+backward step(s) of the oracle restatement (torch autograd, f32), same B/L"}
+    # roofline of the step's dominant kernel (by time, among the kernels whose work is counted): f32-equivalent FLOPs against the f32 MFMA peak
+    counted = {k: v for k, v in prof.items() if v["total_work"] > 0 and v["total_ms"] > 0}
+    if counted:
+        k = max(counted, key=lambda n: counted[n]["total_ms"])
+        ach = counted[k]["total_work"] / (counted[k]["total_ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+                           "avg_launch_us": round(1e3 * counted[k]["total_ms"] / counted[k]["launches"], 2), "launches_per_step": counted[k]["launches"] // 3, "traffic": None}
+    out["step_frac_of_f32_mfma_peak"] = round(flops / dt / 1e12 / 157.3, 4)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=196)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cdm", action="store_true", help="train the ADM (CDM Perceiver over N=8192 points) instead of the AMDM")
+    ap.add_argument("--scene", action="store_true", help="train the SceneMapEncoder too (N=8192 points per sample, batch-statistics BatchNorm)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    if a.cdm:
+        return main_cdm(a, dev)
+    print(json.dumps(measure_cmdm(a.batch, a.frames, a.scene, a.steps, a.warmup, a.cpu_steps, dev)))
 
 
 if __name__ == "__main__":
