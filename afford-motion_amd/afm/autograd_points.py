@@ -131,17 +131,17 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, *, relu: bool = False, residual: Opt
 # Deterministic scatter-adds (round 6): the backward of every row gather is a segmented sum over the INVERSE of its index list
 # (afm_scatter_plan: for every destination row its entries, ascending), built once per index tensor and shared by every operator that
 # scatters through it (the k / v / position gathers and the grouping of a layer use ONE kNN list) - no f32 atomics, so two training steps on
-# the same data produce the same bits.  The cache is keyed by the index TENSOR OBJECT (a weak reference: an address alone could be a recycled
-# allocation with other contents) and a miss only costs a rebuild.
+# the same data produce the same bits.  The cache is keyed by (address, size, destinations) and HOLDS the index tensor (autograd hands the
+# backward a new Python object for the same storage, so object identity would miss every time; while the entry lives the address cannot be
+# recycled for other contents), checks the tensor's version counter, and keeps the most recent 48 lists.
 _PLANS: dict = {}
 
 
 def scatter_plan(idx: torch.Tensor, n_dst: int) -> torch.Tensor:
     """int32 plan of afm_scatter_plan for `idx` (any shape, flattened) over `n_dst` destination rows."""
-    import weakref
-    key = (id(idx), int(n_dst))
+    key = (idx.data_ptr(), idx.numel(), int(n_dst), str(idx.device))
     hit = _PLANS.get(key)
-    if hit is not None and hit[0]() is idx and hit[1] == idx._version:
+    if hit is not None and hit[1] == idx._version:
         return hit[2]
     lib = ffi.load()
     words = lib.afm_scatter_plan_words(idx.numel(), int(n_dst))
@@ -149,10 +149,10 @@ def scatter_plan(idx: torch.Tensor, n_dst: int) -> torch.Tensor:
         ffi.check(int(words), "afm_scatter_plan_words")
     plan = torch.empty(int(words), dtype=torch.int32, device=idx.device)
     ffi.check(lib.afm_scatter_plan(idx.data_ptr(), idx.numel(), int(n_dst), plan.data_ptr(), _st(idx)), "afm_scatter_plan")
-    if len(_PLANS) > 64:                               # entries of dead tensors
-        for k_ in [k_ for k_, v_ in _PLANS.items() if v_[0]() is None]:
-            del _PLANS[k_]
-    _PLANS[key] = (weakref.ref(idx), idx._version, plan)
+    _PLANS.pop(key, None)
+    while len(_PLANS) >= 48:                           # (dicts keep insertion order: the oldest list goes first)
+        _PLANS.pop(next(iter(_PLANS)))
+    _PLANS[key] = (idx, idx._version, plan)
     return plan
 
 

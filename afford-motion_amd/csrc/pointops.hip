@@ -22,11 +22,17 @@
 int afm_probe_fps_threads = 0;
 int afm_probe_fps_prune = -1;                           // 0: plain fps_kernel even where the pruned one applies; 256 / 512 / 1024: its threads
 __device__ unsigned long long afm_probe_fps_cyc[8];     // summed phase cycles of wave 0 of workgroup 0 (tools/points_probe.hip)
+__device__ int afm_probe_fps_rounds[4];                 // [rounds of workgroup 0, picks taken as 1st / 2nd+ ...] (tools/fps_ks_probe.hip)
 #endif
 #ifdef AFM_PROBE_TIMELINE      // with -DAFM_PROBE: per-phase cycle stamps inside the FPS round (they lengthen the round by ~15 %)
 #define AFM_FPS_STAMP(k) do { if (probe_) { const unsigned long long t_ = __builtin_readcyclecounter(); cyc_[k] += t_ - last_; last_ = t_; } } while (0)
 #else
 #define AFM_FPS_STAMP(k) do { } while (0)
+#endif
+
+#ifndef AFM_FPS_KS
+#define AFM_FPS_KS 1             // samples per round of fps_pruned_kernel: 1 in the library.  KS = 2 / 4 / 8 (tools/fps_ks_probe.hip builds) are exact - same indices,
+                                 // 2047 -> 1082 / 663 / 571 rounds at n = 8192, m = 2048 - and NOT faster: 1.48 -> 1.54 / 1.53 / 1.63 ms (profiles/r06_fps_speculation.md)
 #endif
 
 namespace {
@@ -154,7 +160,20 @@ __device__ __forceinline__ unsigned morton_part10(unsigned x) {
     return x;
 }
 
-template <int PPT, int T>
+// KS > 1 (round 6): up to KS samples PER ROUND.  A round's cost is its dependent chain (winner's coordinates -> box test -> scan -> wave arg-max ->
+// LDS hop -> barrier -> cross-wave arg-max: ~1500 cycles), and the chain of m - 1 rounds is the kernel.  But the point with the SECOND largest
+// running minimum is almost always far from the one with the largest: if its distance to the new sample is not below its own running minimum, that
+// minimum does not change, every other minimum can only shrink, and it IS the next sample - provably, not heuristically (keys are (distance
+// bits, lowest index), all unique).  So a round takes the best point, then the next best while that one is unaffected by every point taken before it
+// in the round (checked with the same float expression the scan uses), and the next round scans with all of them as centres.  What a wave
+// publishes is its best key and the distance bits of its SECOND best point: a candidate from another wave is only taken while its distance is
+// strictly above the second-best distance of every wave whose best was already taken (whose other points are not published).  Measured on
+// the synthetic scenes (profiles/r06_fps_speculation.md): 2047 rounds -> 1082 / 663 / 571 with KS = 2 / 4 / 8 (n = 8192, m = 2048), the sampled
+// indices identical by construction and by test (tests/test_gpu_points.py ran green on a KS = 4 build) - and the kernel NO faster: a round grows
+// from 0.72 to 1.42 / 2.31 / 2.85 us.  The 16 waves of a sample share ONE compute unit, whose four SIMDs issue every wave's per-round
+// instructions: the uniform selection logic of an extra sample (~50 instructions, executed by all 16 waves, plus a box test per centre and
+// wave) costs the CU as many issue slots as the whole one-sample round.  Kept as a measured form (AFM_FPS_KS), not compiled into the library.
+template <int PPT, int T, int KS = 1>
 __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
     constexpr int CAP = T * PPT, NP = PPT / 2;
     static_assert(PPT % 2 == 0 && PPT <= 32 && T % 64 == 0 && T <= 1024, "cell sizes");
@@ -247,6 +266,121 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
             boi = min(boi, min(tmpb[s2] == bd ? oi[s2] : 0xFFFFFFFFu, tmpb[s2 + 1] == bd ? oi[s2 + 1] : 0xFFFFFFFFu));
     };
     cell_argmax();
+    if constexpr (KS > 1) {
+        __shared__ uint4 rec[2][16];                  // per wave: (best distance bits, ~lowest index, second-best distance bits of the wave, -)
+        unsigned long long bestk = 0ull;              // this wave's best key and second-best distance, kept across the rounds in which the wave skips
+        unsigned sec = 0u;
+        int ncen = 1;
+        int cen[KS];
+        float ccx[KS], ccy[KS], ccz[KS];
+#pragma unroll
+        for (int c = 0; c < KS; ++c) { cen[c] = 0; ccx[c] = pts[0]; ccy[c] = pts[1]; ccz[c] = pts[2]; }
+        if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
+        int j = 1, round = 0;
+        while (j < m) {
+            bool scanned = false;
+#pragma unroll
+            for (int c = 0; c < KS; ++c) {
+                if (c < ncen) {                                       // wave-uniform
+                    const float cx = ccx[c], cy = ccy[c], cz = ccz[c];
+                    // lower bound of every computed distance of the cell (same operations, same association as the scan); `bd` may be stale
+                    // (too large) after an earlier centre of this round: the test is then only more often true
+                    const float ex = fmaxf(fmaxf(clo[0] - cx, cx - chi[0]), 0.f), ey = fmaxf(fmaxf(clo[1] - cy, cy - chi[1]), 0.f), ez = fmaxf(fmaxf(clo[2] - cz, cz - chi[2]), 0.f);
+                    const float lb = (ex * ex + ey * ey) + ez * ez;
+                    const bool need = cell_ok && __float_as_uint(lb) < bd;
+                    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                        const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+#pragma unroll
+                        for (int p2 = 0; p2 < NP; ++p2) {
+                            const f32x2 dx = px[p2] - cx2, dy = py[p2] - cy2, dz = pz[p2] - cz2;
+                            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                            tmpb[2 * p2] = min(tmpb[2 * p2], __float_as_uint(d[0]));
+                            tmpb[2 * p2 + 1] = min(tmpb[2 * p2 + 1], __float_as_uint(d[1]));
+                        }
+                        scanned = true;
+                    }
+                }
+            }
+            if (scanned) cell_argmax();
+            if (scanned || round == 0) {
+                const unsigned wmax = wave_max_u32(cell_ok ? bd : 0u);
+                const unsigned long long holders = __builtin_amdgcn_ballot_w64(cell_ok && bd == wmax);
+                bestk = 0ull; sec = 0u;
+                if (holders) {
+                    unsigned wbi;
+                    if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)boi, __builtin_ctzll(holders));
+                    else wbi = wave_min_u32((cell_ok && bd == wmax) ? boi : 0xFFFFFFFFu);
+                    bestk = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
+                    // second-best DISTANCE of the wave: every point but the best one (wmax, wbi); a second point at the same distance counts
+                    unsigned v2 = cell_ok ? bd : 0u;
+                    if (cell_ok && bd == wmax && boi == wbi) {
+                        v2 = 0u;
+#pragma unroll
+                        for (int s2 = 0; s2 < PPT; ++s2) v2 = max(v2, oi[s2] == wbi ? 0u : tmpb[s2]);
+                    }
+                    sec = wave_max_u32(v2);
+                }
+            }
+            if (lane == 0) rec[round & 1][wave] = make_uint4((unsigned)(bestk >> 32), (unsigned)bestk, sec, 0u);
+            __syncthreads();
+            // ---- cross-wave: up to KS picks in key order (every wave computes them redundantly from the published records: no second barrier)
+            const bool has = (lane & 15) < nw;
+            const uint4 rw = rec[round & 1][has ? (lane & 15) : 0];
+            unsigned khi = has ? rw.x : 0u, klo = has ? rw.y : 0u;
+            const unsigned ksec = has ? rw.z : 0u;
+            unsigned thr = 0u;                            // largest second-best distance among the waves whose best was taken this round
+            int nacc = 0;
+            const int room = m - j < KS ? m - j : KS;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                if (i < room && (i == 0 || nacc == i)) {              // wave-uniform: still extending the prefix
+                    unsigned gm = khi;
+                    gm = max(gm, dpp_u32<0xB1>(gm)); gm = max(gm, dpp_u32<0x4E>(gm)); gm = max(gm, dpp_u32<0x141>(gm)); gm = max(gm, dpp_u32<0x140>(gm));
+                    unsigned long long hold = __builtin_amdgcn_ballot_w64(has && lane < 16 && khi == gm);
+                    if (hold & (hold - 1)) {                          // several waves at this distance: the lowest index (largest ~index)
+                        const unsigned wlo = wave_max_u32((has && lane < 16 && khi == gm) ? klo : 0u);
+                        hold = __builtin_amdgcn_ballot_w64(has && lane < 16 && khi == gm && klo == wlo);
+                    }
+                    const int wl = __builtin_ctzll(hold | (1ull << 63)) & 15;
+                    const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)khi, wl), lo_i = (unsigned)__builtin_amdgcn_readlane((int)klo, wl);
+                    const unsigned sec_i = (unsigned)__builtin_amdgcn_readlane((int)ksec, wl);
+                    const int ci = (int)(0xFFFFFFFFu - lo_i);
+                    bool ok = true;
+                    float qx = 0.f, qy = 0.f, qz = 0.f;
+                    if (i > 0) ok = hi_i > thr;                       // (strictly above: a point at the same distance in a taken wave could come first; also excludes distance 0)
+                    if (ok) {
+                        qx = pts[ci * 3 + 0]; qy = pts[ci * 3 + 1]; qz = pts[ci * 3 + 2];
+#pragma unroll
+                        for (int a = 0; a < KS; ++a) {
+                            if (a < i && ok) {                        // unaffected by every point taken before it: the scan's own expression, point minus centre
+                                const float dx = qx - ccx[a], dy = qy - ccy[a], dz = qz - ccz[a];
+                                const float d = (dx * dx + dy * dy) + dz * dz;
+                                ok = __float_as_uint(d) >= hi_i;
+                            }
+                        }
+                    }
+                    if (ok) {
+                        cen[i] = ci; ccx[i] = qx; ccy[i] = qy; ccz[i] = qz;
+                        nacc = i + 1;
+                        thr = max(thr, sec_i);
+                        if ((lane & 15) == wl) { khi = 0u; klo = 0u; }         // taken (all four row copies)
+                    }
+                }
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i)
+                    if (i < nacc) idx_out[(int64_t)b * m + j + i] = b * n + cen[i];
+            }
+            ncen = nacc;
+            j += nacc;
+            ++round;
+        }
+#ifdef AFM_PROBE
+        if (blockIdx.x == 0 && tid == 0) afm_probe_fps_rounds[0] = round;
+#endif
+        return;
+    }
     int cur = 0;
     unsigned long long best = 0ull;                   // this wave's key, kept across the rounds in which the wave skips
     if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
@@ -513,10 +647,10 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
 #define AFM_FPS_PRUNED(P, PT_)                                                                                                          \
     do {                                                                                                                            \
         if (lds > 48 * 1024) {                                                                                                      \
-            hipError_t e__ = hipFuncSetAttribute((const void*)fps_pruned_kernel<P, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            hipError_t e__ = hipFuncSetAttribute((const void*)fps_pruned_kernel<P, PT_, AFM_FPS_KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             if (e__ != hipSuccess) return (int)e__;                                                                                 \
         }                                                                                                                           \
-        hipLaunchKernelGGL((fps_pruned_kernel<P, PT_>), dim3(B), dim3(PT_), lds, s, xyz, n, m, idx_out);                            \
+        hipLaunchKernelGGL((fps_pruned_kernel<P, PT_, AFM_FPS_KS>), dim3(B), dim3(PT_), lds, s, xyz, n, m, idx_out);                \
     } while (0)
 #define AFM_FPS_PRUNED_T(PT_)                                                                                                           \
     do {                                                                                                                            \

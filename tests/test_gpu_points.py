@@ -34,11 +34,14 @@ def test_fps_ties_pick_lowest_index():
     assert torch.equal(got, want) and got.max() < 64
 
 
-@pytest.mark.parametrize("n,shift,m", [(8192, 70, 600), (2048, 33, 300), (512, 1, 256)])
+@pytest.mark.parametrize("n,shift,m", [(8192, 70, 600), (2048, 33, 300), (512, 1, 256), (4096, 17, 3000), (8192, 4097, 8192)])
 def test_fps_ties_across_lanes_and_waves(n, shift, m):
     """Every point twice, the copies `shift` rows apart: the two holders of every maximum sit in different lanes and (n = 8192: 4 waves,
     n = 2048: 1 wave of 32-point threads) different waves, so each round exercises the tie paths of the wave-level and of the workgroup-level
-    arg-max (ballot with more than one holder -> lowest index).  Bit-exact against the oracle."""
+    arg-max (ballot with more than one holder -> lowest index).  m above the number of DISTINCT points (round 6: 3000 of 2048, 8192 of 4096) runs
+    the rounds in which every remaining minimum is zero - where the several-samples-per-round form of fps_pruned_kernel must stop extending a
+    round (a candidate is only taken while its distance is strictly above the second-best distance of the waves already taken from, which
+    excludes distance 0).  Bit-exact against the oracle."""
     from oracle import pointops_ref as po
     base = synth.scene_cloud(1, n // 2, seed=27).reshape(n // 2, 3)
     p = torch.cat([base, base.roll(shift, 0)], 0).contiguous()
