@@ -533,6 +533,22 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
         self._text_cache = (HeldKey((tf,), extra), lat, text)
         return lat
 
+    def _text_similarity(self, pf: torch.Tensor, kwargs, like) -> torch.Tensor:
+        """openscene text-similarity feature (cdm.py:500-503): pc_emb[b, n, 0] = <c_pc_feat[b, n, :], text_emb[b, :]> - one afm_linear per sample
+        ([n, d] x [1, d]: the thin-layer stream kernel), step-invariant, so cached like the backbone features while the same tensors are passed."""
+        tf = kwargs.get("c_text_feat")
+        extra = (None if isinstance(tf, torch.Tensor) else tuple(kwargs["c_text"]),)
+        cache = getattr(self, "_sim_cache", None)
+        if cache is not None and cache[0].matches((pf, tf), extra):
+            return cache[1]
+        text = ffi.f32c(self.encode_text(kwargs).to(like.device))                     # [B, d]
+        pfc = ffi.f32c(pf.to(like))
+        if pfc.shape[-1] != text.shape[-1]:
+            raise ffi.AfmError(f"openscene text-similarity: point features are {pfc.shape[-1]}-wide, the text feature {text.shape[-1]}-wide")
+        sim = torch.stack([ops.linear(pfc[b], text[b:b + 1]) for b in range(pfc.shape[0])])      # [B, n, 1]
+        self._sim_cache = (HeldKey((pf, tf), extra), sim)
+        return sim
+
     def _scene_features(self, xyz, col, like) -> torch.Tensor:
         """Frozen PointTransformerSeg features of the scene batch; step-invariant (the reference re-runs the backbone in every step,
         cdm.py:508), so cached while the SAME live tensors are passed again (`HeldKey` keeps them alive: a freed batch's address
@@ -551,9 +567,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             parts.append(self._scene_features(xyz, col, x))
         elif self.point_feat_dim > 0:
             pf = kwargs["c_pc_feat"]
-            if self.point_feat_dim == 1 and pf.shape[-1] != 1:
-                raise NotImplementedError("openscene text-similarity feature (cdm.py:500-503)")
-            parts.append(pf.to(x))
+            parts.append(self._text_similarity(pf, kwargs, x) if (self.point_feat_dim == 1 and pf.shape[-1] != 1) else pf.to(x))
         if self.contact_model.point_pos_emb:
             parts.append(kwargs["c_pc_xyz"].to(x))
         return torch.cat(parts, dim=-1).contiguous()
@@ -681,9 +695,7 @@ class CDM(_FlatParamsMixin, TextEncoderMixin, nn.Module):
             return self._scene_features(xyz, col, x)
         if self.point_feat_dim > 0:
             pf = kwargs["c_pc_feat"]
-            if self.point_feat_dim == 1 and pf.shape[-1] != 1:
-                raise NotImplementedError("openscene text-similarity feature (cdm.py:500-503)")
-            return pf.to(x)
+            return self._text_similarity(pf, kwargs, x) if (self.point_feat_dim == 1 and pf.shape[-1] != 1) else pf.to(x)
         return None
 
     def forward_mlp(self, x, timesteps, **kwargs):

@@ -216,6 +216,29 @@ def test_config4_full_size_properties():
             assert torch.equal(got, whole[name]), f"{name}: {shards} shards of {per} samples differ from the single batch of {K}"
 
 
+def test_openscene_text_similarity_feature():
+    """cdm.py:500-503: with scene_model.use_openscene and point_feat_dim = 1, wide per-point features are reduced to ONE channel - their inner
+    product with the sample's text feature (einsum 'b n d, b m d -> b n m').  Here: one afm_linear per sample, cached while the same tensors
+    are passed; the denoiser's input block and a forward agree with the einsum in float64 / with the same model fed the reduced channel."""
+    B, N = 3, 512
+    m = create_model(cdm_cfg(num_points=N, point_feats=True, point_feat_dim=1), device=dev())
+    load_named_weights(m)
+    m = m.to(dev()).eval()
+    wide = synth.gaussian("os_feat", (B, N, 512)).to(dev())
+    text = synth.text_feature(B).to(dev())
+    want = torch.einsum("bnd,bd->bn", wide.double(), text.double()).unsqueeze(-1)
+    x, t = synth.gaussian("os_x", (B, N, 6)).to(dev()), torch.tensor([5, 250, 499], device=dev())
+    kw = dict(c_text_feat=text, c_pc_xyz=synth.scene_cloud(B, N, seed=8).to(dev()), c_pc_feat=wide)
+    feat = m._features(x, kw)
+    assert feat.shape == (B, N, 6 + 1 + 3)
+    report("openscene text similarity channel", feat[..., 6:7], want, 2e-4)
+    assert m._features(x, kw)[..., 6:7].data_ptr() != 0 and m._sim_cache is not None          # second call: served from the cache
+    out = m(x, t, **kw)
+    out_ref = m(x, t, **dict(kw, c_pc_feat=feat[..., 6:7].contiguous()))
+    assert torch.isfinite(out).all()
+    report("forward with the wide features vs the reduced channel", out, out_ref, 1e-5)
+
+
 def test_pipelined_sub_batches_are_bit_identical():
     """Round 6: AFM_CDM_PIPELINE - the point kernels of all sub-batches in round-robin order on ONE stream, every sub-batch's latent chain on its
     own side stream between two events (a fixed-phase software pipeline instead of free-running sub-batch streams).  Samples are
