@@ -283,25 +283,57 @@ __global__ __launch_bounds__(256) void plan_count_kernel(const int32_t* __restri
         if (d >= 0 && d < n_dst) atomicAdd(cnt + d, 1);
     }
 }
-// exclusive prefix sum of cnt [n] -> off [n + 1], one workgroup of 1024 threads (a plan is built once per index list: n <= a few 100 k);
-// cnt is left ZERO (the fill pass uses it as its cursors)
-__global__ __launch_bounds__(1024) void plan_scan_kernel(int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ off) {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024, lo = tid * per, hi = lo + per < n ? lo + per : n;
-    int32_t s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += cnt[i];
-    part[tid] = s;
+// exclusive prefix sum of cnt [n] -> off [n + 1] in three small launches (a single workgroup walking 262144 counters serially cost 250 us per index
+// list - 2 ms of a training step): (a) sums of blocks of 1024 counters, (b) their exclusive scan by one workgroup, (c) the scan inside every block
+// plus its block offset.  cnt is left ZERO (the fill pass uses it as its cursors).
+constexpr int PLAN_BLK = 1024;                            // counters per block (256 threads x 4)
+__device__ __forceinline__ int32_t plan_block_scan(int32_t v, int32_t* lds, int* total) {      // exclusive scan of one value per thread over 256 threads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) lds[wave] = x;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan of the 1024 partial sums
-        const int32_t v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + x - v;
+}
+__global__ __launch_bounds__(256) void plan_blocksum_kernel(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ bsum) {
+    __shared__ int32_t lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * PLAN_BLK + threadIdx.x * 4;
+    int32_t s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += i0 + u < n ? cnt[i0 + u] : 0;
+    int total;
+    (void)plan_block_scan(s, lds, &total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void plan_scan_blocks_kernel(int32_t* __restrict__ bsum, int64_t nblk, int32_t* __restrict__ off_last) {
+    __shared__ int32_t lds[4];
+    int32_t carry = 0;
+    for (int64_t b0 = 0; b0 < nblk; b0 += 256) {              // (nblk <= 256 for every index list of this path: one trip)
+        const int64_t b = b0 + threadIdx.x;
+        const int32_t v = b < nblk ? bsum[b] : 0;
+        int total;
+        const int32_t ex = plan_block_scan(v, lds, &total);
+        if (b < nblk) bsum[b] = carry + ex;
+        carry += total;
     }
-    int32_t run = tid ? part[tid - 1] : 0;
-    for (int64_t i = lo; i < hi; ++i) { const int32_t c = cnt[i]; off[i] = run; run += c; cnt[i] = 0; }
-    if (tid == 1023) off[n] = part[1023];
+    if (threadIdx.x == 0) *off_last = carry;                  // off[n]: the number of valid entries
+}
+__global__ __launch_bounds__(256) void plan_scan_kernel(int32_t* __restrict__ cnt, int64_t n, const int32_t* __restrict__ bsum, int32_t* __restrict__ off) {
+    __shared__ int32_t lds[4];
+    const int64_t i0 = (int64_t)blockIdx.x * PLAN_BLK + threadIdx.x * 4;
+    int32_t c[4], s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { c[u] = i0 + u < n ? cnt[i0 + u] : 0; s += c[u]; }
+    int total;
+    int32_t run = bsum[blockIdx.x] + plan_block_scan(s, lds, &total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (i0 + u < n) { off[i0 + u] = run; run += c[u]; cnt[i0 + u] = 0; }
 }
 __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t* __restrict__ idx, int64_t entries, int64_t n_dst, const int32_t* __restrict__ off,
                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
@@ -645,7 +677,7 @@ extern "C" int afm_scatter_add_rows(const float* src, int64_t ld, int32_t col_of
 
 extern "C" int64_t afm_scatter_plan_words(int64_t entries, int64_t n_dst) {
     if (entries < 0 || n_dst < 0 || entries >= (int64_t)1 << 31 || n_dst >= (int64_t)1 << 31) return AFM_E_BADARG;
-    return (n_dst + 1) + entries + /* scratch: counters / cursors + arrival-order list */ n_dst + entries;
+    return (n_dst + 1) + entries + /* scratch: counters / cursors + arrival-order list + block sums of the scan */ n_dst + entries + (n_dst / PLAN_BLK + 1);
 }
 
 extern "C" int afm_scatter_plan(const int32_t* idx, int64_t entries, int64_t n_dst, int32_t* plan, void* stream) {
@@ -655,7 +687,11 @@ extern "C" int afm_scatter_plan(const int32_t* idx, int64_t entries, int64_t n_d
     AfmProf prof(AFM_PROF_POINT_TRAIN, 0.0, s);
     if (hipMemsetAsync(cnt, 0, (size_t)n_dst * 4, s) != hipSuccess) return (int)hipGetLastError();
     if (entries > 0) hipLaunchKernelGGL(plan_count_kernel, dim3(grid_for(entries)), dim3(256), 0, s, idx, entries, n_dst, cnt);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, n_dst, off);
+    const int64_t nblk = (n_dst + PLAN_BLK - 1) / PLAN_BLK;
+    int32_t* bsum = tmp + entries;
+    hipLaunchKernelGGL(plan_blocksum_kernel, dim3((unsigned)nblk), dim3(256), 0, s, cnt, n_dst, bsum);
+    hipLaunchKernelGGL(plan_scan_blocks_kernel, dim3(1), dim3(256), 0, s, bsum, nblk, off + n_dst);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3((unsigned)nblk), dim3(256), 0, s, cnt, n_dst, bsum, off);
     if (entries > 0) {
         hipLaunchKernelGGL(plan_fill_kernel, dim3(grid_for(entries)), dim3(256), 0, s, idx, entries, n_dst, off, cnt, tmp);
         hipLaunchKernelGGL(plan_rank_kernel, dim3(grid_for(entries)), dim3(256), 0, s, idx, n_dst, off, tmp, ent);

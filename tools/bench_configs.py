@@ -179,7 +179,9 @@ def config2(quick):
             roof = {"bound": "mfma", "kernel": dom, "avg_launch_us": round(us, 2), "achieved": round(ach, 2), "peak": 157.3,
                     "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "flops_per_launch": tiles * flop_tile,
                     "traffic": pmc_traffic("cdm" if "H3D" in tag else "cdm_h", dom.split("<")[0]),
-                    "algorithmic_bytes_per_launch": B * N * (9 + 6) * 4,          # a point's 9 inputs read, its 6 outputs written (+ the per-sample tables)
+                    # per point: x_t (6 floats) + xyz (3) + the DDPM update's noise (6) read, x_{t-1} (6) written = 84 B (+ the per-sample tables);
+                    # the 3 xyz floats sit in 36-byte feature rows, so a row-granular fetch moves 108 B per point
+                    "algorithmic_bytes_per_launch": B * N * (6 + 3 + 6 + 6) * 4, "row_granular_bytes_per_launch": B * N * (6 + 9 + 6 + 6) * 4,
                     "counting": f"{f32_mfma} v_mfma_f32_16x16x4_f32 + {16 * nstep} f32-equivalent 16x16x32 products (x 6 bf16 MFMAs) per 16-point tile; the erf-GELU of 256 hidden "
                                 "channels per point (VALU) is not counted as FLOPs",
                     "issue_model": {"note": "what actually bounds the kernel: VALU + MFMA issue slots", "cycles_per_tile": cyc,
