@@ -103,6 +103,44 @@ __global__ __launch_bounds__(256, AFM_WALK_LB) void gemm_f32_split_bf16_walk(con
     }
 }
 
+// ---- WIDE (round 6; MEASUREMENT, tile code 13): a 256 x 128 tile on 512 threads = 4 x 2 waves, each wave the 64 x 64 wave tile of the 128 x 128 program.
+// Per matrix instruction the workgroup stages 25 % fewer operand rows (384 rows for 32 wave-tiles against 256 for 16: global loads, split VALU, LDS stores);
+// the price is one workgroup per CU (139 KB of LDS: the staged accumulators outgrow the operand stages) whose eight waves meet at every K16 barrier.
+// Same tile program text, same products in the same order: bit-identical to every other tile shape.
+template <int NPROD>
+__global__ __launch_bounds__(512, 1) void gemm_f32_split_bf16_wide(const afm_linear_args p, int nbm, int nbn) {
+    constexpr int BM = 256, BN = 128, BKS = 16, KG = 1, RING = 2, GSEG = 1;
+#define AFM_BODY_WM 4
+#define AFM_WG ((int)blockIdx.x)
+#define AFM_TIDX threadIdx.x
+#define AFM_TIMELINE_SLOT blockIdx.x
+#include "gemm_split_body.inc"
+#undef AFM_WG
+#undef AFM_TIDX
+#undef AFM_TIMELINE_SLOT
+#undef AFM_BODY_WM
+}
+
+template <int NPROD>
+int launch_split_wide(const afm_linear_args& a, hipStream_t s) {
+    constexpr int BM = 256, BN = 128, BKS = 16;
+    constexpr int STAGE = 3 * (BM + BN) * (BKS * 2 + 16);
+    constexpr int OPER = 2 * STAGE > BM * (BN + 4) * 4 ? 2 * STAGE : BM * (BN + 4) * 4;
+    constexpr int LDS_BYTES = OPER + 2 * BM * 2 * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
+    if (a.ln_out) return AFM_E_UNSUPPORTED;                 // (the fused LayerNorm's tickets are per 128-row block at most)
+    if (a.aux_dst && a.aux_rows > (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)) return AFM_E_UNSUPPORTED;      // one rider row per workgroup
+    static const int attr = []() {
+        return (int)hipFuncSetAttribute((const void*)gemm_f32_split_bf16_wide<NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }();
+    if (attr != 0) return attr;
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    AfmProf prof(AFM_PROF_GEMM_SPLIT128, 2.0 * a.M * a.N * a.K, s);
+    hipLaunchKernelGGL((gemm_f32_split_bf16_wide<NPROD>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, a, nbm, nbn);
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- PAIR (round 6): two independent problems in ONE grid of 128 x 128 tiles.  Workgroups [0, tiles0) run problem 0's tiles, workgroups
 // [start1, start1 + tiles1) problem 1's (start1 = tiles0 rounded up to a multiple of 8, so that a tile's XCD - blockIdx.x & 7 - is what the
 // tile program's XCD-aware tile order assumes; the < 8 workgroups in between exit at once).  The tile program is the text every other kernel
@@ -236,6 +274,7 @@ int dispatch_split(const afm_linear_args& a, hipStream_t s) {
     // steps/s in one call).  Round 3 also measured 128x64 / 64x128 tiles in the CMDM loop: 431 / 437 steps/s against 449 for this rule.
     const bool full_rounds = tiles128 * 10 >= rounds * resident * 9 && a.K > KSEG;      // >= 90 % of the resident slots used over all rounds
     if (tile == 12) return launch_split_walk<NPROD>(a, s);          // measurement: force the walking form
+    if (tile == 13) return launch_split_wide<NPROD>(a, s);          // measurement: the 256 x 128 tile on 512 threads
     if (tile == 3 || (tile != 5 && !full_rounds)) {
         const int64_t tiles64w = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
         if (tile != 3 && AFM_WALK_GRID > 0 && tiles64w > AFM_WALK_GRID) return launch_split_walk<NPROD>(a, s);      // (A/B builds only: AFM_WALK_GRID is 0 in the library)

@@ -163,7 +163,7 @@ typedef struct {
 #define AFM_ARITH_BF16X9  9
 
 #define AFM_TUNE_NO_DMA      0x1     /* register-staged operand loads instead of global_load_lds                         */
-#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128, 7 = 64x64 with the K segments split over wave groups, 8 = weight-stationary 64-column slabs (row-dot launches with K = 256), 9 = 64x64 on three LDS stages, 10 = split-K on three LDS stages (K = 1024: two groups x two segments), 11 = split-K two groups x two segments on two stages, 12 = 64x64 tiles WALKED by 768 resident workgroups (bf16-split arithmetic) */
+#define AFM_TUNE_TILE_SHIFT  4       /* bits 4..7: force the workgroup tile: 1 = 32x32, 2 = 32x64, 3 = 64x64, 4 = 64x128, 5 = 128x128, 7 = 64x64 with the K segments split over wave groups, 8 = weight-stationary 64-column slabs (row-dot launches with K = 256), 9 = 64x64 on three LDS stages, 10 = split-K on three LDS stages (K = 1024: two groups x two segments), 11 = split-K two groups x two segments on two stages, 12 = 64x64 tiles WALKED by 768 resident workgroups (bf16-split arithmetic), 13 = 256x128 tiles on 512 threads (bf16-split arithmetic; round 6, measurement) */
 #define AFM_TUNE_TILE_MASK   0xF0
 
 int afm_linear(const afm_linear_args* args, void* stream);

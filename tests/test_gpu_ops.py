@@ -147,7 +147,7 @@ def test_linear_fused_layernorm_is_bit_identical_to_two_launches(M, N, K):
     report(f"fused linear+LN {M}x{N}x{K}", ln_out, ref, 2e-4)
 
 
-@pytest.mark.parametrize("M,tile", [(10432, 0), (1304, 0), (777, 3), (5216, 5), (326, 7)])
+@pytest.mark.parametrize("M,tile", [(10432, 0), (1304, 0), (777, 3), (5216, 5), (326, 7), (5216, 13), (3136, 13)])
 def test_linear_layernorm_folded_across_launches(M, tile):
     """ABI v5 (afm_linear_args.stat_out / a_stat / res_stat): a post-LN encoder layer without LayerNorm launches.  The producer stores its
     RAW output and per-row, per-64-column (mean, M2); the next linear runs on the raw rows with gamma folded into its weight and applies
@@ -297,7 +297,7 @@ def test_linear_tile_shapes_are_bit_identical(M, N, K):
         if K == 1024:
             kg += (11,)
         if K >= 128 and K % 16 == 0:
-            kg += (9, 12)                                                # sequential 64x64 on three LDS stages; 64x64 tiles walked by resident workgroups
+            kg += (9, 12, 13)                                            # sequential 64x64 on three LDS stages; 64x64 tiles walked by resident workgroups; round 6: 256x128 tiles on 512 threads
         for products, tiles in ((0, (0, 1, 2, 3, 4, 5)), (9, (0, 3, 5) + kg), (6, (0, 3, 5) + kg)):
             ops.set_gemm_split(products, 0)
             outs = []
