@@ -174,3 +174,12 @@ def test_scene_map_encoder_full_size_vs_oracle():
     got = enc(xyz.to(dev()), contact.to(dev()))
     assert got.shape == (B, 128, 256)
     report("SceneMapEncoder N=8192 vs oracle", got, want, 2e-4)
+    # round 6: the inference path computes FPS / kNN of all levels on a side stream under the feature passes (the training path's geometry
+    # pyramid); same kernels on the same inputs - bit-identical to the level-by-level form, also for a batch and on repeats
+    xb, cb = synth.scene_cloud(3, N, seed=78).to(dev()), synth.contact_map(3, N, seed=78).to(dev())
+    outs = []
+    for overlap in (True, False, True):
+        enc.overlap_geometry = overlap
+        outs.append(enc(xb, cb).clone())
+    enc.overlap_geometry = True
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
