@@ -209,6 +209,8 @@ EXPORTS = {
     "afm_adamw": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_void_p]),
     "afm_fps": (C.c_int, [c_f32p, i32, i32, i32, C.c_void_p, C.c_void_p]),
     "afm_knn": (C.c_int, [i32, c_f32p, c_f32p, i32, i32, i32, C.c_void_p, c_f32p, C.c_void_p]),
+    "afm_knn_workspace_bytes": (C.c_int64, [i32, i32, i32, i32]),
+    "afm_knn_ws": (C.c_int, [i32, c_f32p, c_f32p, i32, i32, i32, C.c_void_p, c_f32p, C.c_void_p, i64, C.c_void_p]),
     "afm_gather_rows": (C.c_int, [c_f32p, C.c_void_p, c_f32p, i64, i32, C.c_void_p]),
     "afm_interpolate": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, i64, i32, i32, C.c_void_p]),
     "afm_segment_mean": (C.c_int, [c_f32p, c_f32p, i32, i32, i32, C.c_void_p]),

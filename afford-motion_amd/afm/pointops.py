@@ -30,9 +30,31 @@ def knn(k: int, xyz: torch.Tensor, new_xyz: torch.Tensor, batch: int, n: int, m:
     assert xyz.shape == (batch * n, 3) and new_xyz.shape == (batch * m, 3)
     idx = torch.empty(batch * m, k, dtype=torch.int32, device=xyz.device)
     d2 = torch.empty(batch * m, k, dtype=torch.float32, device=xyz.device)
+    nbytes = lib.afm_knn_workspace_bytes(k, batch, n, m) if PRUNED_KNN else 0
+    if nbytes < 0:
+        ffi.check(int(nbytes), "afm_knn_workspace_bytes")
+    if nbytes > 0:                                       # exact spatial pruning (round 6): Morton-sorted candidate tiles with bounding boxes; same indices, same order
+        ws = _knn_workspace(int(nbytes), xyz.device)
+        ffi.check(lib.afm_knn_ws(k, xyz.data_ptr(), new_xyz.data_ptr(), batch, n, m, idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 ffi.stream_of(xyz)), "afm_knn_ws")
+        return idx, d2
     ffi.check(lib.afm_knn(k, xyz.data_ptr(), new_xyz.data_ptr(), batch, n, m, idx.data_ptr(), d2.data_ptr(),
                           ffi.stream_of(xyz)), "afm_knn")
     return idx, d2
+
+
+PRUNED_KNN = True            # host-side measurement switch: False = the plain all-pairs kernel everywhere (bit-identical results)
+_KNN_WS: dict = {}
+
+
+def _knn_workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch of afm_knn_ws (sorted copies + tile boxes), one growing buffer per device AND stream (a buffer shared by two streams would be
+    overwritten by the second call while the first still reads it: the training path runs its neighbour searches on a side stream)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _KNN_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _KNN_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -533,6 +533,240 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
     }
 }
 
+// ---------------------------------------------------------------- kNN with an EXACT spatial pruning (round 6)
+// knn_kernel above evaluates every (query, candidate) pair: 2048 x 8192 x 32 samples = 537 M distances for configs[3]'s neighbour lists (0.59 ms),
+// 2.1 G for the level-1 lists (0.82 ms).  Here the candidates of a sample are sorted along a Morton curve once (knn_sort_kernel: bitonic sort in LDS, as
+// fps_pruned_kernel does) and cut into TILES of 64 consecutive sorted points with a bounding box each; the queries are sorted the same way, so the 64
+// queries of a wave are neighbours in space.  A wave first scans the tiles whose box meets the box of its own queries, then walks the remaining
+// tiles and scans one only if, for some lane, the squared distance from the query to the tile's box - computed with the SAME float operations and
+// association as the point distances (rounding is monotonic: a lower bound of every computed distance in the tile) - is not above the lane's current
+// k-th distance.  Visiting order no longer is index order, so the k best are kept as 64-bit keys (distance bits << 32 | original index): unsigned
+// order = (d2, index) lexicographic order (distances are >= +0), the order the plain kernel's strict '<' on ascending indices produces.  Same
+// distances bit for bit, same neighbours in the same order - tests/test_gpu_points.py compares both kernels with the oracle and with each other.
+constexpr int KNN_TS = 64;                              // candidates per tile: one wave-wide load
+
+// grid (B, 2): y = 0 sorts the candidates (and writes the tile boxes), y = 1 the queries (skipped when they are the candidates).  out4[i] = (x, y, z, bits of the
+// original index) of the i-th point along the curve.  Dynamic LDS: 2 x cap words (cap = n rounded up to a power of two, <= 8192).
+__global__ __launch_bounds__(1024) void knn_sort_kernel(const float* __restrict__ xyz, int n, const float* __restrict__ qxyz, int m, int cap_c, int cap_q,
+                                                        float4* __restrict__ cs4, float* __restrict__ tbox, float4* __restrict__ qs4) {
+    constexpr int T = 1024, nw = T / 64;
+    __shared__ float bb[6][16];
+    extern __shared__ unsigned knn_sort_lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool isq = blockIdx.y == 1;
+    if (isq && !qs4) return;
+    const int cnt = isq ? m : n, CAP = isq ? cap_q : cap_c;
+    const float* P = (isq ? qxyz : xyz) + (int64_t)b * cnt * 3;
+    float4* out4 = (isq ? qs4 : cs4) + (int64_t)b * cnt;
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < cnt; i += T) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = P[i * 3 + a]; lo3[a] = fminf(lo3[a], v); hi3[a] = fmaxf(hi3[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], o)); hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], o)); }
+        if (lane == 0) { bb[a][wave] = lo3[a]; bb[3 + a][wave] = hi3[a]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = bb[a][0], h = bb[3 + a][0];
+        for (int w2 = 1; w2 < nw; ++w2) { l = fminf(l, bb[a][w2]); h = fmaxf(h, bb[3 + a][w2]); }
+        lo3[a] = l; hi3[a] = 1023.0f / fmaxf(h - l, 1e-12f);          // hi3 now holds the quantisation scale (any order gives the same neighbours)
+    }
+    unsigned* kk = knn_sort_lds;
+    unsigned* vv = kk + CAP;
+    for (int i = tid; i < CAP; i += T) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < cnt) {
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float f = (P[i * 3 + a] - lo3[a]) * hi3[a]; q[a] = (unsigned)min(1023, max(0, (int)f)); }
+            key = morton_part10(q[0]) | (morton_part10(q[1]) << 1) | (morton_part10(q[2]) << 2);
+        }
+        kk[i] = key; vv[i] = i < cnt ? (unsigned)i : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CAP; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < CAP; i += T) {
+                const int x = i ^ jj;
+                if (x > i) {
+                    const unsigned ka = kk[i], kb = kk[x];
+                    if ((ka > kb) == ((i & k) == 0)) { kk[i] = kb; kk[x] = ka; const unsigned va = vv[i]; vv[i] = vv[x]; vv[x] = va; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < cnt; i += T) {
+        const unsigned o = vv[i];
+        out4[i] = make_float4(P[o * 3 + 0], P[o * 3 + 1], P[o * 3 + 2], __uint_as_float(o));
+    }
+    if (!isq) {                                          // boxes of the tiles of 64 consecutive sorted candidates: one wave per tile
+        const int nt = (cnt + KNN_TS - 1) / KNN_TS;
+        for (int t = wave; t < nt; t += nw) {
+            const int i = t * KNN_TS + lane;
+            const bool ok = i < cnt;
+            const unsigned o = ok ? vv[i] : 0u;
+            float l[3], h[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float v = P[o * 3 + a]; l[a] = ok ? v : INFINITY; h[a] = ok ? v : -INFINITY; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) { l[a] = fminf(l[a], __shfl_xor(l[a], o2)); h[a] = fmaxf(h[a], __shfl_xor(h[a], o2)); }
+            }
+            if (lane == 0) {
+                float* tb = tbox + ((int64_t)b * nt + t) * 6;
+                tb[0] = l[0]; tb[1] = l[1]; tb[2] = l[2]; tb[3] = h[0]; tb[4] = h[1]; tb[5] = h[2];
+            }
+        }
+    }
+}
+
+// A wave = 16 queries x 4 candidate SUB-SLOTS (lane = query + 16 * sub-slot): the sixteen queries are consecutive along the curve (a box sixteen
+// points wide prunes far better than one 64 points wide: the first form of this kernel, 64 queries per wave, scanned 35-46 of 128 tiles and was slower than
+// the plain kernel), every lane evaluates a quarter of a scanned tile's 64 candidates and keeps its own K best; the bound a lane prunes with is the
+// smallest k-th key of its query's four lists (K candidates are known to lie at or below each of them).  At the end the four sorted lists of a query
+// are merged by rank: a key's position in the union is its position in its own list plus the number of smaller keys in the other three.
+template <int K>
+__global__ __launch_bounds__(256) void knn_pruned_kernel(const float4* __restrict__ cs4, const float* __restrict__ tbox, const float4* __restrict__ qs4, int n, int m,
+                                                         int nt, int* __restrict__ idx_out, float* __restrict__ d2_out) {
+    constexpr int BUF = 8;
+    constexpr unsigned long long EMPTY = ((unsigned long long)0x7F800000u << 32) | 0xFFFFFFFFull;      // (+inf, no index): nothing real is above it
+    __shared__ float4 tile[4][KNN_TS];
+    __shared__ unsigned long long buf[4][BUF + 1][64];                  // [wave][entry][lane], row BUF = dump row
+    __shared__ unsigned long long mk[4][K][64];                         // the sorted lists at the end: [wave][position][lane]
+    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qi = lane & 15, sub = lane >> 4;
+    const int qs = (blockIdx.x * 4 + wave) * 16 + qi;
+    const bool valid = qs < m;
+    const float4 Q = qs4[(int64_t)b * m + (valid ? qs : m - 1)];        // slots past the end repeat the last query (a neighbour in space: prunes like it)
+    const float qx = Q.x, qy = Q.y, qz = Q.z;
+    const int qorig = (int)__float_as_uint(Q.w);
+    unsigned long long bk[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) bk[j] = EMPTY;
+    int cnt = 0;
+    auto flush = [&]() {
+        for (int e = 0; e < BUF; ++e) {
+            if (!__any(e < cnt)) break;                              // wave-uniform
+            const unsigned long long key = e < cnt ? buf[wave][e][lane] : ~0ull;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {                        // sorted insert on (distance bits, index): keys are unique
+                const bool up = key < bk[j - 1];
+                const bool here = key < bk[j];
+                bk[j] = up ? bk[j - 1] : (here ? key : bk[j]);
+            }
+            bk[0] = key < bk[0] ? key : bk[0];
+        }
+        cnt = 0;
+    };
+    auto offer = [&](float d, unsigned idbits) {                     // append if it beats the (possibly stale) k-th key: re-checked at the drain
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | idbits;
+        const bool take = key < bk[K - 1];
+        buf[wave][take ? cnt : BUF][lane] = key;
+        cnt += take ? 1 : 0;
+    };
+    const float4* C = cs4 + (int64_t)b * n;
+    const float* TB = tbox + (int64_t)b * nt * 6;
+    auto scan_tile = [&](int t) {
+        const int i0 = t * KNN_TS;
+        // candidate j of the tile goes to slot (j & 15) * 4 + (j >> 4): the four sub-slots read four ADJACENT float4 per step (one 64-byte broadcast read)
+        tile[wave][qi * 4 + sub] = i0 + lane < n ? C[i0 + lane] : make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xFFFFFFFFu));
+        __builtin_amdgcn_wave_barrier();                             // (LDS operations of one wave complete in order: the reads below see the tile)
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const float4 c0 = tile[wave][i * 4 + sub], c1 = tile[wave][(i + 1) * 4 + sub], c2 = tile[wave][(i + 2) * 4 + sub], c3 = tile[wave][(i + 3) * 4 + sub];
+            const float ax = qx - c0.x, ay = qy - c0.y, az = qz - c0.z;
+            const float bx = qx - c1.x, by = qy - c1.y, bz = qz - c1.z;
+            const float ex = qx - c2.x, ey = qy - c2.y, ez = qz - c2.z;
+            const float fx = qx - c3.x, fy = qy - c3.y, fz = qz - c3.z;
+            const float d0 = (ax * ax + ay * ay) + az * az, d1 = (bx * bx + by * by) + bz * bz;
+            const float d2 = (ex * ex + ey * ey) + ez * ez, d3 = (fx * fx + fy * fy) + fz * fz;
+            offer(d0, __float_as_uint(c0.w)); offer(d1, __float_as_uint(c1.w)); offer(d2, __float_as_uint(c2.w)); offer(d3, __float_as_uint(c3.w));
+            if (__any(cnt > BUF - 4)) flush();
+        }
+        __builtin_amdgcn_wave_barrier();                             // every lane has read the tile before the next one overwrites it
+    };
+    // ---- box of this wave's sixteen queries (every sub-slot holds the same sixteen)
+    float wl[3] = {qx, qy, qz}, wh[3] = {qx, qy, qz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        wl[a] = fminf(wl[a], lane_xor<1>(wl[a])); wl[a] = fminf(wl[a], lane_xor<2>(wl[a])); wl[a] = fminf(wl[a], lane_xor<4>(wl[a])); wl[a] = fminf(wl[a], lane_xor<8>(wl[a]));
+        wh[a] = fmaxf(wh[a], lane_xor<1>(wh[a])); wh[a] = fmaxf(wh[a], lane_xor<2>(wh[a])); wh[a] = fmaxf(wh[a], lane_xor<4>(wh[a])); wh[a] = fmaxf(wh[a], lane_xor<8>(wh[a]));
+    }
+    // ---- pass 1: the tiles whose box meets the wave's box (its own neighbourhood: fills the k best with near points)
+    unsigned long long seen[2] = {0ull, 0ull};                       // nt <= 128
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = h * 64 + lane;
+        bool hit = false;
+        if (t < nt) {
+            const float* tb = TB + t * 6;
+            hit = tb[0] <= wh[0] && tb[3] >= wl[0] && tb[1] <= wh[1] && tb[4] >= wl[1] && tb[2] <= wh[2] && tb[5] >= wl[2];
+        }
+        seen[h] = __builtin_amdgcn_ballot_w64(hit);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long mkk = seen[h];
+        while (mkk) {                                                // wave-uniform
+            const int t = h * 64 + __builtin_ctzll(mkk);
+            mkk &= mkk - 1;
+            scan_tile(t);
+        }
+    }
+    flush();
+    // the bound of a query: the smallest k-th distance of its four lists (refreshed after every scan; stale = only ever too large)
+    auto bound = [&]() {
+        float kd = __uint_as_float((unsigned)(bk[K - 1] >> 32));
+        kd = fminf(kd, xor16(kd));
+        return fminf(kd, xor32(kd));
+    };
+    float kd = bound();
+    // ---- pass 2: every other tile, scanned only if some lane's lower bound is not above its query's bound
+    for (int t = 0; t < nt; ++t) {
+        if ((seen[t >> 6] >> (t & 63)) & 1ull) continue;             // wave-uniform
+        const float* tb = TB + t * 6;                                // uniform address: scalar loads
+        const float ex = fmaxf(fmaxf(tb[0] - qx, qx - tb[3]), 0.f), ey = fmaxf(fmaxf(tb[1] - qy, qy - tb[4]), 0.f), ez = fmaxf(fmaxf(tb[2] - qz, qz - tb[5]), 0.f);
+        const float lb = (ex * ex + ey * ey) + ez * ez;
+        if (__builtin_amdgcn_ballot_w64(lb <= kd) != 0ull) {
+            scan_tile(t);
+            flush();
+            kd = bound();
+        }
+    }
+    // ---- merge the four lists of every query by rank
+#pragma unroll
+    for (int j = 0; j < K; ++j) mk[wave][j][lane] = bk[j];
+    __builtin_amdgcn_wave_barrier();
+    int rank[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) rank[j] = j;
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+        const int other = qi + 16 * ((sub + o) & 3);
+        unsigned long long ok[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) ok[i] = mk[wave][i][other];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int i = 0; i < K; ++i) rank[j] += ok[i] < bk[j] ? 1 : 0;
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (rank[j] < K && (unsigned)bk[j] != 0xFFFFFFFFu) {         // (n >= 1024 > K: the K best of the union are real points)
+                idx_out[((int64_t)b * m + qorig) * K + rank[j]] = b * n + (int)(unsigned)bk[j];
+                d2_out[((int64_t)b * m + qorig) * K + rank[j]] = __uint_as_float((unsigned)(bk[j] >> 32));
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
                                                           float* __restrict__ out, int64_t rows, int c) {
     const int64_t total = rows * c;
@@ -718,6 +952,52 @@ extern "C" int afm_knn(int32_t k, const float* xyz, const float* new_xyz, int32_
         case 8: hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;
         case 16: hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, s, xyz, new_xyz, n, m, idx_out, dist2_out); break;
         default: return AFM_E_UNSUPPORTED;
+    }
+    AFM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Workspace of afm_knn_ws: sorted candidates (float4) + tile boxes + sorted queries (float4); 0 = the pruned form does not apply (plain kernel, no workspace)
+// Measured (round 6, B = 32, one call; pruned vs plain): self-search 8192 x 8192, k = 8: 0.604 vs 0.827 ms - the only shape of this path where the pruned form wins;
+// 8192 -> 2048, k = 16: 0.858 vs 0.586; self 2048, k = 16: 0.395 vs 0.181; 2048 <- 8192 queries, k = 3: 0.284 vs 0.196 (sort + box walk + key bookkeeping cost more
+// than the ~4-6 x fewer pair evaluations save: 8192 points in a room are too few for tiles of 64 to be small against the k-NN radius).  So: large self-searches only.
+static bool knn_pruned_applies(int k, int n, int m) { return (k == 3 || k == 8 || k == 16) && n >= 4096 && n <= 8192 && m >= n && m <= 8192; }
+extern "C" int64_t afm_knn_workspace_bytes(int32_t k, int32_t B, int32_t n, int32_t m) {
+    if (B < 0 || n <= 0 || m < 0) return AFM_E_BADARG;
+    if (!knn_pruned_applies(k, n, m)) return 0;
+    const int64_t nt = (n + KNN_TS - 1) / KNN_TS;
+    return (int64_t)B * n * 16 + ((int64_t)B * nt * 6 * 4 + 255) / 256 * 256 + (int64_t)B * m * 16;
+}
+
+extern "C" int afm_knn_ws(int32_t k, const float* xyz, const float* new_xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, float* dist2_out,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!xyz || !new_xyz || !idx_out || !dist2_out || B < 0 || n <= 0 || m < 0) return AFM_E_BADARG;
+    if (B == 0 || m == 0) return 0;
+    if (!knn_pruned_applies(k, n, m) || !workspace) return afm_knn(k, xyz, new_xyz, B, n, m, idx_out, dist2_out, stream);
+    if (workspace_bytes < afm_knn_workspace_bytes(k, B, n, m) || ((uintptr_t)workspace & 15)) return AFM_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = (n + KNN_TS - 1) / KNN_TS;
+    char* wp = (char*)workspace;
+    float4* cs4 = (float4*)wp; wp += (int64_t)B * n * 16;
+    float* tbox = (float*)wp; wp += ((int64_t)B * nt * 6 * 4 + 255) / 256 * 256;
+    const bool self = new_xyz == xyz && m == n;
+    float4* qs4 = self ? nullptr : (float4*)wp;
+    int cap_c = 1024, cap_q = 1024;
+    while (cap_c < n) cap_c <<= 1;
+    while (cap_q < m) cap_q <<= 1;
+    const size_t lds = (size_t)2 * (cap_c > cap_q ? cap_c : cap_q) * sizeof(unsigned);
+    AfmProf prof(AFM_PROF_KNN, (double)B * m * n, s);
+    if (lds > 48 * 1024) {
+        static const int attr = (int)hipFuncSetAttribute((const void*)knn_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 4);
+        if (attr != 0) return attr;
+    }
+    hipLaunchKernelGGL(knn_sort_kernel, dim3(B, self ? 1 : 2), dim3(1024), lds, s, xyz, n, new_xyz, m, cap_c, cap_q, cs4, tbox, qs4);
+    const dim3 grid((m + 63) / 64, B), block(256);              // 16 queries per wave, 4 waves per workgroup
+    const float4* q4 = self ? cs4 : qs4;
+    switch (k) {
+        case 3: hipLaunchKernelGGL(knn_pruned_kernel<3>, grid, block, 0, s, cs4, tbox, q4, n, m, nt, idx_out, dist2_out); break;
+        case 8: hipLaunchKernelGGL(knn_pruned_kernel<8>, grid, block, 0, s, cs4, tbox, q4, n, m, nt, idx_out, dist2_out); break;
+        default: hipLaunchKernelGGL(knn_pruned_kernel<16>, grid, block, 0, s, cs4, tbox, q4, n, m, nt, idx_out, dist2_out); break;
     }
     AFM_CHECK_LAUNCH();
     return 0;

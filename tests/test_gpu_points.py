@@ -68,6 +68,39 @@ def test_knn_bit_exact(k, B, n, m):
     assert torch.equal(gd.cpu(), wd)
 
 
+@pytest.mark.parametrize("k,B,n,m,dup", [(8, 2, 8192, 8192, False), (16, 2, 8192, 8192, True), (3, 1, 4096, 8192, False), (16, 3, 5000, 5000, False),
+                                         (8, 1, 4100, 4100, True), (16, 2, 8192, 2048, False), (3, 2, 2048, 8192, False)])
+def test_knn_pruned_equals_plain_kernel_and_oracle(k, B, n, m, dup):
+    """Round 6: afm_knn_ws - Morton-sorted candidate tiles with bounding boxes, wave-level skipping, the k best as (distance bits, index) keys -
+    against the plain all-pairs kernel (afm_knn) bit for bit, indices AND distances, and against the oracle: ragged tile counts (n = 5000, 4100), more
+    queries than candidates, self-search, shapes the pruned form does not take (they fall through to the plain kernel), and DUPLICATED points (every point twice, copies far apart in index: ties in d2 must
+    come out in index order although the tiles are not visited in index order)."""
+    from oracle import pointops_ref as po
+    p = synth.scene_cloud(B, n, seed=31).reshape(B * n, 3)
+    if dup:
+        h = n // 2
+        p = p.view(B, n, 3).clone()
+        p[:, h:2 * h] = p[:, :h].roll(17, 1)
+        p = p.reshape(B * n, 3).contiguous()
+    q = p if m == n else (p.view(B, n, 3)[:, torch.randperm(n, generator=torch.Generator().manual_seed(5))[:m]].reshape(B * m, 3).contiguous() if dup and m <= n
+                          else synth.scene_cloud(B, m, seed=32).reshape(B * m, 3))
+    pd, qd = p.to(dev()), (None if m == n else q.to(dev()))
+    qd = pd if qd is None else qd
+    assert pointops.PRUNED_KNN
+    gi, gd = pointops.knn(k, pd, qd, B, n, m)
+    pointops.PRUNED_KNN = False
+    try:
+        pi, pdist = pointops.knn(k, pd, qd, B, n, m)
+    finally:
+        pointops.PRUNED_KNN = True
+    assert torch.equal(gi, pi), f"{(gi != pi).sum().item()} of {gi.numel()} indices differ from the plain kernel"
+    assert torch.equal(gd, pdist)
+    o = torch.arange(1, B + 1, dtype=torch.int32) * n
+    no = torch.arange(1, B + 1, dtype=torch.int32) * m
+    wi, wd = po.knn_query(k, p, q, o, no)
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
+
+
 @pytest.mark.parametrize("stride", [4, 8])
 def test_transition_down_vs_reference_golden(stride):
     g = golden(f"transition_down_s{stride}")
