@@ -473,7 +473,12 @@ static int sample_loop_impl(const afm_cmdm_weights* w, float* x, const float* co
     Recorder* recs = nullptr;
     if (paired) {
         for (int i = 0; i < NEV; ++i)
-            if (hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+            if (hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) {
+                const int rc_ev = (int)hipGetLastError();
+                for (int u = 0; u < i; ++u) (void)hipEventDestroy(pev[u]);          // nothing created so far may leak
+                if (fork) (void)hipEventDestroy(fork);
+                return rc_ev;
+            }
         recs = new Recorder[2];
     }
     for (int j = 0; j < n_steps && rc == 0; ++j) {

@@ -681,6 +681,7 @@ extern "C" int64_t afm_scatter_plan_words(int64_t entries, int64_t n_dst) {
 }
 
 extern "C" int afm_scatter_plan(const int32_t* idx, int64_t entries, int64_t n_dst, int32_t* plan, void* stream) {
+    if (n_dst == 0 && entries == 0) return 0;                   // empty batch: nothing to invert
     if (entries < 0 || n_dst <= 0 || entries >= (int64_t)1 << 31 || n_dst >= (int64_t)1 << 31 || !plan || (entries > 0 && !idx)) return AFM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     int32_t *off = plan, *ent = plan + (n_dst + 1), *cnt = ent + entries, *tmp = cnt + n_dst;

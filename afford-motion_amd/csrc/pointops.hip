@@ -35,6 +35,11 @@ __device__ int afm_probe_fps_rounds[4];                 // [rounds of workgroup 
                                  // 2047 -> 1082 / 663 / 571 rounds at n = 8192, m = 2048 - and NOT faster: 1.48 -> 1.54 / 1.53 / 1.63 ms (profiles/r06_fps_speculation.md)
 #endif
 
+#ifndef AFM_FPS_CELLS
+#define AFM_FPS_CELLS 1          // cells per thread of the pruned FPS: 1 = fps_pruned_kernel on 1024 threads (the library); 2 / 4 = fps_cells_kernel on 512 / 256 threads
+                                 // (probe builds): identical indices, 1.48 -> 1.72 / 2.30 ms at n = 8192, m = 2048 (profiles/r06_fps_speculation.md)
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -412,6 +417,175 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
                 unsigned wbi;
                 if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)boi, __builtin_ctzll(holders));
                 else wbi = wave_min_u32((cell_ok && bd == wmax) ? boi : 0xFFFFFFFFu);
+                best = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
+            }
+        }
+        if (lane == 0) keys[j & 1][wave] = best;
+        __syncthreads();
+        const bool has = (lane & 15) < nw;
+        const unsigned long long kw = keys[j & 1][has ? (lane & 15) : 0];
+        const unsigned khi = has ? (unsigned)(kw >> 32) : 0u, klo = has ? (unsigned)kw : 0u;
+        unsigned gm = khi;
+        gm = max(gm, dpp_u32<0xB1>(gm)); gm = max(gm, dpp_u32<0x4E>(gm)); gm = max(gm, dpp_u32<0x141>(gm)); gm = max(gm, dpp_u32<0x140>(gm));
+        const unsigned long long hold2 = __builtin_amdgcn_ballot_w64(has && lane < 16 && khi == gm);
+        unsigned wlo;
+        if ((hold2 & (hold2 - 1)) == 0) wlo = (unsigned)__builtin_amdgcn_readlane((int)klo, __builtin_ctzll(hold2 | (1ull << 63)));
+        else wlo = wave_max_u32((has && khi == gm) ? klo : 0u);
+        cur = __builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu - wlo));
+        if (tid == 0) idx_out[(int64_t)b * m + j] = b * n + cur;
+    }
+}
+
+// ---------------------------------------------------------------- FPS, several cells per thread (round 6)
+// A TEST of the hypothesis that fps_pruned_kernel's round is bound by the instruction slots of the one compute unit a sample occupies (of ~1300 slots per round,
+// ~720 are work every wave repeats whatever it owns: the cross-wave arg-max, publish + barrier, the box test) - REFUTED by this kernel: with the same cells on
+// half / a quarter of the waves the kernel is 16 % / 55 % SLOWER (1.48 -> 1.72 / 2.30 ms).  The round is a dependent latency chain per wave (winner's coordinates ->
+// box test -> scan -> arg-max -> LDS -> barrier -> cross-wave arg-max), and sixteen waves walk their cells in parallel where eight or four walk them in turn.
+// MEASUREMENT form (AFM_FPS_CELLS, probe builds only).  A thread owns CELLS cells of PPT sorted points each (cell c of thread t = sorted points [(c T + t) PPT, + PPT): slot c of a wave's 64 lanes is what one
+// wave of the T x CELLS-thread layout owns), so the pruning granularity and the wave-level skip are unchanged while the per-wave overheads are paid by T / 64
+// waves instead of CELLS T / 64.  Same state, same arithmetic, same (distance bits, lowest original index) order: identical indices.
+template <int PPT, int T, int CELLS>
+__global__ __launch_bounds__(T) void fps_cells_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
+    constexpr int CAP = T * PPT * CELLS, NP = PPT / 2;
+    static_assert(PPT % 2 == 0 && PPT <= 16 && T % 64 == 0 && T <= 1024 && CELLS >= 1 && CELLS <= 8, "cell sizes");
+    __shared__ unsigned long long keys[2][16];
+    __shared__ float bb[6][16];
+    extern __shared__ float pts[];                    // first the sort arrays (2 x CAP words), then the [3n] copy of the sample
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nw = T / 64;
+    const float* P = xyz + (int64_t)b * n * 3;
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += T) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = P[i * 3 + a]; lo3[a] = fminf(lo3[a], v); hi3[a] = fmaxf(hi3[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], o)); hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], o)); }
+        if (lane == 0) { bb[a][wave] = lo3[a]; bb[3 + a][wave] = hi3[a]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = bb[a][0], h = bb[3 + a][0];
+        for (int w2 = 1; w2 < nw; ++w2) { l = fminf(l, bb[a][w2]); h = fmaxf(h, bb[3 + a][w2]); }
+        lo3[a] = l; hi3[a] = 1023.0f / fmaxf(h - l, 1e-12f);
+    }
+    unsigned* kk = reinterpret_cast<unsigned*>(pts);
+    unsigned* vv = kk + CAP;
+    for (int i = tid; i < CAP; i += T) {
+        unsigned key = 0xFFFFFFFFu;
+        if (i < n) {
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float f = (P[i * 3 + a] - lo3[a]) * hi3[a]; q[a] = (unsigned)min(1023, max(0, (int)f)); }
+            key = morton_part10(q[0]) | (morton_part10(q[1]) << 1) | (morton_part10(q[2]) << 2);
+        }
+        kk[i] = key; vv[i] = i < n ? (unsigned)i : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CAP; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < CAP; i += T) {
+                const int x = i ^ jj;
+                if (x > i) {
+                    const unsigned ka = kk[i], kb = kk[x];
+                    if ((ka > kb) == ((i & k) == 0)) { kk[i] = kb; kk[x] = ka; const unsigned va = vv[i]; vv[i] = vv[x]; vv[x] = va; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- this thread's cells
+    unsigned oi[CELLS][PPT];
+    f32x2 px[CELLS][NP], py[CELLS][NP], pz[CELLS][NP];
+    float clo[CELLS][3], chi[CELLS][3];
+    bool cell_ok[CELLS];
+#pragma unroll
+    for (int c = 0; c < CELLS; ++c) {
+        cell_ok[c] = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { clo[c][a] = INFINITY; chi[c][a] = -INFINITY; }
+#pragma unroll
+        for (int s2 = 0; s2 < PPT; ++s2) {
+            oi[c][s2] = vv[(c * T + tid) * PPT + s2];
+            const bool ok = oi[c][s2] != 0xFFFFFFFFu;
+            cell_ok[c] = cell_ok[c] || ok;
+            const float x = ok ? P[oi[c][s2] * 3 + 0] : 0.f, y = ok ? P[oi[c][s2] * 3 + 1] : 0.f, z = ok ? P[oi[c][s2] * 3 + 2] : 0.f;
+            px[c][s2 >> 1][s2 & 1] = x; py[c][s2 >> 1][s2 & 1] = y; pz[c][s2 >> 1][s2 & 1] = z;
+            if (ok) { clo[c][0] = fminf(clo[c][0], x); chi[c][0] = fmaxf(chi[c][0], x); clo[c][1] = fminf(clo[c][1], y); chi[c][1] = fmaxf(chi[c][1], y);
+                      clo[c][2] = fminf(clo[c][2], z); chi[c][2] = fmaxf(chi[c][2], z); }
+        }
+    }
+    __syncthreads();                                  // the sort arrays are dead: the same LDS becomes the copy of the sample
+    for (int i0 = tid; i0 < 3 * n; i0 += 8 * T) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + u * T < 3 * n ? P[i0 + u * T] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * T < 3 * n) pts[i0 + u * T] = v[u];
+    }
+    __syncthreads();
+    unsigned tmpb[CELLS][PPT], bd[CELLS], boi[CELLS];
+    auto cell_argmax = [&](int c) {
+        unsigned d = 0u;
+#pragma unroll
+        for (int s2 = 0; s2 < PPT; s2 += 2) d = max(d, max(tmpb[c][s2], tmpb[c][s2 + 1]));
+        unsigned o = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s2 = 0; s2 < PPT; s2 += 2)
+            o = min(o, min(tmpb[c][s2] == d ? oi[c][s2] : 0xFFFFFFFFu, tmpb[c][s2 + 1] == d ? oi[c][s2 + 1] : 0xFFFFFFFFu));
+        bd[c] = d; boi[c] = o;
+    };
+    bool any_ok = false;
+#pragma unroll
+    for (int c = 0; c < CELLS; ++c) {
+#pragma unroll
+        for (int s2 = 0; s2 < PPT; ++s2) tmpb[c][s2] = oi[c][s2] != 0xFFFFFFFFu ? __float_as_uint(1e10f) : 0u;
+        cell_argmax(c);
+        any_ok = any_ok || cell_ok[c];
+    }
+    int cur = 0;
+    unsigned long long best = 0ull;                   // this wave's key, kept across the rounds in which the wave skips
+    if (tid == 0 && m > 0) idx_out[(int64_t)b * m] = b * n;
+    for (int j = 1; j < m; ++j) {
+        const float cx = pts[cur * 3 + 0], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
+        bool scanned = false;
+#pragma unroll
+        for (int c = 0; c < CELLS; ++c) {
+            const float ex = fmaxf(fmaxf(clo[c][0] - cx, cx - chi[c][0]), 0.f), ey = fmaxf(fmaxf(clo[c][1] - cy, cy - chi[c][1]), 0.f),
+                        ez = fmaxf(fmaxf(clo[c][2] - cz, cz - chi[c][2]), 0.f);
+            const float lb = (ex * ex + ey * ey) + ez * ez;
+            const bool need = cell_ok[c] && __float_as_uint(lb) < bd[c];
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {          // wave-uniform: some cell of slot c can change
+                const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+#pragma unroll
+                for (int p2 = 0; p2 < NP; ++p2) {
+                    const f32x2 dx = px[c][p2] - cx2, dy = py[c][p2] - cy2, dz = pz[c][p2] - cz2;
+                    const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                    tmpb[c][2 * p2] = min(tmpb[c][2 * p2], __float_as_uint(d[0]));
+                    tmpb[c][2 * p2 + 1] = min(tmpb[c][2 * p2 + 1], __float_as_uint(d[1]));
+                }
+                cell_argmax(c);
+                scanned = true;
+            }
+        }
+        if (scanned || j == 1) {
+            // this thread's best over its cells: (distance bits, lowest original index)
+            unsigned tb = bd[0], to = boi[0];
+#pragma unroll
+            for (int c = 1; c < CELLS; ++c) {
+                const bool better = bd[c] > tb || (bd[c] == tb && boi[c] < to);
+                tb = better ? bd[c] : tb; to = better ? boi[c] : to;
+            }
+            const unsigned wmax = wave_max_u32(any_ok ? tb : 0u);
+            const unsigned long long holders = __builtin_amdgcn_ballot_w64(any_ok && tb == wmax);
+            best = 0ull;
+            if (holders) {
+                unsigned wbi;
+                if ((holders & (holders - 1)) == 0) wbi = (unsigned)__builtin_amdgcn_readlane((int)to, __builtin_ctzll(holders));
+                else wbi = wave_min_u32((any_ok && tb == wmax) ? to : 0xFFFFFFFFu);
                 best = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - wbi);
             }
         }
@@ -875,6 +1049,26 @@ extern "C" int afm_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_
         if (afm_probe_fps_prune == 0) prune = false;
         if (afm_probe_fps_prune > 0) PT = afm_probe_fps_prune;
 #endif
+        if (prune && AFM_FPS_KS == 1 && AFM_FPS_CELLS > 1 && PT == 1024) {
+            // round 6: CELLS cells of 8 sorted points per thread on 1024 / CELLS threads (same cells, same pruning, fewer waves to pay the per-wave overheads)
+            AfmProf prof(AFM_PROF_FPS, (double)B * (m - 1) * n, s);
+            const size_t lds = (size_t)max(3 * n, 2 * np2) * sizeof(float);
+            constexpr int TC = 1024 / AFM_FPS_CELLS;
+#define AFM_FPS_CELLS_GO(P)                                                                                                                 \
+    do {                                                                                                                            \
+        if (lds > 48 * 1024) {                                                                                                      \
+            hipError_t e__ = hipFuncSetAttribute((const void*)fps_cells_kernel<P, TC, AFM_FPS_CELLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            if (e__ != hipSuccess) return (int)e__;                                                                                 \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((fps_cells_kernel<P, TC, AFM_FPS_CELLS>), dim3(B), dim3(TC), lds, s, xyz, n, m, idx_out);                \
+    } while (0)
+            if (np2 == 2048) AFM_FPS_CELLS_GO(2);
+            else if (np2 == 4096) AFM_FPS_CELLS_GO(4);
+            else AFM_FPS_CELLS_GO(8);
+#undef AFM_FPS_CELLS_GO
+            AFM_CHECK_LAUNCH();
+            return 0;
+        }
         if (prune) {
             AfmProf prof(AFM_PROF_FPS, (double)B * (m - 1) * n, s);
             const size_t lds = (size_t)max(3 * n, 2 * np2) * sizeof(float);

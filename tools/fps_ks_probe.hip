@@ -7,6 +7,7 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 int main(int argc, char** argv) {
+    printf("AFM_FPS_CELLS=%d\n", AFM_FPS_CELLS);
     const int B = atoi(argv[2]), n = atoi(argv[3]);
     std::vector<float> p((size_t)B * n * 3);
     FILE* f = fopen(argv[1], "rb");
